@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X-native Kart hot path on synthetic 150 bp paired-end reads.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], the largest configuration that can be built on the box in
+the time allowed): an E. coli-sized seeded synthetic genome (one 4,639,675 bp contig behind a 2 kb
+decoy contig), its FM-index built here by kart_amd.index_build, and 10 M read pairs (20 M reads of
+150 bp, 1 % substitution errors + 0.1 % haplotype substitutions) generated directly in HBM.
+One "step" = one pass of the GPU hot path over one batch of 20 M resident reads:
+kg_seed_batch_device = search (FM-index backward search) + scan + locate (SA recovery) + sort.
+Every rank owns one GPU with a replicated index and its own read shard (weak scaling, no data-path
+collective); RCCL is used only for the final counter all-reduce.
+
+The JSON line carries `roofline` for the dominant kernel (search_kernel; HIP events recorded on
+the launch stream by the library) and `cpu_baseline` (the CPU oracle port of the same step, all
+host cores, on a bounded sample; rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GENOME_LEN = 4_639_675
+DECOY_LEN = 2_000
+READ_LEN = 150
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_genome(seed):
+    from kart_amd import synth
+    return synth.make_genome([("decoy", DECOY_LEN), ("chrE", GENOME_LEN)], seed=seed, gc=0.508)
+
+
+def gen_reads_device(genome_codes, n_pairs, seed, err, dev):
+    """(enc uint8 [2*n_pairs*150], offsets int64) on the device, reads as the mapper sees them:
+    mate 1 as sequenced, mate 2 reverse-complemented (reference src/GetData.cpp:125-135)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    L = genome_codes.numel()
+    enc = torch.empty(2 * n_pairs * READ_LEN, dtype=torch.uint8, device=dev)
+    view = enc.view(n_pairs, 2, READ_LEN)
+    ar = torch.arange(READ_LEN, device=dev)
+    chunk = 1 << 20
+    for s in range(0, n_pairs, chunk):
+        m = min(chunk, n_pairs - s)
+        frag = torch.clamp((torch.randn(m, generator=g, device=dev) * 50 + 500).round().long(), min=READ_LEN)
+        pos = DECOY_LEN + (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (L - DECOY_LEN - frag)).long()
+        left = genome_codes[pos[:, None] + ar]                       # forward strand, fragment start
+        right_fwd = genome_codes[(pos + frag - READ_LEN)[:, None] + ar]  # forward strand, fragment end
+        flip = torch.rand(m, generator=g, device=dev) < 0.5
+        # pair orientation: read 1 forward / read 2 (after the mapper's revcomp) forward, or both on the reverse strand
+        rc = lambda x: (3 - x).flip(1)
+        r1 = torch.where(flip[:, None], rc(right_fwd), left)
+        r2 = torch.where(flip[:, None], rc(left), right_fwd)
+        both = torch.stack([r1, r2], 1)
+        e = torch.rand(both.shape, generator=g, device=dev) < err
+        bump = torch.randint(1, 4, both.shape, generator=g, device=dev, dtype=torch.uint8)
+        both = torch.where(e, (both + bump) & 3, both)
+        view[s:s + m] = both
+    offsets = torch.arange(0, 2 * n_pairs + 1, device=dev, dtype=torch.int64) * READ_LEN
+    return enc, offsets
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU per step")
+    ap.add_argument("--sa", choices=["sampled", "full"], default="sampled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from kart_amd import api, index_build, synth
+
+    # ---- index (built once by rank 0, replicated per GPU) ------------------------------------------
+    workdir = os.environ.get("KART_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "kart_bench_%d" % os.getuid())
+    os.makedirs(workdir, exist_ok=True)
+    prefix = os.path.join(workdir, "ecoli_like")
+    t_idx = time.time()
+    genome = make_genome(seed=2)
+    if rank == 0 and not all(os.path.exists(prefix + e) for e in (".bwt", ".sa", ".pac", ".ann", ".amb")):
+        fa = os.path.join(workdir, "ecoli_like.fa")
+        synth.write_fasta(fa, genome)
+        index_build.build_index(fa, prefix + ".tmp", device=str(dev))
+        for e in (".bwt", ".sa", ".pac", ".ann", ".amb"):
+            os.replace(prefix + ".tmp" + e, prefix + e)
+    if world > 1:
+        dist.barrier()
+    ix = api.Index(prefix, local, api.KG_SA_FULL if args.sa == "full" else api.KG_SA_SAMPLED)
+    t_idx = time.time() - t_idx
+    codes = torch.from_numpy(np.concatenate([synth.encode(genome["decoy"]), synth.encode(genome["chrE"])])).to(dev)
+
+    # ---- resident inputs ----------------------------------------------------------------------------
+    n_pairs = args.pairs
+    n_reads = 2 * n_pairs
+    n_bases = n_reads * READ_LEN
+    batches = [gen_reads_device(codes, n_pairs, seed=1000 + 17 * rank + b, err=0.011, dev=dev) for b in range(2)]
+    seed_cap = 6 * n_reads + 1024
+    d_seed_off = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)
+    d_seeds = torch.empty(seed_cap * 16, dtype=torch.uint8, device=dev)
+    ws = api.Workspace(ix, n_reads, n_bases)
+    ws.set_profiling(True)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    mode = api.KG_MODE_FAST
+
+    def step(b):
+        enc, off = batches[b % 2]
+        ws.seed_batch_device(enc.data_ptr(), off.data_ptr(), n_reads, n_bases, d_seed_off.data_ptr(), d_seeds.data_ptr(),
+                             seed_cap, mode, stream=stream)
+
+    # ---- parity spot check on this very input (not timed) ------------------------------------------
+    parity = "skipped"
+    if rank == 0:
+        from oracle import oracle as O
+        step(0)
+        torch.cuda.synchronize(dev)
+        assert ws.overflow() == 0, "seed buffer too small"
+        k = 4000
+        enc_h = batches[0][0][: k * READ_LEN].cpu().numpy()
+        off_h = np.arange(k + 1, dtype=np.int64) * READ_LEN
+        orc = O.Oracle(prefix)
+        so_o, s_o = orc.seed_batch(enc_h, off_h, 0, threads=min(8, os.cpu_count() or 1))
+        so_g = d_seed_off[: k + 1].cpu().numpy()
+        s_g = d_seeds[: int(so_g[k]) * 16].cpu().numpy().view(api.SEED_DT)
+        assert (so_g == so_o).all() and (s_g == s_o.astype(api.SEED_DT)).all(), "GPU seeds differ from the oracle"
+        parity = "ok (%d reads bit-identical to the oracle)" % k
+
+    # ---- timed region ---------------------------------------------------------------------------------
+    for w in range(args.warmup):
+        step(w)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(s)
+        # event queries happen after the step has been enqueued; they synchronise on the step's last
+        # event, which is inside the timed region anyway (steps are serialised on one stream)
+        kernel_ms.append(ws.kernel_ms())
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    cnt = ws.counters()
+    totals = torch.tensor([n_reads * args.steps, int(cnt.seeds)], dtype=torch.int64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(totals)                      # the path's only collective: counters
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    kms = np.array(kernel_ms)                                  # (steps, 4): search, scan, locate, sort
+    search_ms = float(kms[:, 0].mean())
+    c = cnt.as_dict()
+    search_bytes = 64 * (c["lf1"] + 2 * c["lf2"]) + c["bases"]            # search kernel's share of bytes_seed
+    locate_bytes = 64 * c["inv"] + 8 * c["sa"] + 16 * c["seeds"]
+    achieved = search_bytes / (search_ms * 1e-3) / 1e9
+    value = float(totals[0].item()) / elapsed
+    line = {
+        "metric": "mapped reads/sec (whole node), 150 bp PE",
+        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "configs[1]: E. coli-like 4.64 Mbp synthetic genome (seed 2), %d x 150 bp PE reads per GPU per step, "
+                               "1%% substitution errors + 0.1%% haplotype substitutions; step = seeding hot path "
+                               "(BWT search + SA locate + sort) on HBM-resident reads" % n_reads,
+                   "reads_per_gpu_per_step": n_reads, "sa_mode": args.sa, "index_bytes": int(ix.info.device_bytes),
+                   "index_residency": "index (%.1f MB) fits the 256 MiB Infinity Cache; reads stream from HBM" % (ix.info.device_bytes / 1e6),
+                   "parallelism": "read-sharded x%d, index replicated" % world,
+                   "index_build_s": round(t_idx, 2), "parity_sample": parity},
+        "roofline": {"bound": "hbm", "kernel": "search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": search_bytes, "avg_launch_ms": search_ms},
+        "kernels_ms": {"search": search_ms, "scan": float(kms[:, 1].mean()), "locate": float(kms[:, 2].mean()), "sort": float(kms[:, 3].mean())},
+        "bytes_seed_per_read": (search_bytes + locate_bytes) / n_reads,
+        "work_per_read": {k2: v / n_reads for k2, v in c.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(prefix, batches[0][0], READ_LEN)
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(prefix, enc_dev, read_len):
+    """The CPU oracle port of the same step (seeding incl. SA locate and sort) on all host cores, on a
+    bounded sample of the same reads (sized for roughly 10-20 s of CPU work)."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    orc = O.Oracle(prefix)
+    k = 20000
+    enc = enc_dev[: k * read_len].cpu().numpy()
+    off = np.arange(k + 1, dtype=np.int64) * read_len
+    t = time.perf_counter()
+    orc.seed_batch(enc, off, 0, threads=cores)
+    rate = k / (time.perf_counter() - t)
+    n = int(min(enc_dev.numel() // read_len, max(k, rate * 12)))
+    enc = enc_dev[: n * read_len].cpu().numpy()
+    off = np.arange(n + 1, dtype=np.int64) * read_len
+    t = time.perf_counter()
+    orc.seed_batch(enc, off, 0, threads=cores)
+    dt = time.perf_counter() - t
+    return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "%d reads of the same batch, oracle/liboracle.so seed_batch (FM search + SA locate + sort), %d threads, %.1f s" % (n, cores, dt)}
+
+
+if __name__ == "__main__":
+    main()

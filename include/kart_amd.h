@@ -1,0 +1,148 @@
+/* kart_amd.h -- C ABI of the MI355X-native Kart hot path (libkart_amd.so).
+ *
+ * The reference (hsinnan75/Kart v2.5.6) has no plugin/FFI layer: its "operator API" for the
+ * seed-and-extend path is the set of extern C++ prototypes in src/structure.h:177-229 that the
+ * worker loop ReadMapping() (src/Mapping.cpp:488-637) calls once per read.  This header is the
+ * batched, device-backed replacement for exactly those calls.  Everything is plain C: opaque
+ * handles, pointers and sizes, int status codes (0 = KG_OK) instead of the reference's exit(1).
+ *
+ *   reference call (file:line)                                   replaced by
+ *   -----------------------------------------------------------  ---------------------------
+ *   bwa_idx_load + RestoreReferenceInfo (src/bwt_index.cpp:148,230; src/main.cpp:192-207)
+ *                                                                kg_index_load / kg_index_destroy
+ *   Mapping(): MinSeedLength choice (src/Mapping.cpp:645)        kg_index_info().min_seed_len
+ *   BWT_Search (src/structure.h:178, src/bwt_search.cpp:140)     } kg_seed_batch (+ _device form)
+ *   IdentifySeedPairs_FastMode / _SensitiveMode                  }   mode KG_MODE_FAST / _SENSITIVE
+ *       (src/structure.h:189,191; src/AlignmentCandidates.cpp:49,132)
+ *   nw_alignment (src/structure.h:229, src/nw_alignment.cpp:18)  kg_nw_batch (+ _device form)
+ *
+ * Threading: an index handle is immutable after load and may be shared by any number of host
+ * threads; a workspace (kg_workspace) owns the scratch of one in-flight batch and must not be
+ * used by two calls at once -- the analogue of the reference's "each worker owns its chunk".
+ * There is no CPU fallback: every entry point fails with KG_ERR_NO_DEVICE when no gfx950
+ * device is usable.
+ */
+#ifndef KART_AMD_H
+#define KART_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KG_OK                0
+#define KG_ERR_NO_DEVICE     1   /* no HIP device / HIP runtime error (see kg_last_error) */
+#define KG_ERR_IO            2   /* index files missing or malformed */
+#define KG_ERR_ARG           3   /* bad argument */
+#define KG_ERR_CAPACITY      4   /* caller-provided output buffer too small (needed size reported) */
+#define KG_ERR_NOMEM         5
+
+#define KG_MODE_FAST         0   /* IdentifySeedPairs_FastMode      (Illumina) */
+#define KG_MODE_SENSITIVE    1   /* IdentifySeedPairs_SensitiveMode (-pacbio)  */
+
+#define KG_OCC_THR_DEFAULT   50  /* OCC_Thr, src/bwt_search.cpp:3 */
+
+/* SA placement on the device: the reference layout (one sample per 32 ranks, LF-walk to locate,
+ * src/bwt_search.cpp:128-138) or the full suffix array expanded once at load into HBM. */
+#define KG_SA_SAMPLED        0
+#define KG_SA_FULL           1
+
+typedef struct kg_index kg_index;
+typedef struct kg_workspace kg_workspace;
+
+/* One exact-match seed = the non-derivable part of SeedPair_t (src/structure.h:106-114):
+ * bSimple = true, gLen = rLen = len, PosDiff = gPos - rPos. */
+typedef struct {
+	int64_t gPos;   /* text coordinate in [0, 2L): forward strand < L <= reverse strand */
+	int32_t rPos;
+	int32_t len;
+} kg_seed;
+
+typedef struct {
+	int64_t  genome_size;    /* l_pac  (GenomeSize) */
+	uint64_t seq_len;        /* 2*l_pac (TwoGenomeSize) = BWT length */
+	uint64_t primary;
+	int32_t  n_contigs;
+	int32_t  min_seed_len;   /* 13..16, src/Mapping.cpp:645 */
+	int32_t  sa_mode;        /* KG_SA_SAMPLED / KG_SA_FULL */
+	int32_t  device;
+	uint64_t device_bytes;   /* HBM held by the index */
+} kg_index_info_t;
+
+typedef struct {
+	const char *name;
+	int64_t fwd_start;       /* Chromosome_t::FowardLocation */
+	int64_t rev_start;       /* Chromosome_t::ReverseLocation */
+	int64_t len;
+} kg_contig_t;
+
+/* Work counters of the last kg_seed_batch* call on a workspace, in the units of the algorithmic
+ * byte count bytes_seed = 64*(lf1 + 2*lf2 + inv) + 8*sa + bases + 16*seeds. */
+typedef struct {
+	uint64_t searches, lf1, lf2, inv, sa, seeds, bases;
+} kg_counters_t;
+
+const char *kg_last_error(void);            /* thread-local message of the last failure */
+int  kg_device_count(void);                 /* number of usable HIP devices (0 if none) */
+
+/* ---- index ------------------------------------------------------------------------------ */
+/* Reads <prefix>.bwt/.sa/.ann/.amb/.pac (BWA 0.7-era format written by the reference's
+ * bwt_index) and uploads the FM-index + 2-bit reference to `device`. */
+int  kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out);
+void kg_index_destroy(kg_index *ix);
+int  kg_index_info(const kg_index *ix, kg_index_info_t *info);
+int  kg_index_contig(const kg_index *ix, int i, kg_contig_t *out);
+
+/* ---- workspace ---------------------------------------------------------------------------- */
+/* Scratch for batches of up to max_reads reads / max_bases bases on the index's device. */
+int  kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_workspace **out);
+void kg_workspace_destroy(kg_workspace *ws);
+int  kg_workspace_counters(kg_workspace *ws, kg_counters_t *out);   /* synchronises the device */
+/* Per-kernel timing: when enabled, every kg_seed_batch* call brackets its kernels with HIP events
+ * on the launch stream; kg_workspace_kernel_ms() synchronises and returns the durations of the
+ * last call in milliseconds: ms[0] search, ms[1] scan+offsets, ms[2] locate, ms[3] sort. */
+int  kg_workspace_set_profiling(kg_workspace *ws, int enabled);
+int  kg_workspace_kernel_ms(kg_workspace *ws, float ms[4]);
+
+/* ---- seeding ------------------------------------------------------------------------------ */
+/* Host-buffer form.  enc_bases: concatenated reads, 1 byte/base, codes 0..3 = ACGT, >3 = ambiguous
+ * (EnCodeReadSeq, src/Mapping.cpp:482-485); read_offsets[n_reads+1].  On return
+ * seed_offsets[n_reads+1] is filled and *seeds points at a library-owned pinned array of
+ * seed_offsets[n_reads] entries, valid until the next call on the same workspace.  Per read the
+ * entries equal what IdentifySeedPairs_{Fast,Sensitive}Mode returns, in the same order
+ * (sorted by (PosDiff,rPos) resp. (gPos,rPos)). */
+int  kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr,
+                   const uint8_t *enc_bases, const int64_t *read_offsets, int64_t n_reads,
+                   int64_t *seed_offsets, const kg_seed **seeds);
+
+/* Device-pointer form (inputs already resident in HBM; asynchronous on `stream`, a hipStream_t
+ * passed as void*, NULL = default stream).  d_seed_offsets[n_reads+1] and d_seeds[seed_capacity]
+ * are device buffers; if the batch produces more than seed_capacity seeds the surplus is dropped
+ * and kg_workspace_overflow() reports the required capacity after the stream is synchronised. */
+int  kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_thr,
+                          const uint8_t *d_enc_bases, const int64_t *d_read_offsets, int64_t n_reads,
+                          int64_t n_bases, int64_t *d_seed_offsets, kg_seed *d_seeds,
+                          int64_t seed_capacity, void *stream);
+int64_t kg_workspace_overflow(kg_workspace *ws);   /* 0 = fitted, else seeds needed */
+
+/* ---- Needleman-Wunsch gap closing ----------------------------------------------------------- */
+/* n fragment pairs: frag1 (read side, raw characters) concatenated with offsets off1[n+1], frag2
+ * (genome side) with off2[n+1].  For pair i the alignment is returned as ops[ops_off[i] ..
+ * ops_off[i]+aln_len[i]) with ops_off[i] = off1[i]+off2[i], one byte per column, left to right:
+ *   KG_OP_DIAG both consume a character; KG_OP_GAP1 '-' inserted into frag1 (consumes frag2);
+ *   KG_OP_GAP2 '-' inserted into frag2 (consumes frag1).
+ * Re-inserting the gaps gives byte-identical strings to nw_alignment()'s in-place result. */
+#define KG_OP_DIAG 0
+#define KG_OP_GAP1 1
+#define KG_OP_GAP2 2
+int  kg_nw_batch(kg_index *ix, const char *frag1, const int64_t *off1, const char *frag2,
+                 const int64_t *off2, int64_t n, uint8_t *ops, int32_t *aln_len);
+int  kg_nw_batch_device(kg_index *ix, const char *d_frag1, const int64_t *d_off1, const char *d_frag2,
+                        const int64_t *d_off2, int64_t n, int64_t max_len, uint8_t *d_ops,
+                        int32_t *d_aln_len, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KART_AMD_H */

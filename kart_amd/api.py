@@ -1,0 +1,270 @@
+"""Host-side mirror of Kart's operator interface for the seed-and-extend path, bound to
+libkart_amd.so (HIP kernels for gfx950) through its C ABI (include/kart_amd.h) with ctypes.
+
+The names follow the reference's extern prototypes (reference src/structure.h:177-229):
+
+    reference (one read per call)                  here (one batch per call)
+    ---------------------------------------------  -----------------------------------------
+    bwa_idx_load / RestoreReferenceInfo            Index(prefix, device, sa_mode)
+    IdentifySeedPairs_FastMode(rlen, EncodeSeq)    Index.IdentifySeedPairs_FastMode(reads)
+    IdentifySeedPairs_SensitiveMode(...)           Index.IdentifySeedPairs_SensitiveMode(reads)
+    nw_alignment(m, s1, n, s2)  (in-place)         Index.nw_alignment(pairs) -> gapped strings
+
+There is no CPU fallback here: if the shared library or a GPU is missing the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkart_amd.so")
+
+KG_OK = 0
+KG_MODE_FAST, KG_MODE_SENSITIVE = 0, 1
+KG_SA_SAMPLED, KG_SA_FULL = 0, 1
+KG_OCC_THR_DEFAULT = 50
+KG_OP_DIAG, KG_OP_GAP1, KG_OP_GAP2 = 0, 1, 2
+
+SEED_DT = np.dtype([("gPos", "<i8"), ("rPos", "<i4"), ("len", "<i4")])
+
+# every symbol include/kart_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "kg_last_error", "kg_device_count", "kg_index_load", "kg_index_destroy", "kg_index_info",
+    "kg_index_contig", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters",
+    "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
+)
+
+
+class KartAmdError(RuntimeError):
+    pass
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("genome_size", C.c_int64), ("seq_len", C.c_uint64), ("primary", C.c_uint64),
+                ("n_contigs", C.c_int32), ("min_seed_len", C.c_int32), ("sa_mode", C.c_int32),
+                ("device", C.c_int32), ("device_bytes", C.c_uint64)]
+
+
+class Contig(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("fwd_start", C.c_int64), ("rev_start", C.c_int64), ("len", C.c_int64)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("searches", "lf1", "lf2", "inv", "sa", "seeds", "bases")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+    def algorithmic_bytes(self) -> int:
+        """bytes_seed of SURVEY.md section 8(d)."""
+        return 64 * (self.lf1 + 2 * self.lf2 + self.inv) + 8 * self.sa + self.bases + 16 * self.seeds
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libkart_amd.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KartAmdError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.kg_last_error.restype = C.c_char_p
+    L.kg_index_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.kg_index_destroy.argtypes = [C.c_void_p]
+    L.kg_index_destroy.restype = None
+    L.kg_index_info.argtypes = [C.c_void_p, C.POINTER(IndexInfo)]
+    L.kg_index_contig.argtypes = [C.c_void_p, C.c_int, C.POINTER(Contig)]
+    L.kg_workspace_create.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]
+    L.kg_workspace_destroy.argtypes = [C.c_void_p]
+    L.kg_workspace_destroy.restype = None
+    L.kg_workspace_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+    L.kg_workspace_overflow.argtypes = [C.c_void_p]
+    L.kg_workspace_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.kg_workspace_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float * 4)]
+    L.kg_workspace_overflow.restype = C.c_int64
+    L.kg_seed_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                C.c_void_p, C.POINTER(C.c_void_p)]
+    L.kg_seed_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.kg_nw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.kg_nw_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != KG_OK:
+        raise KartAmdError(f"{what} failed (status {rc}): {load_library().kg_last_error().decode()}")
+
+
+def device_count() -> int:
+    return int(load_library().kg_device_count())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def concat_reads(reads):
+    """list of uint8 code arrays -> (enc, offsets)."""
+    lens = np.fromiter((len(r) for r in reads), dtype=np.int64, count=len(reads))
+    offsets = np.zeros(len(reads) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    enc = np.concatenate(reads).astype(np.uint8, copy=False) if len(reads) else np.zeros(0, dtype=np.uint8)
+    return np.ascontiguousarray(enc), offsets
+
+
+class Workspace:
+    def __init__(self, index: "Index", max_reads: int, max_bases: int):
+        self.index = index
+        self.lib = index.lib
+        h = C.c_void_p()
+        _check(self.lib.kg_workspace_create(index.h, max_reads, max_bases, C.byref(h)), "kg_workspace_create")
+        self.h = h
+        self.max_reads, self.max_bases = max_reads, max_bases
+
+    def close(self):
+        if self.h:
+            self.lib.kg_workspace_destroy(self.h)
+            self.h = None
+
+    def counters(self) -> Counters:
+        c = Counters()
+        _check(self.lib.kg_workspace_counters(self.h, C.byref(c)), "kg_workspace_counters")
+        return c
+
+    def overflow(self) -> int:
+        return int(self.lib.kg_workspace_overflow(self.h))
+
+    def set_profiling(self, enabled: bool = True):
+        _check(self.lib.kg_workspace_set_profiling(self.h, int(enabled)), "kg_workspace_set_profiling")
+
+    def kernel_ms(self):
+        """(search, scan, locate, sort) durations of the last seed batch, HIP events on its stream."""
+        ms = (C.c_float * 4)()
+        _check(self.lib.kg_workspace_kernel_ms(self.h, C.byref(ms)), "kg_workspace_kernel_ms")
+        return [float(x) for x in ms]
+
+    def seed_batch(self, enc: np.ndarray, offsets: np.ndarray, mode: int, min_seed_len=None, occ_thr=KG_OCC_THR_DEFAULT):
+        """Host-buffer form: returns (seed_offsets[n+1], seeds structured array)."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        so = np.zeros(n + 1, dtype=np.int64)
+        out = C.c_void_p()
+        _check(self.lib.kg_seed_batch(self.h, mode, min_seed_len or self.index.min_seed_len, occ_thr, _ptr(enc), _ptr(offsets),
+                                      n, _ptr(so), C.byref(out)), "kg_seed_batch")
+        total = int(so[n])
+        if total == 0:
+            return so, np.zeros(0, dtype=SEED_DT)
+        buf = (C.c_char * (total * SEED_DT.itemsize)).from_address(out.value)
+        return so, np.frombuffer(buf, dtype=SEED_DT).copy()
+
+    def seed_batch_device(self, d_enc, d_offsets, n_reads, n_bases, d_seed_offsets, d_seeds, seed_capacity, mode,
+                          min_seed_len=None, occ_thr=KG_OCC_THR_DEFAULT, stream=0):
+        """Device-pointer form: arguments are raw device addresses (e.g. torch tensor .data_ptr())."""
+        _check(self.lib.kg_seed_batch_device(self.h, mode, min_seed_len or self.index.min_seed_len, occ_thr, d_enc, d_offsets,
+                                             n_reads, n_bases, d_seed_offsets, d_seeds, seed_capacity, stream),
+               "kg_seed_batch_device")
+
+
+class Index:
+    """Device-resident FM-index + reference (bwa_idx_load + RestoreReferenceInfo of the reference)."""
+
+    def __init__(self, prefix: str, device: int = 0, sa_mode: int = KG_SA_SAMPLED):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib.kg_index_load(prefix.encode(), device, sa_mode, C.byref(h)), "kg_index_load")
+        self.h = h
+        info = IndexInfo()
+        _check(self.lib.kg_index_info(self.h, C.byref(info)), "kg_index_info")
+        self.info = info
+        self.genome_size = int(info.genome_size)
+        self.seq_len = int(info.seq_len)
+        self.min_seed_len = int(info.min_seed_len)
+        self.n_contigs = int(info.n_contigs)
+        self.contigs = []
+        for i in range(self.n_contigs):
+            c = Contig()
+            _check(self.lib.kg_index_contig(self.h, i, C.byref(c)), "kg_index_contig")
+            self.contigs.append((c.name.decode(), int(c.fwd_start), int(c.rev_start), int(c.len)))
+        self._ws = None
+
+    def close(self):
+        if self._ws is not None:
+            self._ws.close()
+            self._ws = None
+        if self.h:
+            self.lib.kg_index_destroy(self.h)
+            self.h = None
+
+    def workspace(self, n_reads: int, n_bases: int) -> Workspace:
+        ws = self._ws
+        if ws is None or ws.max_reads < n_reads or ws.max_bases < n_bases:
+            if ws is not None:
+                ws.close()
+            ws = self._ws = Workspace(self, max(n_reads, 1024), max(n_bases, 1 << 16))
+        return ws
+
+    # -- seeding ------------------------------------------------------------------------------
+    def _seed(self, reads, mode, min_seed_len, occ_thr):
+        enc, offsets = concat_reads(reads)
+        ws = self.workspace(len(reads), len(enc))
+        so, seeds = ws.seed_batch(enc, offsets, mode, min_seed_len, occ_thr)
+        return [seeds[so[i]:so[i + 1]] for i in range(len(reads))]
+
+    def IdentifySeedPairs_FastMode(self, reads, min_seed_len=None, occ_thr=KG_OCC_THR_DEFAULT):
+        """reads: list of uint8 code arrays (EnCodeReadSeq output).  Returns one seed array per read,
+        ordered as the reference's vector<SeedPair_t> (sorted by (PosDiff, rPos))."""
+        return self._seed(reads, KG_MODE_FAST, min_seed_len, occ_thr)
+
+    def IdentifySeedPairs_SensitiveMode(self, reads, min_seed_len=None, occ_thr=KG_OCC_THR_DEFAULT):
+        return self._seed(reads, KG_MODE_SENSITIVE, min_seed_len, occ_thr)
+
+    # -- NW -----------------------------------------------------------------------------------------
+    def nw_ops(self, pairs):
+        """pairs: list of (bytes s1, bytes s2).  Returns list of uint8 op arrays (KG_OP_*)."""
+        n = len(pairs)
+        if n == 0:
+            return []
+        off1 = np.zeros(n + 1, dtype=np.int64)
+        off2 = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(a) for a, _ in pairs], out=off1[1:])
+        np.cumsum([len(b) for _, b in pairs], out=off2[1:])
+        f1 = np.frombuffer(b"".join(a for a, _ in pairs) + b"\0", dtype=np.uint8).copy()
+        f2 = np.frombuffer(b"".join(b for _, b in pairs) + b"\0", dtype=np.uint8).copy()
+        ops = np.zeros(int(off1[n] + off2[n]) + 1, dtype=np.uint8)
+        alen = np.zeros(n, dtype=np.int32)
+        _check(self.lib.kg_nw_batch(self.h, _ptr(f1), _ptr(off1), _ptr(f2), _ptr(off2), n, _ptr(ops), _ptr(alen)), "kg_nw_batch")
+        oo = off1 + off2
+        return [ops[oo[i]:oo[i] + alen[i]].copy() for i in range(n)]
+
+    def nw_alignment(self, pairs):
+        """Mirror of nw_alignment(m, s1, n, s2): returns the two gapped strings for every pair."""
+        out = []
+        for (s1, s2), ops in zip(pairs, self.nw_ops(pairs)):
+            out.append(apply_ops(s1, s2, ops))
+        return out
+
+
+def apply_ops(s1: bytes, s2: bytes, ops: np.ndarray):
+    """Re-insert the gaps described by an op string (what nw_alignment does in place)."""
+    a, b = bytearray(), bytearray()
+    i = j = 0
+    for op in ops:
+        if op == KG_OP_DIAG:
+            a.append(s1[i]); b.append(s2[j]); i += 1; j += 1
+        elif op == KG_OP_GAP1:
+            a.append(0x2D); b.append(s2[j]); j += 1
+        else:
+            a.append(s1[i]); b.append(0x2D); i += 1
+    assert i == len(s1) and j == len(s2), "op string does not consume both fragments"
+    return bytes(a), bytes(b)

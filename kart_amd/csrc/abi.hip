@@ -1,0 +1,525 @@
+// abi.hip -- the extern "C" boundary of libkart_amd.so (declared in include/kart_amd.h).
+//
+// Host side of the boundary: index files -> HBM, per-batch workspaces, kernel launches.  No
+// CPU implementation of the kernels lives here: without a usable HIP device every entry point
+// returns KG_ERR_NO_DEVICE.
+#include "seed_kernels.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace kg;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+	do {                                                                                               \
+		hipError_t e_ = (expr);                                                                        \
+		if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? KG_ERR_NOMEM : KG_ERR_NO_DEVICE, \
+		                                  "%s: %s", #expr, hipGetErrorString(e_));                     \
+	} while (0)
+
+bool read_file(const std::string &path, std::vector<unsigned char> &buf)
+{
+	FILE *fp = fopen(path.c_str(), "rb");
+	if (!fp) return false;
+	fseek(fp, 0, SEEK_END);
+	long sz = ftell(fp);
+	fseek(fp, 0, SEEK_SET);
+	buf.resize((size_t)sz);
+	size_t got = 0;
+	while (got < (size_t)sz) {
+		size_t x = fread(buf.data() + got, 1, (size_t)sz - got, fp);
+		if (x == 0) break;
+		got += x;
+	}
+	fclose(fp);
+	return got == (size_t)sz;
+}
+
+struct ContigRec {
+	std::string name;
+	int64_t fwd_start, rev_start, len;
+};
+
+}  // namespace
+
+struct kg_index {
+	int device = 0;
+	int n_cu = 256;
+	int sa_mode = KG_SA_SAMPLED;
+	FmView view{};
+	int64_t l_pac = 0;
+	uint64_t n_sa = 0;
+	std::vector<ContigRec> contigs;
+	std::vector<uint8_t> pac;   // forward strand, 2 bits/base (host copy)
+	// device allocations
+	uint32_t *d_occ = nullptr;
+	uint64_t *d_sa = nullptr;
+	void *d_fsa = nullptr;
+	uint8_t *d_pac = nullptr;
+	uint64_t device_bytes = 0;
+};
+
+struct kg_workspace {
+	kg_index *ix = nullptr;
+	int64_t max_reads = 0, max_bases = 0, max_hits = 0;
+	// device scratch
+	Hit *d_hits = nullptr;
+	int32_t *d_seeds_per_read = nullptr;
+	unsigned long long *d_ctl = nullptr;
+	void *d_scan_temp = nullptr;
+	size_t scan_bytes = 0;
+	// staging for the host-buffer entry point
+	uint8_t *d_enc = nullptr;
+	int64_t *d_read_off = nullptr;
+	int64_t *d_seed_off = nullptr;
+	kg_seed *d_seeds = nullptr;
+	int64_t seed_capacity = 0;
+	kg_seed *h_seeds = nullptr;     // pinned
+	int64_t h_seed_capacity = 0;
+	hipStream_t stream = nullptr;
+	bool profiling = false;
+	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+extern "C" {
+
+const char *kg_last_error(void) { return g_err; }
+
+int kg_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+// Replaces bwa_idx_load + RestoreReferenceInfo (reference src/bwt_index.cpp:16-36, 47-71, 103-122,
+// 148-160, 230-259): same five files, same derived quantities, but the result lives in HBM.
+int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
+{
+	if (!prefix || !out) return fail(KG_ERR_ARG, "kg_index_load: null argument");
+	*out = nullptr;
+	int ndev = kg_device_count();
+	if (ndev <= 0) return fail(KG_ERR_NO_DEVICE, "kg_index_load: no HIP device available (this library has no CPU path)");
+	if (device < 0 || device >= ndev) return fail(KG_ERR_ARG, "kg_index_load: device %d out of range (have %d)", device, ndev);
+	HIP_TRY(hipSetDevice(device));
+
+	std::string pre(prefix);
+	std::vector<unsigned char> bwt, sa, pac;
+	if (!read_file(pre + ".bwt", bwt) || bwt.size() < 40 + 64) return fail(KG_ERR_IO, "cannot read %s.bwt", prefix);
+	if (!read_file(pre + ".sa", sa) || sa.size() < 56) return fail(KG_ERR_IO, "cannot read %s.sa", prefix);
+	if (!read_file(pre + ".pac", pac) || pac.empty()) return fail(KG_ERR_IO, "cannot read %s.pac", prefix);
+
+	std::unique_ptr<kg_index> ix(new kg_index());
+	ix->device = device;
+	ix->sa_mode = sa_mode;
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+	FmView &v = ix->view;
+	memcpy(&v.primary, bwt.data(), 8);
+	v.L2[0] = 0;
+	memcpy(&v.L2[1], bwt.data() + 8, 32);
+	v.seq_len = v.L2[4];
+	size_t n_words = (bwt.size() - 40) / 4;
+	uint64_t sa_intv = 0, sa_len = 0;
+	memcpy(&sa_intv, sa.data() + 40, 8);
+	memcpy(&sa_len, sa.data() + 48, 8);
+	if (sa_intv != 32) return fail(KG_ERR_IO, "%s.sa: unsupported SA interval %llu (expected 32)", prefix, (unsigned long long)sa_intv);
+	if (sa_len != v.seq_len) return fail(KG_ERR_IO, "%s: .sa and .bwt disagree on the sequence length", prefix);
+	ix->n_sa = (v.seq_len + 32) / 32;
+	if ((sa.size() - 56) / 8 < ix->n_sa - 1) return fail(KG_ERR_IO, "%s.sa is truncated", prefix);
+
+	// .ann: "l_pac n_seqs seed" then per contig "gi name [comment]" / "offset len n_ambs"
+	{
+		FILE *fp = fopen((pre + ".ann").c_str(), "r");
+		if (!fp) return fail(KG_ERR_IO, "cannot read %s.ann", prefix);
+		long long l_pac = 0;
+		int n_seqs = 0;
+		unsigned seed = 0;
+		if (fscanf(fp, "%lld%d%u", &l_pac, &n_seqs, &seed) != 3) { fclose(fp); return fail(KG_ERR_IO, "%s.ann: bad header", prefix); }
+		ix->l_pac = l_pac;
+		int64_t total = 0;
+		for (int i = 0; i < n_seqs; ++i) {
+			unsigned gi;
+			char name[1024];
+			long long off;
+			int len, n_ambs, ch;
+			if (fscanf(fp, "%u%1023s", &gi, name) != 2) { fclose(fp); return fail(KG_ERR_IO, "%s.ann: bad contig record %d", prefix, i); }
+			while ((ch = fgetc(fp)) != '\n' && ch != EOF) {}
+			if (fscanf(fp, "%lld%d%d", &off, &len, &n_ambs) != 3) { fclose(fp); return fail(KG_ERR_IO, "%s.ann: bad contig record %d", prefix, i); }
+			ContigRec c;
+			c.name = name;
+			c.len = len;
+			c.fwd_start = total;
+			total += len;
+			c.rev_start = 2 * ix->l_pac - total;
+			ix->contigs.push_back(c);
+		}
+		fclose(fp);
+		if ((uint64_t)(2 * ix->l_pac) != v.seq_len) return fail(KG_ERR_IO, "%s: .ann l_pac does not match the BWT length", prefix);
+	}
+	size_t pac_bytes = (size_t)(ix->l_pac / 4 + 1);
+	if (pac.size() < pac_bytes) return fail(KG_ERR_IO, "%s.pac is truncated", prefix);
+	ix->pac.assign(pac.begin(), pac.begin() + pac_bytes);
+
+	// upload: Occ/BWT blocks (+ one zero block of padding so a 64-byte fetch of the last,
+	// partial block stays inside the allocation), SA samples, 2-bit reference
+	size_t occ_bytes = n_words * 4 + 128;
+	HIP_TRY(hipMalloc((void **)&ix->d_occ, occ_bytes));
+	HIP_TRY(hipMemset(ix->d_occ, 0, occ_bytes));
+	HIP_TRY(hipMemcpy(ix->d_occ, bwt.data() + 40, n_words * 4, hipMemcpyHostToDevice));
+	std::vector<uint64_t> samples(ix->n_sa);
+	samples[0] = (uint64_t)-1;
+	memcpy(samples.data() + 1, sa.data() + 56, (ix->n_sa - 1) * 8);
+	HIP_TRY(hipMalloc((void **)&ix->d_sa, ix->n_sa * 8));
+	HIP_TRY(hipMemcpy(ix->d_sa, samples.data(), ix->n_sa * 8, hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void **)&ix->d_pac, pac_bytes));
+	HIP_TRY(hipMemcpy(ix->d_pac, ix->pac.data(), pac_bytes, hipMemcpyHostToDevice));
+	ix->device_bytes = occ_bytes + ix->n_sa * 8 + pac_bytes;
+	v.occ = ix->d_occ;
+	v.sa = ix->d_sa;
+	v.fsa32 = nullptr;
+	v.fsa64 = nullptr;
+
+	if (sa_mode == KG_SA_FULL) {
+		bool narrow = v.seq_len < 0xFFFFFFFFull;
+		size_t fsa_bytes = (size_t)(v.seq_len + 1) * (narrow ? 4 : 8);
+		HIP_TRY(hipMalloc(&ix->d_fsa, fsa_bytes));
+		uint32_t *f32 = narrow ? (uint32_t *)ix->d_fsa : nullptr;
+		uint64_t *f64 = narrow ? nullptr : (uint64_t *)ix->d_fsa;
+		HIP_TRY(launch_expand_sa(v, ix->n_sa, f32, f64, nullptr));
+		HIP_TRY(hipDeviceSynchronize());
+		v.fsa32 = f32;
+		v.fsa64 = f64;
+		ix->device_bytes += fsa_bytes;
+	} else if (sa_mode != KG_SA_SAMPLED) {
+		return fail(KG_ERR_ARG, "kg_index_load: unknown sa_mode %d", sa_mode);
+	}
+	*out = ix.release();
+	return KG_OK;
+}
+
+void kg_index_destroy(kg_index *ix)
+{
+	if (!ix) return;
+	(void)hipSetDevice(ix->device);
+	if (ix->d_occ) (void)hipFree(ix->d_occ);
+	if (ix->d_sa) (void)hipFree(ix->d_sa);
+	if (ix->d_fsa) (void)hipFree(ix->d_fsa);
+	if (ix->d_pac) (void)hipFree(ix->d_pac);
+	delete ix;
+}
+
+int kg_index_info(const kg_index *ix, kg_index_info_t *info)
+{
+	if (!ix || !info) return fail(KG_ERR_ARG, "kg_index_info: null argument");
+	info->genome_size = ix->l_pac;
+	info->seq_len = ix->view.seq_len;
+	info->primary = ix->view.primary;
+	info->n_contigs = (int32_t)ix->contigs.size();
+	// MinSeedLength: smallest k in 13..15 with 2L < 4^k, else 16 (reference src/Mapping.cpp:645)
+	int k = 13;
+	for (; k < 16; ++k)
+		if ((double)(2 * ix->l_pac) < (double)(1ull << (2 * k))) break;
+	info->min_seed_len = k;
+	info->sa_mode = ix->sa_mode;
+	info->device = ix->device;
+	info->device_bytes = ix->device_bytes;
+	return KG_OK;
+}
+
+int kg_index_contig(const kg_index *ix, int i, kg_contig_t *out)
+{
+	if (!ix || !out || i < 0 || i >= (int)ix->contigs.size()) return fail(KG_ERR_ARG, "kg_index_contig: bad argument");
+	const ContigRec &c = ix->contigs[(size_t)i];
+	out->name = c.name.c_str();
+	out->fwd_start = c.fwd_start;
+	out->rev_start = c.rev_start;
+	out->len = c.len;
+	return KG_OK;
+}
+
+int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_workspace **out)
+{
+	if (!ix || !out || max_reads <= 0 || max_bases <= 0) return fail(KG_ERR_ARG, "kg_workspace_create: bad argument");
+	*out = nullptr;
+	HIP_TRY(hipSetDevice(ix->device));
+	std::unique_ptr<kg_workspace> ws(new kg_workspace());
+	ws->ix = ix;
+	ws->max_reads = max_reads;
+	ws->max_bases = max_bases;
+	// every hit consumes at least 13 read bases (MinSeedLength >= 13), plus one per read of slack
+	ws->max_hits = max_bases / 13 + max_reads + 64;
+	HIP_TRY(hipMalloc((void **)&ws->d_hits, sizeof(Hit) * (size_t)ws->max_hits));
+	HIP_TRY(hipMalloc((void **)&ws->d_seeds_per_read, 4 * (size_t)max_reads));
+	HIP_TRY(hipMalloc((void **)&ws->d_ctl, 8 * kCtlWords));
+	HIP_TRY(hipMemset(ws->d_ctl, 0, 8 * kCtlWords));
+	ws->scan_bytes = scan_temp_bytes(max_reads);
+	HIP_TRY(hipMalloc(&ws->d_scan_temp, ws->scan_bytes ? ws->scan_bytes : 256));
+	HIP_TRY(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+	*out = ws.release();
+	return KG_OK;
+}
+
+void kg_workspace_destroy(kg_workspace *ws)
+{
+	if (!ws) return;
+	(void)hipSetDevice(ws->ix->device);
+	if (ws->stream) { (void)hipStreamSynchronize(ws->stream); (void)hipStreamDestroy(ws->stream); }
+	void *ptrs[] = {ws->d_hits, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
+	for (void *p : ptrs)
+		if (p) (void)hipFree(p);
+	if (ws->h_seeds) (void)hipHostFree(ws->h_seeds);
+	for (hipEvent_t e : ws->ev)
+		if (e) (void)hipEventDestroy(e);
+	delete ws;
+}
+
+int kg_workspace_counters(kg_workspace *ws, kg_counters_t *out)
+{
+	if (!ws || !out) return fail(KG_ERR_ARG, "kg_workspace_counters: null argument");
+	HIP_TRY(hipSetDevice(ws->ix->device));
+	HIP_TRY(hipDeviceSynchronize());
+	unsigned long long ctl[kCtlWords];
+	HIP_TRY(hipMemcpy(ctl, ws->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+	out->searches = ctl[4]; out->lf1 = ctl[5]; out->lf2 = ctl[6]; out->inv = ctl[7];
+	out->sa = ctl[8]; out->seeds = ctl[9]; out->bases = ctl[10];
+	return KG_OK;
+}
+
+int kg_workspace_set_profiling(kg_workspace *ws, int enabled)
+{
+	if (!ws) return fail(KG_ERR_ARG, "kg_workspace_set_profiling: null workspace");
+	HIP_TRY(hipSetDevice(ws->ix->device));
+	if (enabled && !ws->ev[0])
+		for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&ws->ev[i]));
+	ws->profiling = enabled != 0;
+	return KG_OK;
+}
+
+int kg_workspace_kernel_ms(kg_workspace *ws, float ms[4])
+{
+	if (!ws || !ms) return fail(KG_ERR_ARG, "kg_workspace_kernel_ms: null argument");
+	if (!ws->profiling || !ws->ev[0]) return fail(KG_ERR_ARG, "kg_workspace_kernel_ms: profiling is not enabled");
+	HIP_TRY(hipSetDevice(ws->ix->device));
+	HIP_TRY(hipEventSynchronize(ws->ev[4]));
+	for (int i = 0; i < 4; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], ws->ev[i], ws->ev[i + 1]));
+	return KG_OK;
+}
+
+int64_t kg_workspace_overflow(kg_workspace *ws)
+{
+	if (!ws) return -1;
+	if (hipSetDevice(ws->ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+	unsigned long long v = 0;
+	if (hipMemcpy(&v, ws->d_ctl + 11, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return (int64_t)v;
+}
+
+static int check_seed_args(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, int64_t n_reads, int64_t n_bases)
+{
+	if (!ws) return fail(KG_ERR_ARG, "kg_seed_batch: null workspace");
+	if (mode != KG_MODE_FAST && mode != KG_MODE_SENSITIVE) return fail(KG_ERR_ARG, "kg_seed_batch: unknown mode %d", mode);
+	if (min_seed_len < 13 || min_seed_len > 16) return fail(KG_ERR_ARG, "kg_seed_batch: min_seed_len %d outside 13..16", min_seed_len);
+	if (occ_thr < 1 || occ_thr > 1000000) return fail(KG_ERR_ARG, "kg_seed_batch: occ_thr %d out of range", occ_thr);
+	if (n_reads < 0 || n_reads > ws->max_reads) return fail(KG_ERR_CAPACITY, "kg_seed_batch: %lld reads exceed the workspace (%lld)", (long long)n_reads, (long long)ws->max_reads);
+	if (n_bases < 0 || n_bases > ws->max_bases) return fail(KG_ERR_CAPACITY, "kg_seed_batch: %lld bases exceed the workspace (%lld)", (long long)n_bases, (long long)ws->max_bases);
+	return KG_OK;
+}
+
+int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, const uint8_t *d_enc_bases,
+                         const int64_t *d_read_offsets, int64_t n_reads, int64_t n_bases, int64_t *d_seed_offsets,
+                         kg_seed *d_seeds, int64_t seed_capacity, void *stream)
+{
+	int rc = check_seed_args(ws, mode, min_seed_len, occ_thr, n_reads, n_bases);
+	if (rc != KG_OK) return rc;
+	if (!d_read_offsets || !d_seed_offsets || (n_bases > 0 && !d_enc_bases) || (seed_capacity > 0 && !d_seeds) || seed_capacity < 0)
+		return fail(KG_ERR_ARG, "kg_seed_batch_device: null buffer");
+	HIP_TRY(hipSetDevice(ws->ix->device));
+	hipStream_t st = (hipStream_t)stream;
+	if (n_reads == 0) {
+		HIP_TRY(hipMemsetAsync(d_seed_offsets, 0, 8, st));
+		return KG_OK;
+	}
+	SeedArgs a;
+	a.ix = ws->ix->view;
+	a.enc = d_enc_bases;
+	a.read_off = d_read_offsets;
+	a.n_reads = n_reads;
+	a.n_bases = n_bases;
+	a.mode = mode;
+	a.min_seed_len = min_seed_len;
+	a.occ_thr = occ_thr;
+	a.hits = ws->d_hits;
+	a.max_hits = ws->max_hits;
+	a.seeds_per_read = ws->d_seeds_per_read;
+	a.read_queue = ws->d_ctl + 0;
+	a.hit_count = ws->d_ctl + 1;
+	a.locate_queue = ws->d_ctl + 2;
+	a.counters = ws->d_ctl + 4;
+	a.seed_off = d_seed_offsets;
+	a.seeds = d_seeds;
+	a.seed_capacity = seed_capacity;
+	HIP_TRY(launch_seed_batch(a, ws->d_scan_temp, ws->scan_bytes, ws->ix->n_cu, st, ws->profiling ? ws->ev : nullptr));
+	return KG_OK;
+}
+
+int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, const uint8_t *enc_bases,
+                  const int64_t *read_offsets, int64_t n_reads, int64_t *seed_offsets, const kg_seed **seeds)
+{
+	if (!ws || !read_offsets || !seed_offsets || !seeds) return fail(KG_ERR_ARG, "kg_seed_batch: null argument");
+	*seeds = nullptr;
+	int64_t n_bases = n_reads > 0 ? read_offsets[n_reads] - read_offsets[0] : 0;
+	if (n_reads > 0 && read_offsets[0] != 0) return fail(KG_ERR_ARG, "kg_seed_batch: read_offsets[0] must be 0");
+	int rc = check_seed_args(ws, mode, min_seed_len, occ_thr, n_reads, n_bases);
+	if (rc != KG_OK) return rc;
+	if (n_reads == 0) { seed_offsets[0] = 0; return KG_OK; }
+	HIP_TRY(hipSetDevice(ws->ix->device));
+	if (!ws->d_enc) {
+		HIP_TRY(hipMalloc((void **)&ws->d_enc, (size_t)ws->max_bases + 64));
+		HIP_TRY(hipMalloc((void **)&ws->d_read_off, 8 * (size_t)(ws->max_reads + 1)));
+		HIP_TRY(hipMalloc((void **)&ws->d_seed_off, 8 * (size_t)(ws->max_reads + 1)));
+	}
+	HIP_TRY(hipMemcpyAsync(ws->d_enc, enc_bases, (size_t)n_bases, hipMemcpyHostToDevice, ws->stream));
+	HIP_TRY(hipMemcpyAsync(ws->d_read_off, read_offsets, 8 * (size_t)(n_reads + 1), hipMemcpyHostToDevice, ws->stream));
+	// output capacity grows on demand: run, and if the batch overflowed, re-run once with the exact size
+	int64_t want = std::max<int64_t>(ws->seed_capacity, 8 * n_reads + 1024);
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		if (want > ws->seed_capacity) {
+			if (ws->d_seeds) HIP_TRY(hipFree(ws->d_seeds));
+			ws->d_seeds = nullptr;
+			HIP_TRY(hipMalloc((void **)&ws->d_seeds, sizeof(kg_seed) * (size_t)want));
+			ws->seed_capacity = want;
+		}
+		rc = kg_seed_batch_device(ws, mode, min_seed_len, occ_thr, ws->d_enc, ws->d_read_off, n_reads, n_bases,
+		                          ws->d_seed_off, ws->d_seeds, ws->seed_capacity, ws->stream);
+		if (rc != KG_OK) return rc;
+		HIP_TRY(hipMemcpyAsync(seed_offsets, ws->d_seed_off, 8 * (size_t)(n_reads + 1), hipMemcpyDeviceToHost, ws->stream));
+		HIP_TRY(hipStreamSynchronize(ws->stream));
+		if (seed_offsets[n_reads] <= ws->seed_capacity) break;
+		want = seed_offsets[n_reads];
+		if (attempt == 1) return fail(KG_ERR_CAPACITY, "kg_seed_batch: seed buffer overflow persisted");
+	}
+	int64_t total = seed_offsets[n_reads];
+	if (total > ws->h_seed_capacity) {
+		if (ws->h_seeds) HIP_TRY(hipHostFree(ws->h_seeds));
+		ws->h_seeds = nullptr;
+		int64_t cap = std::max<int64_t>(total, ws->seed_capacity);
+		HIP_TRY(hipHostMalloc((void **)&ws->h_seeds, sizeof(kg_seed) * (size_t)cap, hipHostMallocDefault));
+		ws->h_seed_capacity = cap;
+	}
+	if (total > 0) {
+		HIP_TRY(hipMemcpyAsync(ws->h_seeds, ws->d_seeds, sizeof(kg_seed) * (size_t)total, hipMemcpyDeviceToHost, ws->stream));
+		HIP_TRY(hipStreamSynchronize(ws->stream));
+	}
+	*seeds = ws->h_seeds;
+	return KG_OK;
+}
+
+// ---- NW -------------------------------------------------------------------------------------------
+
+int kg_nw_batch_device(kg_index *ix, const char *d_frag1, const int64_t *d_off1, const char *d_frag2, const int64_t *d_off2,
+                       int64_t n, int64_t max_len, uint8_t *d_ops, int32_t *d_aln_len, void *stream)
+{
+	if (!ix) return fail(KG_ERR_ARG, "kg_nw_batch_device: null index");
+	if (n < 0 || n > 0x7fffffff) return fail(KG_ERR_ARG, "kg_nw_batch_device: bad pair count");
+	if (n == 0) return KG_OK;
+	if (!d_frag1 || !d_off1 || !d_frag2 || !d_off2 || !d_ops || !d_aln_len) return fail(KG_ERR_ARG, "kg_nw_batch_device: null buffer");
+	if (max_len > kNwMaxLen) return fail(KG_ERR_ARG, "kg_nw_batch_device: fragment of %lld bases exceeds the supported %d", (long long)max_len, kNwMaxLen);
+	HIP_TRY(hipSetDevice(ix->device));
+	hipStream_t st = (hipStream_t)stream;
+	NwArgs a;
+	a.f1 = d_frag1; a.off1 = d_off1; a.f2 = d_frag2; a.off2 = d_off2; a.n = n;
+	a.ops = d_ops; a.aln_len = d_aln_len;
+	// per-call scratch (stream-ordered allocation keeps the call asynchronous)
+	int32_t *lists = nullptr;
+	unsigned long long *queue = nullptr;
+	uint32_t *dir = nullptr;
+	HIP_TRY(hipMallocAsync((void **)&lists, 4 * 3 * (size_t)n, st));
+	HIP_TRY(hipMallocAsync((void **)&queue, 8 * 4, st));
+	a.big_list = lists;
+	a.queue = queue;
+	a.dir_scratch = nullptr;
+	a.dir_words_per_wave = 0;
+	a.big_waves = 0;
+	a.big_lds_bytes = 0;
+	if (max_len > 32) {
+		a.big_lds_bytes = nw_big_lds_bytes((int)max_len);
+		int per_cu = std::max(1, std::min(16, (160 * 1024) / std::max(a.big_lds_bytes, 1024)));
+		int64_t waves = std::min<int64_t>((int64_t)ix->n_cu * per_cu, n);
+		a.dir_words_per_wave = nw_dir_words((int)max_len);
+		// bound the slab pool to 8 GiB
+		while (waves > 1 && waves * a.dir_words_per_wave * 4 > (8ll << 30)) waves /= 2;
+		a.big_waves = (int)waves;
+		HIP_TRY(hipMallocAsync((void **)&dir, (size_t)(waves * a.dir_words_per_wave) * 4, st));
+		a.dir_scratch = dir;
+	}
+	HIP_TRY(launch_nw_batch(a, ix->n_cu, st));
+	HIP_TRY(hipFreeAsync(lists, st));
+	HIP_TRY(hipFreeAsync(queue, st));
+	if (dir) HIP_TRY(hipFreeAsync(dir, st));
+	return KG_OK;
+}
+
+int kg_nw_batch(kg_index *ix, const char *frag1, const int64_t *off1, const char *frag2, const int64_t *off2, int64_t n,
+                uint8_t *ops, int32_t *aln_len)
+{
+	if (!ix) return fail(KG_ERR_ARG, "kg_nw_batch: null index");
+	if (n < 0) return fail(KG_ERR_ARG, "kg_nw_batch: bad pair count");
+	if (n == 0) return KG_OK;
+	if (!frag1 || !off1 || !frag2 || !off2 || !ops || !aln_len) return fail(KG_ERR_ARG, "kg_nw_batch: null argument");
+	if (off1[0] != 0 || off2[0] != 0) return fail(KG_ERR_ARG, "kg_nw_batch: offsets must start at 0");
+	int64_t b1 = off1[n], b2 = off2[n], max_len = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		int64_t m = off1[i + 1] - off1[i], q = off2[i + 1] - off2[i];
+		if (m < 0 || q < 0) return fail(KG_ERR_ARG, "kg_nw_batch: offsets must be non-decreasing");
+		max_len = std::max(max_len, std::max(m, q));
+	}
+	HIP_TRY(hipSetDevice(ix->device));
+	char *d1 = nullptr, *d2 = nullptr;
+	int64_t *do1 = nullptr, *do2 = nullptr;
+	uint8_t *dops = nullptr;
+	int32_t *dlen = nullptr;
+	hipStream_t st = nullptr;
+	HIP_TRY(hipMalloc((void **)&d1, (size_t)b1 + 16));
+	HIP_TRY(hipMalloc((void **)&d2, (size_t)b2 + 16));
+	HIP_TRY(hipMalloc((void **)&do1, 8 * (size_t)(n + 1)));
+	HIP_TRY(hipMalloc((void **)&do2, 8 * (size_t)(n + 1)));
+	HIP_TRY(hipMalloc((void **)&dops, (size_t)(b1 + b2) + 16));
+	HIP_TRY(hipMalloc((void **)&dlen, 4 * (size_t)n));
+	HIP_TRY(hipMemcpy(d1, frag1, (size_t)b1, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d2, frag2, (size_t)b2, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(do1, off1, 8 * (size_t)(n + 1), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(do2, off2, 8 * (size_t)(n + 1), hipMemcpyHostToDevice));
+	int rc = kg_nw_batch_device(ix, d1, do1, d2, do2, n, max_len, dops, dlen, st);
+	if (rc == KG_OK) {
+		hipError_t e = hipDeviceSynchronize();
+		if (e == hipSuccess) e = hipMemcpy(ops, dops, (size_t)(b1 + b2), hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(aln_len, dlen, 4 * (size_t)n, hipMemcpyDeviceToHost);
+		if (e != hipSuccess) rc = fail(KG_ERR_NO_DEVICE, "kg_nw_batch: %s", hipGetErrorString(e));
+	}
+	(void)hipFree(d1); (void)hipFree(d2); (void)hipFree(do1); (void)hipFree(do2); (void)hipFree(dops); (void)hipFree(dlen);
+	return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+// nw_kernels.hip -- batched Needleman-Wunsch gap closing on gfx950.
+//
+// Replaces nw_alignment() (reference src/nw_alignment.cpp:18-80) for a batch of fragment pairs.
+// The reference computes three float matrices whose values are all multiples of 0.5
+// (match +1.5, mismatch -1.5, first gap base -1.5, further gap bases -0.5, boundaries -1-0.5*i,
+// :3-6,36-47,53-55), so the DP here is exact 32-bit integer arithmetic on doubled scores:
+//   r(i,j) = max(r(i,j-1) - 1, s(i,j-1) - 3)      gap in sequence 1 (consumes a base of sequence 2)
+//   t(i,j) = max(t(i-1,j) - 1, s(i-1,j) - 3)      gap in sequence 2
+//   s(i,j) = max(s(i-1,j-1) +- 3, r, t)           bases compared through nst_nt4_table (case-blind, N==N)
+// and the traceback keeps the reference's tie order (:60-72): s==r first, then s==t, else diagonal.
+// Two direction bits per cell (s==r, s==t) are all the traceback needs.  It is a FULL DP (the
+// reference is not banded); no MFMA -- this is integer max-plus work, not a contraction.
+//
+// Work is binned by max(m,n) in a classify pass (ballot-compacted lists):
+//   class 0 (<= 8)   one pair per lane, everything in registers, 8x8 cells fully unrolled
+//                    (97 % of Illumina gap fragments)
+//   class 1 (<= 32)  one pair per lane, score rows in registers, direction words in LDS
+//   class 2 (> 32)   one pair per wave: 64 lanes sweep the anti-diagonals of a 64-column stripe,
+//                    neighbours exchanged with DPP shuffles, stripe boundaries in LDS, direction
+//                    words in a per-wave HBM scratch slab
+#include "seed_kernels.hpp"
+
+namespace kg {
+
+constexpr int NEG = -(1 << 20);
+
+__device__ __forceinline__ int nt4_code(unsigned char ch)  // nst_nt4_table, src/BWT_Index/bntseq.c:40-57
+{
+	unsigned u = ch & 0xDFu;
+	return u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
+}
+
+__device__ __forceinline__ int lane_rank_nw(uint64_t mask)
+{
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+__device__ __forceinline__ void append(bool want, unsigned long long *count, int32_t *list, int32_t value)
+{
+	uint64_t mask = __ballot(want);
+	if (mask == 0) return;
+	int leader = __ffsll((unsigned long long)mask) - 1;
+	unsigned long long base = 0;
+	if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(count, (unsigned long long)__popcll(mask));
+	base = __shfl(base, leader);
+	if (want) list[base + lane_rank_nw(mask)] = value;
+}
+
+// queue words: [0..2] list sizes of the three classes, [3] class-2 work queue head
+__global__ __launch_bounds__(256) void nw_classify_kernel(NwArgs a)
+{
+	int64_t base_idx = (int64_t)blockIdx.x * blockDim.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; base_idx < a.n; base_idx += stride) {
+		int64_t p = base_idx + threadIdx.x;
+		int cls = -1;
+		if (p < a.n) {
+			int m = (int)(a.off1[p + 1] - a.off1[p]), n = (int)(a.off2[p + 1] - a.off2[p]);
+			int mx = m > n ? m : n;
+			cls = mx <= 8 ? 0 : mx <= 32 ? 1 : 2;
+		}
+		append(cls == 0, a.queue + 0, a.big_list + 0 * a.n, (int32_t)p);
+		append(cls == 1, a.queue + 1, a.big_list + 1 * a.n, (int32_t)p);
+		append(cls == 2, a.queue + 2, a.big_list + 2 * a.n, (int32_t)p);
+	}
+}
+
+// reverse ops[0..len) in place (traceback produces the columns right to left)
+__device__ __forceinline__ void reverse_ops(uint8_t *ops, int len)
+{
+	for (int x = 0, y = len - 1; x < y; ++x, --y) { uint8_t t = ops[x]; ops[x] = ops[y]; ops[y] = t; }
+}
+
+// ---- class 0: up to 8x8, registers only -----------------------------------------------------------
+__global__ __launch_bounds__(256) void nw_small8_kernel(NwArgs a)
+{
+	const unsigned long long count = a.queue[0];
+	const int32_t *list = a.big_list;
+	unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+	for (; t < count; t += stride) {
+		int64_t p = list[t];
+		int64_t o1 = a.off1[p], o2 = a.off2[p];
+		int m = (int)(a.off1[p + 1] - o1), n = (int)(a.off2[p + 1] - o2);
+		int c2[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) c2[j] = j < n ? nt4_code((unsigned char)a.f2[o2 + j]) : 8 + j;
+		int S[9], T[9];
+		S[0] = 0; T[0] = 0;
+#pragma unroll
+		for (int j = 1; j <= 8; ++j) { S[j] = -2 - j; T[j] = NEG; }
+		uint64_t fr = 0, ft = 0;  // bit 8*(i-1)+(j-1)
+#pragma unroll
+		for (int i = 1; i <= 8; ++i) {
+			if (i <= m) {
+				int c1 = nt4_code((unsigned char)a.f1[o1 + i - 1]);
+				int diag = S[0];
+				S[0] = -2 - i;
+				int left_s = S[0], left_r = NEG;
+#pragma unroll
+				for (int j = 1; j <= 8; ++j) {
+					int up_s = S[j], up_t = T[j];
+					int r = max(left_r - 1, left_s - 3);
+					int tt = max(up_t - 1, up_s - 3);
+					int d = diag + (c1 == c2[j - 1] ? 3 : -3);
+					int s = max(d, max(r, tt));
+					fr |= (uint64_t)(s == r) << (8 * (i - 1) + (j - 1));
+					ft |= (uint64_t)(s == tt) << (8 * (i - 1) + (j - 1));
+					diag = up_s; S[j] = s; T[j] = tt; left_s = s; left_r = r;
+				}
+			}
+		}
+		uint8_t *ops = a.ops + o1 + o2;
+		int i = m, j = n, len = 0;
+		while (i > 0 || j > 0) {
+			int bit = 8 * (i - 1) + (j - 1);
+			bool g1 = i == 0 || (j > 0 && ((fr >> bit) & 1));
+			bool g2 = !g1 && (j == 0 || ((ft >> bit) & 1));
+			ops[len++] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
+			if (g1) j--; else if (g2) i--; else { i--; j--; }
+		}
+		reverse_ops(ops, len);
+		a.aln_len[p] = len;
+	}
+}
+
+// ---- class 1: up to 32x32, direction words in LDS ---------------------------------------------------
+__global__ __launch_bounds__(256) void nw_small32_kernel(NwArgs a)
+{
+	__shared__ uint2 dirs[32][256];  // [row][thread] -> (s==r bits, s==t bits), 64 KB
+	const unsigned long long count = a.queue[1];
+	const int32_t *list = a.big_list + a.n;
+	unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+	for (; t < count; t += stride) {
+		int64_t p = list[t];
+		int64_t o1 = a.off1[p], o2 = a.off2[p];
+		int m = (int)(a.off1[p + 1] - o1), n = (int)(a.off2[p + 1] - o2);
+		int c2[32];
+#pragma unroll
+		for (int j = 0; j < 32; ++j) c2[j] = j < n ? nt4_code((unsigned char)a.f2[o2 + j]) : 8 + j;
+		int S[33], T[33];
+		S[0] = 0; T[0] = 0;
+#pragma unroll
+		for (int j = 1; j <= 32; ++j) { S[j] = -2 - j; T[j] = NEG; }
+		for (int i = 1; i <= m; ++i) {
+			int c1 = nt4_code((unsigned char)a.f1[o1 + i - 1]);
+			int diag = S[0];
+			S[0] = -2 - i;
+			int left_s = S[0], left_r = NEG;
+			uint32_t fr = 0, ft = 0;
+#pragma unroll
+			for (int j = 1; j <= 32; ++j) {
+				int up_s = S[j], up_t = T[j];
+				int r = max(left_r - 1, left_s - 3);
+				int tt = max(up_t - 1, up_s - 3);
+				int d = diag + (c1 == c2[j - 1] ? 3 : -3);
+				int s = max(d, max(r, tt));
+				fr |= (uint32_t)(s == r) << (j - 1);
+				ft |= (uint32_t)(s == tt) << (j - 1);
+				diag = up_s; S[j] = s; T[j] = tt; left_s = s; left_r = r;
+			}
+			dirs[i - 1][threadIdx.x] = make_uint2(fr, ft);
+		}
+		uint8_t *ops = a.ops + o1 + o2;
+		int i = m, j = n, len = 0;
+		while (i > 0 || j > 0) {
+			uint2 w = i > 0 ? dirs[i - 1][threadIdx.x] : make_uint2(0, 0);
+			bool g1 = i == 0 || (j > 0 && ((w.x >> (j - 1)) & 1));
+			bool g2 = !g1 && (j == 0 || ((w.y >> (j - 1)) & 1));
+			ops[len++] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
+			if (g1) j--; else if (g2) i--; else { i--; j--; }
+		}
+		reverse_ops(ops, len);
+		a.aln_len[p] = len;
+	}
+}
+
+// ---- class 2: one pair per wave, anti-diagonal sweep -------------------------------------------------
+// LDS per wave: boundary column S,R for rows 0..m (column 64*stripe), updated in place: lane 63
+// rewrites row i 63 steps after lane 0 consumed it.
+
+__global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
+{
+	extern __shared__ int lds[];
+	const int lane = threadIdx.x;
+	const unsigned long long count = a.queue[2];
+	const int32_t *list = a.big_list + 2 * a.n;
+	uint32_t *dir = a.dir_scratch + (int64_t)blockIdx.x * a.dir_words_per_wave;
+	for (;;) {
+		unsigned long long t = 0;
+		if (lane == 0) t = atomicAdd(a.queue + 3, 1ull);
+		t = __shfl(t, 0);
+		if (t >= count) break;
+		int64_t p = list[t];
+		int64_t o1 = a.off1[p], o2 = a.off2[p];
+		int m = (int)(a.off1[p + 1] - o1), n = (int)(a.off2[p + 1] - o2);
+		int *bS = lds, *bR = lds + (m + 1);
+		unsigned char *s1c = reinterpret_cast<unsigned char *>(lds + 2 * (m + 1));  // fits: see nw_big_lds_bytes()
+		for (int i = lane; i <= m; i += 64) { bS[i] = i == 0 ? 0 : -2 - i; bR[i] = i == 0 ? 0 : NEG; }
+		for (int i = lane; i < m; i += 64) s1c[i] = (unsigned char)nt4_code((unsigned char)a.f1[o1 + i]);
+		__syncthreads();
+		const int n_stripes = (n + 63) >> 6;
+		const int words_per_col = (m + 15) >> 4;
+		const int64_t ncols_pad = (int64_t)n_stripes * 64;
+		for (int st = 0; st < n_stripes; ++st) {
+			int j = st * 64 + lane + 1;          // 1-based column of this lane
+			int c2 = j <= n ? nt4_code((unsigned char)a.f2[o2 + j - 1]) : 9;
+			int up_s = -2 - j, up_t = NEG;       // row 0
+			int res_s = 0, res_r = 0;            // this lane's last result (what lane+1 sees as "left")
+			int diag_s = 0;
+			uint32_t wr = 0, wt = 0;
+			for (int d = 1; d <= m + 63; ++d) {
+				int i = d - lane;
+				// left neighbour = lane-1's result of the previous step; lane 0 reads the boundary
+				int left_s = __shfl_up(res_s, 1), left_r = __shfl_up(res_r, 1);
+				int bi = d <= m ? d : m;
+				int b_s = bS[bi], b_r = bR[bi], b_d = bS[bi - 1];
+				if (lane == 0) { left_s = b_s; left_r = b_r; }
+				bool valid = i >= 1 && i <= m;
+				if (valid) {
+					if (i == 1) diag_s = j == 1 ? 0 : -2 - (j - 1);
+					if (lane == 0) diag_s = b_d;
+					int c1 = s1c[i - 1];
+					int r = max(left_r - 1, left_s - 3);
+					int tt = max(up_t - 1, up_s - 3);
+					int dd = diag_s + (c1 == c2 ? 3 : -3);
+					int s = max(dd, max(r, tt));
+					int sh = ((i - 1) & 15) << 1;
+					wr |= (uint32_t)(s == r) << sh;
+					wt |= (uint32_t)(s == tt) << sh;
+					if (((i & 15) == 0 || i == m) && j <= n) {
+						int64_t w = (int64_t)((i - 1) >> 4) * ncols_pad + (j - 1);
+						dir[2 * w] = wr; dir[2 * w + 1] = wt;
+						wr = wt = 0;
+					} else if ((i & 15) == 0 || i == m) { wr = wt = 0; }
+					diag_s = left_s;   // cell (i, j-1) is the diagonal of the next row
+					up_s = s; up_t = tt;
+					res_s = s; res_r = r;
+				}
+				// lane 63 publishes its column as the next stripe's boundary (row i of column 64*(st+1))
+				if (lane == 63 && valid) { bS[i] = res_s; bR[i] = res_r; }
+			}
+			// row 0 of the next boundary column
+			if (lane == 63) { bS[0] = -2 - (st * 64 + 64); bR[0] = -2 - (st * 64 + 64); }
+			__syncthreads();
+		}
+		(void)words_per_col;
+		// traceback by lane 0
+		uint8_t *ops = a.ops + o1 + o2;
+		int len = 0;
+		if (lane == 0) {
+			int i = m, jj = n;
+			int64_t cached = -1;
+			uint32_t cr = 0, ct = 0;
+			while (i > 0 || jj > 0) {
+				bool g1, g2;
+				if (i == 0) { g1 = true; g2 = false; }
+				else if (jj == 0) { g1 = false; g2 = true; }
+				else {
+					int64_t w = (int64_t)((i - 1) >> 4) * ncols_pad + (jj - 1);
+					if (w != cached) { cr = dir[2 * w]; ct = dir[2 * w + 1]; cached = w; }
+					int sh = ((i - 1) & 15) << 1;
+					g1 = (cr >> sh) & 1;
+					g2 = !g1 && ((ct >> sh) & 1);
+				}
+				ops[len++] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
+				if (g1) jj--; else if (g2) i--; else { i--; jj--; }
+			}
+			a.aln_len[p] = len;
+		}
+		len = __shfl(len, 0);
+		__threadfence_block();
+		__syncthreads();
+		for (int x = lane; x < len / 2; x += 64) {
+			uint8_t t0 = ops[x], t1 = ops[len - 1 - x];
+			ops[x] = t1; ops[len - 1 - x] = t0;
+		}
+		__syncthreads();
+	}
+}
+
+static inline int grid_for_nw(int64_t items, int block, int max_blocks)
+{
+	int64_t g = (items + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > max_blocks) g = max_blocks;
+	return (int)g;
+}
+
+hipError_t launch_nw_batch(const NwArgs &a, int n_cu, hipStream_t stream)
+{
+	if (a.n <= 0) return hipSuccess;
+	hipError_t e;
+	if ((e = hipMemsetAsync(a.queue, 0, sizeof(unsigned long long) * 4, stream)) != hipSuccess) return e;
+	hipLaunchKernelGGL(nw_classify_kernel, dim3(grid_for_nw(a.n, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(nw_small8_kernel, dim3(grid_for_nw(a.n, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(nw_small32_kernel, dim3(grid_for_nw(a.n, 256, n_cu * 2)), dim3(256), 0, stream, a);
+	if (a.dir_scratch && a.big_waves > 0) {
+		if (a.big_lds_bytes > 48 * 1024 &&
+		    (e = hipFuncSetAttribute(reinterpret_cast<const void *>(nw_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, a.big_lds_bytes)) != hipSuccess)
+			return e;
+		hipLaunchKernelGGL(nw_big_kernel, dim3(a.big_waves), dim3(64), a.big_lds_bytes, stream, a);
+	}
+	return hipGetLastError();
+}
+
+}  // namespace kg

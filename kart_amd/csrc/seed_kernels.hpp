@@ -1,0 +1,72 @@
+// seed_kernels.hpp -- argument blocks shared by seed_kernels.hip and the C-ABI layer.
+#pragma once
+#include "../../include/kart_amd.h"
+#include "fm_device.hpp"
+
+namespace kg {
+
+// one successful BWT_Search (len >= MinSeedLength, freq <= OCC_Thr): the interval on the
+// reverse-complement side plus where its seeds go inside the read's output segment
+struct Hit {
+	uint64_t k;          // first rank of the interval (x[1] of the reference's bi-interval)
+	int32_t read;
+	int32_t rpos;
+	int32_t len;
+	int32_t n;           // interval size = number of seeds
+	int32_t seed_start;  // running seed count of the read before this hit
+	int32_t pad;
+};
+
+// device control block: zeroed by one hipMemsetAsync per batch
+//   [0] read queue head  [1] hit count  [2] locate queue head  [3] unused
+//   [4..11] counters: searches, lf1, lf2, inv, sa, seeds, bases, overflow(needed seeds or 0)
+constexpr int kCtlWords = 12;
+
+struct SeedArgs {
+	FmView ix;
+	const uint8_t *enc;
+	const int64_t *read_off;
+	int64_t n_reads;
+	int64_t n_bases;
+	int mode, min_seed_len, occ_thr;
+	// scratch
+	Hit *hits;
+	int64_t max_hits;
+	int32_t *seeds_per_read;
+	unsigned long long *read_queue, *hit_count, *locate_queue, *counters;
+	// outputs
+	int64_t *seed_off;
+	kg_seed *seeds;
+	int64_t seed_capacity;
+};
+
+size_t scan_temp_bytes(int64_t max_reads);
+// ev: optional array of 5 events recorded before/after the four phases (search | scan | locate | sort)
+hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream, hipEvent_t *ev);
+hipError_t launch_expand_sa(const FmView &ix, uint64_t n_sa, uint32_t *fsa32, uint64_t *fsa64, hipStream_t stream);
+
+struct NwArgs {
+	const char *f1;
+	const int64_t *off1;
+	const char *f2;
+	const int64_t *off2;
+	int64_t n;
+	uint8_t *ops;
+	int32_t *aln_len;
+	// scratch: three class lists of n entries each, queue words, and for the wave-per-pair kernel
+	// one direction-word slab per resident wave
+	int32_t *big_list;
+	unsigned long long *queue;   // [0..2] class list sizes, [3] class-2 work queue head
+	uint32_t *dir_scratch;
+	int64_t dir_words_per_wave;
+	int big_waves;               // number of slabs = grid of the wave-per-pair kernel
+	int big_lds_bytes;           // boundary column + sequence-1 codes for the longest pair
+};
+
+constexpr int kNwMaxLen = 7000;  // longest fragment the wave-per-pair kernel's 64 KB LDS holds
+inline int nw_big_lds_bytes(int max_len) { return 8 * (max_len + 1) + ((max_len + 15) & ~15) + 16; }
+inline int64_t nw_dir_words(int max_len) { return 2ll * ((max_len + 15) / 16) * (((int64_t)max_len + 63) / 64 * 64); }
+
+hipError_t launch_nw_batch(const NwArgs &a, int n_cu, hipStream_t stream);
+
+}  // namespace kg
