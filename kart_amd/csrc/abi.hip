@@ -269,7 +269,8 @@ int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_w
 	ws->max_reads = max_reads;
 	ws->max_bases = max_bases;
 	// every hit consumes at least 13 read bases (MinSeedLength >= 13), plus one per read of slack
-	ws->max_hits = max_bases / 13 + max_reads + 64;
+	// ... plus the slack of the per-wave slot pools (one 256-slot chunk per resident wave)
+	ws->max_hits = max_bases / 13 + max_reads + (int64_t)ix->n_cu * 32 * 256 + 4096;
 	HIP_TRY(hipMalloc((void **)&ws->d_hits, sizeof(Hit) * (size_t)ws->max_hits));
 	HIP_TRY(hipMalloc((void **)&ws->d_seeds_per_read, 4 * (size_t)max_reads));
 	HIP_TRY(hipMalloc((void **)&ws->d_ctl, 8 * kCtlWords));

@@ -40,17 +40,36 @@ __device__ __forceinline__ int lane_rank(uint64_t mask)
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
-// wave-aggregated "take one ticket each" for the lanes with want == true
-__device__ __forceinline__ unsigned long long take_tickets(unsigned long long *counter, bool want)
+// Wave-local ticket pool.  A single global counter hit by every wave every iteration saturates
+// at ~90 M atomics/s on one word (MI355X_MICROARCH.md "dequeue"), which was the whole kernel's
+// ceiling; instead one atomic reserves kPoolChunk consecutive tickets for the wave and lanes draw
+// from that pool with ballot-prefix arithmetic.  `next`/`end` are wave-uniform.
+constexpr unsigned long long kPoolChunk = 256;
+
+struct WavePool {
+	unsigned long long next = 0, end = 0;
+};
+
+__device__ __forceinline__ unsigned long long pool_take(WavePool &p, unsigned long long *counter, bool want)
 {
 	uint64_t mask = __ballot(want);
-	unsigned long long base = 0;
 	if (mask == 0) return 0;
-	int leader = __ffsll((unsigned long long)mask) - 1;
-	int lane = threadIdx.x & 63;
-	if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
-	base = __shfl(base, leader);
-	return base + lane_rank(mask);
+	unsigned long long cnt = (unsigned long long)__popcll(mask);
+	unsigned long long avail = p.end - p.next;
+	unsigned long long rank = (unsigned long long)lane_rank(mask);
+	unsigned long long ticket = p.next + rank;
+	if (cnt > avail) {  // wave-uniform branch
+		unsigned long long base = 0;
+		int leader = __ffsll((unsigned long long)mask) - 1;
+		if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, kPoolChunk);
+		base = __shfl(base, leader);
+		if (rank >= avail) ticket = base + (rank - avail);
+		p.next = base + (cnt - avail);
+		p.end = base + kPoolChunk;
+	} else {
+		p.next += cnt;
+	}
+	return ticket;
 }
 
 __device__ __forceinline__ int code_at(const uint8_t *enc, int64_t base, int i, int rlen)
@@ -72,6 +91,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 	uint64_t k = 0, n = 0;
 	// local work counters
 	uint32_t c_search = 0, c_lf1 = 0, c_lf2 = 0;
+	WavePool read_pool, hit_pool;
 
 	for (;;) {
 		// ---- phase A: lanes without a live interval start their next search / next read --------
@@ -79,7 +99,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 			bool idle = !done && !active;
 			if (__ballot(idle) == 0) break;
 			bool want_read = idle && !have_read;
-			unsigned long long t = take_tickets(a.read_queue, want_read);
+			unsigned long long t = pool_take(read_pool, a.read_queue, want_read);
 			if (want_read) {
 				if (t >= (unsigned long long)a.n_reads) done = true;
 				else {
@@ -149,8 +169,8 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 				hit = len >= a.min_seed_len && n <= (uint64_t)a.occ_thr;
 			}
 		}
-		// dense hit list, wave-aggregated append (called by the whole wave: ballot is convergent)
-		unsigned long long slot = take_tickets(a.hit_count, hit);
+		// hit list: slots come from the wave's pool (called by the whole wave: ballot is convergent)
+		unsigned long long slot = pool_take(hit_pool, a.hit_count, hit);
 		if (hit) {
 			Hit h;
 			h.k = k; h.read = (int32_t)r; h.rpos = pos; h.len = len; h.n = (int32_t)n; h.seed_start = seed_cnt; h.pad = 0;
@@ -167,6 +187,8 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 			active = false;
 		}
 	}
+	// the slots this wave reserved but never filled are marked empty for the locate kernel
+	for (unsigned long long x = hit_pool.next + (threadIdx.x & 63); x < hit_pool.end; x += 64) a.hits[x].n = 0;
 	// work counters: one atomic per wave
 	uint64_t s0 = c_search, s1 = c_lf1, s2 = c_lf2;
 	for (int off = 32; off > 0; off >>= 1) {
@@ -195,12 +217,13 @@ __global__ __launch_bounds__(256) void locate_sampled_kernel(SeedArgs a)
 	int i = 0;
 	uint64_t k = 0, steps = 0;
 	uint32_t c_inv = 0, c_sa = 0;
+	WavePool pool;
 	for (;;) {
 		for (;;) {
 			bool idle = !done && !walking;
 			if (__ballot(idle) == 0) break;
 			bool want = idle && i >= h.n;
-			unsigned long long t = take_tickets(a.locate_queue, want);
+			unsigned long long t = pool_take(pool, a.locate_queue, want);
 			if (want) {
 				if (t >= n_hits) done = true;
 				else { h = a.hits[t]; i = 0; }
