@@ -36,9 +36,9 @@ READ_LEN = 150
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def make_genome(seed):
+def make_genome(seed, length=GENOME_LEN):
     from kart_amd import synth
-    return synth.make_genome([("decoy", DECOY_LEN), ("chrE", GENOME_LEN)], seed=seed, gc=0.508)
+    return synth.make_genome([("decoy", DECOY_LEN), ("chrE", length)], seed=seed, gc=0.508)
 
 
 def gen_reads_device(genome_codes, n_pairs, seed, err, dev):
@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU per step")
     ap.add_argument("--sa", choices=["sampled", "full"], default="sampled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--genome-len", type=int, default=GENOME_LEN, help="experiment knob: synthetic genome length (default = configs[1])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,11 +105,11 @@ def main():
     # ---- index (built once by rank 0, replicated per GPU) ------------------------------------------
     workdir = os.environ.get("KART_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "kart_bench_%d" % os.getuid())
     os.makedirs(workdir, exist_ok=True)
-    prefix = os.path.join(workdir, "ecoli_like")
+    prefix = os.path.join(workdir, "ecoli_like" if args.genome_len == GENOME_LEN else "synth_%d" % args.genome_len)
     t_idx = time.time()
-    genome = make_genome(seed=2)
+    genome = make_genome(seed=2, length=args.genome_len)
     if rank == 0 and not all(os.path.exists(prefix + e) for e in (".bwt", ".sa", ".pac", ".ann", ".amb")):
-        fa = os.path.join(workdir, "ecoli_like.fa")
+        fa = prefix + ".fa"
         synth.write_fasta(fa, genome)
         index_build.build_index(fa, prefix + ".tmp", device=str(dev))
         for e in (".bwt", ".sa", ".pac", ".ann", ".amb"):
@@ -195,7 +196,7 @@ def main():
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "configs[1]: E. coli-like 4.64 Mbp synthetic genome (seed 2), %d x 150 bp PE reads per GPU per step, "
+        "config": {"workload": ("configs[1]: E. coli-like 4.64 Mbp" if args.genome_len == GENOME_LEN else "EXPERIMENT: %d bp" % args.genome_len) + " synthetic genome (seed 2), %d x 150 bp PE reads per GPU per step, "
                                "1%% substitution errors + 0.1%% haplotype substitutions; step = seeding hot path "
                                "(BWT search + SA locate + sort) on HBM-resident reads" % n_reads,
                    "reads_per_gpu_per_step": n_reads, "sa_mode": args.sa, "index_bytes": int(ix.info.device_bytes),

@@ -72,6 +72,7 @@ struct kg_index {
 	std::vector<uint8_t> pac;   // forward strand, 2 bits/base (host copy)
 	// device allocations
 	uint32_t *d_occ = nullptr;
+	uint4 *d_planes = nullptr;
 	uint64_t *d_sa = nullptr;
 	void *d_fsa = nullptr;
 	uint8_t *d_pac = nullptr;
@@ -198,6 +199,17 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	ix->device_bytes = occ_bytes + ix->n_sa * 8 + pac_bytes;
 	v.occ = ix->d_occ;
 	v.sa = ix->d_sa;
+	{
+		// device-private rank structure (bit-planes, 1 byte/symbol), built from the uploaded blocks;
+		// the source blocks are padded to a whole number of 128-symbol blocks by the zero fill above
+		uint64_t n_blocks64 = ((v.seq_len + 127) / 128) * 2;
+		size_t plane_bytes = (size_t)n_blocks64 * 64 + 64;
+		HIP_TRY(hipMalloc((void **)&ix->d_planes, plane_bytes));
+		HIP_TRY(launch_build_planes(ix->d_occ, n_blocks64, ix->d_planes, nullptr));
+		HIP_TRY(hipDeviceSynchronize());
+		v.planes = ix->d_planes;
+		ix->device_bytes += plane_bytes;
+	}
 	v.fsa32 = nullptr;
 	v.fsa64 = nullptr;
 
@@ -224,6 +236,7 @@ void kg_index_destroy(kg_index *ix)
 	if (!ix) return;
 	(void)hipSetDevice(ix->device);
 	if (ix->d_occ) (void)hipFree(ix->d_occ);
+	if (ix->d_planes) (void)hipFree(ix->d_planes);
 	if (ix->d_sa) (void)hipFree(ix->d_sa);
 	if (ix->d_fsa) (void)hipFree(ix->d_fsa);
 	if (ix->d_pac) (void)hipFree(ix->d_pac);

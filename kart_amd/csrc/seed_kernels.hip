@@ -26,6 +26,7 @@
 #include "seed_kernels.hpp"
 
 #include <hipcub/hipcub.hpp>
+#include <cstdlib>
 
 namespace kg {
 
@@ -72,119 +73,168 @@ __device__ __forceinline__ unsigned long long pool_take(WavePool &p, unsigned lo
 	return ticket;
 }
 
-__device__ __forceinline__ int code_at(const uint8_t *enc, int64_t base, int i, int rlen)
+// ---- read window ------------------------------------------------------------------------------
+// The ABI hands over one byte per base (the reference's EncodeSeq).  The search loop keeps the
+// read's codes in registers: a "window word" holds 16 positions, 4 bits each.  A word is made from
+// ONE unaligned 16-byte load of the raw bytes (gfx950 global loads need no alignment) and ~60 bit
+// ops; bytes > 3 become nibbles > 3 (ambiguous) and positions >= rlen read as 4, which is also what
+// makes SensitiveMode's look past the read end behave like 'N' (SURVEY.md App. B-10).
+struct __attribute__((packed, aligned(1))) Raw16 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint32_t nibbles_of(uint32_t x)   // 4 bytes -> 4 nibbles in the low 16 bits
 {
-	// positions past the read end behave as ambiguous bases: the reference's SensitiveMode can ask
-	// for them after an N run, where it reads past its own buffer
-	return i < rlen ? (int)enc[base + i] : 4;
+	uint32_t y = x & 0xFCFCFCFCu;                                            // anything above 3?
+	uint32_t nz = (((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;     // 0x80 per non-zero byte
+	uint32_t nib = (x & 0x03030303u) | (nz >> 5);                            // 0..3, or 4..7 when ambiguous
+	nib = (nib | (nib >> 4)) & 0x00FF00FFu;
+	return (nib | (nib >> 8)) & 0x0000FFFFu;
 }
 
+__device__ __forceinline__ uint64_t window_word(const uint8_t *enc, int64_t n_bases, int64_t base, int rlen, int w)
+{
+	int64_t at = base + ((int64_t)w << 4);
+	int valid = rlen - (w << 4);                  // positions of this word that exist
+	uint32_t a, b, c, d;
+	if (at + 16 <= n_bases) {
+		Raw16 v = *reinterpret_cast<const Raw16 *>(enc + at);
+		a = v.x; b = v.y; c = v.z; d = v.w;
+	} else {                                      // last bytes of the batch: stay inside the buffer
+		uint32_t t[4] = {0, 0, 0, 0};
+		for (int j = 0; j < 16; ++j)
+			if (at + j < n_bases) t[j >> 2] |= (uint32_t)enc[at + j] << ((j & 3) << 3);
+		a = t[0]; b = t[1]; c = t[2]; d = t[3];
+	}
+	uint64_t word = (uint64_t)(nibbles_of(a) | (nibbles_of(b) << 16)) | ((uint64_t)(nibbles_of(c) | (nibbles_of(d) << 16)) << 32);
+	uint64_t keep = valid >= 16 ? ~0ull : valid <= 0 ? 0ull : ((1ull << (valid << 2)) - 1);
+	return (word & keep) | (0x4444444444444444ull & ~keep);
+}
+
+// ---- search ---------------------------------------------------------------------------------------
+// One predicated loop, one LF step per lane per iteration:
+//   C  extension step of the live interval (two 16-byte rank gathers),
+//   D  end-of-search bookkeeping (hit record, next start position),
+//   A  lanes without a read draw one from the wave's pool (wave-uniform, infrequent branch),
+//   B  lanes without a live interval start their next search.
+// State transitions are selects, not branches: the first version of this kernel spent 58 % of its
+// wave cycles in SQ_WAIT_INST_ANY (exec-mask juggling and refetch after ~35 divergent branches per
+// iteration, 64-bit VALU, dependent byte loads for the read codes).  The read's codes live in a
+// two-word register window (32 positions) that is refilled one word ahead.
+template <typename idx_t>
 __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 {
 	const FmView &ix = a.ix;
-	// per-lane read state
+	const idx_t primary = (idx_t)ix.primary;
+	const idx_t l2_0 = (idx_t)ix.L2[0], l2_1 = (idx_t)ix.L2[1], l2_2 = (idx_t)ix.L2[2], l2_3 = (idx_t)ix.L2[3], l2_4 = (idx_t)ix.L2[4];
+	const bool fast = a.mode == KG_MODE_FAST;
+	const int msl = a.min_seed_len;
+	const idx_t occ_thr = (idx_t)a.occ_thr;
+
 	bool have_read = false, done = false, active = false;
-	int64_t r = 0, base = 0;
-	int rlen = 0, pos = 0, stop_pos = 0, end_pos = 0, seed_cnt = 0;
-	// per-lane search state
-	int cur = 0, stop = 0, next_code = 4;
-	uint64_t k = 0, n = 0;
-	// local work counters
+	int r = 0, rlen = 0, pos = 0, stop_pos = 0, end_pos = 0, seed_cnt = 0;
+	int cur = 0, stop = 0, wword = 0;
+	int64_t base = 0;
+	uint64_t win = 0x4444444444444444ull, wnext = 0x4444444444444444ull;
+	idx_t k = 0, n = 0;
 	uint32_t c_search = 0, c_lf1 = 0, c_lf2 = 0;
 	WavePool read_pool, hit_pool;
 
 	for (;;) {
-		// ---- phase A: lanes without a live interval start their next search / next read --------
-		for (;;) {
-			bool idle = !done && !active;
-			if (__ballot(idle) == 0) break;
-			bool want_read = idle && !have_read;
+		// ---- C: one extension step ------------------------------------------------------------------
+		int code = (int)((win >> ((cur & 15) << 2)) & 15);
+		bool do_step = active && cur < stop && code <= 3;
+		int c = do_step ? 3 - code : 0;
+		idx_t kk = do_step ? k - 1 : 0, ll = do_step ? k - 1 + n : 0;   // bwt_2occ4(x1-1, x1-1+x2), :157
+		kk -= (kk >= primary);
+		ll -= (ll >= primary);
+		uint4 vk = ix.planes[(((uint64_t)(kk >> 6)) << 2) + (uint32_t)c];
+		uint4 vl = ix.planes[(((uint64_t)(ll >> 6)) << 2) + (uint32_t)c];
+		uint64_t mk = (2ull << (kk & 63)) - 1, ml = (2ull << (ll & 63)) - 1;
+		idx_t ok = (idx_t)(((uint64_t)vk.y << 32) | vk.x) + (idx_t)__popcll((((uint64_t)vk.w << 32) | vk.z) & mk);
+		idx_t ol = (idx_t)(((uint64_t)vl.y << 32) | vl.x) + (idx_t)__popcll((((uint64_t)vl.w << 32) | vl.z) & ml);
+		idx_t nn = ol - ok;
+		bool cont = do_step && nn != 0;
+		c_lf1 += (do_step && (kk >> 7) == (ll >> 7)) ? 1 : 0;            // reference block accounting
+		c_lf2 += (do_step && (kk >> 7) != (ll >> 7)) ? 1 : 0;
+		idx_t l2c = c == 0 ? l2_0 : c == 1 ? l2_1 : c == 2 ? l2_2 : l2_3;
+		k = cont ? l2c + 1 + ok : k;
+		n = cont ? nn : n;
+		cur += cont ? 1 : 0;
+		if (cont && (cur & 15) == 0) {          // window slides one word; the new look-ahead word is a prefetch
+			win = wnext;
+			wword++;
+			wnext = window_word(a.enc, a.n_bases, base, rlen, wword + 1);
+		}
+
+		// ---- D: end of a search ---------------------------------------------------------------------
+		bool ended = active && !cont;
+		int len = cur - pos;
+		bool hit = ended && len >= msl && n <= occ_thr;
+		unsigned long long slot = pool_take(hit_pool, a.hit_count, hit);
+		if (hit) {
+			uint4 *dst = reinterpret_cast<uint4 *>(a.hits + slot);
+			uint64_t k64 = (uint64_t)k;
+			dst[0] = make_uint4((uint32_t)k64, (uint32_t)(k64 >> 32), (uint32_t)r, (uint32_t)pos);
+			dst[1] = make_uint4((uint32_t)len, (uint32_t)n, (uint32_t)seed_cnt, 0u);
+			seed_cnt += (int)n;
+		}
+		if (ended) {
+			int adv = fast ? len + 1 : (hit ? len : msl);                 // :74 / :157-161
+			pos += adv;
+			stop_pos += fast ? 0 : adv;
+			stop_pos = stop_pos > rlen ? rlen : stop_pos;               // :163
+			active = false;
+		}
+
+		// ---- A: new reads for lanes that have none -------------------------------------------------------
+		bool want_read = !have_read && !done;
+		if (__ballot(want_read)) {
 			unsigned long long t = pool_take(read_pool, a.read_queue, want_read);
 			if (want_read) {
 				if (t >= (unsigned long long)a.n_reads) done = true;
 				else {
-					r = (int64_t)t;
-					base = a.read_off[r];
-					rlen = (int)(a.read_off[r + 1] - base);
-					pos = 0; stop_pos = 30; end_pos = rlen - a.min_seed_len; seed_cnt = 0;
+					r = (int)t;
+					base = a.read_off[t];
+					rlen = (int)(a.read_off[t + 1] - base);
+					win = window_word(a.enc, a.n_bases, base, rlen, 0);
+					wnext = window_word(a.enc, a.n_bases, base, rlen, 1);
+					wword = 0;
+					pos = 0; stop_pos = 30; end_pos = rlen - msl; seed_cnt = 0;
 					have_read = true;
-				}
-			} else if (idle) {
-				// skip ambiguous bases (FastMode :59, SensitiveMode :142)
-				while (pos < end_pos && a.enc[base + pos] > 3) { pos++; stop_pos++; }
-				if (pos >= end_pos) {
-					a.seeds_per_read[r] = seed_cnt;
-					have_read = false;
-				} else {
-					int p = a.enc[base + pos];
-					k = l2_of(ix, 3 - p) + 1;                 // x[1] of BWT_Search :149
-					n = l2_of(ix, p + 1) - l2_of(ix, p);      // x[2] :150
-					cur = pos + 1;
-					stop = a.mode == KG_MODE_FAST ? rlen : stop_pos;
-					next_code = cur < stop ? code_at(a.enc, base, cur, rlen) : 4;
-					active = true;
-					c_search++;
 				}
 			}
 		}
 		if (__ballot(!done) == 0) break;
 
-		// ---- phase B: one extension step for every live interval -------------------------------
-		bool ended = false, hit = false;
-		int len = 0;
-		if (active) {
-			ended = true;
-			if (cur < stop && next_code <= 3) {
-				int c = 3 - next_code;
-				uint32_t pat = (uint32_t)c * 0x55555555u;
-				uint64_t kk = k - 1, ll = k - 1 + n;              // bwt_2occ4(x1-1, x1-1+x2) :157
-				kk -= (kk >= ix.primary);
-				ll -= (ll >= ix.primary);
-				uint64_t bk = kk >> 7, bl = ll >> 7;
-				OccBlock B = load_block(ix, bk, c);
-				int pre = cur + 1 < stop ? code_at(a.enc, base, cur + 1, rlen) : 4;  // overlaps the gathers
-				uint64_t ok, ol;
-				if (bk == bl) {
-					uint32_t n1, n2;
-					count_head2(B, pat, (int)(kk & 127) + 1, (int)(ll & 127) + 1, n1, n2);
-					ok = B.cnt + n1; ol = B.cnt + n2;
-					c_lf1++;
-				} else {
-					OccBlock B2 = load_block(ix, bl, c);
-					ok = B.cnt + count_head(B, pat, (int)(kk & 127) + 1);
-					ol = B2.cnt + count_head(B2, pat, (int)(ll & 127) + 1);
-					c_lf2++;
-				}
-				uint64_t nn = ol - ok;
-				if (nn != 0) {
-					k = l2_of(ix, c) + 1 + ok;
-					n = nn;
-					cur++;
-					next_code = pre;
-					ended = false;
-				}
-			}
-			if (ended) {
-				len = cur - pos;
-				hit = len >= a.min_seed_len && n <= (uint64_t)a.occ_thr;
-			}
+		// ---- B: start the next search ---------------------------------------------------------------------
+		bool idle = have_read && !active;
+		bool finished = idle && pos >= end_pos;
+		if (finished) {
+			a.seeds_per_read[r] = seed_cnt;
+			have_read = false;
 		}
-		// hit list: slots come from the wave's pool (called by the whole wave: ballot is convergent)
-		unsigned long long slot = pool_take(hit_pool, a.hit_count, hit);
-		if (hit) {
-			Hit h;
-			h.k = k; h.read = (int32_t)r; h.rpos = pos; h.len = len; h.n = (int32_t)n; h.seed_start = seed_cnt; h.pad = 0;
-			a.hits[slot] = h;
-			seed_cnt += (int)n;
+		bool starting = idle && !finished;
+		int w = pos >> 4;
+		if (starting && w != wword) {           // the new start lies outside the window's first word
+			if (w == wword + 1) win = wnext; else win = window_word(a.enc, a.n_bases, base, rlen, w);
+			wnext = window_word(a.enc, a.n_bases, base, rlen, w + 1);
+			wword = w;
 		}
-		if (ended) {
-			if (a.mode == KG_MODE_FAST) pos += len + 1;               // :74
-			else {                                                     // :157-163
-				int adv = hit ? len : a.min_seed_len;
-				pos += adv; stop_pos += adv;
-				if (stop_pos > rlen) stop_pos = rlen;
-			}
-			active = false;
+		int code0 = (int)((win >> ((pos & 15) << 2)) & 15);
+		bool skip = starting && code0 > 3;          // ambiguous base: FastMode :59, SensitiveMode :142
+		pos += skip ? 1 : 0;
+		stop_pos += skip ? 1 : 0;
+		bool go = starting && !skip;
+		if (go) {
+			idx_t lo = code0 == 0 ? l2_0 : code0 == 1 ? l2_1 : code0 == 2 ? l2_2 : l2_3;
+			idx_t hi = code0 == 0 ? l2_1 : code0 == 1 ? l2_2 : code0 == 2 ? l2_3 : l2_4;
+			int cc = 3 - code0;
+			k = (cc == 0 ? l2_0 : cc == 1 ? l2_1 : cc == 2 ? l2_2 : l2_3) + 1;   // x[1], :149
+			n = hi - lo;                                                       // x[2], :150
+			cur = pos + 1;
+			stop = fast ? rlen : stop_pos;
+			active = true;
+			c_search++;
+			if ((cur & 15) == 0) { win = wnext; wword++; wnext = window_word(a.enc, a.n_bases, base, rlen, wword + 1); }
 		}
 	}
 	// the slots this wave reserved but never filled are marked empty for the locate kernel
@@ -249,7 +299,7 @@ __global__ __launch_bounds__(256) void locate_sampled_kernel(SeedArgs a)
 				i++;
 				walking = false;
 			} else {
-				k = lf_step(ix, k);
+				k = lf_step_plane(ix, k);
 				steps++;
 				c_inv++;
 			}
@@ -333,10 +383,33 @@ __global__ __launch_bounds__(256) void expand_sa_kernel(FmView ix, uint64_t n_sa
 		uint64_t p = j == 0 ? ix.seq_len : ix.sa[j];
 		for (;;) {
 			if (fsa32) fsa32[k] = (uint32_t)p; else fsa64[k] = p;
-			k = lf_step(ix, k);
+			k = lf_step_plane(ix, k);
 			p--;
 			if ((k & 31) == 0) break;
 		}
+	}
+}
+
+// Index-load-time conversion of the reference's 2-bit Occ/BWT blocks into the bit-plane layout.
+// One thread per 64-symbol block.
+__global__ __launch_bounds__(256) void build_planes_kernel(const uint32_t *occ, uint64_t n_blocks64, uint4 *planes)
+{
+	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; b < n_blocks64; b += stride) {
+		const uint32_t *rb = occ + ((b >> 1) << 4);      // reference block of 128 symbols
+		int half = (int)(b & 1);
+		uint64_t cnt[4];
+		for (int c = 0; c < 4; ++c) cnt[c] = (uint64_t)rb[2 * c] | ((uint64_t)rb[2 * c + 1] << 32);
+		uint64_t plane[4] = {0, 0, 0, 0};
+		for (int j = 0; j < 128; ++j) {
+			uint32_t w = rb[8 + (j >> 4)];
+			int sym = (w >> (30 - 2 * (j & 15))) & 3;
+			if (j < 64 && half) cnt[sym]++;              // first half counted into the second half's base
+			else if ((j >> 6) == half) plane[sym] |= 1ull << (j & 63);
+		}
+		for (int c = 0; c < 4; ++c)
+			planes[(b << 2) + c] = make_uint4((uint32_t)cnt[c], (uint32_t)(cnt[c] >> 32), (uint32_t)plane[c], (uint32_t)(plane[c] >> 32));
 	}
 }
 
@@ -346,6 +419,12 @@ static inline int grid_for(int64_t items, int block, int max_blocks)
 	if (g < 1) g = 1;
 	if (g > max_blocks) g = max_blocks;
 	return (int)g;
+}
+
+hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *planes, hipStream_t stream)
+{
+	hipLaunchKernelGGL(build_planes_kernel, dim3(grid_for((int64_t)n_blocks64, 256, 256 * 64)), dim3(256), 0, stream, occ, n_blocks64, planes);
+	return hipGetLastError();
 }
 
 hipError_t launch_expand_sa(const FmView &ix, uint64_t n_sa, uint32_t *fsa32, uint64_t *fsa64, hipStream_t stream)
@@ -374,9 +453,14 @@ hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_tem
 	// queue heads, hit count and counters are zeroed on the stream every call
 	if ((e = hipMemsetAsync(a.read_queue, 0, sizeof(unsigned long long) * kCtlWords, stream)) != hipSuccess) return e;
 	// persistent lanes: 8 blocks of 256 threads per CU (= 32 waves/CU) unless the batch is smaller
-	int blocks = grid_for(a.n_reads, 256, n_cu * 8);
+	int per_cu = 8;
+	if (const char *env = getenv("KG_SEARCH_BLOCKS_PER_CU")) per_cu = atoi(env) > 0 ? atoi(env) : 8;  // tuning knob
+	int blocks = grid_for(a.n_reads, 256, n_cu * per_cu);
 	if (ev) (void)hipEventRecord(ev[0], stream);
-	hipLaunchKernelGGL(search_kernel, dim3(blocks), dim3(256), 0, stream, a);
+	if (a.ix.seq_len < 0xFFFFFF00ull)
+		hipLaunchKernelGGL(search_kernel<uint32_t>, dim3(blocks), dim3(256), 0, stream, a);
+	else
+		hipLaunchKernelGGL(search_kernel<uint64_t>, dim3(blocks), dim3(256), 0, stream, a);
 	if (ev) (void)hipEventRecord(ev[1], stream);
 	size_t tb = scan_temp_bytes;
 	WideIter it(a.seeds_per_read, WidenOp());
