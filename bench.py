@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU per step")
-    ap.add_argument("--sa", choices=["sampled", "full"], default="sampled")
+    ap.add_argument("--sa", choices=["sampled", "full"], default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--genome-len", type=int, default=GENOME_LEN, help="experiment knob: synthetic genome length (default = configs[1])")
     args = ap.parse_args()
@@ -191,6 +191,7 @@ def main():
     locate_bytes = 64 * c["inv"] + 8 * c["sa"] + 16 * c["seeds"]
     achieved = search_bytes / (search_ms * 1e-3) / 1e9
     value = float(totals[0].item()) / elapsed
+    traffic, traffic_src = measured_traffic(n_reads, args)
     line = {
         "metric": "mapped reads/sec (whole node), 150 bp PE",
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -204,7 +205,7 @@ def main():
                    "parallelism": "read-sharded x%d, index replicated" % world,
                    "index_build_s": round(t_idx, 2), "parity_sample": parity},
         "roofline": {"bound": "hbm", "kernel": "search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": search_bytes, "avg_launch_ms": search_ms},
         "kernels_ms": {"search": search_ms, "scan": float(kms[:, 1].mean()), "locate": float(kms[:, 2].mean()), "sort": float(kms[:, 3].mean())},
         "bytes_seed_per_read": (search_bytes + locate_bytes) / n_reads,
@@ -215,6 +216,23 @@ def main():
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(n_reads, args):
+    """HBM/fabric bytes per search_kernel launch from the committed PMC passes of this exact command
+    (rocprofv3 --pmc, separate passes; profiles/*_pmc_summary.json, corrected for gfx950 as
+    MI355X_MICROARCH.md prescribes).  bench.py cannot run the profiler on itself, so the figure is
+    only reported when the workload matches the profiled one; otherwise null."""
+    best = None
+    for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        if f.endswith("_pmc_summary.json"):
+            try:
+                t = json.load(open(os.path.join(ROOT, "profiles", f))).get("_search_traffic")
+            except Exception:
+                t = None
+            if t and t.get("reads_per_launch") == n_reads and args.genome_len == GENOME_LEN:
+                best = (t["traffic_bytes_per_launch"], "profiles/" + f)
+    return best if best else (None, None)
 
 
 def cpu_baseline(prefix, enc_dev, read_len):

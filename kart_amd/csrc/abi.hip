@@ -73,6 +73,7 @@ struct kg_index {
 	// device allocations
 	uint32_t *d_occ = nullptr;
 	uint4 *d_planes = nullptr;
+	void *d_qtab = nullptr;
 	uint64_t *d_sa = nullptr;
 	void *d_fsa = nullptr;
 	uint8_t *d_pac = nullptr;
@@ -84,6 +85,7 @@ struct kg_workspace {
 	int64_t max_reads = 0, max_bases = 0, max_hits = 0;
 	// device scratch
 	Hit *d_hits = nullptr;
+	uint64_t *d_packed = nullptr;
 	int32_t *d_seeds_per_read = nullptr;
 	unsigned long long *d_ctl = nullptr;
 	void *d_scan_temp = nullptr;
@@ -209,6 +211,18 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		HIP_TRY(hipDeviceSynchronize());
 		v.planes = ix->d_planes;
 		ix->device_bytes += plane_bytes;
+		// q-mer interval table (4^12 entries)
+		v.qtab32 = nullptr;
+		v.qtab64 = nullptr;
+		if (!getenv("KG_NO_QTAB")) {
+			bool narrow = v.seq_len < 0xFFFFFF00ull;
+			size_t tab_bytes = ((size_t)1 << (2 * kQmer)) * (narrow ? 8 : 16);
+			HIP_TRY(hipMalloc(&ix->d_qtab, tab_bytes));
+			HIP_TRY(launch_build_qtab(v, narrow ? (uint2 *)ix->d_qtab : nullptr, narrow ? nullptr : (uint4 *)ix->d_qtab, nullptr));
+			HIP_TRY(hipDeviceSynchronize());
+			if (narrow) v.qtab32 = (const uint2 *)ix->d_qtab; else v.qtab64 = (const uint4 *)ix->d_qtab;
+			ix->device_bytes += tab_bytes;
+		}
 	}
 	v.fsa32 = nullptr;
 	v.fsa64 = nullptr;
@@ -237,6 +251,7 @@ void kg_index_destroy(kg_index *ix)
 	(void)hipSetDevice(ix->device);
 	if (ix->d_occ) (void)hipFree(ix->d_occ);
 	if (ix->d_planes) (void)hipFree(ix->d_planes);
+	if (ix->d_qtab) (void)hipFree(ix->d_qtab);
 	if (ix->d_sa) (void)hipFree(ix->d_sa);
 	if (ix->d_fsa) (void)hipFree(ix->d_fsa);
 	if (ix->d_pac) (void)hipFree(ix->d_pac);
@@ -285,6 +300,7 @@ int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_w
 	// ... plus the slack of the per-wave slot pools (one 256-slot chunk per resident wave)
 	ws->max_hits = max_bases / 13 + max_reads + (int64_t)ix->n_cu * 32 * 256 + 4096;
 	HIP_TRY(hipMalloc((void **)&ws->d_hits, sizeof(Hit) * (size_t)ws->max_hits));
+	HIP_TRY(hipMalloc((void **)&ws->d_packed, 8 * (size_t)(max_bases / 16 + 3 * max_reads + 64)));
 	HIP_TRY(hipMalloc((void **)&ws->d_seeds_per_read, 4 * (size_t)max_reads));
 	HIP_TRY(hipMalloc((void **)&ws->d_ctl, 8 * kCtlWords));
 	HIP_TRY(hipMemset(ws->d_ctl, 0, 8 * kCtlWords));
@@ -300,7 +316,7 @@ void kg_workspace_destroy(kg_workspace *ws)
 	if (!ws) return;
 	(void)hipSetDevice(ws->ix->device);
 	if (ws->stream) { (void)hipStreamSynchronize(ws->stream); (void)hipStreamDestroy(ws->stream); }
-	void *ptrs[] = {ws->d_hits, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
+	void *ptrs[] = {ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (ws->h_seeds) (void)hipHostFree(ws->h_seeds);
@@ -384,6 +400,7 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.mode = mode;
 	a.min_seed_len = min_seed_len;
 	a.occ_thr = occ_thr;
+	a.packed = ws->d_packed;
 	a.hits = ws->d_hits;
 	a.max_hits = ws->max_hits;
 	a.seeds_per_read = ws->d_seeds_per_read;

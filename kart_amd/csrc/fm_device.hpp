@@ -8,8 +8,9 @@
 //           One block = one 64-byte HBM/L2 access; a lane fetches it with a dwordx2 (its base's
 //           count) and two dwordx4 (the symbols).
 //   planes: DEVICE-PRIVATE re-layout built once at load (build_planes_kernel): per 64 BWT symbols one
-//           64-byte block of four 16-byte segments, segment c = { u64 count of base c before the
-//           block, u64 bit-plane: bit j set iff symbol j of the block == c }.  A rank query is ONE
+//           64-byte block of four 16-byte segments, segment c = { u64 bit-plane: bit j set iff symbol
+//           j of the block == c, u64 count of base c before the block } (plane first, so a 32-bit
+//           index needs one dwordx3 per rank).  A rank query is ONE
 //           16-byte load + mask + popcount (the 2-bit layout costs ~150 VALU ops per LF step, which
 //           made the search kernel VALU-bound even with the index in L2).  1 byte/symbol: 9.3 MB
 //           for E. coli, 6.2 GB for hg38 -- cheap against 288 GB of HBM; every rank still touches
@@ -29,10 +30,18 @@ struct FmView {
 	const uint64_t *sa;
 	const uint32_t *fsa32;
 	const uint64_t *fsa64;
+	// q-mer interval table (device-private, built at load): for the first kQmer bases of a search,
+	// the interval after kQmer-1 extension steps.  Entry = { k, n | lf2 << 28 } (u32 index) or
+	// { k lo, k hi, n, lf2 } (u64 index); n == 0 means "no such q-mer / not representable": the
+	// search then starts step by step, so results never depend on the table.
+	const uint2 *qtab32;
+	const uint4 *qtab64;
 	uint64_t primary;
 	uint64_t seq_len;
 	uint64_t L2[5];
 };
+
+constexpr int kQmer = 12;
 
 // bit 2i set for every 2-bit field of w (16 fields, MSB first) equal to the base whose
 // replicated pattern is `pat` (= base * 0x55555555)
@@ -128,8 +137,8 @@ __device__ __forceinline__ uint64_t lf_step(const FmView &ix, uint64_t k)
 __device__ __forceinline__ uint64_t rank_plane(const FmView &ix, uint64_t kk, int c)
 {
 	uint4 v = ix.planes[((kk >> 6) << 2) + (uint64_t)c];
-	uint64_t cnt = ((uint64_t)v.y << 32) | v.x;
-	uint64_t bits = ((uint64_t)v.w << 32) | v.z;
+	uint64_t bits = ((uint64_t)v.y << 32) | v.x;
+	uint64_t cnt = ((uint64_t)v.w << 32) | v.z;
 	uint64_t m = (2ull << (kk & 63)) - 1;          // bits 0..pos (pos = 63 wraps to all ones)
 	return cnt + (uint64_t)__popcll(bits & m);
 }
@@ -143,11 +152,11 @@ __device__ __forceinline__ uint64_t lf_step_plane(const FmView &ix, uint64_t k)
 	const uint4 *p = ix.planes + ((kk >> 6) << 2);
 	uint4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
 	uint32_t pos = (uint32_t)(kk & 63);
-	uint64_t b1 = ((uint64_t)s1.w << 32) | s1.z, b2 = ((uint64_t)s2.w << 32) | s2.z, b3 = ((uint64_t)s3.w << 32) | s3.z;
+	uint64_t b1 = ((uint64_t)s1.y << 32) | s1.x, b2 = ((uint64_t)s2.y << 32) | s2.x, b3 = ((uint64_t)s3.y << 32) | s3.x;
 	int c = ((b1 >> pos) & 1) ? 1 : ((b2 >> pos) & 1) ? 2 : ((b3 >> pos) & 1) ? 3 : 0;
 	uint4 v = c == 0 ? s0 : c == 1 ? s1 : c == 2 ? s2 : s3;
-	uint64_t cnt = ((uint64_t)v.y << 32) | v.x;
-	uint64_t bits = ((uint64_t)v.w << 32) | v.z;
+	uint64_t bits = ((uint64_t)v.y << 32) | v.x;
+	uint64_t cnt = ((uint64_t)v.w << 32) | v.z;
 	uint64_t m = (2ull << pos) - 1;
 	uint64_t l2 = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
 	return l2 + cnt + (uint64_t)__popcll(bits & m);

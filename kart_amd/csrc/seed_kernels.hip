@@ -109,138 +109,195 @@ __device__ __forceinline__ uint64_t window_word(const uint8_t *enc, int64_t n_ba
 	return (word & keep) | (0x4444444444444444ull & ~keep);
 }
 
+// Pack pre-pass: 16 lanes per read, lane w of a group builds window word w (one unaligned 16-byte
+// load each, consecutive lanes read consecutive bytes).  Read r's words start at packed word
+// (read_off[r] >> 4) + 3 r -- a closed form, no scan -- which leaves room for the two all-'N'
+// padding words every read gets.  Cost: 150 B in + 104 B out per read, against ~10 KB of index
+// gathers per read in the search kernel.
+__global__ __launch_bounds__(256) void pack_reads_kernel(SeedArgs a)
+{
+	int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+	int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+	int w0 = threadIdx.x & 15;
+	for (int64_t r = group; r < a.n_reads; r += n_groups) {
+		int64_t base = a.read_off[r];
+		int rlen = (int)(a.read_off[r + 1] - base);
+		uint64_t *out = a.packed + (base >> 4) + 3 * r;
+		int words = (rlen >> 4) + 3;
+		for (int w = w0; w < words; w += 16) out[w] = window_word(a.enc, a.n_bases, base, rlen, w);
+	}
+}
+
 // ---- search ---------------------------------------------------------------------------------------
-// One predicated loop, one LF step per lane per iteration:
-//   C  extension step of the live interval (two 16-byte rank gathers),
-//   D  end-of-search bookkeeping (hit record, next start position),
-//   A  lanes without a read draw one from the wave's pool (wave-uniform, infrequent branch),
-//   B  lanes without a live interval start their next search.
-// State transitions are selects, not branches: the first version of this kernel spent 58 % of its
-// wave cycles in SQ_WAIT_INST_ANY (exec-mask juggling and refetch after ~35 divergent branches per
-// iteration, 64-bit VALU, dependent byte loads for the read codes).  The read's codes live in a
-// two-word register window (32 positions) that is refilled one word ahead.
+// Two-level persistent loop, one read per lane:
+//   tight loop : nothing but extension steps -- window nibble, two 12/16-byte rank gathers, popcount,
+//                interval update (~45 instructions per wave iteration).  A lane whose search ends
+//                parks (`pending`) and the wave keeps stepping the others.
+//   slow path  : entered when kRefill lanes are parked (or none is live): D records hits and
+//                advances the read position, A draws new reads from the wave's pool, B starts the
+//                next search (q-mer table jump).  Its ~350 instructions are amortised over ~8
+//                iterations; parked lanes cost ~6 % of the lane-iterations.
+// History (profiles/): a single state-machine loop spent 57 % of its wave cycles in
+// SQ_WAIT_INST_ANY -- ~300 instructions and ~30 exec-mask branches per iteration, because at wave
+// level some lane always needs the rare path.
+constexpr int kRefill = 8;
+
 template <typename idx_t>
 __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 {
+	__shared__ idx_t l2s[8];
+	if (threadIdx.x < 5) l2s[threadIdx.x] = (idx_t)a.ix.L2[threadIdx.x];
+	__syncthreads();
 	const FmView &ix = a.ix;
 	const idx_t primary = (idx_t)ix.primary;
-	const idx_t l2_0 = (idx_t)ix.L2[0], l2_1 = (idx_t)ix.L2[1], l2_2 = (idx_t)ix.L2[2], l2_3 = (idx_t)ix.L2[3], l2_4 = (idx_t)ix.L2[4];
 	const bool fast = a.mode == KG_MODE_FAST;
 	const int msl = a.min_seed_len;
 	const idx_t occ_thr = (idx_t)a.occ_thr;
+	const bool have_tab = sizeof(idx_t) == 4 ? ix.qtab32 != nullptr : ix.qtab64 != nullptr;
 
-	bool have_read = false, done = false, active = false;
+	bool have_read = false, done = false, active = false, pending = false;
 	int r = 0, rlen = 0, pos = 0, stop_pos = 0, end_pos = 0, seed_cnt = 0;
 	int cur = 0, stop = 0, wword = 0;
-	int64_t base = 0;
+	const uint64_t *pw = a.packed;
 	uint64_t win = 0x4444444444444444ull, wnext = 0x4444444444444444ull;
 	idx_t k = 0, n = 0;
-	uint32_t c_search = 0, c_lf1 = 0, c_lf2 = 0;
+	uint32_t c_search = 0, c_lf = 0, c_lf2 = 0;
 	WavePool read_pool, hit_pool;
 
 	for (;;) {
-		// ---- C: one extension step ------------------------------------------------------------------
-		int code = (int)((win >> ((cur & 15) << 2)) & 15);
-		bool do_step = active && cur < stop && code <= 3;
-		int c = do_step ? 3 - code : 0;
-		idx_t kk = do_step ? k - 1 : 0, ll = do_step ? k - 1 + n : 0;   // bwt_2occ4(x1-1, x1-1+x2), :157
-		kk -= (kk >= primary);
-		ll -= (ll >= primary);
-		uint4 vk = ix.planes[(((uint64_t)(kk >> 6)) << 2) + (uint32_t)c];
-		uint4 vl = ix.planes[(((uint64_t)(ll >> 6)) << 2) + (uint32_t)c];
-		uint64_t mk = (2ull << (kk & 63)) - 1, ml = (2ull << (ll & 63)) - 1;
-		idx_t ok = (idx_t)(((uint64_t)vk.y << 32) | vk.x) + (idx_t)__popcll((((uint64_t)vk.w << 32) | vk.z) & mk);
-		idx_t ol = (idx_t)(((uint64_t)vl.y << 32) | vl.x) + (idx_t)__popcll((((uint64_t)vl.w << 32) | vl.z) & ml);
-		idx_t nn = ol - ok;
-		bool cont = do_step && nn != 0;
-		c_lf1 += (do_step && (kk >> 7) == (ll >> 7)) ? 1 : 0;            // reference block accounting
-		c_lf2 += (do_step && (kk >> 7) != (ll >> 7)) ? 1 : 0;
-		idx_t l2c = c == 0 ? l2_0 : c == 1 ? l2_1 : c == 2 ? l2_2 : l2_3;
-		k = cont ? l2c + 1 + ok : k;
-		n = cont ? nn : n;
-		cur += cont ? 1 : 0;
-		if (cont && (cur & 15) == 0) {          // window slides one word; the new look-ahead word is a prefetch
-			win = wnext;
-			wword++;
-			wnext = window_word(a.enc, a.n_bases, base, rlen, wword + 1);
-		}
-
-		// ---- D: end of a search ---------------------------------------------------------------------
-		bool ended = active && !cont;
-		int len = cur - pos;
-		bool hit = ended && len >= msl && n <= occ_thr;
-		unsigned long long slot = pool_take(hit_pool, a.hit_count, hit);
-		if (hit) {
-			uint4 *dst = reinterpret_cast<uint4 *>(a.hits + slot);
-			uint64_t k64 = (uint64_t)k;
-			dst[0] = make_uint4((uint32_t)k64, (uint32_t)(k64 >> 32), (uint32_t)r, (uint32_t)pos);
-			dst[1] = make_uint4((uint32_t)len, (uint32_t)n, (uint32_t)seed_cnt, 0u);
-			seed_cnt += (int)n;
-		}
-		if (ended) {
-			int adv = fast ? len + 1 : (hit ? len : msl);                 // :74 / :157-161
-			pos += adv;
-			stop_pos += fast ? 0 : adv;
-			stop_pos = stop_pos > rlen ? rlen : stop_pos;               // :163
-			active = false;
-		}
-
-		// ---- A: new reads for lanes that have none -------------------------------------------------------
-		bool want_read = !have_read && !done;
-		if (__ballot(want_read)) {
-			unsigned long long t = pool_take(read_pool, a.read_queue, want_read);
-			if (want_read) {
-				if (t >= (unsigned long long)a.n_reads) done = true;
-				else {
-					r = (int)t;
-					base = a.read_off[t];
-					rlen = (int)(a.read_off[t + 1] - base);
-					win = window_word(a.enc, a.n_bases, base, rlen, 0);
-					wnext = window_word(a.enc, a.n_bases, base, rlen, 1);
-					wword = 0;
-					pos = 0; stop_pos = 30; end_pos = rlen - msl; seed_cnt = 0;
-					have_read = true;
-				}
+		// ================= slow path =================
+		// ---- D: searches that ended in the tight loop -------------------------------------------------
+		{
+			int len = cur - pos;
+			bool hit = pending && len >= msl && n <= occ_thr;
+			unsigned long long slot = pool_take(hit_pool, a.hit_count, hit);
+			if (hit) {
+				uint4 *dst = reinterpret_cast<uint4 *>(a.hits + slot);
+				uint64_t k64 = (uint64_t)k;
+				dst[0] = make_uint4((uint32_t)k64, (uint32_t)(k64 >> 32), (uint32_t)r, (uint32_t)pos);
+				dst[1] = make_uint4((uint32_t)len, (uint32_t)n, (uint32_t)seed_cnt, 0u);
+				seed_cnt += (int)n;
+			}
+			if (pending) {
+				int adv = fast ? len + 1 : (hit ? len : msl);                 // :74 / :157-161
+				pos += adv;
+				stop_pos += fast ? 0 : adv;
+				stop_pos = stop_pos > rlen ? rlen : stop_pos;               // :163
+				pending = false;
 			}
 		}
-		if (__ballot(!done) == 0) break;
+		// ---- A/B passes until every lane is live or done ----------------------------------------------
+		for (;;) {
+			bool want_read = !have_read && !done;
+			if (__ballot(want_read)) {
+				unsigned long long t = pool_take(read_pool, a.read_queue, want_read);
+				if (want_read) {
+					if (t >= (unsigned long long)a.n_reads) done = true;
+					else {
+						r = (int)t;
+						int64_t base = a.read_off[t];
+						rlen = (int)(a.read_off[t + 1] - base);
+						pw = a.packed + (base >> 4) + 3 * (int64_t)t;
+						win = pw[0];
+						wnext = pw[1];
+						wword = 0;
+						pos = 0; stop_pos = 30; end_pos = rlen - msl; seed_cnt = 0;
+						have_read = true;
+					}
+				}
+			}
+			bool idle = have_read && !active;
+			bool finished = idle && pos >= end_pos;
+			if (finished) {
+				a.seeds_per_read[r] = seed_cnt;
+				have_read = false;
+			}
+			bool starting = idle && !finished;
+			int w = pos >> 4;
+			if (starting && w != wword) {           // the new start lies outside the window's first word
+				if (w == wword + 1) win = wnext; else win = pw[w];
+				wnext = pw[w + 1];
+				wword = w;
+			}
+			int code0 = (int)((win >> ((pos & 15) << 2)) & 15);
+			bool skip = starting && code0 > 3;          // ambiguous base: FastMode :59, SensitiveMode :142
+			pos += skip ? 1 : 0;
+			stop_pos += skip ? 1 : 0;
+			bool go = starting && !skip;
+			if (go) {
+				// the next kQmer codes as a 2-bit packed index (code at pos in the lowest bits)
+				int sh = (pos & 15) << 2;
+				uint64_t x = sh ? (win >> sh) | (wnext << (64 - sh)) : win;
+				x &= (1ull << (4 * kQmer)) - 1;
+				bool clean = (x & 0x4444444444444444ull) == 0 && pos + kQmer <= (fast ? rlen : stop_pos) && have_tab;
+				uint64_t y = x & 0x3333333333333333ull;
+				y = (y | (y >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+				y = (y | (y >> 4)) & 0x00FF00FF00FF00FFull;
+				y = (y | (y >> 8)) & 0x0000FFFF0000FFFFull;
+				y = (y | (y >> 16)) & 0x00000000FFFFFFFFull;
+				idx_t tk = 0, tn = 0;
+				uint32_t tlf2 = 0;
+				if (clean) {
+					if (sizeof(idx_t) == 4) {
+						uint2 e = ix.qtab32[y];
+						tk = (idx_t)e.x; tn = (idx_t)(e.y & 0x0FFFFFFFu); tlf2 = e.y >> 28;
+					} else {
+						uint4 e = ix.qtab64[y];
+						tk = (idx_t)(((uint64_t)e.y << 32) | e.x); tn = (idx_t)e.z; tlf2 = e.w;
+					}
+				}
+				bool jump = clean && tn != 0;
+				k = jump ? tk : l2s[3 - code0] + 1;                            // x[1], :149
+				n = jump ? tn : l2s[code0 + 1] - l2s[code0];                  // x[2], :150
+				cur = pos + (jump ? kQmer : 1);
+				// the reference performs these kQmer-1 steps one by one; keep its block accounting
+				c_lf += jump ? (uint32_t)(kQmer - 1) : 0u;
+				c_lf2 += jump ? tlf2 : 0u;
+				stop = fast ? rlen : stop_pos;
+				active = true;
+				c_search++;
+				if ((cur >> 4) != wword) { win = wnext; wword++; wnext = pw[wword + 1]; }
+			}
+			if (__ballot(!done && !active) == 0) break;
+		}
+		if (__ballot(active) == 0) break;               // every lane is done
 
-		// ---- B: start the next search ---------------------------------------------------------------------
-		bool idle = have_read && !active;
-		bool finished = idle && pos >= end_pos;
-		if (finished) {
-			a.seeds_per_read[r] = seed_cnt;
-			have_read = false;
-		}
-		bool starting = idle && !finished;
-		int w = pos >> 4;
-		if (starting && w != wword) {           // the new start lies outside the window's first word
-			if (w == wword + 1) win = wnext; else win = window_word(a.enc, a.n_bases, base, rlen, w);
-			wnext = window_word(a.enc, a.n_bases, base, rlen, w + 1);
-			wword = w;
-		}
-		int code0 = (int)((win >> ((pos & 15) << 2)) & 15);
-		bool skip = starting && code0 > 3;          // ambiguous base: FastMode :59, SensitiveMode :142
-		pos += skip ? 1 : 0;
-		stop_pos += skip ? 1 : 0;
-		bool go = starting && !skip;
-		if (go) {
-			idx_t lo = code0 == 0 ? l2_0 : code0 == 1 ? l2_1 : code0 == 2 ? l2_2 : l2_3;
-			idx_t hi = code0 == 0 ? l2_1 : code0 == 1 ? l2_2 : code0 == 2 ? l2_3 : l2_4;
-			int cc = 3 - code0;
-			k = (cc == 0 ? l2_0 : cc == 1 ? l2_1 : cc == 2 ? l2_2 : l2_3) + 1;   // x[1], :149
-			n = hi - lo;                                                       // x[2], :150
-			cur = pos + 1;
-			stop = fast ? rlen : stop_pos;
-			active = true;
-			c_search++;
-			if ((cur & 15) == 0) { win = wnext; wword++; wnext = window_word(a.enc, a.n_bases, base, rlen, wword + 1); }
+		// ================= tight loop =================
+		for (;;) {
+			int code = (int)((win >> ((cur & 15) << 2)) & 15);
+			bool do_step = active && cur < stop && code <= 3;
+			idx_t nn = 0, ok = 0;
+			int c = 3 - code;
+			if (do_step) {
+				idx_t kk = k - 1, ll = k - 1 + n;                          // bwt_2occ4(x1-1, x1-1+x2), :157
+				kk -= (kk >= primary);
+				ll -= (ll >= primary);
+				uint4 vk = ix.planes[(((uint64_t)(kk >> 6)) << 2) + (uint32_t)c];
+				uint4 vl = ix.planes[(((uint64_t)(ll >> 6)) << 2) + (uint32_t)c];
+				uint64_t mk = (2ull << (kk & 63)) - 1, ml = (2ull << (ll & 63)) - 1;
+				ok = (idx_t)(((uint64_t)vk.w << 32) | vk.z) + (idx_t)__popcll((((uint64_t)vk.y << 32) | vk.x) & mk);
+				idx_t ol = (idx_t)(((uint64_t)vl.w << 32) | vl.z) + (idx_t)__popcll((((uint64_t)vl.y << 32) | vl.x) & ml);
+				nn = ol - ok;
+				c_lf++;
+				c_lf2 += (kk >> 7) != (ll >> 7) ? 1u : 0u;                 // reference 128-symbol block accounting
+			}
+			bool cont = nn != 0;                                            // implies do_step
+			if (cont) {
+				k = l2s[c] + 1 + ok;
+				n = nn;
+				cur++;
+				if ((cur & 15) == 0) { win = wnext; wword++; wnext = pw[wword + 1]; }
+			}
+			pending = pending || (active && !cont);
+			active = cont;
+			uint64_t parked = __ballot(pending);
+			if (__popcll(parked) >= kRefill || __ballot(active) == 0) break;
 		}
 	}
 	// the slots this wave reserved but never filled are marked empty for the locate kernel
 	for (unsigned long long x = hit_pool.next + (threadIdx.x & 63); x < hit_pool.end; x += 64) a.hits[x].n = 0;
 	// work counters: one atomic per wave
-	uint64_t s0 = c_search, s1 = c_lf1, s2 = c_lf2;
+	uint64_t s0 = c_search, s1 = c_lf - c_lf2, s2 = c_lf2;
 	for (int off = 32; off > 0; off >>= 1) {
 		s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off);
 	}
@@ -409,7 +466,37 @@ __global__ __launch_bounds__(256) void build_planes_kernel(const uint32_t *occ, 
 			else if ((j >> 6) == half) plane[sym] |= 1ull << (j & 63);
 		}
 		for (int c = 0; c < 4; ++c)
-			planes[(b << 2) + c] = make_uint4((uint32_t)cnt[c], (uint32_t)(cnt[c] >> 32), (uint32_t)plane[c], (uint32_t)(plane[c] >> 32));
+			planes[(b << 2) + c] = make_uint4((uint32_t)plane[c], (uint32_t)(plane[c] >> 32), (uint32_t)cnt[c], (uint32_t)(cnt[c] >> 32));
+	}
+}
+
+// q-mer table: entry id encodes the codes LSB first (code of the first base in bits 1:0); the value
+// is the state BWT_Search (reference src/bwt_search.cpp:147-168) reaches after those kQmer bases.
+__global__ __launch_bounds__(256) void build_qtab_kernel(FmView ix, uint2 *t32, uint4 *t64)
+{
+	uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; id < (1ull << (2 * kQmer)); id += stride) {
+		int p = (int)(id & 3);
+		uint64_t k = l2_of(ix, 3 - p) + 1, n = l2_of(ix, p + 1) - l2_of(ix, p);
+		uint32_t lf2 = 0;
+		for (int j = 1; j < kQmer && n != 0; ++j) {
+			int c = 3 - (int)((id >> (2 * j)) & 3);
+			uint64_t kk = k - 1, ll = k - 1 + n;
+			kk -= (kk >= ix.primary);
+			ll -= (ll >= ix.primary);
+			lf2 += (kk >> 7) != (ll >> 7);
+			uint64_t ok = rank_plane(ix, kk, c), ol = rank_plane(ix, ll, c);
+			n = ol - ok;
+			k = l2_of(ix, c) + 1 + ok;
+		}
+		if (t32) {
+			if (n >= (1ull << 28)) n = 0;      // not representable: the search falls back to single steps
+			t32[id] = make_uint2((uint32_t)k, (uint32_t)n | (lf2 << 28));
+		} else {
+			if (n >= (1ull << 32)) n = 0;
+			t64[id] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)n, lf2);
+		}
 	}
 }
 
@@ -424,6 +511,12 @@ static inline int grid_for(int64_t items, int block, int max_blocks)
 hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *planes, hipStream_t stream)
 {
 	hipLaunchKernelGGL(build_planes_kernel, dim3(grid_for((int64_t)n_blocks64, 256, 256 * 64)), dim3(256), 0, stream, occ, n_blocks64, planes);
+	return hipGetLastError();
+}
+
+hipError_t launch_build_qtab(const FmView &ix, uint2 *t32, uint4 *t64, hipStream_t stream)
+{
+	hipLaunchKernelGGL(build_qtab_kernel, dim3(256 * 32), dim3(256), 0, stream, ix, t32, t64);
 	return hipGetLastError();
 }
 
@@ -456,6 +549,7 @@ hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_tem
 	int per_cu = 8;
 	if (const char *env = getenv("KG_SEARCH_BLOCKS_PER_CU")) per_cu = atoi(env) > 0 ? atoi(env) : 8;  // tuning knob
 	int blocks = grid_for(a.n_reads, 256, n_cu * per_cu);
+	hipLaunchKernelGGL(pack_reads_kernel, dim3(grid_for(a.n_reads * 16, 256, n_cu * 32)), dim3(256), 0, stream, a);
 	if (ev) (void)hipEventRecord(ev[0], stream);
 	if (a.ix.seq_len < 0xFFFFFF00ull)
 		hipLaunchKernelGGL(search_kernel<uint32_t>, dim3(blocks), dim3(256), 0, stream, a);

@@ -30,6 +30,7 @@ struct SeedArgs {
 	int64_t n_bases;
 	int mode, min_seed_len, occ_thr;
 	// scratch
+	uint64_t *packed;    // 4-bit read codes, 16 per word, read r at word (read_off[r] >> 4) + 3 r
 	Hit *hits;
 	int64_t max_hits;
 	int32_t *seeds_per_read;
@@ -44,6 +45,7 @@ size_t scan_temp_bytes(int64_t max_reads);
 // ev: optional array of 5 events recorded before/after the four phases (search | scan | locate | sort)
 hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream, hipEvent_t *ev);
 hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *planes, hipStream_t stream);
+hipError_t launch_build_qtab(const FmView &ix, uint2 *t32, uint4 *t64, hipStream_t stream);
 hipError_t launch_expand_sa(const FmView &ix, uint64_t n_sa, uint32_t *fsa32, uint64_t *fsa64, hipStream_t stream);
 
 struct NwArgs {
