@@ -1,0 +1,1567 @@
+// mapper.cpp -- host pipeline: reads in, SAM out, kernels through KernelBackend (see mapper.hpp).
+//
+// Every block names the reference code whose observable behaviour it reproduces (paths relative
+// to the reference tree).  The aim is byte-identical output to `kart -t 1`; where the reference
+// has undefined behaviour the choice made here is stated next to the code.
+#include "mapper.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+
+namespace kart {
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------------------------
+inline int nt4(unsigned char ch)  // nst_nt4_table, src/BWT_Index/bntseq.c:40-57
+{
+	switch (ch) {
+	case 'A': case 'a': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': return 3;
+	default: return 4;
+	}
+}
+
+inline char comp_base(char c)  // GetComplementaryBase, src/tools.cpp:3-17
+{
+	switch (c) {
+	case 'A': case 'a': return 'T';
+	case 'C': case 'c': return 'G';
+	case 'G': case 'g': return 'C';
+	case 'T': case 't': return 'A';
+	default: return 'N';
+	}
+}
+
+std::string revcomp(const std::string &s)  // GetComplementarySeq, src/tools.cpp:19-29
+{
+	std::string r(s.size(), 'N');
+	for (size_t i = 0, n = s.size(); i < n; ++i) r[i] = comp_base(s[n - 1 - i]);
+	return r;
+}
+
+bool slurp(const std::string &path, std::vector<unsigned char> &buf)
+{
+	FILE *fp = fopen(path.c_str(), "rb");
+	if (!fp) return false;
+	fseek(fp, 0, SEEK_END);
+	long sz = ftell(fp);
+	fseek(fp, 0, SEEK_SET);
+	buf.resize((size_t)sz);
+	size_t got = sz ? fread(buf.data(), 1, (size_t)sz, fp) : 0;
+	fclose(fp);
+	return got == (size_t)sz;
+}
+
+// ----------------------------------------------------------------------------------------------
+// data carried per read (ReadItem_t, SeedPair_t, AlignmentCandidate_t, AlignmentReport_t;
+// src/structure.h:106-154)
+// ----------------------------------------------------------------------------------------------
+struct Pair {
+	bool simple;
+	int rPos;
+	int64_t gPos;
+	int rLen, gLen;
+	int64_t posDiff;
+};
+
+struct Candidate {
+	int score = 0;
+	int64_t posDiff = 0;
+	int mate = -1;   // PairedAlnCanIdx
+	std::vector<Pair> pairs;
+};
+
+struct Report {
+	int score = 0;          // AlnScore
+	int flag = 0;           // SamFlag (the reference leaves it uninitialised where it never sets it; here 0)
+	int mate = -1;          // PairedAlnCanIdx
+	bool fwd = true;        // coor.bDir
+	std::string cigar;
+	int64_t gPos = 0;
+	int chr = 0;            // coor.ChromosomeIdx (uninitialised in the reference when never assigned; here 0)
+};
+
+struct Read {
+	std::string name, seq, qual;
+	int rlen = 0;
+	int mapq = 0, score = 0, sub_score = 0, can_num = 0, best = 0;
+	std::vector<Report> rep;
+};
+
+typedef std::vector<std::pair<int, char>> CigarVec;
+
+bool pair_by_gpos(const Pair &a, const Pair &b)  // CompByGenomePos, src/AlignmentCandidates.cpp:17-21
+{
+	if (a.gPos == b.gPos) return a.rPos < b.rPos;
+	return a.gPos < b.gPos;
+}
+
+struct Ctx {
+	const Options &opt;
+	const RefData &ref;
+	KernelBackend &kern;
+	int min_seed_len;
+	bool fastq = true;
+	int64_t iPaired = 0, iDistance = 0;   // src/Mapping.cpp:13,20
+	const char *refseq() const { return ref.seq.data(); }
+};
+
+// ----------------------------------------------------------------------------------------------
+// chaining: GenerateAlignmentCandidateForIlluminaSeq / ForPacBioSeq
+// (src/AlignmentCandidates.cpp:82-130, 171-224)
+// ----------------------------------------------------------------------------------------------
+Pair from_seed(const kg_seed &s)
+{
+	Pair p;
+	p.simple = true; p.rPos = s.rPos; p.gPos = s.gPos; p.rLen = p.gLen = s.len; p.posDiff = s.gPos - s.rPos;
+	return p;
+}
+
+int64_t contig_end_of(const RefData &ref, int64_t g)  // GetAlignmentBoundary, src/tools.cpp:399-404
+{
+	std::map<int64_t, int>::const_iterator it = ref.chr_end.lower_bound(g);
+	return it == ref.chr_end.end() ? ref.two_genome_size - 1 : it->first;
+}
+
+void chain_illumina(const Ctx &cx, int rlen, const kg_seed *s, int num, std::vector<Candidate> &out)
+{
+	out.clear();
+	int thr = (int)(rlen * 0.2);
+	if (thr > 50) thr = 50;
+	int i = 0;
+	while (i < num && s[i].gPos - s[i].rPos < 0) i++;
+	while (i < num) {
+		int score = s[i].len;
+		int64_t g_end = contig_end_of(cx.ref, s[i].gPos);
+		int j = i, k = i + 1;
+		for (; k < num; ++k) {
+			int64_t dk = s[k].gPos - s[k].rPos, dj = s[j].gPos - s[j].rPos;
+			if (s[k].gPos > g_end || dk - dj > cx.opt.max_gaps) break;
+			score += s[k].len;
+			j = k;
+		}
+		if (score > thr) {
+			Candidate c;
+			c.score = score;
+			for (int q = i; q < k; ++q) c.pairs.push_back(from_seed(s[q]));
+			if (score - 50 > thr) thr = score - 50;
+			c.posDiff = c.pairs[0].posDiff < 0 ? 0 : c.pairs[0].posDiff;
+			std::sort(c.pairs.begin(), c.pairs.end(), pair_by_gpos);
+			out.push_back(c);
+		}
+		i = k;
+	}
+}
+
+void chain_pacbio(const kg_seed *s, int num, std::vector<Candidate> &out)
+{
+	out.clear();
+	if (num <= 0) return;
+	int thr = 0;
+	std::vector<char> taken((size_t)num, 0);
+	int i = 0;
+	while (i < num && s[i].gPos - s[i].rPos < 0) i++;
+	for (; i < num; ++i) {
+		if (taken[i]) continue;
+		Candidate c;
+		c.score = s[i].len;
+		taken[i] = 1;
+		c.pairs.push_back(from_seed(s[i]));
+		int j = i;
+		for (int k = i + 1; k < num; ++k) {
+			if (taken[k]) continue;
+			int64_t dk = s[k].gPos - s[k].rPos, dj = s[j].gPos - s[j].rPos;
+			if (std::llabs(dk - dj) < 300) {
+				if (s[k].rPos > s[j].rPos) {
+					c.score += s[k].len;
+					c.pairs.push_back(from_seed(s[k]));
+					taken[k] = 1;
+					j = k;
+				}
+			} else if (s[k].gPos - s[j].gPos > 1000) break;
+		}
+		if (c.score >= thr) {
+			thr = c.score;
+			int64_t d = s[i].gPos - s[i].rPos;
+			c.posDiff = d < 0 ? 0 : d;
+			out.push_back(c);
+		}
+	}
+}
+
+// ----------------------------------------------------------------------------------------------
+// normal pairs: IdentifyNormalPairs and its helpers (src/AlignmentCandidates.cpp:226-490)
+// ----------------------------------------------------------------------------------------------
+void erase_empty(std::vector<Pair> &v)
+{
+	v.erase(std::remove_if(v.begin(), v.end(), [](const Pair &p) { return p.rLen == 0; }), v.end());
+}
+
+void remove_tandem_repeats(std::vector<Pair> &v)  // :235-260 -- every read position hit more than once goes
+{
+	int num = (int)v.size();
+	if (num < 2) return;
+	std::vector<std::pair<int, int>> byr((size_t)num);
+	for (int i = 0; i < num; ++i) byr[i] = std::make_pair(v[i].rPos, i);
+	std::sort(byr.begin(), byr.end());
+	bool any = false;
+	for (int i = 0; i < num;) {
+		int j = i + 1;
+		while (j < num && byr[j].first == byr[i].first) j++;
+		if (j - i > 1) {
+			any = true;
+			for (int k = i; k < j; ++k) v[byr[k].second].rLen = v[byr[k].second].gLen = 0;
+		}
+		i = j;
+	}
+	if (any) erase_empty(v);
+}
+
+void remove_translocated(std::vector<Pair> &v)  // :262-321
+{
+	int num = (int)v.size();
+	if (num < 2) return;
+	std::vector<std::pair<int, int>> byr((size_t)num);
+	for (int i = 0; i < num; ++i) byr[i] = std::make_pair(v[i].rPos, i);
+	std::sort(byr.begin(), byr.end());   // read positions are distinct here (tandem repeats already removed)
+	bool any = false;
+	for (int i = 0; i < num; ++i) {
+		if (byr[i].first == v[i].rPos) continue;
+		any = true;
+		int hi = byr[i].second;
+		for (int j = i + 1; j <= hi; ++j)
+			if (byr[j].second > hi) hi = byr[j].second;
+		int s1 = 0, s2 = 0;
+		for (int k = i; k <= hi; ++k) {
+			if (k < byr[k].second) s1 += v[byr[k].second].rLen;
+			else s2 += v[byr[k].second].rLen;
+		}
+		for (int k = i; k <= hi; ++k) {
+			bool drop = s1 > s2 ? k > byr[k].second : k < byr[k].second;
+			if (drop) v[byr[k].second].rLen = v[byr[k].second].gLen = 0;
+		}
+		i = hi;
+	}
+	if (any) erase_empty(v);
+}
+
+bool resolve_overlap(Pair &p1, Pair &p2)  // CheckSeedOverlapping, :323-373
+{
+	bool master = true;
+	int ov;
+	if ((ov = p1.rPos + p1.rLen - p2.rPos) > 0) {
+		if (p1.rLen < p2.rLen) {
+			master = false;
+			if (p1.rLen > ov) p1.gLen = (p1.rLen -= ov);
+			else p1.rLen = p1.gLen = 0;
+		} else if (p2.rLen > ov) {
+			p2.rPos += ov; p2.gPos += ov; p2.gLen = (p2.rLen -= ov);
+		} else p2.rLen = p2.gLen = 0;
+	}
+	if (p1.rLen > 0 && p2.rLen > 0 && (ov = (int)(p1.gPos + p1.gLen - p2.gPos)) > 0) {
+		if (p1.gLen < p2.gLen) {
+			master = false;
+			if (p1.rLen > ov) p1.gLen = (p1.rLen -= ov);
+			else p1.rLen = p1.gLen = 0;
+		} else if (p2.rLen > ov) {
+			p2.rPos += ov; p2.gPos += ov; p2.gLen = (p2.rLen -= ov);
+		} else p2.rLen = p2.gLen = 0;
+	}
+	return master;
+}
+
+void check_overlaps(std::vector<Pair> &v)  // CheckOverlappingSeeds, :375-418
+{
+	int num = (int)v.size();
+	if (num < 2) return;
+	bool any = false;
+	for (int i = 0; i < num;) {
+		if (v[i].rLen > 0) {
+			int r_end = v[i].rPos + v[i].rLen - 1;
+			int64_t g_end = v[i].gPos + v[i].gLen - 1;
+			for (int j = i + 1; j < num; ++j) {
+				if (v[j].rLen == 0) continue;
+				if (r_end < v[j].rPos && g_end < v[j].gPos) break;
+				if (!resolve_overlap(v[i], v[j])) break;
+			}
+			if (v[i].rLen == 0) {
+				any = true;
+				int q = i - 1;
+				while (q > 0 && v[q].rLen == 0) q--;
+				i = q < 0 ? 0 : q;
+			} else i++;
+		} else {
+			any = true;
+			i++;
+		}
+	}
+	if (any) erase_empty(v);
+}
+
+void identify_normal_pairs(int rlen, int glen, std::vector<Pair> &v)  // :420-490
+{
+	Pair np;
+	np.simple = false; np.rPos = 0; np.gPos = 0; np.rLen = np.gLen = 0; np.posDiff = 0;
+	if (v.size() > 1) {
+		remove_tandem_repeats(v);
+		remove_translocated(v);
+		check_overlaps(v);
+		int num = (int)v.size();
+		for (int i = 0, j = 1; j < num; ++i, ++j) {
+			int r_gap = v[j].rPos - (v[i].rPos + v[i].rLen);
+			if (r_gap < 0) r_gap = 0;
+			int g_gap = (int)(v[j].gPos - (v[i].gPos + v[i].gLen));
+			if (g_gap < 0) g_gap = 0;
+			if (r_gap > 0 || g_gap > 0) {
+				np.simple = false;
+				np.rPos = v[i].rPos + v[i].rLen;
+				np.gPos = v[i].gPos + v[i].gLen;
+				np.posDiff = np.gPos - np.rPos;
+				np.rLen = r_gap; np.gLen = g_gap;
+				v.push_back(np);
+			}
+		}
+		if ((int)v.size() > num) std::inplace_merge(v.begin(), v.begin() + num, v.end(), pair_by_gpos);
+	}
+	if (!v.empty()) {
+		int r_gap = v[0].rPos > 0 ? v[0].rPos : 0;
+		int g_gap = glen > 0 ? (int)v[0].gPos : r_gap;
+		if (r_gap > 0 || g_gap > 0) {
+			np.rPos = 0;
+			np.gPos = v[0].gPos - g_gap;
+			if (np.gPos < 0) np.gPos = 0;          // the reference's follow-up "gGaps += gPos" adds zero (:464)
+			np.posDiff = np.gPos;
+			np.simple = false;
+			np.rLen = r_gap; np.gLen = g_gap;
+			v.insert(v.begin(), np);
+		}
+		size_t last = v.size() - 1;
+		r_gap = rlen - (v[last].rPos + v[last].rLen);
+		g_gap = glen > 0 ? (int)(glen - (v[last].gPos + v[last].gLen)) : r_gap;
+		if (r_gap > 0 || g_gap > 0) {
+			np.simple = false;
+			np.rPos = v[last].rPos + v[last].rLen;
+			np.gPos = v[last].gPos + v[last].gLen;
+			np.rLen = r_gap; np.gLen = g_gap;
+			v.push_back(np);
+		}
+	}
+}
+
+// ----------------------------------------------------------------------------------------------
+// 8-mer matcher (src/KmerAnalysis.cpp)
+// ----------------------------------------------------------------------------------------------
+struct Kmer { uint32_t wid, pos; };
+struct KmerHit { int posDiff; uint32_t rPos, gPos; };
+
+uint32_t kmer_id(const char *seq, uint32_t pos)  // CreateKmerID, :25-32
+{
+	uint32_t id = 0;
+	for (uint32_t i = pos; i < pos + 8; ++i) id = (id << 2) + (uint32_t)nt4((unsigned char)seq[i]);
+	return id;
+}
+
+void kmers_of(int len, const char *seq, std::vector<Kmer> &vec)  // CreateKmerVecFromReadSeq, :56-102
+{
+	vec.clear();
+	uint32_t count = 0, head, tail = 0, ulen = (uint32_t)(len < 0 ? 0 : len);
+	while (count < 8 && tail < ulen) {
+		if (seq[tail++] != 'N') count++;
+		else count = 0;
+	}
+	if (count != 8) return;
+	Kmer km;
+	km.pos = (head = tail - 8);
+	km.wid = kmer_id(seq, head);
+	vec.push_back(km);
+	for (head += 1; tail < ulen; head++, tail++) {
+		if (seq[tail] != 'N') {
+			km.pos = head;
+			km.wid = ((km.wid & 0x3FFF) << 2) + (uint32_t)nt4((unsigned char)seq[tail]);
+			vec.push_back(km);
+		} else {
+			count = 0;
+			tail++;
+			while (count < 8 && tail < ulen) {
+				if (seq[tail++] != 'N') count++;
+				else count = 0;
+			}
+			if (count != 8) break;
+			km.pos = (head = tail - 8);
+			km.wid = kmer_id(seq, head);
+			vec.push_back(km);
+		}
+	}
+	std::sort(vec.begin(), vec.end(), [](const Kmer &a, const Kmer &b) { return a.wid < b.wid; });
+}
+
+void common_kmers(int max_shift, const std::vector<Kmer> &v1, const std::vector<Kmer> &v2, std::vector<KmerHit> &out)  // :104-130
+{
+	out.clear();
+	for (size_t i = 0; i < v1.size(); ++i) {
+		uint32_t wid = v1[i].wid;
+		std::vector<Kmer>::const_iterator it =
+		    std::lower_bound(v2.begin(), v2.end(), v1[i], [](const Kmer &a, const Kmer &b) { return a.wid < b.wid; });
+		for (; it != v2.end() && it->wid == wid; ++it) {
+			if ((it->pos >= v1[i].pos && it->pos - v1[i].pos < (uint32_t)max_shift) ||
+			    (it->pos < v1[i].pos && v1[i].pos - it->pos < (uint32_t)max_shift)) {
+				KmerHit h;
+				h.rPos = v1[i].pos;
+				h.gPos = it->pos;
+				h.posDiff = (int)(h.gPos - h.rPos);
+				out.push_back(h);
+			}
+		}
+	}
+	std::sort(out.begin(), out.end(), [](const KmerHit &a, const KmerHit &b) {
+		if (a.posDiff == b.posDiff) return a.rPos < b.rPos;
+		return a.posDiff < b.posDiff;
+	});
+}
+
+void simple_pairs_from_kmers(int min_len, const std::vector<KmerHit> &hits, std::vector<Pair> &out)  // :132-162
+{
+	out.clear();
+	int num = (int)hits.size();
+	for (int i = 0; i < num;) {
+		int pd = hits[i].posDiff, j;
+		uint32_t next = hits[i].rPos + 1;
+		for (j = i + 1; j < num; ++j) {
+			if (hits[j].rPos != next || hits[j].posDiff != pd) break;
+			next++;
+		}
+		int l = 8 + (j - 1 - i);
+		if (l >= min_len) {
+			Pair p;
+			p.simple = true;
+			p.rPos = (int)hits[i].rPos;
+			p.gPos = hits[i].gPos;
+			p.posDiff = hits[i].posDiff;
+			p.rLen = p.gLen = l;
+			out.push_back(p);
+		}
+		i = j;
+	}
+}
+
+void simple_pairs_from_fragments(int max_dist, int len1, const char *f1, int len2, const char *f2, std::vector<Pair> &out)  // :164-179
+{
+	std::vector<Kmer> k1, k2;
+	std::vector<KmerHit> hits;
+	kmers_of(len1, f1, k1);
+	kmers_of(len2, f2, k2);
+	common_kmers(max_dist, k1, k2, hits);
+	simple_pairs_from_kmers(8, hits, out);
+	std::sort(out.begin(), out.end(), pair_by_gpos);
+}
+
+// ----------------------------------------------------------------------------------------------
+// gap closing, two passes around one batched NW call
+// (GenerateNormalPairAlignment / Process{Head,Normal,Tail}SequencePair, src/tools.cpp:142-397)
+// ----------------------------------------------------------------------------------------------
+// Pass 1 turns every normal pair into either an immediate result or a "plan": literal pieces and NW
+// jobs whose concatenation is what GenerateNormalPairAlignment leaves in frag1/frag2.  Every decision
+// up to the NW call depends on the fragment alone, so all jobs of a chunk can be collected first.
+struct Piece {
+	int job;              // >= 0: index into the chunk's job list; -1: literal
+	std::string a, b;
+};
+
+struct Plan {
+	std::vector<Piece> pieces;
+};
+
+void plan_alignment(const Ctx &cx, int rLen, const std::string &frag1, int gLen, const std::string &frag2, Plan &plan,
+                    std::vector<NwJob> &jobs)
+{
+	if (rLen > 30 && gLen > 30) {
+		int max_shift;
+		if (cx.opt.pacbio) {
+			max_shift = rLen > gLen ? (int)(rLen * 0.2) : (int)(gLen * 0.2);
+			if (max_shift > 50) max_shift = 50;
+		} else max_shift = cx.opt.max_gaps;
+		std::vector<Pair> part;
+		simple_pairs_from_fragments(max_shift, rLen, frag1.c_str(), gLen, frag2.c_str(), part);
+		if (!part.empty()) identify_normal_pairs(rLen, gLen, part);
+		if (!part.empty()) {
+			for (size_t i = 0; i < part.size(); ++i) {
+				const Pair &p = part[i];
+				if (p.rLen <= 0 && p.gLen <= 0) continue;
+				Piece pc;
+				pc.job = -1;
+				if (p.gLen == 0) {
+					pc.a = frag1.substr((size_t)p.rPos, (size_t)p.rLen);
+					pc.b.assign((size_t)p.rLen, '-');
+					plan.pieces.push_back(pc);
+				} else if (p.rLen == 0) {
+					pc.a.assign((size_t)p.gLen, '-');
+					pc.b = frag2.substr((size_t)p.gPos, (size_t)p.gLen);
+					plan.pieces.push_back(pc);
+				} else if ((p.rLen == 1 && p.gLen == 1) || p.simple) {
+					pc.a = frag1.substr((size_t)p.rPos, (size_t)p.rLen);
+					pc.b = frag2.substr((size_t)p.gPos, (size_t)p.gLen);
+					plan.pieces.push_back(pc);
+				} else {
+					std::string s1 = frag1.substr((size_t)p.rPos, (size_t)p.rLen), s2 = frag2.substr((size_t)p.gPos, (size_t)p.gLen);
+					if (cx.opt.pacbio && (p.rLen > 300 || p.gLen > 300)) plan_alignment(cx, p.rLen, s1, p.gLen, s2, plan, jobs);
+					else {
+						pc.job = (int)jobs.size();
+						NwJob j;
+						j.a.swap(s1); j.b.swap(s2);
+						jobs.push_back(j);
+						plan.pieces.push_back(pc);
+					}
+				}
+			}
+			return;
+		}
+	}
+	Piece pc;
+	pc.job = (int)jobs.size();
+	NwJob j;
+	j.a = frag1; j.b = frag2;
+	jobs.push_back(j);
+	plan.pieces.push_back(pc);
+}
+
+void stitch(const Plan &plan, const std::vector<NwJob> &jobs, std::string &aln1, std::string &aln2)
+{
+	aln1.clear(); aln2.clear();
+	for (size_t i = 0; i < plan.pieces.size(); ++i) {
+		const Piece &pc = plan.pieces[i];
+		if (pc.job >= 0) { aln1 += jobs[(size_t)pc.job].ra; aln2 += jobs[(size_t)pc.job].rb; }
+		else { aln1 += pc.a; aln2 += pc.b; }
+	}
+}
+
+int mismatches(int len, const char *a, const char *b)  // CalFragPairMismatchBases, src/tools.cpp:40-47 (raw characters)
+{
+	int c = 0;
+	for (int i = 0; i < len; ++i)
+		if (a[i] != b[i]) c++;
+	return c;
+}
+
+int add_cigar(const std::string &s1, const std::string &s2, CigarVec &cig)  // AddNewCigarElements, src/tools.cpp:49-104
+{
+	char state = '*';
+	int c = 0, score = 0;
+	for (size_t i = 0; i < s1.size(); ++i) {
+		char st;
+		if (s1[i] == '-') st = 'D';
+		else if (s2[i] == '-') st = 'I';
+		else {
+			st = 'M';
+			if (s1[i] == s2[i]) score++;
+		}
+		if (st == state) c++;
+		else {
+			if (c > 0) cig.push_back(std::make_pair(c, state));
+			c = 1;
+			state = st;
+		}
+	}
+	if (c > 0) cig.push_back(std::make_pair(c, state));
+	return score;
+}
+
+bool local_quality_ok(const std::string &a1, const std::string &a2)  // CheckLocalAlignmentQuality, src/tools.cpp:255-290
+{
+	int type = -1, n = 0, mis = 0, runs = 0;
+	for (size_t i = 0; i < a1.size(); ++i) {
+		int t;
+		if (a1[i] == '-') t = 0;
+		else if (a2[i] == '-') t = 1;
+		else {
+			t = 2;
+			n++;
+			if (a1[i] != a2[i]) mis++;
+		}
+		if (t != type) { type = t; runs++; }
+	}
+	return !(runs >= 4 || (mis >= 3 && mis >= (int)(n * 0.3)));
+}
+
+// what pass 1 decided for one pair of a candidate
+struct PairWork {
+	enum Kind { NONE, SIMPLE, IMMEDIATE, PLANNED } kind = NONE;
+	CigarVec ops;     // IMMEDIATE
+	int score = 0;    // IMMEDIATE
+	Plan plan;        // PLANNED
+};
+
+struct CandWork {
+	bool valid = false;            // reached the pair loop (Score != 0, coordinates valid)
+	std::vector<PairWork> pairs;
+};
+
+bool quick_match(const Pair &sp, const char *f1, const char *f2, int &n)  // the <=2-mismatch shortcut, src/tools.cpp:240,301,352
+{
+	if (sp.rLen != sp.gLen) return false;
+	n = mismatches(sp.rLen, f1, f2);
+	return n <= 2 && n <= (int)(sp.rLen * 0.2);
+}
+
+// pass 1 for one pair; role: 0 head, 1 inner, 2 tail
+void plan_pair(const Ctx &cx, const Read &rd, const Pair &sp, int role, PairWork &w, std::vector<NwJob> &jobs)
+{
+	if (role == 1 && (sp.rLen == 0 || sp.gLen == 0)) {   // ProcessNormalSequencePair :229-233
+		w.kind = PairWork::IMMEDIATE;
+		if (sp.rLen > 0) w.ops.push_back(std::make_pair(sp.rLen, 'I'));
+		else if (sp.gLen > 0) w.ops.push_back(std::make_pair(sp.gLen, 'D'));
+		return;
+	}
+	std::string f1(rd.seq.data() + sp.rPos, (size_t)sp.rLen), f2(cx.refseq() + sp.gPos, (size_t)sp.gLen);
+	int n = 0;
+	bool shortcut = (role == 1 || !cx.opt.pacbio) && quick_match(sp, f1.c_str(), f2.c_str(), n);
+	if (shortcut) {
+		w.kind = PairWork::IMMEDIATE;
+		w.score = sp.rLen - n;
+		w.ops.push_back(std::make_pair(sp.rLen, 'M'));
+		return;
+	}
+	if (!cx.opt.pacbio && ((role == 0 && sp.rLen > 50) || (role == 2 && sp.rLen > 100))) {   // :307-311, :358-362
+		w.kind = PairWork::IMMEDIATE;
+		w.score = 0;
+		w.ops.push_back(std::make_pair(sp.rLen, 'S'));
+		return;
+	}
+	w.kind = PairWork::PLANNED;
+	plan_alignment(cx, sp.rLen, f1, sp.gLen, f2, w.plan, jobs);
+}
+
+// pass 2: ProcessHeadSequencePair / ProcessTailSequencePair after the alignment is known
+int finish_head(Pair &sp, std::string &a1, std::string &a2, CigarVec &cig)  // src/tools.cpp:314-339
+{
+	if (!local_quality_ok(a1, a2)) {
+		cig.push_back(std::make_pair(sp.rLen, 'S'));
+		return 0;
+	}
+	size_t p = 0;
+	while (p < a1.size() && a1[p] == '-') p++;
+	if (p > 0) {
+		a1.erase(0, p); a2.erase(0, p);
+		sp.gPos += (int64_t)p; sp.gLen -= (int)p;
+	}
+	p = 0;
+	while (p < a2.size() && a2[p] == '-') p++;
+	if (p > 0) {
+		a1.erase(0, p); a2.erase(0, p);
+		sp.rPos += (int)p; sp.rLen -= (int)p;
+		cig.push_back(std::make_pair((int)p, 'S'));
+	}
+	return add_cigar(a1, a2, cig);
+}
+
+int finish_tail(Pair &sp, std::string &a1, std::string &a2, CigarVec &cig)  // src/tools.cpp:366-394
+{
+	if (!local_quality_ok(a1, a2)) {
+		cig.push_back(std::make_pair(sp.rLen, 'S'));
+		return 0;
+	}
+	int c = 0;
+	for (int p = (int)a1.size() - 1; p >= 0 && a1[(size_t)p] == '-'; --p) c++;
+	if (c > 0) {
+		a1.resize(a1.size() - (size_t)c); a2.resize(a2.size() - (size_t)c);
+		sp.gLen -= c;
+	}
+	c = 0;
+	for (int p = (int)a2.size() - 1; p >= 0 && a2[(size_t)p] == '-'; --p) c++;
+	if (c > 0) {
+		a1.resize(a1.size() - (size_t)c); a2.resize(a2.size() - (size_t)c);
+		sp.rLen -= c;
+	}
+	int score = add_cigar(a1, a2, cig);
+	if (c > 0) cig.push_back(std::make_pair(c, 'S'));
+	return score;
+}
+
+// ----------------------------------------------------------------------------------------------
+// report: GenMappingReport and helpers (src/AlignmentCandidates.cpp:492-745)
+// ----------------------------------------------------------------------------------------------
+std::string cigar_string(const CigarVec &cig)  // GenerateCIGAR, :492-513
+{
+	std::string out;
+	char state = '\0', buf[32];
+	int c = 0;
+	for (size_t i = 0; i < cig.size(); ++i) {
+		if (cig[i].second != state) {
+			if (c > 0) { snprintf(buf, sizeof(buf), "%d%c", c, state); out += buf; }
+			c = cig[i].first;
+			state = cig[i].second;
+		} else c += cig[i].first;
+	}
+	if (c > 0) { snprintf(buf, sizeof(buf), "%d%c", c, state); out += buf; }
+	return out;
+}
+
+bool coordinates_valid(const Ctx &cx, const std::vector<Pair> &v)  // CheckCoordinateValidity, :582-610
+{
+	int64_t g1 = 0, g2 = cx.ref.two_genome_size;
+	for (size_t i = 0; i < v.size(); ++i)
+		if (v[i].gLen > 0) { g1 = v[i].gPos; break; }
+	for (size_t i = v.size(); i-- > 0;)
+		if (v[i].gLen > 0) { g2 = v[i].gPos + v[i].gLen - 1; break; }
+	int64_t L = cx.ref.genome_size;
+	if ((g1 < L && g2 >= L) || (g1 >= L && g2 < L)) return false;
+	std::map<int64_t, int>::const_iterator i1 = cx.ref.chr_end.lower_bound(g1), i2 = cx.ref.chr_end.lower_bound(g2);
+	if (i1 == cx.ref.chr_end.end() || i2 == cx.ref.chr_end.end() || i1->second != i2->second) return false;
+	return true;
+}
+
+void make_coordinate(const Ctx &cx, bool first, int64_t gPos, int64_t end_gPos, CigarVec &cig, Report &rp)  // GenCoordinateInfo, :515-562
+{
+	const RefData &ref = cx.ref;
+	int n_chr = (int)ref.contigs.size();
+	if (gPos < ref.genome_size) {
+		rp.fwd = first;
+		if (n_chr == 1) { rp.chr = 0; rp.gPos = gPos + 1; }
+		else {
+			std::map<int64_t, int>::const_iterator it = ref.chr_end.lower_bound(gPos);
+			rp.chr = it->second;
+			rp.gPos = gPos + 1 - ref.contigs[(size_t)rp.chr].fwd_start;
+		}
+	} else {
+		rp.fwd = !first;
+		std::reverse(cig.begin(), cig.end());
+		if (n_chr == 1) { rp.chr = 0; rp.gPos = ref.two_genome_size - end_gPos; }
+		else {
+			std::map<int64_t, int>::const_iterator it = ref.chr_end.lower_bound(gPos);
+			if (it == ref.chr_end.end()) --it;   // beyond the text: undefined in the reference; stay in range
+			rp.gPos = it->first - end_gPos + 1;
+			rp.chr = it->second;
+		}
+	}
+	rp.cigar = cigar_string(cig);
+}
+
+int gap_penalty(const CigarVec &cig)  // GapPenalty, :612-622
+{
+	int gp = 0;
+	for (size_t i = 0; i < cig.size(); ++i)
+		if (cig[i].second == 'I' || cig[i].second == 'D') gp += cig[i].first;
+	return gp;
+}
+
+// pass 1 of GenMappingReport for one read: normal pairs, validity, and the NW jobs of every pair
+void report_plan(const Ctx &cx, Read &rd, std::vector<Candidate> &cands, std::vector<CandWork> &work, std::vector<NwJob> &jobs)
+{
+	work.assign(cands.size(), CandWork());
+	for (size_t i = 0; i < cands.size(); ++i) {
+		if (cands[i].score == 0) continue;
+		// (PacBio: the reference skips this candidate when an earlier one already scored; that is only
+		// known in pass 2, so its jobs are planned anyway and simply never read.)
+		identify_normal_pairs(rd.rlen, -1, cands[i].pairs);
+		if (!coordinates_valid(cx, cands[i].pairs)) continue;
+		CandWork &cw = work[i];
+		cw.valid = true;
+		std::vector<Pair> &v = cands[i].pairs;
+		int num = (int)v.size();
+		cw.pairs.assign((size_t)num, PairWork());
+		for (int j = 0; j < num; ++j) {
+			PairWork &w = cw.pairs[(size_t)j];
+			if (v[j].rLen == 0 && v[j].gLen == 0) continue;
+			if (v[j].simple) { w.kind = PairWork::SIMPLE; continue; }
+			if (j == 0 || j == num - 1) {
+				if (v[j].rLen > 3000) {               // :671-676, :690-695
+					w.kind = PairWork::IMMEDIATE;
+					w.ops.push_back(std::make_pair(v[j].rLen, 'S'));
+					w.score = -1;                     // marks the long soft clip (handled like s == 0 but unconditionally)
+					continue;
+				}
+				plan_pair(cx, rd, v[j], j == 0 ? 0 : 2, w, jobs);
+			} else plan_pair(cx, rd, v[j], 1, w, jobs);
+		}
+	}
+}
+
+// pass 2 of GenMappingReport
+void report_finish(const Ctx &cx, bool first, Read &rd, std::vector<Candidate> &cands, std::vector<CandWork> &work,
+                   const std::vector<NwJob> &jobs)
+{
+	rd.score = rd.sub_score = rd.best = 0;
+	rd.can_num = (int)cands.size();
+	if (rd.can_num == 0) {
+		rd.can_num = 1;
+		rd.best = 0;
+		rd.rep.assign(1, Report());
+		return;
+	}
+	rd.rep.assign((size_t)rd.can_num, Report());
+	std::string a1, a2;
+	for (int i = 0; i < rd.can_num; ++i) {
+		Report &rp = rd.rep[(size_t)i];
+		rp.score = 0;
+		rp.mate = cands[(size_t)i].mate;
+		if (cands[(size_t)i].score == 0) continue;
+		if (cx.opt.pacbio && rd.score > 0) { rd.sub_score = rd.score; continue; }
+		CandWork &cw = work[(size_t)i];
+		if (!cw.valid) continue;
+		std::vector<Pair> &v = cands[(size_t)i].pairs;
+		int num = (int)v.size();
+		CigarVec cig;
+		for (int j = 0; j < num; ++j) {
+			PairWork &w = cw.pairs[(size_t)j];
+			if (w.kind == PairWork::NONE) continue;
+			if (w.kind == PairWork::SIMPLE) {
+				cig.push_back(std::make_pair(v[j].rLen, 'M'));
+				rp.score += v[j].rLen;
+				continue;
+			}
+			bool head = j == 0, tail = j == num - 1 && !head;
+			int s;
+			if (w.kind == PairWork::IMMEDIATE) {
+				cig.insert(cig.end(), w.ops.begin(), w.ops.end());
+				s = w.score;
+			} else {
+				stitch(w.plan, jobs, a1, a2);
+				if (head) s = finish_head(v[j], a1, a2, cig);
+				else if (tail) s = finish_tail(v[j], a1, a2, cig);
+				else s = add_cigar(a1, a2, cig);
+			}
+			if (head) {
+				if (s > 0) rp.score += s;
+				if (s <= 0) {   // s == 0, or the > 3000 soft clip (score -1): collapse the genome side, :674-686
+					v[0].gPos = v[1].gPos;
+					v[0].gLen = 0;
+				}
+			} else if (tail) {
+				if (s > 0) rp.score += s;
+				if (s <= 0) {
+					v[j].gPos = v[j - 1].gPos + v[j - 1].gLen;
+					v[j].gLen = 0;
+				}
+			} else rp.score += s;
+		}
+		if (!cx.opt.pacbio && cig.size() > 1) {
+			rp.score -= gap_penalty(cig);
+			if (rp.score <= 0) { rp.score = 0; continue; }
+		}
+		if (cig.empty()) rp.score = 0;
+		else {
+			make_coordinate(cx, first, v[0].gPos, v[(size_t)num - 1].gPos + v[(size_t)num - 1].gLen - 1, cig, rp);
+			if (rp.gPos <= 0) rp.score = 0;
+		}
+		if (rp.score > rd.score) {
+			rd.best = i;
+			rd.sub_score = rd.score;
+			rd.score = rp.score;
+		} else if (rp.score == rd.score) {
+			rd.sub_score = rd.score;
+			if (!cx.opt.multi_hit && cx.ref.contigs[(size_t)rp.chr].len > cx.ref.contigs[(size_t)rd.rep[(size_t)rd.best].chr].len) rd.best = i;
+		}
+	}
+}
+
+// ----------------------------------------------------------------------------------------------
+// pairing, filters, rescue (src/Mapping.cpp:317-480, src/AlignmentRescue.cpp)
+// ----------------------------------------------------------------------------------------------
+void remove_redundant(const Ctx &cx, std::vector<Candidate> &v)  // RemoveRedundantCandidates, src/Mapping.cpp:317-346
+{
+	if (v.size() <= 1) return;
+	int s1 = 0, s2 = 0;
+	for (size_t i = 0; i < v.size(); ++i) {
+		if (v[i].score > s2) {
+			if (v[i].score >= s1) { s2 = s1; s1 = v[i].score; }
+			else s2 = v[i].score;
+		}
+	}
+	int thr = (cx.opt.pacbio || s1 == s2 || s1 - s2 > 20) ? s1 : s2;
+	for (size_t i = 0; i < v.size(); ++i)
+		if (v[i].score < thr) v[i].score = 0;
+}
+
+bool pair_candidates(const Ctx &cx, int64_t est, std::vector<Candidate> &v1, std::vector<Candidate> &v2)  // CheckPairedAlignmentCandidates, :348-400
+{
+	bool pairing = false;
+	int n1 = (int)v1.size(), n2 = (int)v2.size();
+	if (n1 * n2 > 1000) { remove_redundant(cx, v1); remove_redundant(cx, v2); }
+	for (int i = 0; i < n1; ++i) {
+		if (v1[i].score == 0) continue;
+		int best = -1, s = 0;
+		for (int j = 0; j < n2; ++j) {
+			if (v2[j].score == 0 || v2[j].posDiff < v1[i].posDiff) continue;
+			int64_t dist = v2[j].posDiff - v1[i].posDiff;
+			if (dist < est) {
+				if (v2[j].score > s) { best = j; s = v2[j].score; }
+				else if (v2[j].score == s) best = -1;
+			}
+		}
+		if (s > 0 && best != -1) {
+			int j = best;
+			if (v2[j].mate == -1) {
+				pairing = true;
+				v1[i].mate = j;
+				v2[j].mate = i;
+			} else if (v1[i].score > v1[v2[j].mate].score) {
+				v1[v2[j].mate].mate = -1;
+				v1[i].mate = j;
+				v2[j].mate = i;
+			}
+		}
+	}
+	return pairing;
+}
+
+void remove_unmated(std::vector<Candidate> &v1, std::vector<Candidate> &v2)  // RemoveUnMatedAlignmentCandidates, :402-427
+{
+	for (size_t i = 0; i < v1.size(); ++i) {
+		if (v1[i].mate == -1) v1[i].score = 0;
+		else {
+			int j = v1[i].mate;
+			v1[i].score = v2[j].score = v1[i].score + v2[j].score;
+		}
+	}
+	for (size_t j = 0; j < v2.size(); ++j)
+		if (v2[j].mate == -1) v2[j].score = 0;
+}
+
+int max_score(const std::vector<Candidate> &v)
+{
+	int s = 0;
+	for (size_t i = 0; i < v.size(); ++i)
+		if (v[i].score > s) s = v[i].score;
+	return s;
+}
+
+// IdnetifyRescueCandidate, src/AlignmentRescue.cpp:24-69
+Candidate rescue_candidate(const Ctx &cx, int64_t gPos, std::vector<Pair> &vec)
+{
+	Candidate best;
+	best.score = 0;
+	best.mate = -1;
+	int num = (int)vec.size();
+	for (int i = 0; i < num;) {
+		vec[i].gPos += gPos;
+		int s = vec[i].rLen;
+		std::vector<Pair> grp(1, vec[i]);
+		int j;
+		for (j = i + 1; j < num; ++j) {
+			if (vec[j].posDiff - vec[i].posDiff < cx.opt.max_gaps) {
+				vec[j].gPos += gPos;
+				s += vec[j].rLen;
+				grp.push_back(vec[j]);
+			} else break;
+		}
+		if (s > best.score) {
+			best.score = s;
+			best.posDiff = grp[0].posDiff + gPos;
+			best.pairs = grp;
+		}
+		i = j;
+	}
+	std::sort(best.pairs.begin(), best.pairs.end(), pair_by_gpos);
+	for (size_t i = 0; i < best.pairs.size(); ++i) best.pairs[i].posDiff += gPos;
+	return best;
+}
+
+// RescueUnpairedAlignment, src/AlignmentRescue.cpp:71-168.  The reference can index RefSequence
+// before its start or dereference ChrLocMap.end() here; those windows are
+// clamped to the text instead (inputs that trigger it have no defined reference output).
+bool rescue_unpaired(const Ctx &cx, int est, const Read &r1, const Read &r2, std::vector<Candidate> &v1, std::vector<Candidate> &v2)
+{
+	const RefData &ref = cx.ref;
+	int score1 = max_score(v1), score2 = max_score(v2);
+	int strategy;
+	if (score1 == 0 && score2 == 0) return false;
+	else if (score1 < (int)(r1.rlen * 0.1) && score2 < (int)(r2.rlen * 0.1)) strategy = 4;
+	else if (score1 > score2 && score1 - score2 > 50) strategy = 1;
+	else if (score2 > score1 && score2 - score1 > 50) strategy = 2;
+	else strategy = 3;
+	if (est > cx.opt.max_insert) est = cx.opt.max_insert;
+	bool mated = false;
+	int num1 = (int)v1.size(), num2 = (int)v2.size();
+	std::vector<Kmer> kr, kg;
+	std::vector<KmerHit> hits;
+	std::vector<Pair> sp;
+	if (strategy == 1 || strategy == 3) {
+		int thr = max_score(v1) - 30;
+		if (thr < 50) thr = 50;
+		kmers_of(r2.rlen, r2.seq.c_str(), kr);
+		for (int j = num2, i = 0; i < num1; ++i) {
+			if (v1[i].score < thr) continue;
+			int64_t left = v1[i].posDiff, right = v1[i].posDiff + est + r2.rlen;
+			std::map<int64_t, int>::const_iterator it = ref.chr_end.lower_bound(left);
+			if (it == ref.chr_end.end()) continue;
+			int chr = it->second;
+			if (right < ref.genome_size && right > ref.contigs[(size_t)chr].fwd_start) right = ref.contigs[(size_t)chr].fwd_start - 1;
+			else if (right >= ref.genome_size && right > ref.contigs[(size_t)chr].rev_start) right = ref.contigs[(size_t)chr].rev_start - 1;
+			int slen = (int)(right - left);
+			if (slen < r2.rlen) continue;
+			if (left < 0 || right > ref.two_genome_size) continue;
+			kmers_of(slen, cx.refseq() + left, kg);
+			common_kmers(slen, kr, kg, hits);
+			simple_pairs_from_kmers(10, hits, sp);
+			Candidate c = rescue_candidate(cx, left, sp);
+			if (c.score > score2) {
+				mated = true;
+				c.mate = i;
+				v1[i].mate = j++;
+				v2.push_back(c);
+			}
+		}
+	}
+	if (strategy == 2 || strategy == 3) {
+		int thr = max_score(v2) - 30;   // the rescued entries appended above are included, as in the reference
+		if (thr < 50) thr = 50;
+		kmers_of(r1.rlen, r1.seq.c_str(), kr);
+		for (int i = num1, j = 0; j < num2; ++j) {
+			if (v2[j].score < thr) continue;
+			int64_t left = v2[j].posDiff - est, right = v2[j].posDiff + r2.rlen;
+			std::map<int64_t, int>::const_iterator it = ref.chr_end.lower_bound(right);
+			if (it == ref.chr_end.end()) continue;
+			int chr = it->second;
+			const Contig &cg = ref.contigs[(size_t)chr];
+			if (left < ref.genome_size && left < (cg.fwd_start - cg.len)) left = cg.fwd_start - cg.len + 1;
+			else if (right >= ref.genome_size && left < (cg.rev_start - cg.len)) left = cg.rev_start - cg.len + 1;
+			int slen = (int)(right - left);
+			if (slen < r1.rlen) continue;
+			if (left < 0) { left = 0; slen = (int)(right - left); if (slen < r1.rlen) continue; }
+			if (right > ref.two_genome_size) continue;
+			kmers_of(slen, cx.refseq() + left, kg);
+			common_kmers(slen, kr, kg, hits);
+			simple_pairs_from_kmers(10, hits, sp);
+			Candidate c = rescue_candidate(cx, left, sp);
+			if (c.score > score1) {
+				mated = true;
+				c.mate = j;
+				v2[j].mate = i++;
+				v1.push_back(c);
+			}
+		}
+	}
+	return mated;
+}
+
+void check_final_pair(const Ctx &cx, Read &r1, Read &r2)  // CheckPairedFinalAlignments, src/Mapping.cpp:429-480
+{
+	bool mated = false;
+	if (r1.best != -1 && r2.best != -1) mated = r1.rep[(size_t)r1.best].mate == r2.best;
+	if (!cx.opt.multi_hit && mated) return;
+	if (!mated && r1.score > 0 && r2.score > 0) {
+		int s = 0;
+		for (int i = 0; i < r1.can_num; ++i) {
+			int j;
+			if (r1.rep[(size_t)i].score > 0 && (j = r1.rep[(size_t)i].mate) != -1 && r2.rep[(size_t)j].score > 0) {
+				mated = true;
+				if (s < r1.rep[(size_t)i].score + r2.rep[(size_t)j].score) {
+					s = r1.rep[(size_t)i].score + r2.rep[(size_t)j].score;
+					r1.best = i; r1.score = r1.rep[(size_t)i].score;
+					r2.best = j; r2.score = r2.rep[(size_t)j].score;
+				}
+			}
+		}
+	}
+	if (mated) {
+		for (int i = 0; i < r1.can_num; ++i) {
+			int j;
+			if (r1.rep[(size_t)i].score != r1.score || ((j = r1.rep[(size_t)i].mate) != -1 && r2.rep[(size_t)j].score != r2.score)) {
+				r1.rep[(size_t)i].score = 0;
+				r1.rep[(size_t)i].mate = -1;
+			}
+		}
+	} else {
+		for (int i = 0; i < r1.can_num; ++i) {
+			r1.rep[(size_t)i].mate = -1;
+			if (r1.rep[(size_t)i].score > 0 && r1.rep[(size_t)i].score != r1.score) r1.rep[(size_t)i].score = 0;
+		}
+		for (int j = 0; j < r2.can_num; ++j) {
+			r2.rep[(size_t)j].mate = -1;
+			if (r2.rep[(size_t)j].score > 0 && r2.rep[(size_t)j].score != r2.score) r2.rep[(size_t)j].score = 0;
+		}
+	}
+}
+
+void set_single_flag(Read &rd)  // SetSingleAlignmentFlag, src/Mapping.cpp:49-71
+{
+	if (rd.score > rd.sub_score) rd.rep[(size_t)rd.best].flag = rd.rep[(size_t)rd.best].fwd ? 0 : 0x10;
+	else if (rd.score > 0) {
+		for (int i = 0; i < rd.can_num; ++i)
+			if (rd.rep[(size_t)i].score > 0) rd.rep[(size_t)i].flag = rd.rep[(size_t)i].fwd ? 0 : 0x10;
+	} else rd.rep[0].flag = 0x4;
+}
+
+void set_one_mate_flags(Read &me, Read &other, int base_flag)  // the per-mate halves of SetPairedAlignmentFlag, :96-156
+{
+	if (me.score > me.sub_score) {
+		Report &rp = me.rep[(size_t)me.best];
+		rp.flag = base_flag | (rp.fwd ? 0x20 : 0x10);
+		int j = rp.mate;
+		if (j != -1 && other.rep[(size_t)j].score > 0) rp.flag |= 0x2;
+		else rp.flag |= 0x8;
+	} else if (me.score > 0) {
+		for (int i = 0; i < me.can_num; ++i) {
+			Report &rp = me.rep[(size_t)i];
+			if (rp.score <= 0) continue;
+			rp.flag = base_flag | (rp.fwd ? 0x20 : 0x10);
+			int j = rp.mate;
+			if (j != -1 && other.rep[(size_t)j].score > 0) rp.flag |= 0x2;
+			else rp.flag |= 0x8;
+		}
+	} else {
+		me.rep[0].flag = base_flag | 0x4;
+		if (other.score == 0) me.rep[0].flag |= 0x8;
+		else me.rep[0].flag |= (other.rep[(size_t)other.best].fwd ? 0x10 : 0x20);
+	}
+}
+
+void set_paired_flags(Read &r1, Read &r2)  // SetPairedAlignmentFlag, src/Mapping.cpp:73-158
+{
+	if (r1.score > r1.sub_score && r2.score > r2.sub_score) {
+		Report &a = r1.rep[(size_t)r1.best], &b = r2.rep[(size_t)r2.best];
+		a.flag = 0x41;
+		b.flag = 0x81;
+		if (r2.best == a.mate) { a.flag |= 0x2; b.flag |= 0x2; }
+		a.flag |= a.fwd ? 0x20 : 0x10;
+		b.flag |= b.fwd ? 0x20 : 0x10;
+	} else {
+		set_one_mate_flags(r1, r2, 0x41);
+		set_one_mate_flags(r2, r1, 0x81);
+	}
+}
+
+void evaluate_mapq(const Ctx &cx, Read &rd)  // EvaluateMAPQ, src/Mapping.cpp:160-175
+{
+	if (rd.score == 0 || rd.score == rd.sub_score) { rd.mapq = 0; return; }
+	if (cx.opt.pacbio) {
+		float scale = 85.0 * (int)(ceil(rd.rlen / 100 + 0.5));
+		if (scale > 2000) scale = 2000;
+		rd.mapq = (int)(60 * (rd.score / scale));
+	} else if (rd.sub_score == 0 || rd.score - rd.sub_score > 5) rd.mapq = 60;
+	else rd.mapq = (int)(30 * (1 - (float)(rd.score - rd.sub_score) / rd.score) * log(rd.score) + 0.4999);
+	if (rd.mapq > 60) rd.mapq = 60;
+}
+
+// ----------------------------------------------------------------------------------------------
+// SAM text (src/Mapping.cpp:177-315; record formats in SURVEY.md App. D)
+// ----------------------------------------------------------------------------------------------
+void sam_unmapped(const Ctx &cx, const Read &rd, std::string &out)
+{
+	char num[32];
+	snprintf(num, sizeof(num), "%d", rd.rep[0].flag);
+	out += rd.name; out += '\t'; out += num;
+	out += "\t*\t0\t0\t*\t*\t0\t0\t";
+	out += rd.seq; out += '\t';
+	out += cx.fastq ? rd.qual : std::string("*");
+	out += "\tAS:i:0\tXS:i:0\n";
+}
+
+void sam_mapped(const Ctx &cx, const Read &rd, const Report &rp, bool has_mate, long long mate_pos, int tlen,
+                const std::string &seq, const std::string &qual, std::string &out)
+{
+	char buf[256];
+	out += rd.name;
+	snprintf(buf, sizeof(buf), "\t%d\t", rp.flag);
+	out += buf;
+	out += cx.ref.contigs[(size_t)rp.chr].name;
+	snprintf(buf, sizeof(buf), "\t%lld\t%d\t", (long long)rp.gPos, rd.mapq);
+	out += buf;
+	out += rp.cigar;
+	if (has_mate) { snprintf(buf, sizeof(buf), "\t=\t%lld\t%d\t", mate_pos, tlen); out += buf; }
+	else out += "\t*\t0\t0\t";
+	out += seq; out += '\t';
+	out += cx.fastq ? qual : std::string("*");
+	snprintf(buf, sizeof(buf), "\tNM:i:%d\tAS:i:%d\tXS:i:%d\n", rd.rlen - rd.score, rd.score, rd.sub_score);
+	out += buf;
+}
+
+// OutputPairedAlignments, src/Mapping.cpp:177-270.  Mate 2 is held reverse-complemented (App. B-2).
+void output_pair(Ctx &cx, const Read &r1, const Read &r2, Stats &st, std::string &out)
+{
+	if (r1.score == 0) { st.unmapped++; sam_unmapped(cx, r1, out); }
+	else {
+		if (r1.mapq == 60) st.unique++;
+		std::string rseq, rqual;
+		bool have_rev = false;
+		for (int i = r1.best; i < r1.can_num; ++i) {
+			const Report &rp = r1.rep[(size_t)i];
+			if (rp.score > 0) {
+				if (!rp.fwd && !have_rev) {
+					rseq = revcomp(r1.seq);
+					if (cx.fastq) { rqual = r1.qual; std::reverse(rqual.begin(), rqual.end()); }
+					have_rev = true;
+				}
+				int j = rp.mate;
+				if (j != -1 && r2.rep[(size_t)j].score > 0) {
+					int dist = (int)(r2.rep[(size_t)j].gPos - rp.gPos + (rp.fwd ? r2.rlen : 0 - r1.rlen));
+					if (i == r1.best) {
+						cx.iPaired += 2;
+						if (abs(dist) < 10000) cx.iDistance += abs(dist);
+					}
+					sam_mapped(cx, r1, rp, true, (long long)r2.rep[(size_t)j].gPos, dist, rp.fwd ? r1.seq : rseq, rp.fwd ? r1.qual : rqual, out);
+				} else sam_mapped(cx, r1, rp, false, 0, 0, rp.fwd ? r1.seq : rseq, rp.fwd ? r1.qual : rqual, out);
+			}
+			if (!cx.opt.multi_hit) break;
+		}
+	}
+	if (r2.score == 0) { st.unmapped++; sam_unmapped(cx, r2, out); }
+	else {
+		if (r2.mapq == 60) st.unique++;
+		std::string fseq, rqual;
+		bool have_fwd = false;
+		for (int j = r2.best; j < r2.can_num; ++j) {
+			const Report &rp = r2.rep[(size_t)j];
+			if (rp.score > 0) {
+				if (rp.fwd && !have_fwd) {
+					fseq = revcomp(r2.seq);
+					if (cx.fastq) { rqual = r2.qual; std::reverse(rqual.begin(), rqual.end()); }
+					have_fwd = true;
+				}
+				int i = rp.mate;
+				if (i != -1 && r1.rep[(size_t)i].score > 0) {
+					int dist = 0 - (int)(rp.gPos - r1.rep[(size_t)i].gPos + (r1.rep[(size_t)i].fwd ? r2.rlen : 0 - r1.rlen));
+					sam_mapped(cx, r2, rp, true, (long long)r1.rep[(size_t)i].gPos, dist, rp.fwd ? fseq : r2.seq, rp.fwd ? rqual : r2.qual, out);
+				} else sam_mapped(cx, r2, rp, false, 0, 0, rp.fwd ? fseq : r2.seq, rp.fwd ? rqual : r2.qual, out);
+			}
+			if (!cx.opt.multi_hit) break;
+		}
+	}
+}
+
+void output_single(Ctx &cx, const Read &rd, Stats &st, std::string &out)  // OutputSingledAlignments, src/Mapping.cpp:272-315
+{
+	if (rd.score == 0) { st.unmapped++; sam_unmapped(cx, rd, out); return; }
+	if (rd.mapq == 60) st.unique++;
+	std::string rseq, rqual;
+	bool have_rev = false;
+	for (int i = rd.best; i < rd.can_num; ++i) {
+		const Report &rp = rd.rep[(size_t)i];
+		if (rp.score == rd.score) {
+			if (!rp.fwd && !have_rev) {
+				rseq = revcomp(rd.seq);
+				if (cx.fastq) { rqual = rd.qual; std::reverse(rqual.begin(), rqual.end()); }
+				have_rev = true;
+			}
+			sam_mapped(cx, rd, rp, false, 0, 0, rp.fwd ? rd.seq : rseq, rp.fwd ? rd.qual : rqual, out);
+			if (!cx.opt.multi_hit) break;
+		}
+	}
+}
+
+// ----------------------------------------------------------------------------------------------
+// input (src/GetData.cpp)
+// ----------------------------------------------------------------------------------------------
+struct Input {
+	FILE *fp = nullptr;
+	gzFile gz = nullptr;
+	char *line = nullptr;
+	size_t cap = 0;
+	std::vector<char> gzbuf;
+	~Input() { close(); }
+	void close()
+	{
+		if (fp) fclose(fp);
+		if (gz) gzclose(gz);
+		fp = nullptr; gz = nullptr;
+		free(line); line = nullptr; cap = 0;
+	}
+};
+
+void header_of(const char *buf, int len, std::string &name)  // IdentifyHeaderBegPos/EndPos, src/GetData.cpp:29-49
+{
+	int p1 = len - 1, p2 = len - 1;
+	for (int i = 1; i < len; ++i)
+		if (buf[i] != '>' && buf[i] != '@') { p1 = i; break; }
+	for (int i = 1; i < len; ++i)
+		if (buf[i] == ' ' || buf[i] == '/' || buf[i] == '\t') { p2 = i; break; }
+	if (p2 > p1) name.assign(buf + p1, (size_t)(p2 - p1));
+	else name.clear();
+}
+
+// GetNextEntry, src/GetData.cpp:51-107.  Like the reference, the last character of every line is taken
+// to be the newline.
+bool next_entry_plain(Input &in, bool fastq, Read &rd)
+{
+	rd = Read();
+	ssize_t len = getline(&in.line, &in.cap, in.fp);
+	if (len == -1) return false;
+	header_of(in.line, (int)len, rd.name);
+	if (fastq) {
+		ssize_t sl = getline(&in.line, &in.cap, in.fp);
+		if (sl == -1) { rd.rlen = 0; return true; }
+		rd.rlen = (int)sl - 1;
+		rd.seq.assign(in.line, (size_t)rd.rlen);
+		getline(&in.line, &in.cap, in.fp);
+		ssize_t ql = getline(&in.line, &in.cap, in.fp);
+		if (ql < 0) ql = 0;
+		rd.qual.assign(in.line, (size_t)std::min<ssize_t>(ql, rd.rlen));
+		rd.qual.resize((size_t)rd.rlen, '\0');
+		rd.qual = std::string(rd.qual.c_str());   // the reference treats it as a C string
+	} else {
+		std::string seq;
+		while (true) {
+			len = getline(&in.line, &in.cap, in.fp);
+			if (len == -1) break;
+			if (in.line[0] == '>') { fseek(in.fp, 0 - len, SEEK_CUR); break; }
+			in.line[len - 1] = '\0';
+			seq += in.line;
+		}
+		rd.rlen = (int)seq.size();
+		rd.seq.swap(seq);
+	}
+	return true;
+}
+
+bool next_entry_gz(Input &in, bool fastq, bool pacbio, Read &rd)  // gzGetNextEntry, src/GetData.cpp:145-182
+{
+	rd = Read();
+	int buf_size = pacbio ? 1000000 : 1000;
+	in.gzbuf.resize((size_t)buf_size);
+	char *buf = in.gzbuf.data();
+	if (gzgets(in.gz, buf, buf_size) == NULL) return false;
+	int len = (int)strlen(buf);
+	std::string name;
+	header_of(buf, len, name);
+	if (!name.empty() && (buf[0] == '@' || buf[0] == '>')) {
+		rd.name = name;
+		if (gzgets(in.gz, buf, buf_size) == NULL) buf[0] = '\0';
+		rd.rlen = (int)strlen(buf) - 1;
+		if (rd.rlen < 0) rd.rlen = 0;
+		rd.seq.assign(buf, (size_t)rd.rlen);
+		if (fastq) {
+			gzgets(in.gz, buf, buf_size);
+			if (gzgets(in.gz, buf, buf_size) == NULL) buf[0] = '\0';
+			rd.qual.assign(buf, std::min<size_t>(strlen(buf), (size_t)rd.rlen));
+		}
+	}
+	return true;
+}
+
+bool next_entry(Input &in, bool fastq, bool pacbio, Read &rd)
+{
+	return in.gz ? next_entry_gz(in, fastq, pacbio, rd) : next_entry_plain(in, fastq, rd);
+}
+
+// GetNextChunk, src/GetData.cpp:109-143 / 184-219
+int next_chunk(const Ctx &cx, bool sep, Input &in1, Input &in2, std::vector<Read> &reads, int limit)
+{
+	int count = 0;
+	Read rd;
+	while (true) {
+		if (!next_entry(in1, cx.fastq, cx.opt.pacbio, rd) || rd.rlen == 0) break;
+		reads.push_back(rd);
+		count++;
+		bool ok = sep ? next_entry(in2, cx.fastq, cx.opt.pacbio, rd) : next_entry(in1, cx.fastq, cx.opt.pacbio, rd);
+		if (!ok || rd.rlen == 0) break;
+		if (cx.opt.paired) {   // mate 2 is stored reverse-complemented, qualities reversed, :125-135
+			rd.seq = revcomp(rd.seq);
+			if (cx.fastq) std::reverse(rd.qual.begin(), rd.qual.end());
+		}
+		reads.push_back(rd);
+		count++;
+		if (count == limit) break;
+	}
+	return count;
+}
+
+bool is_fastq(const std::string &path)  // CheckReadFormat, src/GetData.cpp:8-16
+{
+	gzFile f = gzopen(path.c_str(), "rb");
+	if (!f) return true;
+	char c = 0;
+	gzread(f, &c, 1);
+	gzclose(f);
+	return c == '@';
+}
+
+// ----------------------------------------------------------------------------------------------
+// one library: batches of chunks (ReadMapping, src/Mapping.cpp:488-637)
+// ----------------------------------------------------------------------------------------------
+struct Chunk {
+	int begin, count;   // slice of the batch's read vector
+};
+
+void map_library(Ctx &cx, bool sep, Input &in1, Input &in2, FILE *out, Stats &st)
+{
+	const int chunk_limit = cx.opt.pacbio ? 10 : 4000;   // ReadChunkSize, src/structure.h:21; src/GetData.cpp:140
+	const int mode = cx.opt.pacbio ? KG_MODE_SENSITIVE : KG_MODE_FAST;
+	std::vector<Read> reads;
+	std::vector<Chunk> chunks;
+	std::vector<uint8_t> enc;
+	std::vector<int64_t> off, seed_off;
+	std::vector<kg_seed> seeds;
+	std::string text;
+	bool eof = false;
+	while (!eof) {
+		// ---- read a batch of whole chunks and seed it in one kernel call ------------------------------
+		reads.clear(); chunks.clear();
+		int64_t batch_bases = 0;
+		while ((int64_t)reads.size() < cx.opt.batch_reads && batch_bases < (int64_t)cx.opt.batch_reads * 256) {
+			Chunk ck;
+			ck.begin = (int)reads.size();
+			ck.count = next_chunk(cx, sep, in1, in2, reads, chunk_limit);
+			reads.resize((size_t)(ck.begin + ck.count));
+			if (ck.count == 0) { eof = true; break; }
+			chunks.push_back(ck);
+			for (int i = ck.begin; i < ck.begin + ck.count; ++i) batch_bases += reads[(size_t)i].rlen;
+			if (ck.count < chunk_limit && !cx.opt.pacbio) { /* short chunk = end of input on the next call */ }
+		}
+		if (reads.empty()) break;
+		enc.clear(); off.assign(1, 0);
+		for (size_t i = 0; i < reads.size(); ++i) {
+			const Read &rd = reads[i];
+			// EnCodeReadSeq (src/Mapping.cpp:482-485).  The reference encodes mate 2 with mate 1's length
+			// (:550, App. B-5); with equal-length mates that is the same thing, otherwise it reads or
+			// leaves uninitialised bytes -- here every read is encoded over its own length.
+			for (int p = 0; p < rd.rlen; ++p) enc.push_back((uint8_t)nt4((unsigned char)rd.seq[(size_t)p]));
+			off.push_back((int64_t)enc.size());
+		}
+		cx.kern.seed_batch(mode, enc, off, seed_off, seeds);
+
+		// ---- chunks strictly in input order: EstDistance feeds forward (src/Mapping.cpp:533-540) ---------
+		std::vector<std::vector<Candidate>> cands;
+		std::vector<std::vector<CandWork>> work;
+		std::vector<NwJob> jobs;
+		for (size_t c = 0; c < chunks.size(); ++c) {
+			const Chunk &ck = chunks[c];
+			bool paired = cx.opt.paired && ck.count % 2 == 0 && !cx.opt.pacbio;
+			cands.assign((size_t)ck.count, std::vector<Candidate>());
+			work.assign((size_t)ck.count, std::vector<CandWork>());
+			jobs.clear();
+			int est = cx.opt.max_insert;
+			if (paired && cx.iPaired >= 1000) {
+				est = (int)(cx.iDistance / (cx.iPaired >> 2));
+				est = est + (est >> 1);
+			}
+			for (int q = 0; q < ck.count; ++q) {
+				size_t ri = (size_t)(ck.begin + q);
+				const kg_seed *s = seeds.data() + seed_off[ri];
+				int ns = (int)(seed_off[ri + 1] - seed_off[ri]);
+				if (cx.opt.pacbio) chain_pacbio(s, ns, cands[(size_t)q]);
+				else chain_illumina(cx, reads[ri].rlen, s, ns, cands[(size_t)q]);
+			}
+			if (paired) {
+				for (int q = 0; q < ck.count; q += 2) {
+					std::vector<Candidate> &v1 = cands[(size_t)q], &v2 = cands[(size_t)q + 1];
+					Read &r1 = reads[(size_t)(ck.begin + q)], &r2 = reads[(size_t)(ck.begin + q + 1)];
+					bool pairing = pair_candidates(cx, est, v1, v2);
+					if (!pairing) pairing = rescue_unpaired(cx, est, r1, r2, v1, v2);
+					if (pairing) remove_unmated(v1, v2);
+					remove_redundant(cx, v1);
+					remove_redundant(cx, v2);
+				}
+			} else {
+				for (int q = 0; q < ck.count; ++q) remove_redundant(cx, cands[(size_t)q]);
+			}
+			// report pass 1 -> one NW batch for the whole chunk -> report pass 2
+			for (int q = 0; q < ck.count; ++q) report_plan(cx, reads[(size_t)(ck.begin + q)], cands[(size_t)q], work[(size_t)q], jobs);
+			if (!jobs.empty()) cx.kern.nw_batch(jobs);
+			for (int q = 0; q < ck.count; ++q) {
+				bool first = paired ? (q % 2 == 0) : true;
+				report_finish(cx, first, reads[(size_t)(ck.begin + q)], cands[(size_t)q], work[(size_t)q], jobs);
+			}
+			text.clear();
+			if (paired) {
+				for (int q = 0; q < ck.count; q += 2) {
+					Read &r1 = reads[(size_t)(ck.begin + q)], &r2 = reads[(size_t)(ck.begin + q + 1)];
+					check_final_pair(cx, r1, r2);
+					set_paired_flags(r1, r2);
+					evaluate_mapq(cx, r1);
+					evaluate_mapq(cx, r2);
+				}
+				for (int q = 0; q < ck.count; q += 2) output_pair(cx, reads[(size_t)(ck.begin + q)], reads[(size_t)(ck.begin + q + 1)], st, text);
+			} else {
+				for (int q = 0; q < ck.count; ++q) {
+					Read &rd = reads[(size_t)(ck.begin + q)];
+					set_single_flag(rd);
+					evaluate_mapq(cx, rd);
+				}
+				for (int q = 0; q < ck.count; ++q) output_single(cx, reads[(size_t)(ck.begin + q)], st, text);
+			}
+			st.total_reads += ck.count;
+			fwrite(text.data(), 1, text.size(), out);
+		}
+	}
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------
+// public entry points
+// ----------------------------------------------------------------------------------------------
+bool RefData::load(const std::string &prefix, std::string &err)
+{
+	FILE *fp = fopen((prefix + ".ann").c_str(), "r");
+	if (!fp) { err = "cannot read " + prefix + ".ann"; return false; }
+	long long l_pac;
+	int n_seqs;
+	unsigned seed;
+	if (fscanf(fp, "%lld%d%u", &l_pac, &n_seqs, &seed) != 3) { fclose(fp); err = "bad .ann header"; return false; }
+	genome_size = l_pac;
+	two_genome_size = 2 * genome_size;
+	int64_t total = 0;
+	for (int i = 0; i < n_seqs; ++i) {
+		unsigned gi;
+		char name[1024];
+		long long offv;
+		int len, n_ambs, ch;
+		if (fscanf(fp, "%u%1023s", &gi, name) != 2) { fclose(fp); err = "bad .ann record"; return false; }
+		while ((ch = fgetc(fp)) != '\n' && ch != EOF) {}
+		if (fscanf(fp, "%lld%d%d", &offv, &len, &n_ambs) != 3) { fclose(fp); err = "bad .ann record"; return false; }
+		Contig c;
+		c.name = name;
+		c.len = len;
+		c.fwd_start = total;
+		total += len;
+		c.rev_start = two_genome_size - total;
+		chr_end[c.fwd_start + c.len - 1] = i;
+		chr_end[c.rev_start + c.len - 1] = i;
+		contigs.push_back(c);
+	}
+	fclose(fp);
+	std::vector<unsigned char> pac;
+	if (!slurp(prefix + ".pac", pac) || (int64_t)pac.size() < genome_size / 4 + 1) { err = "cannot read " + prefix + ".pac"; return false; }
+	seq.assign((size_t)(two_genome_size + 1), '\0');
+	static const char fw[4] = {'A', 'C', 'G', 'T'}, rc[4] = {'T', 'G', 'C', 'A'};
+	for (int64_t f = 0; f < genome_size; ++f) {
+		int b = pac[(size_t)(f >> 2)] >> ((~f & 3) << 1) & 3;
+		seq[(size_t)f] = fw[b];
+		seq[(size_t)(two_genome_size - 1 - f)] = rc[b];
+	}
+	return true;
+}
+
+int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FILE *out, Stats &stats)
+{
+	Ctx cx{opt, ref, kern, kern.min_seed_len()};
+	Options &o = const_cast<Options &>(opt);
+	// header: @PG first, then @SQ, no @HD (src/Mapping.cpp:664-675)
+	fprintf(out, "@PG\tID:kart\tPN:Kart\tVN:%s\n", "2.5.6");
+	for (size_t i = 0; i < ref.contigs.size(); ++i) fprintf(out, "@SQ\tSN:%s\tLN:%lld\n", ref.contigs[i].name.c_str(), (long long)ref.contigs[i].len);
+	for (size_t lib = 0; lib < opt.files1.size(); ++lib) {
+		const std::string &f1 = opt.files1[lib];
+		bool gz = f1.size() >= 2 && f1.substr(f1.find_last_of('.') + 1) == "gz";   // src/Mapping.cpp:688
+		cx.fastq = is_fastq(f1);
+		Input in1, in2;
+		if (gz) in1.gz = gzopen(f1.c_str(), "rb"); else in1.fp = fopen(f1.c_str(), "r");
+		bool sep = false;
+		if (opt.files1.size() == opt.files2.size()) {
+			sep = true;
+			o.paired = true;
+			const std::string &f2 = opt.files2[lib];
+			if (cx.fastq != is_fastq(f2)) {
+				fprintf(stdout, "Error! %s and %s are with different format...\n", f1.c_str(), f2.c_str());
+				continue;
+			}
+			if (gz) in2.gz = gzopen(f2.c_str(), "rb"); else in2.fp = fopen(f2.c_str(), "r");
+		}
+		if (!in1.fp && !in1.gz) continue;
+		if (sep && !in2.fp && !in2.gz) continue;
+		map_library(cx, sep, in1, in2, out, stats);
+	}
+	stats.paired = cx.iPaired;
+	stats.distance = cx.iDistance;
+	return 0;
+}
+
+}  // namespace kart

@@ -1,0 +1,81 @@
+// mapper.hpp -- host side of the MI355X-native Kart pipeline (FASTQ -> SAM).
+//
+// Mirrors the reference's driver (reference src/Mapping.cpp, src/GetData.cpp, src/main.cpp) above
+// the C ABI of include/kart_amd.h.  The three hot-path stages are batched:
+//     seeding      -> KernelBackend::seed_batch  (kg_seed_batch,   HIP)
+//     gap closing  -> KernelBackend::nw_batch    (kg_nw_batch,     HIP)
+// everything else here is the reference's per-read control flow restated on the host (chaining,
+// pairing with the EstDistance feedback, mate rescue, report, flags, MAPQ, SAM text), written to
+// reproduce `kart -t 1` byte for byte.  The only KernelBackend in the product is the HIP one
+// (hip_backend.cpp); a CPU backend exists solely under tests/ to exercise this host logic where
+// no GPU is present.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../include/kart_amd.h"
+
+namespace kart {
+
+struct Options {
+	std::string index_prefix;
+	std::vector<std::string> files1, files2;
+	std::string out_name = "output.sam";
+	int threads = 4;          // accepted for CLI compatibility; output is always the -t 1 order
+	int max_gaps = 5;         // -g   (reference src/main.cpp:92)
+	int max_insert = 1500;    // MaxInsertSize (src/main.cpp:96)
+	bool paired = false;      // -p / -f2
+	bool pacbio = false;      // -pacbio
+	bool multi_hit = false;   // -m
+	bool silent = false;      // -silent
+	int device = 0;
+	int sa_mode = KG_SA_FULL;
+	int64_t batch_reads = 400000;   // reads seeded per GPU call (a whole number of 4000-read chunks)
+};
+
+// one fragment pair handed to the gap-closing kernel
+struct NwJob {
+	std::string a, b;     // read fragment, genome fragment (raw characters)
+	std::string ra, rb;   // result: the two gapped strings nw_alignment() would leave in place
+};
+
+struct KernelBackend {
+	virtual ~KernelBackend() {}
+	// index constants the host needs
+	virtual int min_seed_len() const = 0;
+	// IdentifySeedPairs_{Fast,Sensitive}Mode for a batch: enc = concatenated codes, off[n+1]
+	virtual void seed_batch(int mode, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off,
+	                        std::vector<int64_t> &seed_off, std::vector<kg_seed> &seeds) = 0;
+	// nw_alignment for a batch of jobs (fills ra/rb)
+	virtual void nw_batch(std::vector<NwJob> &jobs) = 0;
+};
+
+struct Contig {
+	std::string name;
+	int64_t fwd_start, rev_start, len;
+};
+
+// RestoreReferenceInfo (reference src/bwt_index.cpp:230-259): contigs, ChrLocMap, RefSequence
+struct RefData {
+	int64_t genome_size = 0, two_genome_size = 0;
+	std::vector<Contig> contigs;
+	std::map<int64_t, int> chr_end;     // last coordinate of each strand copy -> contig index
+	std::vector<char> seq;              // 2L + 1, forward then reverse complement
+	bool load(const std::string &prefix, std::string &err);
+};
+
+struct Stats {
+	int64_t total_reads = 0, unmapped = 0, unique = 0, paired = 0, distance = 0;
+};
+
+// Mapping() of the reference: maps every input library and writes SAM to `out`.
+// Returns 0 on success; `summary` receives the reference's end-of-run statistics.
+int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FILE *out, Stats &stats);
+
+int parse_cli(int argc, char **argv, Options &opt);   // reference src/main.cpp:106-190; <0 = exit(code)
+
+}  // namespace kart

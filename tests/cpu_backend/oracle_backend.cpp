@@ -1,0 +1,58 @@
+// tests/cpu_backend/oracle_backend.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Binds the product's HOST pipeline (kart_amd/csrc/host/mapper.cpp, cli.cpp) to the CPU oracle
+// (oracle/liboracle.so) instead of the HIP library, so the host-side control flow (chaining, pairing,
+// rescue, report, SAM text) can be checked against the reference's golden SAM in a container without a
+// GPU.  The resulting binary (tests/_build/kart-host-oracle) is never shipped: the product binary
+// kart_amd/bin/kart-amd links hip_backend.cpp and nothing else.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../kart_amd/csrc/host/mapper.hpp"
+#include "../../oracle/kart_oracle.h"
+
+namespace kart {
+int cli_main(int argc, char **argv, KernelBackend *(*make_backend)(const Options &, std::string &));
+
+class OracleBackend : public KernelBackend {
+public:
+	explicit OracleBackend(ko_index *ix) : ix_(ix) {}
+	~OracleBackend() override { ko_index_free(ix_); }
+	int min_seed_len() const override { return ko_min_seed_len(ix_); }
+	void seed_batch(int mode, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off, std::vector<int64_t> &seed_off,
+	                std::vector<kg_seed> &seeds) override
+	{
+		int64_t n = (int64_t)off.size() - 1;
+		seed_off.assign(off.size(), 0);
+		std::vector<ko_seed> buf((size_t)(64 * n + 65536));
+		int64_t t = ko_seed_batch(ix_, mode, ko_min_seed_len(ix_), enc.data(), off.data(), n, seed_off.data(), buf.data(), (int64_t)buf.size(), 4);
+		if (t < 0) {
+			buf.resize((size_t)(-t));
+			t = ko_seed_batch(ix_, mode, ko_min_seed_len(ix_), enc.data(), off.data(), n, seed_off.data(), buf.data(), (int64_t)buf.size(), 4);
+		}
+		seeds.resize((size_t)t);
+		for (int64_t i = 0; i < t; ++i) { seeds[(size_t)i].gPos = buf[(size_t)i].gPos; seeds[(size_t)i].rPos = buf[(size_t)i].rPos; seeds[(size_t)i].len = buf[(size_t)i].len; }
+	}
+	void nw_batch(std::vector<NwJob> &jobs) override
+	{
+		for (NwJob &j : jobs) {
+			std::vector<char> o1(j.a.size() + j.b.size() + 2), o2(j.a.size() + j.b.size() + 2);
+			int len = ko_nw(j.a.data(), (int)j.a.size(), j.b.data(), (int)j.b.size(), o1.data(), o2.data());
+			j.ra.assign(o1.data(), (size_t)len);
+			j.rb.assign(o2.data(), (size_t)len);
+		}
+	}
+
+private:
+	ko_index *ix_;
+};
+
+static KernelBackend *make_oracle_backend(const Options &opt, std::string &err)
+{
+	ko_index *ix = ko_index_load(opt.index_prefix.c_str());
+	if (!ix) { err = "oracle: cannot load index"; return nullptr; }
+	return new OracleBackend(ix);
+}
+}  // namespace kart
+
+int main(int argc, char **argv) { return kart::cli_main(argc, argv, kart::make_oracle_backend); }
