@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -61,7 +62,23 @@ struct ContigRec {
 
 }  // namespace
 
+// Scratch of one in-flight kg_nw_batch* call.  Cached in the index handle and recycled once the event
+// recorded behind the call's last kernel has completed: steady state allocates nothing, and the
+// device-pointer entry stays asynchronous.  (hipMallocAsync/hipFreeAsync were used first; with calls of
+// varying size on the null stream the recycled pool blocks produced intermittently empty work lists.)
+struct NwScratch {
+	int32_t *lists = nullptr;
+	size_t list_words = 0;
+	unsigned long long *queue = nullptr;
+	uint32_t *dir = nullptr;
+	size_t dir_words = 0;
+	hipEvent_t done = nullptr;
+	bool busy = false;
+};
+
 struct kg_index {
+	std::mutex nw_mu;
+	std::vector<NwScratch *> nw_pool;
 	int device = 0;
 	int n_cu = 256;
 	int sa_mode = KG_SA_SAMPLED;
@@ -252,6 +269,13 @@ void kg_index_destroy(kg_index *ix)
 	if (ix->d_occ) (void)hipFree(ix->d_occ);
 	if (ix->d_planes) (void)hipFree(ix->d_planes);
 	if (ix->d_qtab) (void)hipFree(ix->d_qtab);
+	for (NwScratch *sc : ix->nw_pool) {
+		if (sc->done) { (void)hipEventSynchronize(sc->done); (void)hipEventDestroy(sc->done); }
+		if (sc->lists) (void)hipFree(sc->lists);
+		if (sc->queue) (void)hipFree(sc->queue);
+		if (sc->dir) (void)hipFree(sc->dir);
+		delete sc;
+	}
 	if (ix->d_sa) (void)hipFree(ix->d_sa);
 	if (ix->d_fsa) (void)hipFree(ix->d_fsa);
 	if (ix->d_pac) (void)hipFree(ix->d_pac);
@@ -469,6 +493,71 @@ int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, con
 
 // ---- NW -------------------------------------------------------------------------------------------
 
+static int nw_acquire(kg_index *ix, size_t list_words, size_t dir_words, NwScratch **out)
+{
+	std::lock_guard<std::mutex> lock(ix->nw_mu);
+	NwScratch *pick = nullptr;
+	for (NwScratch *s : ix->nw_pool) {
+		if (s->busy && hipEventQuery(s->done) == hipSuccess) s->busy = false;
+		if (!s->busy && (!pick || (s->list_words >= list_words && s->dir_words >= dir_words))) pick = s;
+	}
+	if (!pick) {
+		pick = new NwScratch();
+		HIP_TRY(hipEventCreateWithFlags(&pick->done, hipEventDisableTiming));
+		HIP_TRY(hipMalloc((void **)&pick->queue, 8 * 4));
+		ix->nw_pool.push_back(pick);
+	}
+	if (pick->list_words < list_words) {
+		if (pick->lists) HIP_TRY(hipFree(pick->lists));
+		pick->lists = nullptr;
+		size_t want = list_words + list_words / 2 + 1024;
+		HIP_TRY(hipMalloc((void **)&pick->lists, want * 4));
+		pick->list_words = want;
+	}
+	if (pick->dir_words < dir_words) {
+		if (pick->dir) HIP_TRY(hipFree(pick->dir));
+		pick->dir = nullptr;
+		HIP_TRY(hipMalloc((void **)&pick->dir, dir_words * 4));
+		pick->dir_words = dir_words;
+	}
+	pick->busy = true;
+	*out = pick;
+	return KG_OK;
+}
+
+// shared launcher: scratch = 3n list words + 4 queue words (+ direction slabs when a pair is longer than 32)
+static int nw_run(kg_index *ix, const char *d_frag1, const int64_t *d_off1, const char *d_frag2, const int64_t *d_off2, int64_t n,
+                  int64_t max_len, uint8_t *d_ops, int32_t *d_aln_len, hipStream_t st)
+{
+	NwArgs a;
+	a.f1 = d_frag1; a.off1 = d_off1; a.f2 = d_frag2; a.off2 = d_off2; a.n = n;
+	a.ops = d_ops; a.aln_len = d_aln_len;
+	a.dir_scratch = nullptr;
+	a.dir_words_per_wave = 0;
+	a.big_waves = 0;
+	a.big_lds_bytes = 0;
+	size_t dir_words = 0;
+	if (max_len > 32) {
+		a.big_lds_bytes = nw_big_lds_bytes((int)max_len);
+		int per_cu = std::max(1, std::min(16, (160 * 1024) / std::max(a.big_lds_bytes, 1024)));
+		int64_t waves = std::min<int64_t>((int64_t)ix->n_cu * per_cu, n);
+		a.dir_words_per_wave = nw_dir_words((int)max_len);
+		while (waves > 1 && waves * a.dir_words_per_wave * 4 > (8ll << 30)) waves /= 2;   // slab pool <= 8 GiB
+		a.big_waves = (int)waves;
+		dir_words = (size_t)(waves * a.dir_words_per_wave);
+	}
+	NwScratch *sc = nullptr;
+	int rc = nw_acquire(ix, 3 * (size_t)n, dir_words, &sc);
+	if (rc != KG_OK) return rc;
+	a.big_list = sc->lists;
+	a.queue = sc->queue;
+	if (dir_words) a.dir_scratch = sc->dir;
+	hipError_t e = launch_nw_batch(a, ix->n_cu, st);
+	hipError_t e2 = hipEventRecord(sc->done, st);
+	if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_nw_batch: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+	return KG_OK;
+}
+
 int kg_nw_batch_device(kg_index *ix, const char *d_frag1, const int64_t *d_off1, const char *d_frag2, const int64_t *d_off2,
                        int64_t n, int64_t max_len, uint8_t *d_ops, int32_t *d_aln_len, void *stream)
 {
@@ -478,38 +567,7 @@ int kg_nw_batch_device(kg_index *ix, const char *d_frag1, const int64_t *d_off1,
 	if (!d_frag1 || !d_off1 || !d_frag2 || !d_off2 || !d_ops || !d_aln_len) return fail(KG_ERR_ARG, "kg_nw_batch_device: null buffer");
 	if (max_len > kNwMaxLen) return fail(KG_ERR_ARG, "kg_nw_batch_device: fragment of %lld bases exceeds the supported %d", (long long)max_len, kNwMaxLen);
 	HIP_TRY(hipSetDevice(ix->device));
-	hipStream_t st = (hipStream_t)stream;
-	NwArgs a;
-	a.f1 = d_frag1; a.off1 = d_off1; a.f2 = d_frag2; a.off2 = d_off2; a.n = n;
-	a.ops = d_ops; a.aln_len = d_aln_len;
-	// per-call scratch (stream-ordered allocation keeps the call asynchronous)
-	int32_t *lists = nullptr;
-	unsigned long long *queue = nullptr;
-	uint32_t *dir = nullptr;
-	HIP_TRY(hipMallocAsync((void **)&lists, 4 * 3 * (size_t)n, st));
-	HIP_TRY(hipMallocAsync((void **)&queue, 8 * 4, st));
-	a.big_list = lists;
-	a.queue = queue;
-	a.dir_scratch = nullptr;
-	a.dir_words_per_wave = 0;
-	a.big_waves = 0;
-	a.big_lds_bytes = 0;
-	if (max_len > 32) {
-		a.big_lds_bytes = nw_big_lds_bytes((int)max_len);
-		int per_cu = std::max(1, std::min(16, (160 * 1024) / std::max(a.big_lds_bytes, 1024)));
-		int64_t waves = std::min<int64_t>((int64_t)ix->n_cu * per_cu, n);
-		a.dir_words_per_wave = nw_dir_words((int)max_len);
-		// bound the slab pool to 8 GiB
-		while (waves > 1 && waves * a.dir_words_per_wave * 4 > (8ll << 30)) waves /= 2;
-		a.big_waves = (int)waves;
-		HIP_TRY(hipMallocAsync((void **)&dir, (size_t)(waves * a.dir_words_per_wave) * 4, st));
-		a.dir_scratch = dir;
-	}
-	HIP_TRY(launch_nw_batch(a, ix->n_cu, st));
-	HIP_TRY(hipFreeAsync(lists, st));
-	HIP_TRY(hipFreeAsync(queue, st));
-	if (dir) HIP_TRY(hipFreeAsync(dir, st));
-	return KG_OK;
+	return nw_run(ix, d_frag1, d_off1, d_frag2, d_off2, n, max_len, d_ops, d_aln_len, (hipStream_t)stream);
 }
 
 int kg_nw_batch(kg_index *ix, const char *frag1, const int64_t *off1, const char *frag2, const int64_t *off2, int64_t n,
@@ -542,7 +600,8 @@ int kg_nw_batch(kg_index *ix, const char *frag1, const int64_t *off1, const char
 	HIP_TRY(hipMemcpy(d2, frag2, (size_t)b2, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(do1, off1, 8 * (size_t)(n + 1), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(do2, off2, 8 * (size_t)(n + 1), hipMemcpyHostToDevice));
-	int rc = kg_nw_batch_device(ix, d1, do1, d2, do2, n, max_len, dops, dlen, st);
+	if (max_len > kNwMaxLen) return fail(KG_ERR_ARG, "kg_nw_batch: fragment of %lld bases exceeds the supported %d", (long long)max_len, kNwMaxLen);
+	int rc = nw_run(ix, d1, do1, d2, do2, n, max_len, dops, dlen, st);
 	if (rc == KG_OK) {
 		hipError_t e = hipDeviceSynchronize();
 		if (e == hipSuccess) e = hipMemcpy(ops, dops, (size_t)(b1 + b2), hipMemcpyDeviceToHost);

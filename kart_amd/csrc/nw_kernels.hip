@@ -46,6 +46,13 @@ __device__ __forceinline__ void append(bool want, unsigned long long *count, int
 	if (want) list[base + lane_rank_nw(mask)] = value;
 }
 
+// counter reset as a kernel: same-queue kernel->kernel ordering is what every later launch relies on anyway
+// (a hipMemsetAsync of freshly pool-allocated words was observed to land after the classify kernel)
+__global__ void nw_reset_kernel(unsigned long long *queue)
+{
+	if (threadIdx.x < 4) queue[threadIdx.x] = 0;
+}
+
 // queue words: [0..2] list sizes of the three classes, [3] class-2 work queue head
 __global__ __launch_bounds__(256) void nw_classify_kernel(NwArgs a)
 {
@@ -292,10 +299,14 @@ hipError_t launch_nw_batch(const NwArgs &a, int n_cu, hipStream_t stream)
 {
 	if (a.n <= 0) return hipSuccess;
 	hipError_t e;
-	if ((e = hipMemsetAsync(a.queue, 0, sizeof(unsigned long long) * 4, stream)) != hipSuccess) return e;
+	hipLaunchKernelGGL(nw_reset_kernel, dim3(1), dim3(64), 0, stream, a.queue);
+	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL(nw_classify_kernel, dim3(grid_for_nw(a.n, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL(nw_small8_kernel, dim3(grid_for_nw(a.n, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL(nw_small32_kernel, dim3(grid_for_nw(a.n, 256, n_cu * 2)), dim3(256), 0, stream, a);
+	if ((e = hipGetLastError()) != hipSuccess) return e;
 	if (a.dir_scratch && a.big_waves > 0) {
 		if (a.big_lds_bytes > 48 * 1024 &&
 		    (e = hipFuncSetAttribute(reinterpret_cast<const void *>(nw_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, a.big_lds_bytes)) != hipSuccess)

@@ -500,6 +500,11 @@ __global__ __launch_bounds__(256) void build_qtab_kernel(FmView ix, uint2 *t32, 
 	}
 }
 
+__global__ void seed_reset_kernel(unsigned long long *ctl)
+{
+	if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0;
+}
+
 static inline int grid_for(int64_t items, int block, int max_blocks)
 {
 	int64_t g = (items + block - 1) / block;
@@ -544,7 +549,8 @@ hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_tem
 	if (a.n_reads <= 0) return hipSuccess;
 	hipError_t e;
 	// queue heads, hit count and counters are zeroed on the stream every call
-	if ((e = hipMemsetAsync(a.read_queue, 0, sizeof(unsigned long long) * kCtlWords, stream)) != hipSuccess) return e;
+	hipLaunchKernelGGL(seed_reset_kernel, dim3(1), dim3(64), 0, stream, a.read_queue);
+	if ((e = hipGetLastError()) != hipSuccess) return e;
 	// persistent lanes: 8 blocks of 256 threads per CU (= 32 waves/CU) unless the batch is smaller
 	int per_cu = 8;
 	if (const char *env = getenv("KG_SEARCH_BLOCKS_PER_CU")) per_cu = atoi(env) > 0 ? atoi(env) : 8;  // tuning knob
