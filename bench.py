@@ -100,7 +100,7 @@ def main():
         entry.build()
     if world > 1:
         dist.barrier()
-    from kart_amd import api, index_build, synth
+    from kart_amd import api, index_build, shard, synth
 
     # ---- index (built once by rank 0, replicated per GPU) ------------------------------------------
     workdir = os.environ.get("KART_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "kart_bench_%d" % os.getuid())
@@ -173,12 +173,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     cnt = ws.counters()
-    totals = torch.tensor([n_reads * args.steps, int(cnt.seeds)], dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(totals)                      # the path's only collective: counters
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    totals = shard.allreduce_counters([n_reads * args.steps, int(cnt.seeds)], device=dev)   # the path's only collective
+    elapsed = shard.max_over_ranks(elapsed, device=dev)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -190,7 +186,7 @@ def main():
     search_bytes = 64 * (c["lf1"] + 2 * c["lf2"]) + c["bases"]            # search kernel's share of bytes_seed
     locate_bytes = 64 * c["inv"] + 8 * c["sa"] + 16 * c["seeds"]
     achieved = search_bytes / (search_ms * 1e-3) / 1e9
-    value = float(totals[0].item()) / elapsed
+    value = float(totals[0]) / elapsed
     traffic, traffic_src = measured_traffic(n_reads, args)
     line = {
         "metric": "mapped reads/sec (whole node), 150 bp PE",
