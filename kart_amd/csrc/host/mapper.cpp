@@ -10,8 +10,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
+#include <climits>
 #include <cstring>
 #include <ctime>
+#include <functional>
+#include <thread>
 
 namespace kart {
 
@@ -112,8 +116,17 @@ struct Ctx {
 	KernelBackend &kern;
 	int min_seed_len;
 	bool fastq = true;
-	int64_t iPaired = 0, iDistance = 0;   // src/Mapping.cpp:13,20
 	const char *refseq() const { return ref.seq.data(); }
+};
+
+// What one 4000-read chunk contributes to the run-wide pairing statistics (iPaired / iDistance,
+// src/Mapping.cpp:13,20,209-213), and for which EstDistance values its pairing decisions hold.
+struct PairStats {
+	int64_t paired = 0, distance = 0;
+	// every "dist < EstiDistance" test of CheckPairedAlignmentCandidates (:372) narrows the interval
+	// (lo, hi] of EstDistance values that would have produced the same outcome
+	int64_t lo = -1, hi = INT64_MAX;
+	bool rescue_used = false;      // rescue windows depend on min(EstDistance, MaxInsertSize)
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -881,7 +894,7 @@ void remove_redundant(const Ctx &cx, std::vector<Candidate> &v)  // RemoveRedund
 		if (v[i].score < thr) v[i].score = 0;
 }
 
-bool pair_candidates(const Ctx &cx, int64_t est, std::vector<Candidate> &v1, std::vector<Candidate> &v2)  // CheckPairedAlignmentCandidates, :348-400
+bool pair_candidates(const Ctx &cx, int64_t est, std::vector<Candidate> &v1, std::vector<Candidate> &v2, PairStats &ps)  // CheckPairedAlignmentCandidates, :348-400
 {
 	bool pairing = false;
 	int n1 = (int)v1.size(), n2 = (int)v2.size();
@@ -892,6 +905,7 @@ bool pair_candidates(const Ctx &cx, int64_t est, std::vector<Candidate> &v1, std
 		for (int j = 0; j < n2; ++j) {
 			if (v2[j].score == 0 || v2[j].posDiff < v1[i].posDiff) continue;
 			int64_t dist = v2[j].posDiff - v1[i].posDiff;
+			if (dist < est) { if (dist > ps.lo) ps.lo = dist; } else if (dist < ps.hi) ps.hi = dist;
 			if (dist < est) {
 				if (v2[j].score > s) { best = j; s = v2[j].score; }
 				else if (v2[j].score == s) best = -1;
@@ -1176,7 +1190,7 @@ void sam_mapped(const Ctx &cx, const Read &rd, const Report &rp, bool has_mate, 
 }
 
 // OutputPairedAlignments, src/Mapping.cpp:177-270.  Mate 2 is held reverse-complemented (App. B-2).
-void output_pair(Ctx &cx, const Read &r1, const Read &r2, Stats &st, std::string &out)
+void output_pair(const Ctx &cx, const Read &r1, const Read &r2, Stats &st, PairStats &ps, std::string &out)
 {
 	if (r1.score == 0) { st.unmapped++; sam_unmapped(cx, r1, out); }
 	else {
@@ -1195,8 +1209,8 @@ void output_pair(Ctx &cx, const Read &r1, const Read &r2, Stats &st, std::string
 				if (j != -1 && r2.rep[(size_t)j].score > 0) {
 					int dist = (int)(r2.rep[(size_t)j].gPos - rp.gPos + (rp.fwd ? r2.rlen : 0 - r1.rlen));
 					if (i == r1.best) {
-						cx.iPaired += 2;
-						if (abs(dist) < 10000) cx.iDistance += abs(dist);
+						ps.paired += 2;
+						if (abs(dist) < 10000) ps.distance += abs(dist);
 					}
 					sam_mapped(cx, r1, rp, true, (long long)r2.rep[(size_t)j].gPos, dist, rp.fwd ? r1.seq : rseq, rp.fwd ? r1.qual : rqual, out);
 				} else sam_mapped(cx, r1, rp, false, 0, 0, rp.fwd ? r1.seq : rseq, rp.fwd ? r1.qual : rqual, out);
@@ -1228,7 +1242,7 @@ void output_pair(Ctx &cx, const Read &r1, const Read &r2, Stats &st, std::string
 	}
 }
 
-void output_single(Ctx &cx, const Read &rd, Stats &st, std::string &out)  // OutputSingledAlignments, src/Mapping.cpp:272-315
+void output_single(const Ctx &cx, const Read &rd, Stats &st, std::string &out)  // OutputSingledAlignments, src/Mapping.cpp:272-315
 {
 	if (rd.score == 0) { st.unmapped++; sam_unmapped(cx, rd, out); return; }
 	if (rd.mapq == 60) st.unique++;
@@ -1377,109 +1391,204 @@ bool is_fastq(const std::string &path)  // CheckReadFormat, src/GetData.cpp:8-16
 // ----------------------------------------------------------------------------------------------
 // one library: batches of chunks (ReadMapping, src/Mapping.cpp:488-637)
 // ----------------------------------------------------------------------------------------------
-struct Chunk {
-	int begin, count;   // slice of the batch's read vector
+// The reference is only deterministic at -t 1, where chunk k sees EstDistance computed from the final
+// alignments of chunks < k (:533-540).  To run chunks concurrently and still write exactly that output,
+// every chunk is mapped with a SPECULATED EstDistance (the latest committed value) and records the
+// interval of values for which its decisions hold; a commit step walks the chunks in input order,
+// derives the true value from the committed totals and re-runs the (rare) chunk that falls outside.
+struct ChunkState {
+	int begin = 0, count = 0;
+	bool paired = false;
+	int est_used = 0;
+	PairStats ps;
+	Stats st;
+	std::vector<std::vector<Candidate>> cands;
+	std::vector<std::vector<CandWork>> work;
+	std::vector<NwJob> jobs;
+	std::string text;
 };
 
-void map_library(Ctx &cx, bool sep, Input &in1, Input &in2, FILE *out, Stats &st)
+void parallel_for(int n_threads, int n_items, const std::function<void(int)> &fn)
+{
+	if (n_items <= 0) return;
+	if (n_threads <= 1 || n_items == 1) {
+		for (int i = 0; i < n_items; ++i) fn(i);
+		return;
+	}
+	std::atomic<int> next(0);
+	std::vector<std::thread> pool;
+	int nt = std::min(n_threads, n_items);
+	for (int t = 0; t < nt; ++t)
+		pool.emplace_back([&]() {
+			for (int i; (i = next.fetch_add(1)) < n_items;) fn(i);
+		});
+	for (std::thread &th : pool) th.join();
+}
+
+int est_distance(const Ctx &cx, int64_t iPaired, int64_t iDistance)  // src/Mapping.cpp:534-539
+{
+	if (iPaired < 1000) return cx.opt.max_insert;
+	int est = (int)(iDistance / (iPaired >> 2));
+	return est + (est >> 1);
+}
+
+// stage A: chaining, pairing, rescue, filters, report pass 1 (collects the chunk's NW jobs)
+void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<int64_t> &seed_off, const std::vector<kg_seed> &seeds,
+                   ChunkState &ck, int est)
+{
+	ck.est_used = est;
+	ck.ps = PairStats();
+	ck.st = Stats();
+	ck.cands.assign((size_t)ck.count, std::vector<Candidate>());
+	ck.work.assign((size_t)ck.count, std::vector<CandWork>());
+	ck.jobs.clear();
+	for (int q = 0; q < ck.count; ++q) {
+		size_t ri = (size_t)(ck.begin + q);
+		const kg_seed *s = seeds.data() + seed_off[ri];
+		int ns = (int)(seed_off[ri + 1] - seed_off[ri]);
+		if (cx.opt.pacbio) chain_pacbio(s, ns, ck.cands[(size_t)q]);
+		else chain_illumina(cx, reads[ri].rlen, s, ns, ck.cands[(size_t)q]);
+	}
+	if (ck.paired) {
+		for (int q = 0; q < ck.count; q += 2) {
+			std::vector<Candidate> &v1 = ck.cands[(size_t)q], &v2 = ck.cands[(size_t)q + 1];
+			Read &r1 = reads[(size_t)(ck.begin + q)], &r2 = reads[(size_t)(ck.begin + q + 1)];
+			bool pairing = pair_candidates(cx, est, v1, v2, ck.ps);
+			if (!pairing) {
+				ck.ps.rescue_used = true;
+				pairing = rescue_unpaired(cx, est, r1, r2, v1, v2);
+			}
+			if (pairing) remove_unmated(v1, v2);
+			remove_redundant(cx, v1);
+			remove_redundant(cx, v2);
+		}
+	} else {
+		for (int q = 0; q < ck.count; ++q) remove_redundant(cx, ck.cands[(size_t)q]);
+	}
+	for (int q = 0; q < ck.count; ++q) report_plan(cx, reads[(size_t)(ck.begin + q)], ck.cands[(size_t)q], ck.work[(size_t)q], ck.jobs);
+}
+
+// stage C: report pass 2, final pair check, flags, MAPQ, SAM text
+void chunk_stage_c(const Ctx &cx, std::vector<Read> &reads, ChunkState &ck)
+{
+	for (int q = 0; q < ck.count; ++q) {
+		bool first = ck.paired ? (q % 2 == 0) : true;
+		report_finish(cx, first, reads[(size_t)(ck.begin + q)], ck.cands[(size_t)q], ck.work[(size_t)q], ck.jobs);
+	}
+	ck.text.clear();
+	if (ck.paired) {
+		for (int q = 0; q < ck.count; q += 2) {
+			Read &r1 = reads[(size_t)(ck.begin + q)], &r2 = reads[(size_t)(ck.begin + q + 1)];
+			check_final_pair(cx, r1, r2);
+			set_paired_flags(r1, r2);
+			evaluate_mapq(cx, r1);
+			evaluate_mapq(cx, r2);
+		}
+		for (int q = 0; q < ck.count; q += 2)
+			output_pair(cx, reads[(size_t)(ck.begin + q)], reads[(size_t)(ck.begin + q + 1)], ck.st, ck.ps, ck.text);
+	} else {
+		for (int q = 0; q < ck.count; ++q) {
+			Read &rd = reads[(size_t)(ck.begin + q)];
+			set_single_flag(rd);
+			evaluate_mapq(cx, rd);
+		}
+		for (int q = 0; q < ck.count; ++q) output_single(cx, reads[(size_t)(ck.begin + q)], ck.st, ck.text);
+	}
+	ck.st.total_reads = ck.count;
+	ck.cands.clear(); ck.work.clear();
+}
+
+// one NW kernel call for the jobs of many chunks
+void run_nw(const Ctx &cx, std::vector<ChunkState> &chunks, size_t from, size_t to)
+{
+	std::vector<NwJob> all;
+	size_t total = 0;
+	for (size_t c = from; c < to; ++c) total += chunks[c].jobs.size();
+	if (total == 0) return;
+	all.reserve(total);
+	for (size_t c = from; c < to; ++c)
+		for (NwJob &j : chunks[c].jobs) all.push_back(std::move(j));
+	cx.kern.nw_batch(all);
+	size_t at = 0;
+	for (size_t c = from; c < to; ++c)
+		for (NwJob &j : chunks[c].jobs) j = std::move(all[at++]);
+}
+
+struct RunTotals {
+	int64_t iPaired = 0, iDistance = 0;   // src/Mapping.cpp:13,20
+};
+
+void map_library(Ctx &cx, bool sep, Input &in1, Input &in2, FILE *out, Stats &st, RunTotals &tot)
 {
 	const int chunk_limit = cx.opt.pacbio ? 10 : 4000;   // ReadChunkSize, src/structure.h:21; src/GetData.cpp:140
 	const int mode = cx.opt.pacbio ? KG_MODE_SENSITIVE : KG_MODE_FAST;
+	const int nthreads = std::max(1, cx.opt.threads);
 	std::vector<Read> reads;
-	std::vector<Chunk> chunks;
+	std::vector<ChunkState> chunks;
 	std::vector<uint8_t> enc;
 	std::vector<int64_t> off, seed_off;
 	std::vector<kg_seed> seeds;
-	std::string text;
 	bool eof = false;
+	// small batches first: the estimate moves fastest while the totals are small
+	int64_t batch_chunks = 1;
+	const int64_t max_batch_chunks = std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit);
 	while (!eof) {
 		// ---- read a batch of whole chunks and seed it in one kernel call ------------------------------
 		reads.clear(); chunks.clear();
-		int64_t batch_bases = 0;
-		while ((int64_t)reads.size() < cx.opt.batch_reads && batch_bases < (int64_t)cx.opt.batch_reads * 256) {
-			Chunk ck;
+		while ((int64_t)chunks.size() < batch_chunks) {
+			ChunkState ck;
 			ck.begin = (int)reads.size();
 			ck.count = next_chunk(cx, sep, in1, in2, reads, chunk_limit);
-			reads.resize((size_t)(ck.begin + ck.count));
 			if (ck.count == 0) { eof = true; break; }
-			chunks.push_back(ck);
-			for (int i = ck.begin; i < ck.begin + ck.count; ++i) batch_bases += reads[(size_t)i].rlen;
-			if (ck.count < chunk_limit && !cx.opt.pacbio) { /* short chunk = end of input on the next call */ }
+			ck.paired = cx.opt.paired && ck.count % 2 == 0 && !cx.opt.pacbio;
+			chunks.push_back(std::move(ck));
 		}
 		if (reads.empty()) break;
-		enc.clear(); off.assign(1, 0);
-		for (size_t i = 0; i < reads.size(); ++i) {
-			const Read &rd = reads[i];
-			// EnCodeReadSeq (src/Mapping.cpp:482-485).  The reference encodes mate 2 with mate 1's length
-			// (:550, App. B-5); with equal-length mates that is the same thing, otherwise it reads or
-			// leaves uninitialised bytes -- here every read is encoded over its own length.
-			for (int p = 0; p < rd.rlen; ++p) enc.push_back((uint8_t)nt4((unsigned char)rd.seq[(size_t)p]));
-			off.push_back((int64_t)enc.size());
-		}
+		batch_chunks = std::min(max_batch_chunks, batch_chunks * 2);
+		// EnCodeReadSeq (src/Mapping.cpp:482-485).  The reference encodes mate 2 with mate 1's length (:550,
+		// App. B-5); with equal-length mates that is the same thing, otherwise it reads or leaves
+		// uninitialised bytes -- here every read is encoded over its own length.
+		off.assign(reads.size() + 1, 0);
+		for (size_t i = 0; i < reads.size(); ++i) off[i + 1] = off[i] + reads[i].rlen;
+		enc.resize((size_t)off[reads.size()]);
+		parallel_for(nthreads, (int)((reads.size() + 4095) / 4096), [&](int blk) {
+			size_t lo = (size_t)blk * 4096, hi = std::min(reads.size(), lo + 4096);
+			for (size_t i = lo; i < hi; ++i) {
+				uint8_t *dst = enc.data() + off[i];
+				const std::string &sq = reads[i].seq;
+				for (int p = 0; p < reads[i].rlen; ++p) dst[p] = (uint8_t)nt4((unsigned char)sq[(size_t)p]);
+			}
+		});
 		cx.kern.seed_batch(mode, enc, off, seed_off, seeds);
 
-		// ---- chunks strictly in input order: EstDistance feeds forward (src/Mapping.cpp:533-540) ---------
-		std::vector<std::vector<Candidate>> cands;
-		std::vector<std::vector<CandWork>> work;
-		std::vector<NwJob> jobs;
+		// ---- speculative pass over all chunks of the batch ---------------------------------------------
+		int est_guess = est_distance(cx, tot.iPaired, tot.iDistance);
+		parallel_for(nthreads, (int)chunks.size(), [&](int c) { chunk_stage_a(cx, reads, seed_off, seeds, chunks[(size_t)c], est_guess); });
+		run_nw(cx, chunks, 0, chunks.size());
+		parallel_for(nthreads, (int)chunks.size(), [&](int c) { chunk_stage_c(cx, reads, chunks[(size_t)c]); });
+
+		// ---- in-order commit: EstDistance feeds forward (src/Mapping.cpp:533-540) ---------------------------
 		for (size_t c = 0; c < chunks.size(); ++c) {
-			const Chunk &ck = chunks[c];
-			bool paired = cx.opt.paired && ck.count % 2 == 0 && !cx.opt.pacbio;
-			cands.assign((size_t)ck.count, std::vector<Candidate>());
-			work.assign((size_t)ck.count, std::vector<CandWork>());
-			jobs.clear();
-			int est = cx.opt.max_insert;
-			if (paired && cx.iPaired >= 1000) {
-				est = (int)(cx.iDistance / (cx.iPaired >> 2));
-				est = est + (est >> 1);
-			}
-			for (int q = 0; q < ck.count; ++q) {
-				size_t ri = (size_t)(ck.begin + q);
-				const kg_seed *s = seeds.data() + seed_off[ri];
-				int ns = (int)(seed_off[ri + 1] - seed_off[ri]);
-				if (cx.opt.pacbio) chain_pacbio(s, ns, cands[(size_t)q]);
-				else chain_illumina(cx, reads[ri].rlen, s, ns, cands[(size_t)q]);
-			}
-			if (paired) {
-				for (int q = 0; q < ck.count; q += 2) {
-					std::vector<Candidate> &v1 = cands[(size_t)q], &v2 = cands[(size_t)q + 1];
-					Read &r1 = reads[(size_t)(ck.begin + q)], &r2 = reads[(size_t)(ck.begin + q + 1)];
-					bool pairing = pair_candidates(cx, est, v1, v2);
-					if (!pairing) pairing = rescue_unpaired(cx, est, r1, r2, v1, v2);
-					if (pairing) remove_unmated(v1, v2);
-					remove_redundant(cx, v1);
-					remove_redundant(cx, v2);
+			ChunkState &ck = chunks[c];
+			if (ck.paired) {
+				int est_true = est_distance(cx, tot.iPaired, tot.iDistance);
+				bool valid = est_true == ck.est_used ||
+				             (ck.ps.lo < est_true && est_true <= ck.ps.hi &&
+				              (!ck.ps.rescue_used || std::min(est_true, cx.opt.max_insert) == std::min(ck.est_used, cx.opt.max_insert)));
+				if (!valid) {   // mapped under an estimate that would have decided differently: redo with the true one
+					st.respeculated++;
+					chunk_stage_a(cx, reads, seed_off, seeds, ck, est_true);
+					run_nw(cx, chunks, c, c + 1);
+					chunk_stage_c(cx, reads, ck);
 				}
-			} else {
-				for (int q = 0; q < ck.count; ++q) remove_redundant(cx, cands[(size_t)q]);
 			}
-			// report pass 1 -> one NW batch for the whole chunk -> report pass 2
-			for (int q = 0; q < ck.count; ++q) report_plan(cx, reads[(size_t)(ck.begin + q)], cands[(size_t)q], work[(size_t)q], jobs);
-			if (!jobs.empty()) cx.kern.nw_batch(jobs);
-			for (int q = 0; q < ck.count; ++q) {
-				bool first = paired ? (q % 2 == 0) : true;
-				report_finish(cx, first, reads[(size_t)(ck.begin + q)], cands[(size_t)q], work[(size_t)q], jobs);
-			}
-			text.clear();
-			if (paired) {
-				for (int q = 0; q < ck.count; q += 2) {
-					Read &r1 = reads[(size_t)(ck.begin + q)], &r2 = reads[(size_t)(ck.begin + q + 1)];
-					check_final_pair(cx, r1, r2);
-					set_paired_flags(r1, r2);
-					evaluate_mapq(cx, r1);
-					evaluate_mapq(cx, r2);
-				}
-				for (int q = 0; q < ck.count; q += 2) output_pair(cx, reads[(size_t)(ck.begin + q)], reads[(size_t)(ck.begin + q + 1)], st, text);
-			} else {
-				for (int q = 0; q < ck.count; ++q) {
-					Read &rd = reads[(size_t)(ck.begin + q)];
-					set_single_flag(rd);
-					evaluate_mapq(cx, rd);
-				}
-				for (int q = 0; q < ck.count; ++q) output_single(cx, reads[(size_t)(ck.begin + q)], st, text);
-			}
-			st.total_reads += ck.count;
-			fwrite(text.data(), 1, text.size(), out);
+			fwrite(ck.text.data(), 1, ck.text.size(), out);
+			tot.iPaired += ck.ps.paired;
+			tot.iDistance += ck.ps.distance;
+			st.total_reads += ck.st.total_reads;
+			st.unmapped += ck.st.unmapped;
+			st.unique += ck.st.unique;
+			std::string().swap(ck.text);
 		}
 	}
 }
@@ -1535,6 +1644,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 {
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	Options &o = const_cast<Options &>(opt);
+	RunTotals tot;
 	// header: @PG first, then @SQ, no @HD (src/Mapping.cpp:664-675)
 	fprintf(out, "@PG\tID:kart\tPN:Kart\tVN:%s\n", "2.5.6");
 	for (size_t i = 0; i < ref.contigs.size(); ++i) fprintf(out, "@SQ\tSN:%s\tLN:%lld\n", ref.contigs[i].name.c_str(), (long long)ref.contigs[i].len);
@@ -1557,10 +1667,10 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		}
 		if (!in1.fp && !in1.gz) continue;
 		if (sep && !in2.fp && !in2.gz) continue;
-		map_library(cx, sep, in1, in2, out, stats);
+		map_library(cx, sep, in1, in2, out, stats, tot);
 	}
-	stats.paired = cx.iPaired;
-	stats.distance = cx.iDistance;
+	stats.paired = tot.iPaired;
+	stats.distance = tot.iDistance;
 	return 0;
 }
 

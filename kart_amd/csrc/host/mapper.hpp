@@ -70,6 +70,7 @@ struct RefData {
 
 struct Stats {
 	int64_t total_reads = 0, unmapped = 0, unique = 0, paired = 0, distance = 0;
+	int64_t respeculated = 0;   // chunks re-mapped because their speculated EstDistance did not hold
 };
 
 // Mapping() of the reference: maps every input library and writes SAM to `out`.

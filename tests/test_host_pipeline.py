@@ -63,3 +63,28 @@ def test_summary_statistics(host_oracle_binary, tmp_path):
     _, _, log = run_case(host_oracle_binary, "pe", str(tmp_path))
     assert "All the 9000 paired-end reads have been processed" in log
     assert "# of total mapped sequences" in log and "average insert size" in log
+
+
+@pytest.mark.parametrize("ins_mean,threads", [(250, 8), (500, 3)])
+def test_speculative_chunks_match_live_reference(ins_mean, threads, host_oracle_binary, tmp_path):
+    """30 chunks mapped concurrently under a speculated EstDistance must commit to exactly the -t 1 output
+    (short inserts keep the estimate below MaxInsertSize and moving, so rescue windows and pairing tests
+    depend on it).  Needs the unmodified reference binary (oracle/_ref/kart), i.e. runs where it was built."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "kart")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/kart not present")
+    from kart_amd import synth
+    from kart_amd.index_build import read_fasta
+    genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
+    names, r1, r2 = synth.simulate_pairs(genome, 60000, seed=900 + ins_mean, err=0.02, mut=0.002, indel_frac=0.3,
+                                         ins_mean=float(ins_mean), ins_sd=ins_mean / 8.0)
+    f1, f2 = str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")
+    synth.write_fastq(f1, names, r1, mate=1)
+    synth.write_fastq(f2, names, r2, mate=2)
+    outs = []
+    for binary, extra in ((ref_bin, ["-t", "1"]), (host_oracle_binary, ["-t", str(threads)])):
+        out = str(tmp_path / (os.path.basename(binary) + ".sam"))
+        subprocess.run([binary, "-silent", "-i", SMALL_PREFIX, "-f", f1, "-f2", f2, "-o", out] + extra, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]

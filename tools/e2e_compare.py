@@ -19,7 +19,8 @@ def run(tag, cmd):
     t = time.time(); subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); dt = time.time() - t
     res[tag] = {"seconds": round(dt, 2), "reads_per_s": round(2 * n_pairs / dt)}
 common = ["-silent", "-i", os.path.join(d, "idx"), "-f", f1, "-f2", f2]
-run("kart_amd", ["kart_amd/bin/kart-amd"] + common + ["-o", os.path.join(d, "amd.sam")])
+for t_ in (1, 8, 32, 64):
+    run("kart_amd_t%d" % t_, ["kart_amd/bin/kart-amd"] + common + ["-t", str(t_), "-o", os.path.join(d, "amd.sam")])
 ref = "oracle/_ref/kart"
 if os.path.exists(ref):
     run("ref_t1", [ref] + common + ["-t", "1", "-o", os.path.join(d, "ref1.sam")])
