@@ -5,6 +5,10 @@
 // has undefined behaviour the choice made here is stated next to the code.
 #include "mapper.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -15,6 +19,7 @@
 #include <cstring>
 #include <ctime>
 #include <functional>
+#include <future>
 #include <thread>
 
 namespace kart {
@@ -1378,6 +1383,96 @@ int next_chunk(const Ctx &cx, bool sep, Input &in1, Input &in2, std::vector<Read
 	return count;
 }
 
+// ---- fast path for plain FASTQ: the file is mapped, record boundaries are found with memchr by one
+// thread (exactly the line structure GetNextEntry walks with four getline() calls), and the reads are
+// materialised (copies, mate-2 reverse complement) by the worker threads.
+struct MappedFile {
+	const char *data = nullptr;
+	size_t size = 0, pos = 0;
+	~MappedFile() { if (data) munmap(const_cast<char *>(data), size); }
+	bool open(const std::string &path)
+	{
+		int fd = ::open(path.c_str(), O_RDONLY);
+		if (fd < 0) return false;
+		struct stat sb;
+		if (fstat(fd, &sb) != 0 || sb.st_size == 0) { ::close(fd); return false; }
+		void *p = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+		::close(fd);
+		if (p == MAP_FAILED) return false;
+		madvise(p, (size_t)sb.st_size, MADV_SEQUENTIAL);
+		data = (const char *)p;
+		size = (size_t)sb.st_size;
+		return true;
+	}
+	// getline(): returns the line length including the newline when there is one, -1 at end of file
+	ssize_t line(const char *&start)
+	{
+		if (pos >= size) return -1;
+		start = data + pos;
+		const char *nl = (const char *)memchr(start, '\n', size - pos);
+		size_t len = nl ? (size_t)(nl - start) + 1 : size - pos;
+		pos += len;
+		return (ssize_t)len;
+	}
+};
+
+struct RecView {
+	const char *hdr, *seq, *qual;
+	int hdr_len, rlen, qual_len;
+	bool flip;    // mate 2 of a pair: stored reverse-complemented (src/GetData.cpp:125-135)
+};
+
+// GetNextEntry on a mapped FASTQ (same arithmetic as next_entry_plain)
+bool view_next(MappedFile &f, RecView &v)
+{
+	const char *p;
+	ssize_t len = f.line(p);
+	if (len == -1) return false;
+	v.hdr = p; v.hdr_len = (int)len;
+	ssize_t sl = f.line(p);
+	if (sl == -1) { v.rlen = 0; v.seq = v.qual = nullptr; v.qual_len = 0; return true; }
+	v.seq = p; v.rlen = (int)sl - 1;
+	f.line(p);
+	ssize_t ql = f.line(p);
+	v.qual = p; v.qual_len = ql < 0 ? 0 : (int)ql;
+	return true;
+}
+
+void materialise(const RecView &v, Read &rd)
+{
+	rd = Read();
+	header_of(v.hdr, v.hdr_len, rd.name);
+	rd.rlen = v.rlen;
+	rd.seq.assign(v.seq, (size_t)v.rlen);
+	int ql = std::min(v.qual_len, v.rlen);
+	const char *z = ql > 0 ? (const char *)memchr(v.qual, '\0', (size_t)ql) : nullptr;
+	rd.qual.assign(v.qual ? v.qual : "", (size_t)(z ? z - v.qual : ql));
+	if (v.flip) {
+		rd.seq = revcomp(rd.seq);
+		std::reverse(rd.qual.begin(), rd.qual.end());
+	}
+}
+
+// GetNextChunk over mapped files: the same loop as next_chunk(), producing views
+int next_chunk_views(const Ctx &cx, bool sep, MappedFile &f1, MappedFile &f2, std::vector<RecView> &views, int limit)
+{
+	int count = 0;
+	RecView v;
+	while (true) {
+		if (!view_next(f1, v) || v.rlen == 0) break;
+		v.flip = false;
+		views.push_back(v);
+		count++;
+		bool ok = sep ? view_next(f2, v) : view_next(f1, v);
+		if (!ok || v.rlen == 0) break;
+		v.flip = cx.opt.paired;
+		views.push_back(v);
+		count++;
+		if (count == limit) break;
+	}
+	return count;
+}
+
 bool is_fastq(const std::string &path)  // CheckReadFormat, src/GetData.cpp:8-16
 {
 	gzFile f = gzopen(path.c_str(), "rb");
@@ -1516,35 +1611,77 @@ void run_nw(const Ctx &cx, std::vector<ChunkState> &chunks, size_t from, size_t 
 
 struct RunTotals {
 	int64_t iPaired = 0, iDistance = 0;   // src/Mapping.cpp:13,20
+	double t_read = 0, t_encode = 0, t_seed = 0, t_a = 0, t_nw = 0, t_c = 0, t_commit = 0;   // KART_AMD_VERBOSE stage timers
 };
 
-void map_library(Ctx &cx, bool sep, Input &in1, Input &in2, FILE *out, Stats &st, RunTotals &tot)
+double now_s()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+struct Batch {
+	std::vector<Read> reads;
+	std::vector<ChunkState> chunks;
+	bool eof = false;
+	double seconds = 0;
+};
+
+struct Source {
+	bool sep = false, fast = false;
+	Input in1, in2;            // getline()/gzgets() readers (FASTA, gz)
+	MappedFile m1, m2;         // mapped plain FASTQ
+};
+
+// reads `batch_chunks` whole chunks (GetNextChunk each); runs on the prefetch thread
+void read_batch(const Ctx &cx, Source &src, int64_t batch_chunks, int chunk_limit, int nthreads, Batch &b)
+{
+	double t0 = now_s();
+	b.reads.clear(); b.chunks.clear(); b.eof = false;
+	std::vector<RecView> views;
+	while ((int64_t)b.chunks.size() < batch_chunks) {
+		ChunkState ck;
+		ck.begin = src.fast ? (int)views.size() : (int)b.reads.size();
+		ck.count = src.fast ? next_chunk_views(cx, src.sep, src.m1, src.m2, views, chunk_limit)
+		                    : next_chunk(cx, src.sep, src.in1, src.in2, b.reads, chunk_limit);
+		if (ck.count == 0) { b.eof = true; break; }
+		ck.paired = cx.opt.paired && ck.count % 2 == 0 && !cx.opt.pacbio;
+		b.chunks.push_back(std::move(ck));
+	}
+	if (src.fast) {
+		b.reads.resize(views.size());
+		parallel_for(nthreads, (int)((views.size() + 2047) / 2048), [&](int blk) {
+			size_t lo = (size_t)blk * 2048, hi = std::min(views.size(), lo + 2048);
+			for (size_t i = lo; i < hi; ++i) materialise(views[i], b.reads[i]);
+		});
+	}
+	b.seconds = now_s() - t0;
+}
+
+void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 {
 	const int chunk_limit = cx.opt.pacbio ? 10 : 4000;   // ReadChunkSize, src/structure.h:21; src/GetData.cpp:140
 	const int mode = cx.opt.pacbio ? KG_MODE_SENSITIVE : KG_MODE_FAST;
 	const int nthreads = std::max(1, cx.opt.threads);
-	std::vector<Read> reads;
-	std::vector<ChunkState> chunks;
 	std::vector<uint8_t> enc;
 	std::vector<int64_t> off, seed_off;
 	std::vector<kg_seed> seeds;
-	bool eof = false;
 	// small batches first: the estimate moves fastest while the totals are small
 	int64_t batch_chunks = 1;
 	const int64_t max_batch_chunks = std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit);
-	while (!eof) {
-		// ---- read a batch of whole chunks and seed it in one kernel call ------------------------------
-		reads.clear(); chunks.clear();
-		while ((int64_t)chunks.size() < batch_chunks) {
-			ChunkState ck;
-			ck.begin = (int)reads.size();
-			ck.count = next_chunk(cx, sep, in1, in2, reads, chunk_limit);
-			if (ck.count == 0) { eof = true; break; }
-			ck.paired = cx.opt.paired && ck.count % 2 == 0 && !cx.opt.pacbio;
-			chunks.push_back(std::move(ck));
-		}
-		if (reads.empty()) break;
+	Batch cur, nxt;
+	read_batch(cx, src, batch_chunks, chunk_limit, nthreads, cur);
+	tot.t_read += cur.seconds;
+	while (!cur.reads.empty()) {
+		std::vector<Read> &reads = cur.reads;
+		std::vector<ChunkState> &chunks = cur.chunks;
+		// the next batch is read (and materialised) while this one is mapped
 		batch_chunks = std::min(max_batch_chunks, batch_chunks * 2);
+		std::future<void> prefetch;
+		bool more = !cur.eof;
+		if (more) prefetch = std::async(std::launch::async, [&, batch_chunks]() { read_batch(cx, src, batch_chunks, chunk_limit, std::max(1, nthreads / 2), nxt); });
+		double t1 = now_s();
 		// EnCodeReadSeq (src/Mapping.cpp:482-485).  The reference encodes mate 2 with mate 1's length (:550,
 		// App. B-5); with equal-length mates that is the same thing, otherwise it reads or leaves
 		// uninitialised bytes -- here every read is encoded over its own length.
@@ -1559,13 +1696,18 @@ void map_library(Ctx &cx, bool sep, Input &in1, Input &in2, FILE *out, Stats &st
 				for (int p = 0; p < reads[i].rlen; ++p) dst[p] = (uint8_t)nt4((unsigned char)sq[(size_t)p]);
 			}
 		});
+		double t2 = now_s(); tot.t_encode += t2 - t1;
 		cx.kern.seed_batch(mode, enc, off, seed_off, seeds);
+		double t3 = now_s(); tot.t_seed += t3 - t2;
 
 		// ---- speculative pass over all chunks of the batch ---------------------------------------------
 		int est_guess = est_distance(cx, tot.iPaired, tot.iDistance);
 		parallel_for(nthreads, (int)chunks.size(), [&](int c) { chunk_stage_a(cx, reads, seed_off, seeds, chunks[(size_t)c], est_guess); });
+		double t4 = now_s(); tot.t_a += t4 - t3;
 		run_nw(cx, chunks, 0, chunks.size());
+		double t5 = now_s(); tot.t_nw += t5 - t4;
 		parallel_for(nthreads, (int)chunks.size(), [&](int c) { chunk_stage_c(cx, reads, chunks[(size_t)c]); });
+		double t6 = now_s(); tot.t_c += t6 - t5;
 
 		// ---- in-order commit: EstDistance feeds forward (src/Mapping.cpp:533-540) ---------------------------
 		for (size_t c = 0; c < chunks.size(); ++c) {
@@ -1589,6 +1731,15 @@ void map_library(Ctx &cx, bool sep, Input &in1, Input &in2, FILE *out, Stats &st
 			st.unmapped += ck.st.unmapped;
 			st.unique += ck.st.unique;
 			std::string().swap(ck.text);
+		}
+		tot.t_commit += now_s() - t6;
+		if (more) {
+			double tw = now_s();
+			prefetch.get();
+			tot.t_read += now_s() - tw;   // only the part that was not hidden behind the mapping
+			std::swap(cur, nxt);
+		} else {
+			cur.reads.clear();
 		}
 	}
 }
@@ -1652,7 +1803,9 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		const std::string &f1 = opt.files1[lib];
 		bool gz = f1.size() >= 2 && f1.substr(f1.find_last_of('.') + 1) == "gz";   // src/Mapping.cpp:688
 		cx.fastq = is_fastq(f1);
-		Input in1, in2;
+		Source src;
+		Input &in1 = src.in1, &in2 = src.in2;
+		bool want_fast = !gz && cx.fastq && !getenv("KART_AMD_NO_MMAP");
 		if (gz) in1.gz = gzopen(f1.c_str(), "rb"); else in1.fp = fopen(f1.c_str(), "r");
 		bool sep = false;
 		if (opt.files1.size() == opt.files2.size()) {
@@ -1667,10 +1820,15 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		}
 		if (!in1.fp && !in1.gz) continue;
 		if (sep && !in2.fp && !in2.gz) continue;
-		map_library(cx, sep, in1, in2, out, stats, tot);
+		src.sep = sep;
+		src.fast = want_fast && src.m1.open(f1) && (!sep || src.m2.open(opt.files2[lib]));
+		map_library(cx, src, out, stats, tot);
 	}
 	stats.paired = tot.iPaired;
 	stats.distance = tot.iDistance;
+	if (getenv("KART_AMD_VERBOSE"))
+		fprintf(stdout, "stage seconds: read %.2f encode %.2f seed %.2f chain+pair+plan %.2f nw %.2f finish+format %.2f commit+write %.2f\n",
+		        tot.t_read, tot.t_encode, tot.t_seed, tot.t_a, tot.t_nw, tot.t_c, tot.t_commit);
 	return 0;
 }
 
