@@ -1,7 +1,11 @@
 // hip_backend.cpp -- the product's only KernelBackend: libkart_amd.so through its C ABI.
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <functional>
 #include <stdexcept>
+#include <thread>
 
 #include "mapper.hpp"
 
@@ -20,7 +24,7 @@ namespace {
 
 class HipBackend : public KernelBackend {
 public:
-	HipBackend(kg_index *ix, const Options &opt) : ix_(ix)
+	HipBackend(kg_index *ix, const Options &opt) : ix_(ix), threads_(std::max(1, std::min(opt.threads, 16)))
 	{
 		kg_index_info(ix_, &info_);
 		int64_t max_reads = opt.batch_reads + 8192, max_bases = max_reads * 512;
@@ -46,29 +50,51 @@ public:
 	{
 		int64_t n = (int64_t)jobs.size();
 		std::vector<int64_t> o1((size_t)n + 1, 0), o2((size_t)n + 1, 0);
-		std::string f1, f2;
 		for (int64_t i = 0; i < n; ++i) {
-			f1 += jobs[(size_t)i].a; f2 += jobs[(size_t)i].b;
-			o1[(size_t)i + 1] = (int64_t)f1.size(); o2[(size_t)i + 1] = (int64_t)f2.size();
+			o1[(size_t)i + 1] = o1[(size_t)i] + (int64_t)jobs[(size_t)i].a.size();
+			o2[(size_t)i + 1] = o2[(size_t)i] + (int64_t)jobs[(size_t)i].b.size();
 		}
-		std::vector<uint8_t> ops(f1.size() + f2.size() + 1);
+		std::vector<char> f1((size_t)o1[(size_t)n] + 1), f2((size_t)o2[(size_t)n] + 1);
+		const int T = threads_;
+		auto span = [&](int t, int64_t &lo, int64_t &hi) { lo = n * t / T; hi = n * (t + 1) / T; };
+		auto fan = [&](const std::function<void(int)> &fn) {
+			std::vector<std::thread> th;
+			for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
+			fn(0);
+			for (std::thread &x : th) x.join();
+		};
+		fan([&](int t) {
+			int64_t lo, hi;
+			span(t, lo, hi);
+			for (int64_t i = lo; i < hi; ++i) {
+				memcpy(f1.data() + o1[(size_t)i], jobs[(size_t)i].a.data(), jobs[(size_t)i].a.size());
+				memcpy(f2.data() + o2[(size_t)i], jobs[(size_t)i].b.data(), jobs[(size_t)i].b.size());
+			}
+		});
+		std::vector<uint8_t> ops(f1.size() + f2.size());
 		std::vector<int32_t> len((size_t)n);
 		if (kg_nw_batch(ix_, f1.data(), o1.data(), f2.data(), o2.data(), n, ops.data(), len.data()) != KG_OK) die("kg_nw_batch");
-		for (int64_t i = 0; i < n; ++i) {
-			NwJob &j = jobs[(size_t)i];
-			const uint8_t *op = ops.data() + o1[(size_t)i] + o2[(size_t)i];
-			j.ra.clear(); j.rb.clear();
-			size_t x = 0, y = 0;
-			for (int t = 0; t < len[(size_t)i]; ++t) {
-				if (op[t] == KG_OP_DIAG) { j.ra += j.a[x++]; j.rb += j.b[y++]; }
-				else if (op[t] == KG_OP_GAP1) { j.ra += '-'; j.rb += j.b[y++]; }
-				else { j.ra += j.a[x++]; j.rb += '-'; }
+		fan([&](int t) {
+			int64_t lo, hi;
+			span(t, lo, hi);
+			for (int64_t i = lo; i < hi; ++i) {
+				NwJob &j = jobs[(size_t)i];
+				const uint8_t *op = ops.data() + o1[(size_t)i] + o2[(size_t)i];
+				int L = len[(size_t)i];
+				j.ra.resize((size_t)L); j.rb.resize((size_t)L);
+				size_t x = 0, y = 0;
+				for (int q = 0; q < L; ++q) {
+					if (op[q] == KG_OP_DIAG) { j.ra[(size_t)q] = j.a[x++]; j.rb[(size_t)q] = j.b[y++]; }
+					else if (op[q] == KG_OP_GAP1) { j.ra[(size_t)q] = '-'; j.rb[(size_t)q] = j.b[y++]; }
+					else { j.ra[(size_t)q] = j.a[x++]; j.rb[(size_t)q] = '-'; }
+				}
 			}
-		}
+		});
 	}
 
 private:
 	kg_index *ix_;
+	int threads_;
 	kg_workspace *ws_ = nullptr;
 	kg_index_info_t info_;
 };

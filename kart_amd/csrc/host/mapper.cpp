@@ -18,8 +18,12 @@
 #include <climits>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
+#include <deque>
 #include <functional>
 #include <future>
+#include <malloc.h>
+#include <mutex>
 #include <thread>
 
 namespace kart {
@@ -1503,22 +1507,123 @@ struct ChunkState {
 	std::string text;
 };
 
-void parallel_for(int n_threads, int n_items, const std::function<void(int)> &fn)
-{
-	if (n_items <= 0) return;
-	if (n_threads <= 1 || n_items == 1) {
-		for (int i = 0; i < n_items; ++i) fn(i);
-		return;
+// persistent worker pool: stage after stage reuses the same threads (and their malloc arenas)
+class Pool {
+public:
+	explicit Pool(int n) : n_(std::max(1, n))
+	{
+		for (int t = 1; t < n_; ++t) workers_.emplace_back([this]() { loop(); });
 	}
-	std::atomic<int> next(0);
-	std::vector<std::thread> pool;
-	int nt = std::min(n_threads, n_items);
-	for (int t = 0; t < nt; ++t)
-		pool.emplace_back([&]() {
-			for (int i; (i = next.fetch_add(1)) < n_items;) fn(i);
-		});
-	for (std::thread &th : pool) th.join();
-}
+	~Pool()
+	{
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		for (std::thread &th : workers_) th.join();
+	}
+	int size() const { return n_; }
+	void run(int n_items, const std::function<void(int)> &fn)
+	{
+		if (n_items <= 0) return;
+		if (n_ == 1 || n_items == 1) {
+			for (int i = 0; i < n_items; ++i) fn(i);
+			return;
+		}
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			fn_ = &fn; items_ = n_items; next_.store(0); pending_ = n_ - 1; gen_++;
+		}
+		cv_.notify_all();
+		for (int i; (i = next_.fetch_add(1)) < n_items;) fn(i);
+		std::unique_lock<std::mutex> lk(mu_);
+		done_cv_.wait(lk, [this]() { return pending_ == 0; });
+		fn_ = nullptr;
+	}
+
+private:
+	void loop()
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			const std::function<void(int)> *fn;
+			int items;
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_.wait(lk, [&]() { return stop_ || gen_ != seen; });
+				if (stop_) return;
+				seen = gen_;
+				fn = fn_; items = items_;
+			}
+			for (int i; (i = next_.fetch_add(1)) < items;) (*fn)(i);
+			{
+				std::lock_guard<std::mutex> lk(mu_);
+				if (--pending_ == 0) done_cv_.notify_one();
+			}
+		}
+	}
+	int n_;
+	std::vector<std::thread> workers_;
+	std::mutex mu_;
+	std::condition_variable cv_, done_cv_;
+	const std::function<void(int)> *fn_ = nullptr;
+	int items_ = 0, pending_ = 0;
+	std::atomic<int> next_{0};
+	uint64_t gen_ = 0;
+	bool stop_ = false;
+};
+
+// SAM text leaves through one writer thread so the commit loop never waits for the file system
+class Writer {
+public:
+	explicit Writer(FILE *out) : fd_(fileno(out)), th_([this]() { loop(); }) { fflush(out); }
+	~Writer() { finish(); }
+	void push(std::string &&text)
+	{
+		std::lock_guard<std::mutex> lk(mu_);
+		q_.push_back(std::move(text));
+		cv_.notify_one();
+	}
+	void finish()
+	{
+		if (!th_.joinable()) return;
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			stop_ = true;
+		}
+		cv_.notify_one();
+		th_.join();
+	}
+
+private:
+	void loop()
+	{
+		for (;;) {
+			std::string text;
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_.wait(lk, [this]() { return stop_ || !q_.empty(); });
+				if (q_.empty()) return;
+				text.swap(q_.front());
+				q_.pop_front();
+			}
+			const char *p = text.data();
+			size_t left = text.size();
+			while (left > 0) {
+				ssize_t w = ::write(fd_, p, left);
+				if (w <= 0) { perror("write"); exit(1); }
+				p += w; left -= (size_t)w;
+			}
+		}
+	}
+	int fd_;
+	std::mutex mu_;
+	std::condition_variable cv_;
+	std::deque<std::string> q_;
+	bool stop_ = false;
+	std::thread th_;
+};
 
 int est_distance(const Ctx &cx, int64_t iPaired, int64_t iDistance)  // src/Mapping.cpp:534-539
 {
@@ -1635,7 +1740,7 @@ struct Source {
 };
 
 // reads `batch_chunks` whole chunks (GetNextChunk each); runs on the prefetch thread
-void read_batch(const Ctx &cx, Source &src, int64_t batch_chunks, int chunk_limit, int nthreads, Batch &b)
+void read_batch(const Ctx &cx, Source &src, int64_t batch_chunks, int chunk_limit, Pool &pool, Batch &b)
 {
 	double t0 = now_s();
 	b.reads.clear(); b.chunks.clear(); b.eof = false;
@@ -1651,7 +1756,7 @@ void read_batch(const Ctx &cx, Source &src, int64_t batch_chunks, int chunk_limi
 	}
 	if (src.fast) {
 		b.reads.resize(views.size());
-		parallel_for(nthreads, (int)((views.size() + 2047) / 2048), [&](int blk) {
+		pool.run((int)((views.size() + 2047) / 2048), [&](int blk) {
 			size_t lo = (size_t)blk * 2048, hi = std::min(views.size(), lo + 2048);
 			for (size_t i = lo; i < hi; ++i) materialise(views[i], b.reads[i]);
 		});
@@ -1670,8 +1775,10 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	// small batches first: the estimate moves fastest while the totals are small
 	int64_t batch_chunks = 1;
 	const int64_t max_batch_chunks = std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit);
+	Pool pool(nthreads), read_pool(std::max(1, nthreads / 4));
+	Writer writer(out);
 	Batch cur, nxt;
-	read_batch(cx, src, batch_chunks, chunk_limit, nthreads, cur);
+	read_batch(cx, src, batch_chunks, chunk_limit, pool, cur);
 	tot.t_read += cur.seconds;
 	while (!cur.reads.empty()) {
 		std::vector<Read> &reads = cur.reads;
@@ -1680,7 +1787,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 		batch_chunks = std::min(max_batch_chunks, batch_chunks * 2);
 		std::future<void> prefetch;
 		bool more = !cur.eof;
-		if (more) prefetch = std::async(std::launch::async, [&, batch_chunks]() { read_batch(cx, src, batch_chunks, chunk_limit, std::max(1, nthreads / 2), nxt); });
+		if (more) prefetch = std::async(std::launch::async, [&, batch_chunks]() { read_batch(cx, src, batch_chunks, chunk_limit, read_pool, nxt); });
 		double t1 = now_s();
 		// EnCodeReadSeq (src/Mapping.cpp:482-485).  The reference encodes mate 2 with mate 1's length (:550,
 		// App. B-5); with equal-length mates that is the same thing, otherwise it reads or leaves
@@ -1688,7 +1795,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 		off.assign(reads.size() + 1, 0);
 		for (size_t i = 0; i < reads.size(); ++i) off[i + 1] = off[i] + reads[i].rlen;
 		enc.resize((size_t)off[reads.size()]);
-		parallel_for(nthreads, (int)((reads.size() + 4095) / 4096), [&](int blk) {
+		pool.run((int)((reads.size() + 4095) / 4096), [&](int blk) {
 			size_t lo = (size_t)blk * 4096, hi = std::min(reads.size(), lo + 4096);
 			for (size_t i = lo; i < hi; ++i) {
 				uint8_t *dst = enc.data() + off[i];
@@ -1702,11 +1809,11 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 
 		// ---- speculative pass over all chunks of the batch ---------------------------------------------
 		int est_guess = est_distance(cx, tot.iPaired, tot.iDistance);
-		parallel_for(nthreads, (int)chunks.size(), [&](int c) { chunk_stage_a(cx, reads, seed_off, seeds, chunks[(size_t)c], est_guess); });
+		pool.run((int)chunks.size(), [&](int c) { chunk_stage_a(cx, reads, seed_off, seeds, chunks[(size_t)c], est_guess); });
 		double t4 = now_s(); tot.t_a += t4 - t3;
 		run_nw(cx, chunks, 0, chunks.size());
 		double t5 = now_s(); tot.t_nw += t5 - t4;
-		parallel_for(nthreads, (int)chunks.size(), [&](int c) { chunk_stage_c(cx, reads, chunks[(size_t)c]); });
+		pool.run((int)chunks.size(), [&](int c) { chunk_stage_c(cx, reads, chunks[(size_t)c]); });
 		double t6 = now_s(); tot.t_c += t6 - t5;
 
 		// ---- in-order commit: EstDistance feeds forward (src/Mapping.cpp:533-540) ---------------------------
@@ -1724,13 +1831,12 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 					chunk_stage_c(cx, reads, ck);
 				}
 			}
-			fwrite(ck.text.data(), 1, ck.text.size(), out);
+			writer.push(std::move(ck.text));
 			tot.iPaired += ck.ps.paired;
 			tot.iDistance += ck.ps.distance;
 			st.total_reads += ck.st.total_reads;
 			st.unmapped += ck.st.unmapped;
 			st.unique += ck.st.unique;
-			std::string().swap(ck.text);
 		}
 		tot.t_commit += now_s() - t6;
 		if (more) {
@@ -1742,6 +1848,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 			cur.reads.clear();
 		}
 	}
+	writer.finish();
 }
 
 }  // namespace
@@ -1793,6 +1900,11 @@ bool RefData::load(const std::string &prefix, std::string &err)
 
 int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FILE *out, Stats &stats)
 {
+	// keep freed memory inside the arenas: the per-read strings/vectors of one batch are reused by the next,
+	// and handing pages back to the kernel serialises every worker on the address-space lock
+	mallopt(M_MMAP_THRESHOLD, 1 << 30);
+	mallopt(M_TRIM_THRESHOLD, -1);
+	mallopt(M_TOP_PAD, 64 << 20);
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	Options &o = const_cast<Options &>(opt);
 	RunTotals tot;
