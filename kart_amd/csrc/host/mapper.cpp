@@ -1413,11 +1413,51 @@ struct MappedFile {
 	{
 		if (pos >= size) return -1;
 		start = data + pos;
-		const char *nl = (const char *)memchr(start, '\n', size - pos);
-		size_t len = nl ? (size_t)(nl - start) + 1 : size - pos;
+		size_t len;
+		if (next_line < line_end.size()) len = line_end[next_line++] - pos;      // indexed window
+		else {
+			const char *nl = (const char *)memchr(start, '\n', size - pos);
+			len = nl ? (size_t)(nl - start) + 1 : size - pos;
+		}
 		pos += len;
 		return (ssize_t)len;
 	}
+	// Index the lines of the next `bytes` of the file with all workers: every worker counts the newlines
+	// of its slice, a prefix sum places them, a second sweep records the line ends.
+	template <class PoolT>
+	void index_ahead(PoolT &pool, size_t bytes)
+	{
+		line_end.clear(); next_line = 0;
+		size_t lo = pos, hi = std::min(size, pos + bytes);
+		if (hi <= lo) return;
+		int parts = std::max(1, std::min<int>(pool.size() * 4, (int)((hi - lo) >> 16) + 1));
+		std::vector<size_t> cnt((size_t)parts + 1, 0);
+		auto slice = [&](int t, size_t &a, size_t &b) { a = lo + (hi - lo) * (size_t)t / (size_t)parts; b = lo + (hi - lo) * (size_t)(t + 1) / (size_t)parts; };
+		pool.run(parts, [&](int t) {
+			size_t a, b, c = 0;
+			slice(t, a, b);
+			for (const char *p = data + a, *e = data + b; p < e;) {
+				const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+				if (!nl) break;
+				c++; p = nl + 1;
+			}
+			cnt[(size_t)t + 1] = c;
+		});
+		for (int t = 0; t < parts; ++t) cnt[(size_t)t + 1] += cnt[(size_t)t];
+		line_end.resize(cnt[(size_t)parts]);
+		pool.run(parts, [&](int t) {
+			size_t a, b, at = cnt[(size_t)t];
+			slice(t, a, b);
+			for (const char *p = data + a, *e = data + b; p < e;) {
+				const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+				if (!nl) break;
+				line_end[at++] = (size_t)(nl - data) + 1;
+				p = nl + 1;
+			}
+		});
+	}
+	std::vector<size_t> line_end;   // absolute end offsets (one past the newline) of the indexed lines
+	size_t next_line = 0;
 };
 
 struct RecView {
@@ -1745,6 +1785,12 @@ void read_batch(const Ctx &cx, Source &src, int64_t batch_chunks, int chunk_limi
 	double t0 = now_s();
 	b.reads.clear(); b.chunks.clear(); b.eof = false;
 	std::vector<RecView> views;
+	if (src.fast) {
+		// roughly the bytes this batch will consume (header + 2 x read + "+"), indexed in parallel
+		size_t per_file = (size_t)batch_chunks * (size_t)chunk_limit * 400 / (src.sep ? 2 : 1) + (1 << 20);
+		src.m1.index_ahead(pool, per_file);
+		if (src.sep) src.m2.index_ahead(pool, per_file);
+	}
 	while ((int64_t)b.chunks.size() < batch_chunks) {
 		ChunkState ck;
 		ck.begin = src.fast ? (int)views.size() : (int)b.reads.size();
@@ -1775,10 +1821,10 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	// small batches first: the estimate moves fastest while the totals are small
 	int64_t batch_chunks = 1;
 	const int64_t max_batch_chunks = std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit);
-	Pool pool(nthreads), read_pool(std::max(1, nthreads / 4));
+	Pool pool(nthreads), read_pool(nthreads);
 	Writer writer(out);
 	Batch cur, nxt;
-	read_batch(cx, src, batch_chunks, chunk_limit, pool, cur);
+	read_batch(cx, src, batch_chunks, chunk_limit, read_pool, cur);
 	tot.t_read += cur.seconds;
 	while (!cur.reads.empty()) {
 		std::vector<Read> &reads = cur.reads;
