@@ -23,7 +23,9 @@
 #include <functional>
 #include <future>
 #include <malloc.h>
+#include <memory>
 #include <mutex>
+#include <string_view>
 #include <thread>
 
 namespace kart {
@@ -55,7 +57,7 @@ inline char comp_base(char c)  // GetComplementaryBase, src/tools.cpp:3-17
 	}
 }
 
-std::string revcomp(const std::string &s)  // GetComplementarySeq, src/tools.cpp:19-29
+std::string revcomp(std::string_view s)  // GetComplementarySeq, src/tools.cpp:19-29
 {
 	std::string r(s.size(), 'N');
 	for (size_t i = 0, n = s.size(); i < n; ++i) r[i] = comp_base(s[n - 1 - i]);
@@ -105,7 +107,9 @@ struct Report {
 };
 
 struct Read {
-	std::string name, seq, qual;
+	// views into the mapped input file, or into the batch's own storage (reverse-complemented mates, the
+	// getline()/gzgets() readers); no per-read allocation
+	std::string_view name, seq, qual;
 	int rlen = 0;
 	int mapq = 0, score = 0, sub_score = 0, can_num = 0, best = 0;
 	std::vector<Report> rep;
@@ -1010,7 +1014,7 @@ bool rescue_unpaired(const Ctx &cx, int est, const Read &r1, const Read &r2, std
 	if (strategy == 1 || strategy == 3) {
 		int thr = max_score(v1) - 30;
 		if (thr < 50) thr = 50;
-		kmers_of(r2.rlen, r2.seq.c_str(), kr);
+		kmers_of(r2.rlen, r2.seq.data(), kr);
 		for (int j = num2, i = 0; i < num1; ++i) {
 			if (v1[i].score < thr) continue;
 			int64_t left = v1[i].posDiff, right = v1[i].posDiff + est + r2.rlen;
@@ -1037,7 +1041,7 @@ bool rescue_unpaired(const Ctx &cx, int est, const Read &r1, const Read &r2, std
 	if (strategy == 2 || strategy == 3) {
 		int thr = max_score(v2) - 30;   // the rescued entries appended above are included, as in the reference
 		if (thr < 50) thr = 50;
-		kmers_of(r1.rlen, r1.seq.c_str(), kr);
+		kmers_of(r1.rlen, r1.seq.data(), kr);
 		for (int i = num1, j = 0; j < num2; ++j) {
 			if (v2[j].score < thr) continue;
 			int64_t left = v2[j].posDiff - est, right = v2[j].posDiff + r2.rlen;
@@ -1175,12 +1179,12 @@ void sam_unmapped(const Ctx &cx, const Read &rd, std::string &out)
 	out += rd.name; out += '\t'; out += num;
 	out += "\t*\t0\t0\t*\t*\t0\t0\t";
 	out += rd.seq; out += '\t';
-	out += cx.fastq ? rd.qual : std::string("*");
+	if (cx.fastq) out += rd.qual; else out += '*';
 	out += "\tAS:i:0\tXS:i:0\n";
 }
 
 void sam_mapped(const Ctx &cx, const Read &rd, const Report &rp, bool has_mate, long long mate_pos, int tlen,
-                const std::string &seq, const std::string &qual, std::string &out)
+                std::string_view seq, std::string_view qual, std::string &out)
 {
 	char buf[256];
 	out += rd.name;
@@ -1193,7 +1197,7 @@ void sam_mapped(const Ctx &cx, const Read &rd, const Report &rp, bool has_mate, 
 	if (has_mate) { snprintf(buf, sizeof(buf), "\t=\t%lld\t%d\t", mate_pos, tlen); out += buf; }
 	else out += "\t*\t0\t0\t";
 	out += seq; out += '\t';
-	out += cx.fastq ? qual : std::string("*");
+	if (cx.fastq) out += qual; else out += '*';
 	snprintf(buf, sizeof(buf), "\tNM:i:%d\tAS:i:%d\tXS:i:%d\n", rd.rlen - rd.score, rd.score, rd.sub_score);
 	out += buf;
 }
@@ -1211,7 +1215,7 @@ void output_pair(const Ctx &cx, const Read &r1, const Read &r2, Stats &st, PairS
 			if (rp.score > 0) {
 				if (!rp.fwd && !have_rev) {
 					rseq = revcomp(r1.seq);
-					if (cx.fastq) { rqual = r1.qual; std::reverse(rqual.begin(), rqual.end()); }
+					if (cx.fastq) { rqual.assign(r1.qual); std::reverse(rqual.begin(), rqual.end()); }
 					have_rev = true;
 				}
 				int j = rp.mate;
@@ -1221,8 +1225,8 @@ void output_pair(const Ctx &cx, const Read &r1, const Read &r2, Stats &st, PairS
 						ps.paired += 2;
 						if (abs(dist) < 10000) ps.distance += abs(dist);
 					}
-					sam_mapped(cx, r1, rp, true, (long long)r2.rep[(size_t)j].gPos, dist, rp.fwd ? r1.seq : rseq, rp.fwd ? r1.qual : rqual, out);
-				} else sam_mapped(cx, r1, rp, false, 0, 0, rp.fwd ? r1.seq : rseq, rp.fwd ? r1.qual : rqual, out);
+					sam_mapped(cx, r1, rp, true, (long long)r2.rep[(size_t)j].gPos, dist, rp.fwd ? r1.seq : std::string_view(rseq), rp.fwd ? r1.qual : std::string_view(rqual), out);
+				} else sam_mapped(cx, r1, rp, false, 0, 0, rp.fwd ? r1.seq : std::string_view(rseq), rp.fwd ? r1.qual : std::string_view(rqual), out);
 			}
 			if (!cx.opt.multi_hit) break;
 		}
@@ -1237,14 +1241,14 @@ void output_pair(const Ctx &cx, const Read &r1, const Read &r2, Stats &st, PairS
 			if (rp.score > 0) {
 				if (rp.fwd && !have_fwd) {
 					fseq = revcomp(r2.seq);
-					if (cx.fastq) { rqual = r2.qual; std::reverse(rqual.begin(), rqual.end()); }
+					if (cx.fastq) { rqual.assign(r2.qual); std::reverse(rqual.begin(), rqual.end()); }
 					have_fwd = true;
 				}
 				int i = rp.mate;
 				if (i != -1 && r1.rep[(size_t)i].score > 0) {
 					int dist = 0 - (int)(rp.gPos - r1.rep[(size_t)i].gPos + (r1.rep[(size_t)i].fwd ? r2.rlen : 0 - r1.rlen));
-					sam_mapped(cx, r2, rp, true, (long long)r1.rep[(size_t)i].gPos, dist, rp.fwd ? fseq : r2.seq, rp.fwd ? rqual : r2.qual, out);
-				} else sam_mapped(cx, r2, rp, false, 0, 0, rp.fwd ? fseq : r2.seq, rp.fwd ? rqual : r2.qual, out);
+					sam_mapped(cx, r2, rp, true, (long long)r1.rep[(size_t)i].gPos, dist, rp.fwd ? std::string_view(fseq) : r2.seq, rp.fwd ? std::string_view(rqual) : r2.qual, out);
+				} else sam_mapped(cx, r2, rp, false, 0, 0, rp.fwd ? std::string_view(fseq) : r2.seq, rp.fwd ? std::string_view(rqual) : r2.qual, out);
 			}
 			if (!cx.opt.multi_hit) break;
 		}
@@ -1262,10 +1266,10 @@ void output_single(const Ctx &cx, const Read &rd, Stats &st, std::string &out)  
 		if (rp.score == rd.score) {
 			if (!rp.fwd && !have_rev) {
 				rseq = revcomp(rd.seq);
-				if (cx.fastq) { rqual = rd.qual; std::reverse(rqual.begin(), rqual.end()); }
+				if (cx.fastq) { rqual.assign(rd.qual); std::reverse(rqual.begin(), rqual.end()); }
 				have_rev = true;
 			}
-			sam_mapped(cx, rd, rp, false, 0, 0, rp.fwd ? rd.seq : rseq, rp.fwd ? rd.qual : rqual, out);
+			sam_mapped(cx, rd, rp, false, 0, 0, rp.fwd ? rd.seq : std::string_view(rseq), rp.fwd ? rd.qual : std::string_view(rqual), out);
 			if (!cx.opt.multi_hit) break;
 		}
 	}
@@ -1290,25 +1294,30 @@ struct Input {
 	}
 };
 
-void header_of(const char *buf, int len, std::string &name)  // IdentifyHeaderBegPos/EndPos, src/GetData.cpp:29-49
+std::string_view header_view(const char *buf, int len)  // IdentifyHeaderBegPos/EndPos, src/GetData.cpp:29-49
 {
 	int p1 = len - 1, p2 = len - 1;
 	for (int i = 1; i < len; ++i)
 		if (buf[i] != '>' && buf[i] != '@') { p1 = i; break; }
 	for (int i = 1; i < len; ++i)
 		if (buf[i] == ' ' || buf[i] == '/' || buf[i] == '\t') { p2 = i; break; }
-	if (p2 > p1) name.assign(buf + p1, (size_t)(p2 - p1));
-	else name.clear();
+	return p2 > p1 ? std::string_view(buf + p1, (size_t)(p2 - p1)) : std::string_view();
 }
+
+// a read owned by the reader itself (getline()/gzgets() paths)
+struct OwnedRead {
+	std::string name, seq, qual;
+	int rlen = 0;
+};
 
 // GetNextEntry, src/GetData.cpp:51-107.  Like the reference, the last character of every line is taken
 // to be the newline.
-bool next_entry_plain(Input &in, bool fastq, Read &rd)
+bool next_entry_plain(Input &in, bool fastq, OwnedRead &rd)
 {
-	rd = Read();
+	rd = OwnedRead();
 	ssize_t len = getline(&in.line, &in.cap, in.fp);
 	if (len == -1) return false;
-	header_of(in.line, (int)len, rd.name);
+	rd.name.assign(header_view(in.line, (int)len));
 	if (fastq) {
 		ssize_t sl = getline(&in.line, &in.cap, in.fp);
 		if (sl == -1) { rd.rlen = 0; return true; }
@@ -1335,16 +1344,15 @@ bool next_entry_plain(Input &in, bool fastq, Read &rd)
 	return true;
 }
 
-bool next_entry_gz(Input &in, bool fastq, bool pacbio, Read &rd)  // gzGetNextEntry, src/GetData.cpp:145-182
+bool next_entry_gz(Input &in, bool fastq, bool pacbio, OwnedRead &rd)  // gzGetNextEntry, src/GetData.cpp:145-182
 {
-	rd = Read();
+	rd = OwnedRead();
 	int buf_size = pacbio ? 1000000 : 1000;
 	in.gzbuf.resize((size_t)buf_size);
 	char *buf = in.gzbuf.data();
 	if (gzgets(in.gz, buf, buf_size) == NULL) return false;
 	int len = (int)strlen(buf);
-	std::string name;
-	header_of(buf, len, name);
+	std::string name(header_view(buf, len));
 	if (!name.empty() && (buf[0] == '@' || buf[0] == '>')) {
 		rd.name = name;
 		if (gzgets(in.gz, buf, buf_size) == NULL) buf[0] = '\0';
@@ -1360,16 +1368,16 @@ bool next_entry_gz(Input &in, bool fastq, bool pacbio, Read &rd)  // gzGetNextEn
 	return true;
 }
 
-bool next_entry(Input &in, bool fastq, bool pacbio, Read &rd)
+bool next_entry(Input &in, bool fastq, bool pacbio, OwnedRead &rd)
 {
 	return in.gz ? next_entry_gz(in, fastq, pacbio, rd) : next_entry_plain(in, fastq, rd);
 }
 
 // GetNextChunk, src/GetData.cpp:109-143 / 184-219
-int next_chunk(const Ctx &cx, bool sep, Input &in1, Input &in2, std::vector<Read> &reads, int limit)
+int next_chunk(const Ctx &cx, bool sep, Input &in1, Input &in2, std::deque<OwnedRead> &reads, int limit)
 {
 	int count = 0;
-	Read rd;
+	OwnedRead rd;
 	while (true) {
 		if (!next_entry(in1, cx.fastq, cx.opt.pacbio, rd) || rd.rlen == 0) break;
 		reads.push_back(rd);
@@ -1482,19 +1490,26 @@ bool view_next(MappedFile &f, RecView &v)
 	return true;
 }
 
-void materialise(const RecView &v, Read &rd)
+// `arena` receives the reverse-complemented copy of a flipped mate (2 * rlen bytes)
+void materialise(const RecView &v, Read &rd, char *&arena)
 {
 	rd = Read();
-	header_of(v.hdr, v.hdr_len, rd.name);
+	rd.name = header_view(v.hdr, v.hdr_len);
 	rd.rlen = v.rlen;
-	rd.seq.assign(v.seq, (size_t)v.rlen);
 	int ql = std::min(v.qual_len, v.rlen);
 	const char *z = ql > 0 ? (const char *)memchr(v.qual, '\0', (size_t)ql) : nullptr;
-	rd.qual.assign(v.qual ? v.qual : "", (size_t)(z ? z - v.qual : ql));
-	if (v.flip) {
-		rd.seq = revcomp(rd.seq);
-		std::reverse(rd.qual.begin(), rd.qual.end());
+	if (z) ql = (int)(z - v.qual);
+	if (!v.flip) {
+		rd.seq = std::string_view(v.seq, (size_t)v.rlen);
+		rd.qual = std::string_view(v.qual ? v.qual : "", (size_t)ql);
+		return;
 	}
+	char *sq = arena, *qq = arena + v.rlen;
+	arena += 2 * (size_t)v.rlen;
+	for (int i = 0; i < v.rlen; ++i) sq[i] = comp_base(v.seq[v.rlen - 1 - i]);
+	for (int i = 0; i < ql; ++i) qq[i] = v.qual[ql - 1 - i];
+	rd.seq = std::string_view(sq, (size_t)v.rlen);
+	rd.qual = std::string_view(qq, (size_t)ql);
 }
 
 // GetNextChunk over mapped files: the same loop as next_chunk(), producing views
@@ -1769,6 +1784,8 @@ double now_s()
 struct Batch {
 	std::vector<Read> reads;
 	std::vector<ChunkState> chunks;
+	std::deque<OwnedRead> owned;                    // storage behind the views (getline()/gzgets() readers)
+	std::vector<std::unique_ptr<char[]>> arenas;    // storage behind reverse-complemented mates (mapped files)
 	bool eof = false;
 	double seconds = 0;
 };
@@ -1783,7 +1800,7 @@ struct Source {
 void read_batch(const Ctx &cx, Source &src, int64_t batch_chunks, int chunk_limit, Pool &pool, Batch &b)
 {
 	double t0 = now_s();
-	b.reads.clear(); b.chunks.clear(); b.eof = false;
+	b.reads.clear(); b.chunks.clear(); b.owned.clear(); b.arenas.clear(); b.eof = false;
 	std::vector<RecView> views;
 	if (src.fast) {
 		// roughly the bytes this batch will consume (header + 2 x read + "+"), indexed in parallel
@@ -1793,19 +1810,33 @@ void read_batch(const Ctx &cx, Source &src, int64_t batch_chunks, int chunk_limi
 	}
 	while ((int64_t)b.chunks.size() < batch_chunks) {
 		ChunkState ck;
-		ck.begin = src.fast ? (int)views.size() : (int)b.reads.size();
+		ck.begin = src.fast ? (int)views.size() : (int)b.owned.size();
 		ck.count = src.fast ? next_chunk_views(cx, src.sep, src.m1, src.m2, views, chunk_limit)
-		                    : next_chunk(cx, src.sep, src.in1, src.in2, b.reads, chunk_limit);
+		                    : next_chunk(cx, src.sep, src.in1, src.in2, b.owned, chunk_limit);
 		if (ck.count == 0) { b.eof = true; break; }
 		ck.paired = cx.opt.paired && ck.count % 2 == 0 && !cx.opt.pacbio;
 		b.chunks.push_back(std::move(ck));
 	}
 	if (src.fast) {
 		b.reads.resize(views.size());
-		pool.run((int)((views.size() + 2047) / 2048), [&](int blk) {
-			size_t lo = (size_t)blk * 2048, hi = std::min(views.size(), lo + 2048);
-			for (size_t i = lo; i < hi; ++i) materialise(views[i], b.reads[i]);
+		int blocks = (int)((views.size() + 2047) / 2048);
+		b.arenas.resize((size_t)blocks);
+		pool.run(blocks, [&](int blk) {
+			size_t lo = (size_t)blk * 2048, hi = std::min(views.size(), lo + 2048), need = 0;
+			for (size_t i = lo; i < hi; ++i)
+				if (views[i].flip) need += 2 * (size_t)views[i].rlen;
+			b.arenas[(size_t)blk].reset(new char[need + 1]);
+			char *arena = b.arenas[(size_t)blk].get();
+			for (size_t i = lo; i < hi; ++i) materialise(views[i], b.reads[i], arena);
 		});
+	} else {
+		b.reads.resize(b.owned.size());
+		for (size_t i = 0; i < b.owned.size(); ++i) {
+			const OwnedRead &o = b.owned[i];
+			Read &rd = b.reads[i];
+			rd = Read();
+			rd.name = o.name; rd.seq = o.seq; rd.qual = o.qual; rd.rlen = o.rlen;
+		}
 	}
 	b.seconds = now_s() - t0;
 }
@@ -1845,7 +1876,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 			size_t lo = (size_t)blk * 4096, hi = std::min(reads.size(), lo + 4096);
 			for (size_t i = lo; i < hi; ++i) {
 				uint8_t *dst = enc.data() + off[i];
-				const std::string &sq = reads[i].seq;
+				std::string_view sq = reads[i].seq;
 				for (int p = 0; p < reads[i].rlen; ++p) dst[p] = (uint8_t)nt4((unsigned char)sq[(size_t)p]);
 			}
 		});
