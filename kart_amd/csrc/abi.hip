@@ -74,6 +74,10 @@ struct NwScratch {
 	size_t dir_words = 0;
 	hipEvent_t done = nullptr;
 	bool busy = false;
+	// staging of the host-buffer entry (kg_nw_batch): inputs, offsets and outputs, grown on demand
+	char *io = nullptr;
+	size_t io_bytes = 0;
+	bool io_busy = false;
 };
 
 struct kg_index {
@@ -274,6 +278,7 @@ void kg_index_destroy(kg_index *ix)
 		if (sc->lists) (void)hipFree(sc->lists);
 		if (sc->queue) (void)hipFree(sc->queue);
 		if (sc->dir) (void)hipFree(sc->dir);
+		if (sc->io) (void)hipFree(sc->io);
 		delete sc;
 	}
 	if (ix->d_sa) (void)hipFree(ix->d_sa);
@@ -585,30 +590,54 @@ int kg_nw_batch(kg_index *ix, const char *frag1, const int64_t *off1, const char
 		max_len = std::max(max_len, std::max(m, q));
 	}
 	HIP_TRY(hipSetDevice(ix->device));
-	char *d1 = nullptr, *d2 = nullptr;
-	int64_t *do1 = nullptr, *do2 = nullptr;
-	uint8_t *dops = nullptr;
-	int32_t *dlen = nullptr;
-	hipStream_t st = nullptr;
-	HIP_TRY(hipMalloc((void **)&d1, (size_t)b1 + 16));
-	HIP_TRY(hipMalloc((void **)&d2, (size_t)b2 + 16));
-	HIP_TRY(hipMalloc((void **)&do1, 8 * (size_t)(n + 1)));
-	HIP_TRY(hipMalloc((void **)&do2, 8 * (size_t)(n + 1)));
-	HIP_TRY(hipMalloc((void **)&dops, (size_t)(b1 + b2) + 16));
-	HIP_TRY(hipMalloc((void **)&dlen, 4 * (size_t)n));
-	HIP_TRY(hipMemcpy(d1, frag1, (size_t)b1, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(d2, frag2, (size_t)b2, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(do1, off1, 8 * (size_t)(n + 1), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(do2, off2, 8 * (size_t)(n + 1), hipMemcpyHostToDevice));
 	if (max_len > kNwMaxLen) return fail(KG_ERR_ARG, "kg_nw_batch: fragment of %lld bases exceeds the supported %d", (long long)max_len, kNwMaxLen);
-	int rc = nw_run(ix, d1, do1, d2, do2, n, max_len, dops, dlen, st);
+	// one cached device block per call: [frag1 | frag2 | off1 | off2 | ops | aln_len], 256-byte aligned parts
+	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	size_t p_f1 = 0, p_f2 = p_f1 + up((size_t)b1 + 16), p_o1 = p_f2 + up((size_t)b2 + 16), p_o2 = p_o1 + up(8 * (size_t)(n + 1)),
+	       p_ops = p_o2 + up(8 * (size_t)(n + 1)), p_len = p_ops + up((size_t)(b1 + b2) + 16), total = p_len + up(4 * (size_t)n);
+	NwScratch *io = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(ix->nw_mu);
+		for (NwScratch *s : ix->nw_pool)
+			if (!s->io_busy && s->io_bytes >= total) { io = s; break; }
+		if (!io) {
+			for (NwScratch *s : ix->nw_pool)
+				if (!s->io_busy) { io = s; break; }
+			if (!io) {
+				io = new NwScratch();
+				HIP_TRY(hipEventCreateWithFlags(&io->done, hipEventDisableTiming));
+				HIP_TRY(hipMalloc((void **)&io->queue, 8 * 4));
+				ix->nw_pool.push_back(io);
+			}
+			if (io->io) HIP_TRY(hipFree(io->io));
+			io->io = nullptr;
+			size_t want = total + total / 4;
+			HIP_TRY(hipMalloc((void **)&io->io, want));
+			io->io_bytes = want;
+		}
+		io->io_busy = true;   // holds the staging block; the kernels' own scratch comes from nw_acquire below
+	}
+	char *base = io->io;
+	hipStream_t st = nullptr;
+	hipError_t e = hipMemcpy(base + p_f1, frag1, (size_t)b1, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(base + p_f2, frag2, (size_t)b2, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(base + p_o1, off1, 8 * (size_t)(n + 1), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(base + p_o2, off2, 8 * (size_t)(n + 1), hipMemcpyHostToDevice);
+	int rc = KG_OK;
+	if (e != hipSuccess) rc = fail(KG_ERR_NO_DEVICE, "kg_nw_batch: %s", hipGetErrorString(e));
+	if (rc == KG_OK)
+		rc = nw_run(ix, base + p_f1, (const int64_t *)(base + p_o1), base + p_f2, (const int64_t *)(base + p_o2), n, max_len,
+		            (uint8_t *)(base + p_ops), (int32_t *)(base + p_len), st);
 	if (rc == KG_OK) {
-		hipError_t e = hipDeviceSynchronize();
-		if (e == hipSuccess) e = hipMemcpy(ops, dops, (size_t)(b1 + b2), hipMemcpyDeviceToHost);
-		if (e == hipSuccess) e = hipMemcpy(aln_len, dlen, 4 * (size_t)n, hipMemcpyDeviceToHost);
+		e = hipDeviceSynchronize();
+		if (e == hipSuccess) e = hipMemcpy(ops, base + p_ops, (size_t)(b1 + b2), hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(aln_len, base + p_len, 4 * (size_t)n, hipMemcpyDeviceToHost);
 		if (e != hipSuccess) rc = fail(KG_ERR_NO_DEVICE, "kg_nw_batch: %s", hipGetErrorString(e));
 	}
-	(void)hipFree(d1); (void)hipFree(d2); (void)hipFree(do1); (void)hipFree(do2); (void)hipFree(dops); (void)hipFree(dlen);
+	{
+		std::lock_guard<std::mutex> lock(ix->nw_mu);
+		io->io_busy = false;
+	}
 	return rc;
 }
 

@@ -1567,7 +1567,7 @@ class Pool {
 public:
 	explicit Pool(int n) : n_(std::max(1, n))
 	{
-		for (int t = 1; t < n_; ++t) workers_.emplace_back([this]() { loop(); });
+		for (int t = 1; t < n_; ++t) workers_.emplace_back([this, t]() { loop(t); });
 	}
 	~Pool()
 	{
@@ -1588,17 +1588,19 @@ public:
 		}
 		{
 			std::lock_guard<std::mutex> lk(mu_);
-			fn_ = &fn; items_ = n_items; next_.store(0); pending_ = n_ - 1; gen_++;
+			fn_ = &fn; items_ = n_items; pending_ = n_ - 1; gen_++;
 		}
 		cv_.notify_all();
-		for (int i; (i = next_.fetch_add(1)) < n_items;) fn(i);
+		// static assignment (item i -> worker i mod n): the chunk a worker built in one stage is the chunk it
+		// finishes and frees in the next, so allocations never cross threads
+		for (int i = 0; i < n_items; i += n_) fn(i);
 		std::unique_lock<std::mutex> lk(mu_);
 		done_cv_.wait(lk, [this]() { return pending_ == 0; });
 		fn_ = nullptr;
 	}
 
 private:
-	void loop()
+	void loop(int me)
 	{
 		uint64_t seen = 0;
 		for (;;) {
@@ -1611,7 +1613,7 @@ private:
 				seen = gen_;
 				fn = fn_; items = items_;
 			}
-			for (int i; (i = next_.fetch_add(1)) < items;) (*fn)(i);
+			for (int i = me; i < items; i += n_) (*fn)(i);
 			{
 				std::lock_guard<std::mutex> lk(mu_);
 				if (--pending_ == 0) done_cv_.notify_one();
@@ -1624,7 +1626,6 @@ private:
 	std::condition_variable cv_, done_cv_;
 	const std::function<void(int)> *fn_ = nullptr;
 	int items_ = 0, pending_ = 0;
-	std::atomic<int> next_{0};
 	uint64_t gen_ = 0;
 	bool stop_ = false;
 };
@@ -1731,6 +1732,7 @@ void chunk_stage_c(const Ctx &cx, std::vector<Read> &reads, ChunkState &ck)
 		report_finish(cx, first, reads[(size_t)(ck.begin + q)], ck.cands[(size_t)q], ck.work[(size_t)q], ck.jobs);
 	}
 	ck.text.clear();
+	ck.text.reserve((size_t)ck.count * 400);
 	if (ck.paired) {
 		for (int q = 0; q < ck.count; q += 2) {
 			Read &r1 = reads[(size_t)(ck.begin + q)], &r2 = reads[(size_t)(ck.begin + q + 1)];
