@@ -46,55 +46,39 @@ public:
 		if (kg_seed_batch(ws_, mode, info_.min_seed_len, KG_OCC_THR_DEFAULT, enc.data(), off.data(), n, seed_off.data(), &out) != KG_OK) die("kg_seed_batch");
 		seeds.assign(out, out + seed_off[(size_t)n]);
 	}
-	void nw_batch(std::vector<NwJob> &jobs) override
+	void nw_batch(std::vector<NwJobs *> &parts) override
 	{
-		int64_t n = (int64_t)jobs.size();
-		std::vector<int64_t> o1((size_t)n + 1, 0), o2((size_t)n + 1, 0);
-		for (int64_t i = 0; i < n; ++i) {
-			o1[(size_t)i + 1] = o1[(size_t)i] + (int64_t)jobs[(size_t)i].a.size();
-			o2[(size_t)i + 1] = o2[(size_t)i] + (int64_t)jobs[(size_t)i].b.size();
+		// concatenate the parts (a few large copies), one kernel call, scatter the op strings back
+		int64_t n = 0, b1 = 0, b2 = 0;
+		for (NwJobs *p : parts) { n += (int64_t)p->size(); b1 += (int64_t)p->f1.size(); b2 += (int64_t)p->f2.size(); }
+		f1_.resize((size_t)b1 + 1); f2_.resize((size_t)b2 + 1);
+		o1_.resize((size_t)n + 1); o2_.resize((size_t)n + 1);
+		ops_.resize((size_t)(b1 + b2) + 1); len_.resize((size_t)n);
+		int64_t at = 0, a1 = 0, a2 = 0;
+		o1_[0] = o2_[0] = 0;
+		for (NwJobs *p : parts) {
+			memcpy(&f1_[(size_t)a1], p->f1.data(), p->f1.size());
+			memcpy(&f2_[(size_t)a2], p->f2.data(), p->f2.size());
+			for (size_t j = 1; j <= p->size(); ++j) { o1_[(size_t)at + j] = a1 + p->o1[j]; o2_[(size_t)at + j] = a2 + p->o2[j]; }
+			at += (int64_t)p->size(); a1 += (int64_t)p->f1.size(); a2 += (int64_t)p->f2.size();
 		}
-		std::vector<char> f1((size_t)o1[(size_t)n] + 1), f2((size_t)o2[(size_t)n] + 1);
-		const int T = threads_;
-		auto span = [&](int t, int64_t &lo, int64_t &hi) { lo = n * t / T; hi = n * (t + 1) / T; };
-		auto fan = [&](const std::function<void(int)> &fn) {
-			std::vector<std::thread> th;
-			for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
-			fn(0);
-			for (std::thread &x : th) x.join();
-		};
-		fan([&](int t) {
-			int64_t lo, hi;
-			span(t, lo, hi);
-			for (int64_t i = lo; i < hi; ++i) {
-				memcpy(f1.data() + o1[(size_t)i], jobs[(size_t)i].a.data(), jobs[(size_t)i].a.size());
-				memcpy(f2.data() + o2[(size_t)i], jobs[(size_t)i].b.data(), jobs[(size_t)i].b.size());
-			}
-		});
-		std::vector<uint8_t> ops(f1.size() + f2.size());
-		std::vector<int32_t> len((size_t)n);
-		if (kg_nw_batch(ix_, f1.data(), o1.data(), f2.data(), o2.data(), n, ops.data(), len.data()) != KG_OK) die("kg_nw_batch");
-		fan([&](int t) {
-			int64_t lo, hi;
-			span(t, lo, hi);
-			for (int64_t i = lo; i < hi; ++i) {
-				NwJob &j = jobs[(size_t)i];
-				const uint8_t *op = ops.data() + o1[(size_t)i] + o2[(size_t)i];
-				int L = len[(size_t)i];
-				j.ra.resize((size_t)L); j.rb.resize((size_t)L);
-				size_t x = 0, y = 0;
-				for (int q = 0; q < L; ++q) {
-					if (op[q] == KG_OP_DIAG) { j.ra[(size_t)q] = j.a[x++]; j.rb[(size_t)q] = j.b[y++]; }
-					else if (op[q] == KG_OP_GAP1) { j.ra[(size_t)q] = '-'; j.rb[(size_t)q] = j.b[y++]; }
-					else { j.ra[(size_t)q] = j.a[x++]; j.rb[(size_t)q] = '-'; }
-				}
-			}
-		});
+		if (kg_nw_batch(ix_, f1_.data(), o1_.data(), f2_.data(), o2_.data(), n, ops_.data(), len_.data()) != KG_OK) die("kg_nw_batch");
+		at = 0; a1 = 0; a2 = 0;
+		for (NwJobs *p : parts) {
+			// the ops of a part are contiguous in the combined array: ops offset of job j = o1 + o2
+			p->ops.assign(ops_.begin() + (a1 + a2), ops_.begin() + (a1 + a2) + (int64_t)(p->f1.size() + p->f2.size()));
+			p->len.assign(len_.begin() + at, len_.begin() + at + (int64_t)p->size());
+			at += (int64_t)p->size(); a1 += (int64_t)p->f1.size(); a2 += (int64_t)p->f2.size();
+		}
 	}
 
 private:
 	kg_index *ix_;
 	int threads_;
+	std::vector<char> f1_, f2_;
+	std::vector<int64_t> o1_, o2_;
+	std::vector<uint8_t> ops_;
+	std::vector<int32_t> len_;
 	kg_workspace *ws_ = nullptr;
 	kg_index_info_t info_;
 };

@@ -508,7 +508,7 @@ struct Plan {
 };
 
 void plan_alignment(const Ctx &cx, int rLen, const std::string &frag1, int gLen, const std::string &frag2, Plan &plan,
-                    std::vector<NwJob> &jobs)
+                    NwJobs &jobs)
 {
 	if (rLen > 30 && gLen > 30) {
 		int max_shift;
@@ -538,13 +538,11 @@ void plan_alignment(const Ctx &cx, int rLen, const std::string &frag1, int gLen,
 					pc.b = frag2.substr((size_t)p.gPos, (size_t)p.gLen);
 					plan.pieces.push_back(pc);
 				} else {
-					std::string s1 = frag1.substr((size_t)p.rPos, (size_t)p.rLen), s2 = frag2.substr((size_t)p.gPos, (size_t)p.gLen);
-					if (cx.opt.pacbio && (p.rLen > 300 || p.gLen > 300)) plan_alignment(cx, p.rLen, s1, p.gLen, s2, plan, jobs);
-					else {
-						pc.job = (int)jobs.size();
-						NwJob j;
-						j.a.swap(s1); j.b.swap(s2);
-						jobs.push_back(j);
+					if (cx.opt.pacbio && (p.rLen > 300 || p.gLen > 300)) {
+						std::string s1 = frag1.substr((size_t)p.rPos, (size_t)p.rLen), s2 = frag2.substr((size_t)p.gPos, (size_t)p.gLen);
+						plan_alignment(cx, p.rLen, s1, p.gLen, s2, plan, jobs);
+					} else {
+						pc.job = jobs.add(frag1.data() + p.rPos, p.rLen, frag2.data() + p.gPos, p.gLen);
 						plan.pieces.push_back(pc);
 					}
 				}
@@ -553,20 +551,25 @@ void plan_alignment(const Ctx &cx, int rLen, const std::string &frag1, int gLen,
 		}
 	}
 	Piece pc;
-	pc.job = (int)jobs.size();
-	NwJob j;
-	j.a = frag1; j.b = frag2;
-	jobs.push_back(j);
+	pc.job = jobs.add(frag1.data(), rLen, frag2.data(), gLen);
 	plan.pieces.push_back(pc);
 }
 
-void stitch(const Plan &plan, const std::vector<NwJob> &jobs, std::string &aln1, std::string &aln2)
+void stitch(const Plan &plan, const NwJobs &jobs, std::string &aln1, std::string &aln2)
 {
 	aln1.clear(); aln2.clear();
 	for (size_t i = 0; i < plan.pieces.size(); ++i) {
 		const Piece &pc = plan.pieces[i];
-		if (pc.job >= 0) { aln1 += jobs[(size_t)pc.job].ra; aln2 += jobs[(size_t)pc.job].rb; }
-		else { aln1 += pc.a; aln2 += pc.b; }
+		if (pc.job < 0) { aln1 += pc.a; aln2 += pc.b; continue; }
+		// re-insert the gaps the kernel's op string describes (what nw_alignment does in place)
+		size_t j = (size_t)pc.job;
+		const char *a = jobs.f1.data() + jobs.o1[j], *b = jobs.f2.data() + jobs.o2[j];
+		const uint8_t *op = jobs.ops.data() + jobs.o1[j] + jobs.o2[j];
+		for (int t = 0, L = jobs.len[j]; t < L; ++t) {
+			if (op[t] == KG_OP_DIAG) { aln1 += *a++; aln2 += *b++; }
+			else if (op[t] == KG_OP_GAP1) { aln1 += '-'; aln2 += *b++; }
+			else { aln1 += *a++; aln2 += '-'; }
+		}
 	}
 }
 
@@ -639,7 +642,7 @@ bool quick_match(const Pair &sp, const char *f1, const char *f2, int &n)  // the
 }
 
 // pass 1 for one pair; role: 0 head, 1 inner, 2 tail
-void plan_pair(const Ctx &cx, const Read &rd, const Pair &sp, int role, PairWork &w, std::vector<NwJob> &jobs)
+void plan_pair(const Ctx &cx, const Read &rd, const Pair &sp, int role, PairWork &w, NwJobs &jobs)
 {
 	if (role == 1 && (sp.rLen == 0 || sp.gLen == 0)) {   // ProcessNormalSequencePair :229-233
 		w.kind = PairWork::IMMEDIATE;
@@ -780,7 +783,7 @@ int gap_penalty(const CigarVec &cig)  // GapPenalty, :612-622
 }
 
 // pass 1 of GenMappingReport for one read: normal pairs, validity, and the NW jobs of every pair
-void report_plan(const Ctx &cx, Read &rd, std::vector<Candidate> &cands, std::vector<CandWork> &work, std::vector<NwJob> &jobs)
+void report_plan(const Ctx &cx, Read &rd, std::vector<Candidate> &cands, std::vector<CandWork> &work, NwJobs &jobs)
 {
 	work.assign(cands.size(), CandWork());
 	for (size_t i = 0; i < cands.size(); ++i) {
@@ -813,7 +816,7 @@ void report_plan(const Ctx &cx, Read &rd, std::vector<Candidate> &cands, std::ve
 
 // pass 2 of GenMappingReport
 void report_finish(const Ctx &cx, bool first, Read &rd, std::vector<Candidate> &cands, std::vector<CandWork> &work,
-                   const std::vector<NwJob> &jobs)
+                   const NwJobs &jobs)
 {
 	rd.score = rd.sub_score = rd.best = 0;
 	rd.can_num = (int)cands.size();
@@ -1558,7 +1561,7 @@ struct ChunkState {
 	Stats st;
 	std::vector<std::vector<Candidate>> cands;
 	std::vector<std::vector<CandWork>> work;
-	std::vector<NwJob> jobs;
+	NwJobs jobs;
 	std::string text;
 };
 
@@ -1758,17 +1761,10 @@ void chunk_stage_c(const Ctx &cx, std::vector<Read> &reads, ChunkState &ck)
 // one NW kernel call for the jobs of many chunks
 void run_nw(const Ctx &cx, std::vector<ChunkState> &chunks, size_t from, size_t to)
 {
-	std::vector<NwJob> all;
-	size_t total = 0;
-	for (size_t c = from; c < to; ++c) total += chunks[c].jobs.size();
-	if (total == 0) return;
-	all.reserve(total);
+	std::vector<NwJobs *> parts;
 	for (size_t c = from; c < to; ++c)
-		for (NwJob &j : chunks[c].jobs) all.push_back(std::move(j));
-	cx.kern.nw_batch(all);
-	size_t at = 0;
-	for (size_t c = from; c < to; ++c)
-		for (NwJob &j : chunks[c].jobs) j = std::move(all[at++]);
+		if (chunks[c].jobs.size() > 0) parts.push_back(&chunks[c].jobs);
+	if (!parts.empty()) cx.kern.nw_batch(parts);
 }
 
 struct RunTotals {

@@ -37,10 +37,27 @@ struct Options {
 	int64_t batch_reads = 400000;   // reads seeded per GPU call (a whole number of 4000-read chunks)
 };
 
-// one fragment pair handed to the gap-closing kernel
-struct NwJob {
-	std::string a, b;     // read fragment, genome fragment (raw characters)
-	std::string ra, rb;   // result: the two gapped strings nw_alignment() would leave in place
+// The gap-closing jobs of one chunk, flat: fragments concatenated (read side f1, genome side f2) with
+// offsets, results as op codes (KG_OP_*) at ops[o1[j] + o2[j] ...) with len[j] columns -- the same
+// layout kg_nw_batch uses, so batching chunks is a handful of large copies.
+struct NwJobs {
+	std::string f1, f2;
+	std::vector<int64_t> o1{0}, o2{0};
+	std::vector<uint8_t> ops;
+	std::vector<int32_t> len;
+	int add(const char *a, int m, const char *b, int n)
+	{
+		f1.append(a, (size_t)m);
+		f2.append(b, (size_t)n);
+		o1.push_back((int64_t)f1.size());
+		o2.push_back((int64_t)f2.size());
+		return (int)o1.size() - 2;
+	}
+	size_t size() const { return o1.size() - 1; }
+	void clear()
+	{
+		f1.clear(); f2.clear(); o1.assign(1, 0); o2.assign(1, 0); ops.clear(); len.clear();
+	}
 };
 
 struct KernelBackend {
@@ -50,8 +67,8 @@ struct KernelBackend {
 	// IdentifySeedPairs_{Fast,Sensitive}Mode for a batch: enc = concatenated codes, off[n+1]
 	virtual void seed_batch(int mode, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off,
 	                        std::vector<int64_t> &seed_off, std::vector<kg_seed> &seeds) = 0;
-	// nw_alignment for a batch of jobs (fills ra/rb)
-	virtual void nw_batch(std::vector<NwJob> &jobs) = 0;
+	// nw_alignment for the jobs of several chunks in one call (fills ops/len of every part)
+	virtual void nw_batch(std::vector<NwJobs *> &parts) = 0;
 };
 
 struct Contig {

@@ -33,13 +33,19 @@ public:
 		seeds.resize((size_t)t);
 		for (int64_t i = 0; i < t; ++i) { seeds[(size_t)i].gPos = buf[(size_t)i].gPos; seeds[(size_t)i].rPos = buf[(size_t)i].rPos; seeds[(size_t)i].len = buf[(size_t)i].len; }
 	}
-	void nw_batch(std::vector<NwJob> &jobs) override
+	void nw_batch(std::vector<NwJobs *> &parts) override
 	{
-		for (NwJob &j : jobs) {
-			std::vector<char> o1(j.a.size() + j.b.size() + 2), o2(j.a.size() + j.b.size() + 2);
-			int len = ko_nw(j.a.data(), (int)j.a.size(), j.b.data(), (int)j.b.size(), o1.data(), o2.data());
-			j.ra.assign(o1.data(), (size_t)len);
-			j.rb.assign(o2.data(), (size_t)len);
+		for (NwJobs *p : parts) {
+			p->ops.assign(p->f1.size() + p->f2.size() + 1, 0);
+			p->len.assign(p->size(), 0);
+			for (size_t j = 0; j < p->size(); ++j) {
+				int m = (int)(p->o1[j + 1] - p->o1[j]), n = (int)(p->o2[j + 1] - p->o2[j]);
+				std::vector<char> g1((size_t)(m + n + 2)), g2((size_t)(m + n + 2));
+				int L = ko_nw(p->f1.data() + p->o1[j], m, p->f2.data() + p->o2[j], n, g1.data(), g2.data());
+				uint8_t *op = p->ops.data() + p->o1[j] + p->o2[j];
+				for (int t = 0; t < L; ++t) op[t] = g1[(size_t)t] == '-' ? KG_OP_GAP1 : g2[(size_t)t] == '-' ? KG_OP_GAP2 : KG_OP_DIAG;
+				p->len[j] = L;
+			}
 		}
 	}
 
