@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
@@ -48,6 +49,7 @@ public:
 	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
 	{
+		std::lock_guard<std::mutex> lk(nw_mu_);   // the staging vectors below are shared; calls from the commit path are rare
 		// concatenate the parts (a few large copies), one kernel call, scatter the op strings back
 		int64_t n = 0, b1 = 0, b2 = 0;
 		for (NwJobs *p : parts) { n += (int64_t)p->size(); b1 += (int64_t)p->f1.size(); b2 += (int64_t)p->f2.size(); }
@@ -75,6 +77,7 @@ public:
 private:
 	kg_index *ix_;
 	int threads_;
+	std::mutex nw_mu_;
 	std::vector<char> f1_, f2_;
 	std::vector<int64_t> o1_, o2_;
 	std::vector<uint8_t> ops_;

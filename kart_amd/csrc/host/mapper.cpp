@@ -721,16 +721,23 @@ int finish_tail(Pair &sp, std::string &a1, std::string &a2, CigarVec &cig)  // s
 std::string cigar_string(const CigarVec &cig)  // GenerateCIGAR, :492-513
 {
 	std::string out;
-	char state = '\0', buf[32];
+	char state = '\0';
 	int c = 0;
+	auto emit = [&out](int n, char st) {
+		char buf[16];
+		int k = 0;
+		do { buf[k++] = (char)('0' + n % 10); n /= 10; } while (n);
+		while (k) out += buf[--k];
+		out += st;
+	};
 	for (size_t i = 0; i < cig.size(); ++i) {
 		if (cig[i].second != state) {
-			if (c > 0) { snprintf(buf, sizeof(buf), "%d%c", c, state); out += buf; }
+			if (c > 0) emit(c, state);
 			c = cig[i].first;
 			state = cig[i].second;
 		} else c += cig[i].first;
 	}
-	if (c > 0) { snprintf(buf, sizeof(buf), "%d%c", c, state); out += buf; }
+	if (c > 0) emit(c, state);
 	return out;
 }
 
@@ -1175,11 +1182,20 @@ void evaluate_mapq(const Ctx &cx, Read &rd)  // EvaluateMAPQ, src/Mapping.cpp:16
 // ----------------------------------------------------------------------------------------------
 // SAM text (src/Mapping.cpp:177-315; record formats in SURVEY.md App. D)
 // ----------------------------------------------------------------------------------------------
+inline void append_int(std::string &out, long long v)   // what "%d" / "%lld" print
+{
+	char buf[24];
+	int n = 0;
+	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+	do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+	if (v < 0) buf[n++] = '-';
+	while (n) out += buf[--n];
+}
+
 void sam_unmapped(const Ctx &cx, const Read &rd, std::string &out)
 {
-	char num[32];
-	snprintf(num, sizeof(num), "%d", rd.rep[0].flag);
-	out += rd.name; out += '\t'; out += num;
+	out += rd.name; out += '\t';
+	append_int(out, rd.rep[0].flag);
 	out += "\t*\t0\t0\t*\t*\t0\t0\t";
 	out += rd.seq; out += '\t';
 	if (cx.fastq) out += rd.qual; else out += '*';
@@ -1189,20 +1205,20 @@ void sam_unmapped(const Ctx &cx, const Read &rd, std::string &out)
 void sam_mapped(const Ctx &cx, const Read &rd, const Report &rp, bool has_mate, long long mate_pos, int tlen,
                 std::string_view seq, std::string_view qual, std::string &out)
 {
-	char buf[256];
-	out += rd.name;
-	snprintf(buf, sizeof(buf), "\t%d\t", rp.flag);
-	out += buf;
-	out += cx.ref.contigs[(size_t)rp.chr].name;
-	snprintf(buf, sizeof(buf), "\t%lld\t%d\t", (long long)rp.gPos, rd.mapq);
-	out += buf;
+	out += rd.name; out += '\t';
+	append_int(out, rp.flag); out += '\t';
+	out += cx.ref.contigs[(size_t)rp.chr].name; out += '\t';
+	append_int(out, (long long)rp.gPos); out += '\t';
+	append_int(out, rd.mapq); out += '\t';
 	out += rp.cigar;
-	if (has_mate) { snprintf(buf, sizeof(buf), "\t=\t%lld\t%d\t", mate_pos, tlen); out += buf; }
+	if (has_mate) { out += "\t=\t"; append_int(out, mate_pos); out += '\t'; append_int(out, tlen); out += '\t'; }
 	else out += "\t*\t0\t0\t";
 	out += seq; out += '\t';
 	if (cx.fastq) out += qual; else out += '*';
-	snprintf(buf, sizeof(buf), "\tNM:i:%d\tAS:i:%d\tXS:i:%d\n", rd.rlen - rd.score, rd.score, rd.sub_score);
-	out += buf;
+	out += "\tNM:i:"; append_int(out, rd.rlen - rd.score);
+	out += "\tAS:i:"; append_int(out, rd.score);
+	out += "\tXS:i:"; append_int(out, rd.sub_score);
+	out += '\n';
 }
 
 // OutputPairedAlignments, src/Mapping.cpp:177-270.  Mate 2 is held reverse-complemented (App. B-2).
@@ -1782,6 +1798,8 @@ double now_s()
 struct Batch {
 	std::vector<Read> reads;
 	std::vector<ChunkState> chunks;
+	std::vector<int64_t> seed_off;                  // per-read seed ranges of this batch (filled by the seeding stage)
+	std::vector<kg_seed> seeds;
 	std::deque<OwnedRead> owned;                    // storage behind the views (getline()/gzgets() readers)
 	std::vector<std::unique_ptr<char[]>> arenas;    // storage behind reverse-complemented mates (mapped files)
 	bool eof = false;
@@ -1844,25 +1862,66 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	const int chunk_limit = cx.opt.pacbio ? 10 : 4000;   // ReadChunkSize, src/structure.h:21; src/GetData.cpp:140
 	const int mode = cx.opt.pacbio ? KG_MODE_SENSITIVE : KG_MODE_FAST;
 	const int nthreads = std::max(1, cx.opt.threads);
+	// three batches in flight: one being read, one in the front half (encode, seed, chain/pair/plan, NW),
+	// one in the back half (finish, format, in-order commit).  The back half of batch k overlaps the front
+	// half of batch k+1; the speculated EstDistance may therefore lag one more batch, which the commit's
+	// validity check absorbs.
+	Pool front_pool(nthreads), back_pool(nthreads), read_pool(nthreads);
+	Writer writer(out);
 	std::vector<uint8_t> enc;
-	std::vector<int64_t> off, seed_off;
-	std::vector<kg_seed> seeds;
+	std::vector<int64_t> off;
+	std::mutex tot_mu;
 	// small batches first: the estimate moves fastest while the totals are small
 	int64_t batch_chunks = 1;
 	const int64_t max_batch_chunks = std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit);
-	Pool pool(nthreads), read_pool(nthreads);
-	Writer writer(out);
-	Batch cur, nxt;
-	read_batch(cx, src, batch_chunks, chunk_limit, read_pool, cur);
-	tot.t_read += cur.seconds;
-	while (!cur.reads.empty()) {
-		std::vector<Read> &reads = cur.reads;
-		std::vector<ChunkState> &chunks = cur.chunks;
-		// the next batch is read (and materialised) while this one is mapped
+	std::unique_ptr<Batch> cur(new Batch()), nxt(new Batch()), prev;
+	read_batch(cx, src, batch_chunks, chunk_limit, read_pool, *cur);
+	tot.t_read += cur->seconds;
+	std::future<void> back;
+
+	auto back_half = [&](Batch *bp) {
+		Batch &b = *bp;
+		double t5 = now_s();
+		back_pool.run((int)b.chunks.size(), [&](int c) { chunk_stage_c(cx, b.reads, b.chunks[(size_t)c]); });
+		double t6 = now_s();
+		// ---- in-order commit: EstDistance feeds forward (src/Mapping.cpp:533-540) ---------------------------
+		for (size_t c = 0; c < b.chunks.size(); ++c) {
+			ChunkState &ck = b.chunks[c];
+			if (ck.paired) {
+				int est_true = est_distance(cx, tot.iPaired, tot.iDistance);
+				bool valid = est_true == ck.est_used ||
+				             (ck.ps.lo < est_true && est_true <= ck.ps.hi &&
+				              (!ck.ps.rescue_used || std::min(est_true, cx.opt.max_insert) == std::min(ck.est_used, cx.opt.max_insert)));
+				if (!valid) {   // mapped under an estimate that would have decided differently: redo with the true one
+					st.respeculated++;
+					chunk_stage_a(cx, b.reads, b.seed_off, b.seeds, ck, est_true);
+					run_nw(cx, b.chunks, c, c + 1);
+					chunk_stage_c(cx, b.reads, ck);
+				}
+			}
+			writer.push(std::move(ck.text));
+			{
+				std::lock_guard<std::mutex> lk(tot_mu);
+				tot.iPaired += ck.ps.paired;
+				tot.iDistance += ck.ps.distance;
+			}
+			st.total_reads += ck.st.total_reads;
+			st.unmapped += ck.st.unmapped;
+			st.unique += ck.st.unique;
+		}
+		tot.t_c += t6 - t5;
+		tot.t_commit += now_s() - t6;
+	};
+
+	while (!cur->reads.empty()) {
+		std::vector<Read> &reads = cur->reads;
+		std::vector<ChunkState> &chunks = cur->chunks;
+		// the next batch is read while this one is mapped
 		batch_chunks = std::min(max_batch_chunks, batch_chunks * 2);
 		std::future<void> prefetch;
-		bool more = !cur.eof;
-		if (more) prefetch = std::async(std::launch::async, [&, batch_chunks]() { read_batch(cx, src, batch_chunks, chunk_limit, read_pool, nxt); });
+		bool more = !cur->eof;
+		Batch *np = nxt.get();
+		if (more) prefetch = std::async(std::launch::async, [&, batch_chunks, np]() { read_batch(cx, src, batch_chunks, chunk_limit, read_pool, *np); });
 		double t1 = now_s();
 		// EnCodeReadSeq (src/Mapping.cpp:482-485).  The reference encodes mate 2 with mate 1's length (:550,
 		// App. B-5); with equal-length mates that is the same thing, otherwise it reads or leaves
@@ -1870,7 +1929,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 		off.assign(reads.size() + 1, 0);
 		for (size_t i = 0; i < reads.size(); ++i) off[i + 1] = off[i] + reads[i].rlen;
 		enc.resize((size_t)off[reads.size()]);
-		pool.run((int)((reads.size() + 4095) / 4096), [&](int blk) {
+		front_pool.run((int)((reads.size() + 4095) / 4096), [&](int blk) {
 			size_t lo = (size_t)blk * 4096, hi = std::min(reads.size(), lo + 4096);
 			for (size_t i = lo; i < hi; ++i) {
 				uint8_t *dst = enc.data() + off[i];
@@ -1879,50 +1938,36 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 			}
 		});
 		double t2 = now_s(); tot.t_encode += t2 - t1;
-		cx.kern.seed_batch(mode, enc, off, seed_off, seeds);
+		cx.kern.seed_batch(mode, enc, off, cur->seed_off, cur->seeds);
 		double t3 = now_s(); tot.t_seed += t3 - t2;
-
 		// ---- speculative pass over all chunks of the batch ---------------------------------------------
-		int est_guess = est_distance(cx, tot.iPaired, tot.iDistance);
-		pool.run((int)chunks.size(), [&](int c) { chunk_stage_a(cx, reads, seed_off, seeds, chunks[(size_t)c], est_guess); });
+		int est_guess;
+		{
+			std::lock_guard<std::mutex> lk(tot_mu);
+			est_guess = est_distance(cx, tot.iPaired, tot.iDistance);
+		}
+		Batch *cp = cur.get();
+		front_pool.run((int)chunks.size(), [&](int c) { chunk_stage_a(cx, cp->reads, cp->seed_off, cp->seeds, cp->chunks[(size_t)c], est_guess); });
 		double t4 = now_s(); tot.t_a += t4 - t3;
 		run_nw(cx, chunks, 0, chunks.size());
-		double t5 = now_s(); tot.t_nw += t5 - t4;
-		pool.run((int)chunks.size(), [&](int c) { chunk_stage_c(cx, reads, chunks[(size_t)c]); });
-		double t6 = now_s(); tot.t_c += t6 - t5;
-
-		// ---- in-order commit: EstDistance feeds forward (src/Mapping.cpp:533-540) ---------------------------
-		for (size_t c = 0; c < chunks.size(); ++c) {
-			ChunkState &ck = chunks[c];
-			if (ck.paired) {
-				int est_true = est_distance(cx, tot.iPaired, tot.iDistance);
-				bool valid = est_true == ck.est_used ||
-				             (ck.ps.lo < est_true && est_true <= ck.ps.hi &&
-				              (!ck.ps.rescue_used || std::min(est_true, cx.opt.max_insert) == std::min(ck.est_used, cx.opt.max_insert)));
-				if (!valid) {   // mapped under an estimate that would have decided differently: redo with the true one
-					st.respeculated++;
-					chunk_stage_a(cx, reads, seed_off, seeds, ck, est_true);
-					run_nw(cx, chunks, c, c + 1);
-					chunk_stage_c(cx, reads, ck);
-				}
-			}
-			writer.push(std::move(ck.text));
-			tot.iPaired += ck.ps.paired;
-			tot.iDistance += ck.ps.distance;
-			st.total_reads += ck.st.total_reads;
-			st.unmapped += ck.st.unmapped;
-			st.unique += ck.st.unique;
-		}
-		tot.t_commit += now_s() - t6;
+		tot.t_nw += now_s() - t4;
+		// hand the batch to the back half (after the previous one has committed: output stays in order)
+		if (back.valid()) back.get();
+		prev = std::move(cur);
+		Batch *pp = prev.get();
+		back = std::async(std::launch::async, [&, pp]() { back_half(pp); });
 		if (more) {
 			double tw = now_s();
 			prefetch.get();
 			tot.t_read += now_s() - tw;   // only the part that was not hidden behind the mapping
-			std::swap(cur, nxt);
+			cur = std::move(nxt);
+			nxt.reset(new Batch());
 		} else {
-			cur.reads.clear();
+			cur.reset(new Batch());
 		}
+		if (!prev->chunks.empty() && prev->chunks.size() <= 2 && back.valid()) back.get();   // tiny first batches: settle the estimate first
 	}
+	if (back.valid()) back.get();
 	writer.finish();
 }
 
