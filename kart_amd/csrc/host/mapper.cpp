@@ -1598,6 +1598,15 @@ public:
 		for (std::thread &th : workers_) th.join();
 	}
 	int size() const { return n_; }
+	// two item sets in one parallel phase, both with the item -> worker (i mod n) mapping
+	void run2(int n_a, const std::function<void(int)> &fa, int n_b, const std::function<void(int)> &fb)
+	{
+		int n = std::max(n_a, n_b);
+		run(n, [&](int i) {
+			if (i < n_a) fa(i);
+			if (i < n_b) fb(i);
+		});
+	}
 	void run(int n_items, const std::function<void(int)> &fn)
 	{
 		if (n_items <= 0) return;
@@ -1798,12 +1807,14 @@ double now_s()
 struct Batch {
 	std::vector<Read> reads;
 	std::vector<ChunkState> chunks;
+	std::vector<uint8_t> enc;                       // EnCodeReadSeq output, concatenated
+	std::vector<int64_t> off;
 	std::vector<int64_t> seed_off;                  // per-read seed ranges of this batch (filled by the seeding stage)
 	std::vector<kg_seed> seeds;
 	std::deque<OwnedRead> owned;                    // storage behind the views (getline()/gzgets() readers)
 	std::vector<std::unique_ptr<char[]>> arenas;    // storage behind reverse-complemented mates (mapped files)
 	bool eof = false;
-	double seconds = 0;
+	double seconds = 0, seed_seconds = 0;
 };
 
 struct Source {
@@ -1854,6 +1865,21 @@ void read_batch(const Ctx &cx, Source &src, int64_t batch_chunks, int chunk_limi
 			rd.name = o.name; rd.seq = o.seq; rd.qual = o.qual; rd.rlen = o.rlen;
 		}
 	}
+	// EnCodeReadSeq (src/Mapping.cpp:482-485).  The reference encodes mate 2 with mate 1's length (:550,
+	// App. B-5); with equal-length mates that is the same thing, otherwise it reads or leaves
+	// uninitialised bytes -- here every read is encoded over its own length.
+	std::vector<Read> &reads = b.reads;
+	b.off.assign(reads.size() + 1, 0);
+	for (size_t i = 0; i < reads.size(); ++i) b.off[i + 1] = b.off[i] + reads[i].rlen;
+	b.enc.resize((size_t)b.off[reads.size()]);
+	pool.run((int)((reads.size() + 4095) / 4096), [&](int blk) {
+		size_t lo = (size_t)blk * 4096, hi = std::min(reads.size(), lo + 4096);
+		for (size_t i = lo; i < hi; ++i) {
+			uint8_t *dst = b.enc.data() + b.off[i];
+			std::string_view sq = reads[i].seq;
+			for (int p = 0; p < reads[i].rlen; ++p) dst[p] = (uint8_t)nt4((unsigned char)sq[(size_t)p]);
+		}
+	});
 	b.seconds = now_s() - t0;
 }
 
@@ -1862,29 +1888,29 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	const int chunk_limit = cx.opt.pacbio ? 10 : 4000;   // ReadChunkSize, src/structure.h:21; src/GetData.cpp:140
 	const int mode = cx.opt.pacbio ? KG_MODE_SENSITIVE : KG_MODE_FAST;
 	const int nthreads = std::max(1, cx.opt.threads);
-	// three batches in flight: one being read, one in the front half (encode, seed, chain/pair/plan, NW),
-	// one in the back half (finish, format, in-order commit).  The back half of batch k overlaps the front
-	// half of batch k+1; the speculated EstDistance may therefore lag one more batch, which the commit's
-	// validity check absorbs.
-	Pool front_pool(nthreads), back_pool(nthreads), read_pool(nthreads);
+	// Three batches in flight:
+	//   prefetch thread : read + encode + seed (GPU) of batch k+1
+	//   worker pool     : ONE combined phase -- finish/format the chunks of batch k-1 and chain/pair/plan the
+	//                     chunks of batch k, chunk c of either batch on worker c mod n, so whatever a worker
+	//                     allocates for a chunk it also frees (no cross-thread frees)
+	//   main thread     : NW kernel call of batch k, then the in-order commit of batch k-1
+	// The speculated EstDistance therefore lags the committed totals by up to two batches; the commit's
+	// validity check absorbs that.
+	Pool pool(nthreads), read_pool(nthreads);
 	Writer writer(out);
-	std::vector<uint8_t> enc;
-	std::vector<int64_t> off;
-	std::mutex tot_mu;
 	// small batches first: the estimate moves fastest while the totals are small
 	int64_t batch_chunks = 1;
 	const int64_t max_batch_chunks = std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit);
 	std::unique_ptr<Batch> cur(new Batch()), nxt(new Batch()), prev;
-	read_batch(cx, src, batch_chunks, chunk_limit, read_pool, *cur);
-	tot.t_read += cur->seconds;
-	std::future<void> back;
 
-	auto back_half = [&](Batch *bp) {
-		Batch &b = *bp;
-		double t5 = now_s();
-		back_pool.run((int)b.chunks.size(), [&](int c) { chunk_stage_c(cx, b.reads, b.chunks[(size_t)c]); });
-		double t6 = now_s();
-		// ---- in-order commit: EstDistance feeds forward (src/Mapping.cpp:533-540) ---------------------------
+	auto fetch = [&](Batch *b, int64_t n_chunks) {
+		read_batch(cx, src, n_chunks, chunk_limit, read_pool, *b);
+		double t = now_s();
+		if (!b->reads.empty()) cx.kern.seed_batch(mode, b->enc, b->off, b->seed_off, b->seeds);
+		b->seed_seconds = now_s() - t;
+	};
+	auto commit = [&](Batch &b) {   // in-order: EstDistance feeds forward (src/Mapping.cpp:533-540)
+		double t0 = now_s();
 		for (size_t c = 0; c < b.chunks.size(); ++c) {
 			ChunkState &ck = b.chunks[c];
 			if (ck.paired) {
@@ -1900,74 +1926,46 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 				}
 			}
 			writer.push(std::move(ck.text));
-			{
-				std::lock_guard<std::mutex> lk(tot_mu);
-				tot.iPaired += ck.ps.paired;
-				tot.iDistance += ck.ps.distance;
-			}
+			tot.iPaired += ck.ps.paired;
+			tot.iDistance += ck.ps.distance;
 			st.total_reads += ck.st.total_reads;
 			st.unmapped += ck.st.unmapped;
 			st.unique += ck.st.unique;
 		}
-		tot.t_c += t6 - t5;
-		tot.t_commit += now_s() - t6;
+		tot.t_commit += now_s() - t0;
 	};
 
-	while (!cur->reads.empty()) {
-		std::vector<Read> &reads = cur->reads;
-		std::vector<ChunkState> &chunks = cur->chunks;
-		// the next batch is read while this one is mapped
+	fetch(cur.get(), batch_chunks);
+	tot.t_read += cur->seconds;
+	tot.t_seed += cur->seed_seconds;
+	while (!cur->reads.empty() || prev) {
+		bool have_cur = !cur->reads.empty();
 		batch_chunks = std::min(max_batch_chunks, batch_chunks * 2);
 		std::future<void> prefetch;
-		bool more = !cur->eof;
+		bool more = have_cur && !cur->eof;
 		Batch *np = nxt.get();
-		if (more) prefetch = std::async(std::launch::async, [&, batch_chunks, np]() { read_batch(cx, src, batch_chunks, chunk_limit, read_pool, *np); });
-		double t1 = now_s();
-		// EnCodeReadSeq (src/Mapping.cpp:482-485).  The reference encodes mate 2 with mate 1's length (:550,
-		// App. B-5); with equal-length mates that is the same thing, otherwise it reads or leaves
-		// uninitialised bytes -- here every read is encoded over its own length.
-		off.assign(reads.size() + 1, 0);
-		for (size_t i = 0; i < reads.size(); ++i) off[i + 1] = off[i] + reads[i].rlen;
-		enc.resize((size_t)off[reads.size()]);
-		front_pool.run((int)((reads.size() + 4095) / 4096), [&](int blk) {
-			size_t lo = (size_t)blk * 4096, hi = std::min(reads.size(), lo + 4096);
-			for (size_t i = lo; i < hi; ++i) {
-				uint8_t *dst = enc.data() + off[i];
-				std::string_view sq = reads[i].seq;
-				for (int p = 0; p < reads[i].rlen; ++p) dst[p] = (uint8_t)nt4((unsigned char)sq[(size_t)p]);
-			}
-		});
-		double t2 = now_s(); tot.t_encode += t2 - t1;
-		cx.kern.seed_batch(mode, enc, off, cur->seed_off, cur->seeds);
-		double t3 = now_s(); tot.t_seed += t3 - t2;
-		// ---- speculative pass over all chunks of the batch ---------------------------------------------
-		int est_guess;
-		{
-			std::lock_guard<std::mutex> lk(tot_mu);
-			est_guess = est_distance(cx, tot.iPaired, tot.iDistance);
-		}
-		Batch *cp = cur.get();
-		front_pool.run((int)chunks.size(), [&](int c) { chunk_stage_a(cx, cp->reads, cp->seed_off, cp->seeds, cp->chunks[(size_t)c], est_guess); });
+		if (more) prefetch = std::async(std::launch::async, [&, batch_chunks, np]() { fetch(np, batch_chunks); });
+		int est_guess = est_distance(cx, tot.iPaired, tot.iDistance);
+		Batch *cp = cur.get(), *pp = prev.get();
+		double t3 = now_s();
+		pool.run2(pp ? (int)pp->chunks.size() : 0, [&](int c) { chunk_stage_c(cx, pp->reads, pp->chunks[(size_t)c]); },
+		          have_cur ? (int)cp->chunks.size() : 0, [&](int c) { chunk_stage_a(cx, cp->reads, cp->seed_off, cp->seeds, cp->chunks[(size_t)c], est_guess); });
 		double t4 = now_s(); tot.t_a += t4 - t3;
-		run_nw(cx, chunks, 0, chunks.size());
+		if (have_cur) run_nw(cx, cp->chunks, 0, cp->chunks.size());
 		tot.t_nw += now_s() - t4;
-		// hand the batch to the back half (after the previous one has committed: output stays in order)
-		if (back.valid()) back.get();
-		prev = std::move(cur);
-		Batch *pp = prev.get();
-		back = std::async(std::launch::async, [&, pp]() { back_half(pp); });
+		if (pp) commit(*pp);
+		prev = have_cur ? std::move(cur) : nullptr;
 		if (more) {
 			double tw = now_s();
 			prefetch.get();
-			tot.t_read += now_s() - tw;   // only the part that was not hidden behind the mapping
+			tot.t_read += now_s() - tw;   // only the part of read + encode + seed that was not hidden
+			tot.t_seed += nxt->seed_seconds;
 			cur = std::move(nxt);
 			nxt.reset(new Batch());
 		} else {
 			cur.reset(new Batch());
 		}
-		if (!prev->chunks.empty() && prev->chunks.size() <= 2 && back.valid()) back.get();   // tiny first batches: settle the estimate first
 	}
-	if (back.valid()) back.get();
 	writer.finish();
 }
 
@@ -2059,8 +2057,8 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	stats.paired = tot.iPaired;
 	stats.distance = tot.iDistance;
 	if (getenv("KART_AMD_VERBOSE"))
-		fprintf(stdout, "stage seconds: read %.2f encode %.2f seed %.2f chain+pair+plan %.2f nw %.2f finish+format %.2f commit+write %.2f\n",
-		        tot.t_read, tot.t_encode, tot.t_seed, tot.t_a, tot.t_nw, tot.t_c, tot.t_commit);
+		fprintf(stdout, "stage seconds: unhidden read+encode+seed %.2f (seed calls %.2f) | finish+format(k-1) with chain+pair+plan(k) %.2f | nw %.2f | commit %.2f\n",
+		        tot.t_read, tot.t_seed, tot.t_a, tot.t_nw, tot.t_commit);
 	return 0;
 }
 
