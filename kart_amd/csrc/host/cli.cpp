@@ -128,6 +128,7 @@ int cli_main(int argc, char **argv, KernelBackend *(*make_backend)(const Options
 		else
 			fprintf(stdout, "\t# of total mapped sequences = %lld (sensitivity = %.2f%%)\n", mapped, (int)(10000 * (1.0 * mapped / st.total_reads) + 0.5) / 100.0);
 		fprintf(stdout, "Alignment output: %s\n", opt.out_name.c_str());
+		if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "mapping seconds (index load excluded): %.3f\n", st.map_seconds);
 		if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "chunks re-mapped after EstDistance speculation: %lld\n", (long long)st.respeculated);
 	}
 	delete kern;

@@ -28,7 +28,7 @@ public:
 	HipBackend(kg_index *ix, const Options &opt) : ix_(ix), threads_(std::max(1, std::min(opt.threads, 16)))
 	{
 		kg_index_info(ix_, &info_);
-		int64_t max_reads = opt.batch_reads + 8192, max_bases = max_reads * 512;
+		int64_t max_reads = std::max<int64_t>(opt.batch_reads, 4000ll * 4 * std::max(1, opt.threads)) + 8192, max_bases = max_reads * 512;
 		if (opt.pacbio) max_bases = std::max<int64_t>(max_bases, 64ll << 20);
 		if (kg_workspace_create(ix_, max_reads, max_bases, &ws_) != KG_OK) die("kg_workspace_create");
 	}

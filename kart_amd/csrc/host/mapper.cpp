@@ -1900,7 +1900,8 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	Writer writer(out);
 	// small batches first: the estimate moves fastest while the totals are small
 	int64_t batch_chunks = 1;
-	const int64_t max_batch_chunks = std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit);
+	// enough chunks per batch to keep every worker busy (static chunk -> worker assignment)
+	const int64_t max_batch_chunks = std::max<int64_t>(std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit), cx.opt.pacbio ? 64 * nthreads : 4 * nthreads);
 	std::unique_ptr<Batch> cur(new Batch()), nxt(new Batch()), prev;
 
 	auto fetch = [&](Batch *b, int64_t n_chunks) {
@@ -2023,6 +2024,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	mallopt(M_MMAP_THRESHOLD, 1 << 30);
 	mallopt(M_TRIM_THRESHOLD, -1);
 	mallopt(M_TOP_PAD, 64 << 20);
+	double t_begin = now_s();
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	Options &o = const_cast<Options &>(opt);
 	RunTotals tot;
@@ -2056,6 +2058,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	}
 	stats.paired = tot.iPaired;
 	stats.distance = tot.iDistance;
+	stats.map_seconds = now_s() - t_begin;
 	if (getenv("KART_AMD_VERBOSE"))
 		fprintf(stdout, "stage seconds: unhidden read+encode+seed %.2f (seed calls %.2f) | finish+format(k-1) with chain+pair+plan(k) %.2f | nw %.2f | commit %.2f\n",
 		        tot.t_read, tot.t_seed, tot.t_a, tot.t_nw, tot.t_commit);

@@ -87,6 +87,7 @@ struct RefData {
 
 struct Stats {
 	int64_t total_reads = 0, unmapped = 0, unique = 0, paired = 0, distance = 0;
+	double map_seconds = 0;     // first read in -> last SAM byte handed to the writer (index load excluded)
 	int64_t respeculated = 0;   // chunks re-mapped because their speculated EstDistance did not hold
 };
 

@@ -16,10 +16,15 @@ f1, f2 = os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")
 synth.write_fastq(f1, names, r1, mate=1); synth.write_fastq(f2, names, r2, mate=2)
 res = {"pairs": n_pairs, "genome": glen, "index_build_s": round(t_idx, 1)}
 def run(tag, cmd):
-    t = time.time(); subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); dt = time.time() - t
+    t = time.time(); r = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=dict(os.environ, KART_AMD_VERBOSE="1")); dt = time.time() - t
     res[tag] = {"seconds": round(dt, 2), "reads_per_s": round(2 * n_pairs / dt)}
+    for line in r.stdout.decode().splitlines():
+        if line.startswith("mapping seconds"):
+            ms = float(line.split(":")[1])
+            res[tag]["mapping_seconds"] = ms
+            res[tag]["mapping_reads_per_s"] = round(2 * n_pairs / ms)
 common = ["-silent", "-i", os.path.join(d, "idx"), "-f", f1, "-f2", f2]
-for t_ in (1, 8, 32, 64):
+for t_ in (8, 32, 64, 128):
     run("kart_amd_t%d" % t_, ["kart_amd/bin/kart-amd"] + common + ["-t", str(t_), "-o", os.path.join(d, "amd.sam")])
 ref = "oracle/_ref/kart"
 if os.path.exists(ref):
