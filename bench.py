@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU per step")
     ap.add_argument("--sa", choices=["sampled", "full"], default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the bounded FASTQ->SAM leg")
     ap.add_argument("--genome-len", type=int, default=GENOME_LEN, help="experiment knob: synthetic genome length (default = configs[1])")
     args = ap.parse_args()
 
@@ -209,6 +210,10 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(prefix, batches[0][0], READ_LEN)
+    if world == 1 and not args.no_e2e:
+        del d_seeds, d_seed_off, batches
+        torch.cuda.empty_cache()
+        line["end_to_end"] = end_to_end(prefix, genome, workdir)
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
@@ -229,6 +234,50 @@ def measured_traffic(n_reads, args):
             if t and t.get("reads_per_launch") == n_reads and args.genome_len == GENOME_LEN:
                 best = (t["traffic_bytes_per_launch"], "profiles/" + f)
     return best if best else (None, None)
+
+
+def end_to_end(prefix, genome, workdir, n_pairs=500_000):
+    """Bounded FASTQ -> SAM leg (not `value`): kart_amd/bin/kart-amd (host pipeline + the same kernels) on 1 M reads of
+    the same genome, and -- when the unmodified reference binary travelled with the snapshot -- oracle/_ref/kart on
+    the same files at -t 1 (the byte-identity check) and -t 32 (its best setting on this host class)."""
+    import subprocess
+    from kart_amd import synth
+    exe = os.path.join(ROOT, "kart_amd", "bin", "kart-amd")
+    ref = os.path.join(ROOT, "oracle", "_ref", "kart")
+    if not os.path.exists(exe):
+        return None
+    names, r1, r2 = synth.simulate_pairs(genome, n_pairs, seed=5, err=0.01)
+    f1, f2 = os.path.join(workdir, "e2e_1.fq"), os.path.join(workdir, "e2e_2.fq")
+    synth.write_fastq(f1, names, r1, mate=1)
+    synth.write_fastq(f2, names, r2, mate=2)
+    common = ["-silent", "-i", prefix, "-f", f1, "-f2", f2]
+    out = {"reads": 2 * n_pairs, "unit": "reads/s"}
+
+    def run(cmd):
+        t = time.perf_counter()
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=dict(os.environ, KART_AMD_VERBOSE="1"))
+        dt = time.perf_counter() - t
+        ms = [float(l.split(":")[1]) for l in r.stdout.decode().splitlines() if l.startswith("mapping seconds")]
+        return r.returncode, dt, (ms[0] if ms else None)
+
+    threads = min(32, os.cpu_count() or 1)
+    rc, dt, ms = run([exe] + common + ["-t", str(threads), "-o", os.path.join(workdir, "e2e_amd.sam")])
+    if rc != 0:
+        return {"error": "kart-amd failed"}
+    out["kart_amd"] = {"threads": threads, "process_seconds": round(dt, 3), "mapping_seconds": ms,
+                       "reads_per_s_mapping_phase": round(2 * n_pairs / ms) if ms else None, "reads_per_s_process": round(2 * n_pairs / dt)}
+    if os.path.exists(ref):
+        rc1, dt1, _ = run([ref] + common + ["-t", "1", "-o", os.path.join(workdir, "e2e_ref1.sam")])
+        rcn, dtn, _ = run([ref] + common + ["-t", str(threads), "-o", os.path.join(workdir, "e2e_refn.sam")])
+        if rc1 == 0 and rcn == 0:
+            out["reference_kart"] = {"t1_reads_per_s": round(2 * n_pairs / dt1), "t%d_reads_per_s" % threads: round(2 * n_pairs / dtn)}
+            out["sam_identical_to_reference_t1"] = open(os.path.join(workdir, "e2e_amd.sam"), "rb").read() == open(os.path.join(workdir, "e2e_ref1.sam"), "rb").read()
+    for f in (f1, f2, "e2e_amd.sam", "e2e_ref1.sam", "e2e_refn.sam"):
+        try:
+            os.remove(f if os.path.isabs(f) else os.path.join(workdir, f))
+        except OSError:
+            pass
+    return out
 
 
 def cpu_baseline(prefix, enc_dev, read_len):
