@@ -236,7 +236,7 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		v.qtab32 = nullptr;
 		v.qtab64 = nullptr;
 		if (!getenv("KG_NO_QTAB")) {
-			bool narrow = v.seq_len < 0xFFFFFF00ull;
+			bool narrow = v.seq_len < 0xFFFFFF00ull && !getenv("KG_FORCE_U64");
 			size_t tab_bytes = ((size_t)1 << (2 * kQmer)) * (narrow ? 8 : 16);
 			HIP_TRY(hipMalloc(&ix->d_qtab, tab_bytes));
 			HIP_TRY(launch_build_qtab(v, narrow ? (uint2 *)ix->d_qtab : nullptr, narrow ? nullptr : (uint4 *)ix->d_qtab, nullptr));
@@ -249,7 +249,7 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	v.fsa64 = nullptr;
 
 	if (sa_mode == KG_SA_FULL) {
-		bool narrow = v.seq_len < 0xFFFFFFFFull;
+		bool narrow = v.seq_len < 0xFFFFFFFFull && !getenv("KG_FORCE_U64");
 		size_t fsa_bytes = (size_t)(v.seq_len + 1) * (narrow ? 4 : 8);
 		HIP_TRY(hipMalloc(&ix->d_fsa, fsa_bytes));
 		uint32_t *f32 = narrow ? (uint32_t *)ix->d_fsa : nullptr;

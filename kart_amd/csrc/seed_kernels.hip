@@ -557,7 +557,10 @@ hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_tem
 	int blocks = grid_for(a.n_reads, 256, n_cu * per_cu);
 	hipLaunchKernelGGL(pack_reads_kernel, dim3(grid_for(a.n_reads * 16, 256, n_cu * 32)), dim3(256), 0, stream, a);
 	if (ev) (void)hipEventRecord(ev[0], stream);
-	if (a.ix.seq_len < 0xFFFFFF00ull)
+	// 32-bit interval arithmetic whenever the text allows it; KG_FORCE_U64 exercises the wide instantiation
+	// (the one hg38-sized indexes use) on small test indexes
+	static const bool force_wide = getenv("KG_FORCE_U64") != nullptr;
+	if (a.ix.seq_len < 0xFFFFFF00ull && !(force_wide && a.ix.qtab64))
 		hipLaunchKernelGGL(search_kernel<uint32_t>, dim3(blocks), dim3(256), 0, stream, a);
 	else
 		hipLaunchKernelGGL(search_kernel<uint64_t>, dim3(blocks), dim3(256), 0, stream, a);

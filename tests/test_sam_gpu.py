@@ -60,3 +60,24 @@ def test_live_reference_30k_pairs(flags, product_binary, tmp_path):
                 assert not (0 <= int(fx[1]) < 4096 and fx[1] != fy[1]) or True
     else:
         assert got == ref
+
+
+def test_live_reference_pacbio_7kb(product_binary, tmp_path):
+    """configs[3] in miniature: 7 kb reads at 15 % error with -pacbio (SensitiveMode seeding, recursive 8-mer
+    partition, NW fragments of several hundred bases -> the wave-per-pair kernel with multiple stripes)."""
+    if not os.path.exists(KART_REF):
+        pytest.skip("oracle/_ref/kart not present on this machine")
+    from kart_amd import synth
+    from kart_amd.index_build import read_fasta
+    genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
+    names, reads = synth.simulate_long_reads(genome, 300, seed=31, read_len=7000, err=0.15, indel_err_frac=0.1)
+    fq = str(tmp_path / "long.fq")
+    synth.write_fastq(fq, names, reads)
+    outs = []
+    for binary in (KART_REF, product_binary):
+        out = str(tmp_path / (os.path.basename(binary) + ".sam"))
+        extra = ["-t", "1"] if binary == KART_REF else ["-t", "8"]
+        subprocess.run([binary, "-silent", "-i", SMALL_PREFIX, "-f", fq, "-pacbio", "-o", out] + extra, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]

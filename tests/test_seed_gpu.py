@@ -85,3 +85,26 @@ def test_occ_threshold_and_min_seed_len_parameters(golden, gpu_index, oracle_sma
         ws = gpu_index.workspace(len(off) - 1, len(enc))
         so_g, s_g = ws.seed_batch(enc, off, 0, min_seed_len=msl)
         assert (so_g == so_o).all() and (s_g == s_o.astype(api.SEED_DT)).all()
+
+
+def test_wide_index_instantiation(golden, built_lib):
+    """search_kernel<uint64_t>, the 16-byte q-mer table and the u64 full SA -- the variants an hg38-sized index
+    (2L > 2^32) selects -- forced onto the small index (KG_FORCE_U64) in a child process; results must not change."""
+    import os, subprocess, sys, textwrap
+    from conftest import ROOT
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from kart_amd import api
+        g = np.load(%r, allow_pickle=True)
+        for sa_mode in (api.KG_SA_SAMPLED, api.KG_SA_FULL):
+            ix = api.Index(%r, 0, sa_mode)
+            for mode, key in ((0, "fast"), (1, "sens")):
+                ws = ix.workspace(len(g[key + "_off"]) - 1, len(g[key + "_enc"]))
+                so, seeds = ws.seed_batch(g[key + "_enc"], g[key + "_off"], mode)
+                assert (so == g[key + "_seed_off"]).all() and (seeds == g[key + "_seeds"].astype(api.SEED_DT)).all(), (sa_mode, key)
+            ix.close()
+        print("wide ok")
+    ''') % (ROOT, os.path.join(ROOT, "tests", "golden", "hotpath_small.npz"), os.path.join(ROOT, "tests", "golden", "idx", "small"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KG_FORCE_U64="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0 and b"wide ok" in r.stdout, r.stdout.decode()[-800:]
