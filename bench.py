@@ -198,7 +198,8 @@ def main():
                                "1%% substitution errors + 0.1%% haplotype substitutions; step = seeding hot path "
                                "(BWT search + SA locate + sort) on HBM-resident reads" % n_reads,
                    "reads_per_gpu_per_step": n_reads, "sa_mode": args.sa, "index_bytes": int(ix.info.device_bytes),
-                   "index_residency": "index (%.1f MB) fits the 256 MiB Infinity Cache; reads stream from HBM" % (ix.info.device_bytes / 1e6),
+                   "index_residency": ("index (%.1f MB) fits the 256 MiB Infinity Cache; reads stream from HBM" if ix.info.device_bytes < 256e6
+                                       else "index (%.1f MB) exceeds the 256 MiB Infinity Cache: rank gathers are HBM accesses") % (ix.info.device_bytes / 1e6),
                    "parallelism": "read-sharded x%d, index replicated" % world,
                    "index_build_s": round(t_idx, 2), "parity_sample": parity},
         "roofline": {"bound": "hbm", "kernel": "search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

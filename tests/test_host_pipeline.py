@@ -21,6 +21,12 @@ CASES = {
     "pe_g2": ["-f", "pe_1.fq.gz", "-f2", "pe_2.fq.gz", "-g", "2"],
     "pe_interleaved": ["-f", "pe_interleaved.fq", "-p"],
     "pacbio": ["-f", "pacbio.fq.gz", "-pacbio"],
+    # edge cases (oracle/make_golden_edge.py): read lengths 5..300 in one file, N-rich / lowercase / IUPAC / all-N
+    # reads, homopolymers, unmappable reads, cross-contig and far-apart pairs, names with spaces
+    "edge_pe": ["-f", "edge_1.fq", "-f2", "edge_2.fq"],
+    "edge_se": ["-f", "edge_1.fq"],
+    "edge_se_m": ["-f", "edge_2.fq", "-m"],
+    "edge_multi_lib": ["-f", "edge_1.fq", "edge_2.fq"],          # two single-end libraries
 }
 GOLD_OF = {"pe_plain": "pe"}
 
