@@ -28,9 +28,8 @@ public:
 	HipBackend(kg_index *ix, const Options &opt) : ix_(ix), threads_(std::max(1, std::min(opt.threads, 16)))
 	{
 		kg_index_info(ix_, &info_);
-		int64_t max_reads = std::max<int64_t>(opt.batch_reads, 4000ll * 4 * std::max(1, opt.threads)) + 8192, max_bases = max_reads * 512;
-		if (opt.pacbio) max_bases = std::max<int64_t>(max_bases, 64ll << 20);
-		if (kg_workspace_create(ix_, max_reads, max_bases, &ws_) != KG_OK) die("kg_workspace_create");
+		int64_t max_reads = std::max<int64_t>(opt.batch_reads, 4000ll * 4 * std::max(1, opt.threads)) + 8192;
+		reserve(max_reads, max_reads * 256);
 	}
 	~HipBackend() override
 	{
@@ -42,6 +41,7 @@ public:
 	                std::vector<kg_seed> &seeds) override
 	{
 		int64_t n = (int64_t)off.size() - 1;
+		reserve(n, off[(size_t)n]);
 		seed_off.assign(off.size(), 0);
 		const kg_seed *out = nullptr;
 		if (kg_seed_batch(ws_, mode, info_.min_seed_len, KG_OCC_THR_DEFAULT, enc.data(), off.data(), n, seed_off.data(), &out) != KG_OK) die("kg_seed_batch");
@@ -75,6 +75,17 @@ public:
 	}
 
 private:
+	// the seeding workspace grows with the largest batch seen (long-read batches are far larger in bases)
+	void reserve(int64_t reads, int64_t bases)
+	{
+		if (ws_ && reads <= cap_reads_ && bases <= cap_bases_) return;
+		if (ws_) kg_workspace_destroy(ws_);
+		ws_ = nullptr;
+		cap_reads_ = std::max(cap_reads_, reads + reads / 4 + 1024);
+		cap_bases_ = std::max(cap_bases_, bases + bases / 4 + 65536);
+		if (kg_workspace_create(ix_, cap_reads_, cap_bases_, &ws_) != KG_OK) die("kg_workspace_create");
+	}
+	int64_t cap_reads_ = 0, cap_bases_ = 0;
 	kg_index *ix_;
 	int threads_;
 	std::mutex nw_mu_;

@@ -23,7 +23,10 @@ for t_ in (8, 32):
     run("kart_amd_t%d" % t_, ["kart_amd/bin/kart-amd"] + common + ["-t", str(t_), "-o", os.path.join(d, "amd.sam")])
 ref = "oracle/_ref/kart"
 if os.path.exists(ref):
-    run("ref_t1", [ref] + common + ["-t", "1", "-o", os.path.join(d, "ref1.sam")])
     run("ref_t32", [ref] + common + ["-t", "32", "-o", os.path.join(d, "refn.sam")])
-    res["identical_to_ref_t1"] = open(os.path.join(d, "amd.sam"), "rb").read() == open(os.path.join(d, "ref1.sam"), "rb").read()
+    if n <= 8000:
+        run("ref_t1", [ref] + common + ["-t", "1", "-o", os.path.join(d, "ref1.sam")])
+        res["identical_to_ref_t1"] = open(os.path.join(d, "amd.sam"), "rb").read() == open(os.path.join(d, "ref1.sam"), "rb").read()
+    else:   # -t 32 prints the same records in a thread-dependent order: compare as multisets of lines
+        res["same_records_as_ref_t32"] = sorted(open(os.path.join(d, "amd.sam"), "rb").read().split(b"\n")) == sorted(open(os.path.join(d, "refn.sam"), "rb").read().split(b"\n"))
 print(json.dumps(res))
