@@ -150,7 +150,7 @@ def main():
         enc_h = batches[0][0][: k * READ_LEN].cpu().numpy()
         off_h = np.arange(k + 1, dtype=np.int64) * READ_LEN
         orc = O.Oracle(prefix)
-        so_o, s_o = orc.seed_batch(enc_h, off_h, 0, threads=min(8, os.cpu_count() or 1))
+        so_o, s_o = orc.seed_batch(enc_h, off_h, 0, threads=min(8, effective_cores()))
         so_g = d_seed_off[: k + 1].cpu().numpy()
         s_g = d_seeds[: int(so_g[k]) * 16].cpu().numpy().view(api.SEED_DT)
         assert (so_g == so_o).all() and (s_g == s_o.astype(api.SEED_DT)).all(), "GPU seeds differ from the oracle"
@@ -220,6 +220,19 @@ def main():
         dist.destroy_process_group()
 
 
+def effective_cores():
+    """CPUs this process can actually use: the cgroup CPU quota when there is one (the GPU boxes expose 256
+    logical CPUs under a 16-core quota), else the affinity mask / CPU count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def measured_traffic(n_reads, args):
     """HBM/fabric bytes per search_kernel launch from the committed PMC passes of this exact command
     (rocprofv3 --pmc, separate passes; profiles/*_pmc_summary.json, corrected for gfx950 as
@@ -261,7 +274,7 @@ def end_to_end(prefix, genome, workdir, n_pairs=500_000):
         ms = [float(l.split(":")[1]) for l in r.stdout.decode().splitlines() if l.startswith("mapping seconds")]
         return r.returncode, dt, (ms[0] if ms else None)
 
-    threads = min(32, os.cpu_count() or 1)
+    threads = min(32, 2 * effective_cores())
     rc, dt, ms = run([exe] + common + ["-t", str(threads), "-o", os.path.join(workdir, "e2e_amd.sam")])
     if rc != 0:
         return {"error": "kart-amd failed"}
@@ -285,7 +298,7 @@ def cpu_baseline(prefix, enc_dev, read_len):
     """The CPU oracle port of the same step (seeding incl. SA locate and sort) on all host cores, on a
     bounded sample of the same reads (sized for roughly 10-20 s of CPU work)."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     orc = O.Oracle(prefix)
     k = 20000
     enc = enc_dev[: k * read_len].cpu().numpy()
@@ -300,7 +313,8 @@ def cpu_baseline(prefix, enc_dev, read_len):
     orc.seed_batch(enc, off, 0, threads=cores)
     dt = time.perf_counter() - t
     return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "%d reads of the same batch, oracle/liboracle.so seed_batch (FM search + SA locate + sort), %d threads, %.1f s" % (n, cores, dt)}
+            "sample": "%d reads of the same batch, oracle/liboracle.so seed_batch (FM search + SA locate + sort), %d threads = the cgroup CPU quota "
+                      "(%d logical CPUs visible), %.1f s" % (n, cores, os.cpu_count() or 1, dt)}
 
 
 if __name__ == "__main__":
