@@ -86,11 +86,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # debug aid for 1-GPU boxes: KART_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and uses gloo, so the
+    # multi-rank control flow can be exercised where only one GPU exists (never set by the driver)
+    share = os.environ.get("KART_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -174,8 +182,9 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     cnt = ws.counters()
-    totals = shard.allreduce_counters([n_reads * args.steps, int(cnt.seeds)], device=dev)   # the path's only collective
-    elapsed = shard.max_over_ranks(elapsed, device=dev)
+    cdev = None if share else dev
+    totals = shard.allreduce_counters([n_reads * args.steps, int(cnt.seeds)], device=cdev)   # the path's only collective
+    elapsed = shard.max_over_ranks(elapsed, device=cdev)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
