@@ -1946,7 +1946,8 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 		std::future<void> prefetch;
 		bool more = have_cur && !cur->eof;
 		Batch *np = nxt.get();
-		if (more) prefetch = std::async(std::launch::async, [&, batch_chunks, np]() { fetch(np, batch_chunks); });
+		static const bool inline_fetch = getenv("KART_AMD_NO_PREFETCH") != nullptr;   // profiling aid: everything on the main thread
+		if (more) prefetch = std::async(inline_fetch ? std::launch::deferred : std::launch::async, [&, batch_chunks, np]() { fetch(np, batch_chunks); });
 		int est_guess = est_distance(cx, tot.iPaired, tot.iDistance);
 		Batch *cp = cur.get(), *pp = prev.get();
 		double t3 = now_s();

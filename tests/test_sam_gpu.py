@@ -81,3 +81,11 @@ def test_live_reference_pacbio_7kb(product_binary, tmp_path):
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1]
+
+
+def test_repeated_runs_are_deterministic(product_binary, tmp_path):
+    """Regression test for an intermittent race (NW work lists emptied by a late memset of recycled
+    stream-ordered pool memory): the same paired-end input mapped 12 times must give the golden SAM every time."""
+    for it in range(12):
+        got, want, _ = run_case(product_binary, "pe_g2" if it % 2 else "pe", str(tmp_path))
+        assert got == want, "run %d differs" % it
