@@ -41,6 +41,30 @@ def make_genome(seed, length=GENOME_LEN):
     return synth.make_genome([("decoy", DECOY_LEN), ("chrE", length)], seed=seed, gc=0.508)
 
 
+def make_large_codes(length, seed, dev, repeat_frac=0.45):
+    """hg38-like synthetic genome for the large experiments, generated on the device: uniform random bases with
+    `repeat_frac` of the positions overwritten by mutated copies of a short (300 bp) and a long (6 kb) repeat
+    family (10 % / 5 % divergence), so that multi-hit seeds and freq > 50 drops occur.
+    Returns uint8 codes [DECOY_LEN + length] (the decoy contig is plain random)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    total = DECOY_LEN + length
+    codes = torch.randint(0, 4, (total,), generator=g, device=dev, dtype=torch.uint8)
+    for fam_len, share, div in ((300, 0.6, 0.10), (6000, 0.4, 0.05)):
+        fam = torch.randint(0, 4, (fam_len,), generator=g, device=dev, dtype=torch.uint8)
+        n_copies = int(length * repeat_frac * share / fam_len)
+        per = max(1, (1 << 26) // fam_len)
+        ar = torch.arange(fam_len, device=dev)
+        for a in range(0, n_copies, per):
+            m = min(per, n_copies - a)
+            starts = DECOY_LEN + (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (length - fam_len)).long()
+            vals = fam.repeat(m, 1)
+            mut = torch.rand(vals.shape, generator=g, device=dev) < div
+            vals = torch.where(mut, torch.randint(0, 4, vals.shape, generator=g, device=dev, dtype=torch.uint8), vals)
+            codes[(starts[:, None] + ar).reshape(-1)] = vals.reshape(-1)
+    return codes
+
+
 def gen_reads_device(genome_codes, n_pairs, seed, err, dev):
     """(enc uint8 [2*n_pairs*150], offsets int64) on the device, reads as the mapper sees them:
     mate 1 as sequenced, mate 2 reverse-complemented (reference src/GetData.cpp:125-135)."""
@@ -80,6 +104,7 @@ def main():
     ap.add_argument("--sa", choices=["sampled", "full"], default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded FASTQ->SAM leg")
+    ap.add_argument("--bucketed", action="store_true", default=None, help="force the bucketed (large-N) suffix-array builder")
     ap.add_argument("--genome-len", type=int, default=GENOME_LEN, help="experiment knob: synthetic genome length (default = configs[1])")
     args = ap.parse_args()
 
@@ -114,20 +139,34 @@ def main():
     # ---- index (built once by rank 0, replicated per GPU) ------------------------------------------
     workdir = os.environ.get("KART_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "kart_bench_%d" % os.getuid())
     os.makedirs(workdir, exist_ok=True)
-    prefix = os.path.join(workdir, "ecoli_like" if args.genome_len == GENOME_LEN else "synth_%d" % args.genome_len)
+    prefix = os.path.join(workdir, "ecoli_like" if args.genome_len == GENOME_LEN else "synth_%d%s" % (args.genome_len, "_b" if args.bucketed else ""))
     t_idx = time.time()
-    genome = make_genome(seed=2, length=args.genome_len)
-    if rank == 0 and not all(os.path.exists(prefix + e) for e in (".bwt", ".sa", ".pac", ".ann", ".amb")):
-        fa = prefix + ".fa"
-        synth.write_fasta(fa, genome)
-        index_build.build_index(fa, prefix + ".tmp", device=str(dev))
-        for e in (".bwt", ".sa", ".pac", ".ann", ".amb"):
-            os.replace(prefix + ".tmp" + e, prefix + e)
+    large = args.genome_len >= 300_000_000
+    have_index = all(os.path.exists(prefix + e) for e in (".bwt", ".sa", ".pac", ".ann", ".amb"))
+    if large:
+        # large experiments: hg38-like codes made on the device, no FASTA round trip
+        codes = make_large_codes(args.genome_len, seed=3, dev=dev)
+        genome = None
+        if rank == 0 and not have_index:
+            anns = [("decoy", "(null)", 0, DECOY_LEN, 0), ("chrE", "(null)", DECOY_LEN, args.genome_len, 0)]
+            index_build.build_index_from_codes(codes.cpu().numpy(), anns, [], prefix + ".tmp", device=str(dev), bucketed=args.bucketed, verbose=True)
+            for e in (".bwt", ".sa", ".pac", ".ann", ".amb"):
+                os.replace(prefix + ".tmp" + e, prefix + e)
+            torch.cuda.empty_cache()
+    else:
+        genome = make_genome(seed=2, length=args.genome_len)
+        if rank == 0 and not have_index:
+            fa = prefix + ".fa"
+            synth.write_fasta(fa, genome)
+            index_build.build_index(fa, prefix + ".tmp", device=str(dev))
+            for e in (".bwt", ".sa", ".pac", ".ann", ".amb"):
+                os.replace(prefix + ".tmp" + e, prefix + e)
+        codes = torch.from_numpy(np.concatenate([synth.encode(genome["decoy"]), synth.encode(genome["chrE"])])).to(dev)
     if world > 1:
         dist.barrier()
+    t_build = time.time() - t_idx
     ix = api.Index(prefix, local, api.KG_SA_FULL if args.sa == "full" else api.KG_SA_SAMPLED)
     t_idx = time.time() - t_idx
-    codes = torch.from_numpy(np.concatenate([synth.encode(genome["decoy"]), synth.encode(genome["chrE"])])).to(dev)
 
     # ---- resident inputs ----------------------------------------------------------------------------
     n_pairs = args.pairs
@@ -203,14 +242,14 @@ def main():
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": ("configs[1]: E. coli-like 4.64 Mbp" if args.genome_len == GENOME_LEN else "EXPERIMENT: %d bp" % args.genome_len) + " synthetic genome (seed 2), %d x 150 bp PE reads per GPU per step, "
+        "config": {"workload": ("configs[1]: E. coli-like 4.64 Mbp" if args.genome_len == GENOME_LEN else "EXPERIMENT: %d bp%s" % (args.genome_len, " hg38-like (45%% repeats)" if large else "")) + " synthetic genome (seed 2), %d x 150 bp PE reads per GPU per step, "
                                "1%% substitution errors + 0.1%% haplotype substitutions; step = seeding hot path "
                                "(BWT search + SA locate + sort) on HBM-resident reads" % n_reads,
                    "reads_per_gpu_per_step": n_reads, "sa_mode": args.sa, "index_bytes": int(ix.info.device_bytes),
                    "index_residency": ("index (%.1f MB) fits the 256 MiB Infinity Cache; reads stream from HBM" if ix.info.device_bytes < 256e6
                                        else "index (%.1f MB) exceeds the 256 MiB Infinity Cache: rank gathers are HBM accesses") % (ix.info.device_bytes / 1e6),
                    "parallelism": "read-sharded x%d, index replicated" % world,
-                   "index_build_s": round(t_idx, 2), "parity_sample": parity},
+                   "index_build_s": round(t_build, 2), "index_build_plus_load_s": round(t_idx, 2), "parity_sample": parity},
         "roofline": {"bound": "hbm", "kernel": "search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": search_bytes, "avg_launch_ms": search_ms},
@@ -223,7 +262,8 @@ def main():
     if world == 1 and not args.no_e2e:
         del d_seeds, d_seed_off, batches
         torch.cuda.empty_cache()
-        line["end_to_end"] = end_to_end(prefix, genome, workdir)
+        if genome is not None:
+            line["end_to_end"] = end_to_end(prefix, genome, workdir)
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -105,6 +105,99 @@ def suffix_array(text: torch.Tensor) -> torch.Tensor:
     return sa
 
 
+def suffix_array_bucketed(text: torch.Tensor, k_bucket: int = 3, verbose: bool = False) -> torch.Tensor:
+    """Suffix array of text+$ for texts too long for `suffix_array` ((2L)^2 overflowing one 63-bit key, or
+    whole-array sorts not fitting in HBM): hg38 has 2L = 6.2 G.  Suffixes are bucketed by their first
+    `k_bucket` symbols -- the most significant part of every sort key, so buckets are ordered among
+    themselves and sort independently -- and ranks are refined IN PLACE by prefix doubling, one packed key
+    (local rank << 34 | rank[i+h]) and one radix sort per unresolved bucket and round.  Reading a rank that a
+    previous bucket of the same round already refined is harmless (it only orders by more symbols).
+    Everything that touches all 2L positions runs in pieces of <= 2^30 elements (torch.nonzero's limit)."""
+    dev = text.device
+    n = text.numel()
+    n1 = n + 1
+    pad = 64
+    t8 = torch.zeros(n1 + pad, dtype=torch.uint8, device=dev)
+    t8[:n] = text + 1                                     # digit 0 = past the end
+    piece = 1 << 30
+    nb = 5 ** k_bucket
+    # bucket id per suffix, its histogram, and the positions of every bucket
+    bucket = torch.empty(n1, dtype=torch.uint8 if nb <= 255 else torch.int16, device=dev)
+    for a in range(0, n1, piece):
+        b = min(n1, a + piece)
+        acc = torch.zeros(b - a, dtype=torch.int16, device=dev)
+        for d in range(k_bucket):
+            acc = acc * 5 + t8[a + d:b + d]
+        bucket[a:b] = acc.to(bucket.dtype)
+    counts = torch.zeros(nb, dtype=torch.int64, device=dev)
+    for a in range(0, n1, piece):
+        counts += torch.bincount(bucket[a:min(n1, a + piece)].to(torch.int64), minlength=nb)
+    counts_h = counts.cpu().tolist()
+    base = [0] * (nb + 1)
+    for b in range(nb):
+        base[b + 1] = base[b] + counts_h[b]
+    pos_of = [None] * nb
+    for b in range(nb):
+        if counts_h[b] == 0:
+            continue
+        parts = []
+        for a in range(0, n1, piece):
+            e = min(n1, a + piece)
+            parts.append(torch.nonzero(bucket[a:e] == b).view(-1) + a)
+        pos_of[b] = torch.cat(parts) if len(parts) > 1 else parts[0]
+    del bucket
+    rank = torch.empty(n1, dtype=torch.int64, device=dev)
+    # initial ranks: first 27 symbols as a base-5 number, dense ranks inside the bucket
+    h = 27
+    resolved = [True] * nb
+    for b in range(nb):
+        pos = pos_of[b]
+        if pos is None:
+            continue
+        if counts_h[b] == 1:
+            rank[pos] = base[b]
+            continue
+        key = torch.zeros_like(pos)
+        for d in range(h):
+            key = key * 5 + t8[pos + d]
+        srt, order = torch.sort(key)
+        step = torch.zeros_like(srt)
+        step[1:] = (srt[1:] != srt[:-1]).to(torch.int64)
+        dense = torch.cumsum(step, 0)
+        rank[pos[order]] = base[b] + dense
+        resolved[b] = int(dense[-1]) + 1 == counts_h[b]
+        del key, srt, order, step, dense
+    del t8
+    rounds = 0
+    while not all(resolved):
+        for b in range(nb):
+            if resolved[b]:
+                continue
+            pos = pos_of[b]
+            local = rank[pos] - base[b]
+            nx = pos + h
+            inside = nx < n1
+            nxt = torch.zeros_like(pos)
+            nxt[inside] = rank[nx[inside]] + 1            # 0 = suffix shorter than h
+            srt, order = torch.sort((local << 34) | nxt)
+            step = torch.zeros_like(srt)
+            step[1:] = (srt[1:] != srt[:-1]).to(torch.int64)
+            dense = torch.cumsum(step, 0)
+            rank[pos[order]] = base[b] + dense
+            resolved[b] = int(dense[-1]) + 1 == counts_h[b]
+            del local, nx, inside, nxt, srt, order, step, dense
+        h *= 2
+        rounds += 1
+        if verbose:
+            print(f"[index_build] doubling round {rounds}: h={h}, unresolved buckets={sum(not r for r in resolved)}", flush=True)
+    del pos_of
+    sa = torch.empty(n1, dtype=torch.int64, device=dev)
+    for a in range(0, n1, piece):
+        e = min(n1, a + piece)
+        sa[rank[a:e]] = torch.arange(a, e, dtype=torch.int64, device=dev)
+    return sa
+
+
 def _dense_rank(key: torch.Tensor) -> torch.Tensor:
     srt, idx = torch.sort(key)
     step = torch.zeros_like(srt)
@@ -115,32 +208,63 @@ def _dense_rank(key: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def build_index(fasta: str, prefix: str, device: str | None = None) -> dict:
+def build_index(fasta: str, prefix: str, device: str | None = None, bucketed: bool | None = None) -> dict:
     """Write <prefix>.{bwt,sa,pac,ann,amb}; returns {'l_pac','seq_len','primary'}."""
-    if device is None:
-        device = "cuda" if torch.cuda.is_available() else "cpu"
     contigs = read_fasta(fasta)
     fwd, anns, ambs = pack_contigs(contigs)
+    return build_index_from_codes(fwd, anns, ambs, prefix, device, bucketed)
+
+
+def build_index_from_codes(fwd: np.ndarray, anns, ambs, prefix: str, device: str | None = None, bucketed: bool | None = None,
+                           verbose: bool = False) -> dict:
+    """fwd: forward-strand codes 0..3 (uint8); anns/ambs as pack_contigs returns them."""
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
     L = len(fwd)
     N = 2 * L
     text = torch.from_numpy(np.concatenate([fwd, (3 - fwd[::-1])]).astype(np.uint8)).to(device)
-    sa = suffix_array(text)
-    primary = int(torch.nonzero(sa == 0)[0, 0])
-    keep = sa != 0
-    bwt = text[(sa[keep] - 1)]                              # N symbols, the $ row dropped
-    counts = torch.bincount(text.to(torch.int64), minlength=4)
+    if bucketed is None:
+        bucketed = (N + 2) * (N + 2) >= (1 << 62)
+    sa = suffix_array_bucketed(text, verbose=verbose) if bucketed else suffix_array(text)
+    piece = 1 << 30
+    primary = -1
+    for a in range(0, N + 1, piece):
+        hit = torch.nonzero(sa[a:min(N + 1, a + piece)] == 0)
+        if hit.numel():
+            primary = a + int(hit[0, 0])
+    # BWT[i] = text[SA[i] - 1] with the $ row (SA = 0) dropped: N symbols
+    bwt = torch.empty(N, dtype=torch.uint8, device=text.device)
+    for a in range(0, N + 1, piece):
+        e = min(N + 1, a + piece)
+        s_ = sa[a:e]
+        lo = a - (1 if a > primary else 0)                   # rows after the primary shift down by one
+        rows = s_ if not (a <= primary < e) else torch.cat([s_[:primary - a], s_[primary - a + 1:]])
+        bwt[lo:lo + rows.numel()] = text[rows - 1]
+    n_sa = (N + 32) // 32
+    samples = sa[torch.arange(1, n_sa, device=sa.device) * 32].cpu().numpy().astype(np.uint64)
+    del sa
+    counts = torch.zeros(4, dtype=torch.int64, device=text.device)
+    for a in range(0, N, piece):
+        counts += torch.bincount(text[a:min(N, a + piece)].to(torch.int64), minlength=4)
+    del text
     L2 = np.zeros(5, dtype=np.uint64)
     L2[1:] = np.cumsum(counts.cpu().numpy()).astype(np.uint64)
 
     # 128-symbol blocks: running counts before the block, then 8 words of 16 symbols (MSB first)
     n_blocks = (N + 127) // 128
     pad = n_blocks * 128 - N
-    bw = torch.cat([bwt, torch.zeros(pad, dtype=bwt.dtype, device=bwt.device)]).view(n_blocks, 128)
-    valid = (torch.arange(n_blocks * 128, device=bwt.device) < N).view(n_blocks, 128)
-    per_block = torch.stack([((bw == c) & valid).sum(1) for c in range(4)], 1).to(torch.int64)   # (n_blocks, 4)
-    before = torch.cumsum(per_block, 0) - per_block
+    bwt = torch.cat([bwt, torch.full((pad,), 255, dtype=bwt.dtype, device=bwt.device)])    # 255 = "no symbol"
+    per_block = torch.empty(n_blocks, 4, dtype=torch.int64, device=bwt.device)
+    words = torch.empty(n_blocks, 8, dtype=torch.int64, device=bwt.device)
     shifts = (30 - 2 * torch.arange(16, device=bwt.device)).to(torch.int64)
-    words = (bw.view(n_blocks, 8, 16).to(torch.int64) << shifts).sum(2)                            # (n_blocks, 8)
+    bpiece = 1 << 22                                          # blocks per piece (2^29 symbols)
+    for a in range(0, n_blocks, bpiece):
+        e = min(n_blocks, a + bpiece)
+        bw = bwt[a * 128:e * 128].view(e - a, 128)
+        for c in range(4):
+            per_block[a:e, c] = (bw == c).sum(1)
+        words[a:e] = ((bw.view(e - a, 8, 16).to(torch.int64) & 3) * (bw.view(e - a, 8, 16) != 255) << shifts).sum(2)
+    before = torch.cumsum(per_block, 0) - per_block
     inter = torch.zeros(n_blocks, 16, dtype=torch.int64, device=bwt.device)
     inter[:, 0:8:2] = before & 0xFFFFFFFF
     inter[:, 1:8:2] = before >> 32
@@ -155,8 +279,6 @@ def build_index(fasta: str, prefix: str, device: str | None = None) -> dict:
         fh.write(L2[1:].tobytes())
         fh.write(body.tobytes())
         fh.write(total.tobytes())
-    n_sa = (N + 32) // 32
-    samples = sa[torch.arange(1, n_sa, device=sa.device) * 32].cpu().numpy().astype(np.uint64)
     with open(prefix + ".sa", "wb") as fh:
         fh.write(np.uint64(primary).tobytes())
         fh.write(L2[1:].tobytes())
