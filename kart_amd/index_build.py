@@ -129,9 +129,7 @@ def suffix_array_bucketed(text: torch.Tensor, k_bucket: int = 3, verbose: bool =
         for d in range(k_bucket):
             acc = acc * 5 + t8[a + d:b + d]
         bucket[a:b] = acc.to(bucket.dtype)
-    counts = torch.zeros(nb, dtype=torch.int64, device=dev)
-    for a in range(0, n1, piece):
-        counts += torch.bincount(bucket[a:min(n1, a + piece)].to(torch.int64), minlength=nb)
+    counts = _histogram(bucket, nb)
     counts_h = counts.cpu().tolist()
     base = [0] * (nb + 1)
     for b in range(nb):
@@ -198,6 +196,15 @@ def suffix_array_bucketed(text: torch.Tensor, k_bucket: int = 3, verbose: bool =
     return sa
 
 
+def _histogram(x: torch.Tensor, nbins: int) -> torch.Tensor:
+    """bincount in pieces of 2^27 elements (torch.bincount raised SIGFPE on a 2^30-element input on ROCm)."""
+    out = torch.zeros(nbins, dtype=torch.int64, device=x.device)
+    step = 1 << 27
+    for a in range(0, x.numel(), step):
+        out += torch.bincount(x[a:a + step].to(torch.int64), minlength=nbins)
+    return out
+
+
 def _dense_rank(key: torch.Tensor) -> torch.Tensor:
     srt, idx = torch.sort(key)
     step = torch.zeros_like(srt)
@@ -243,9 +250,7 @@ def build_index_from_codes(fwd: np.ndarray, anns, ambs, prefix: str, device: str
     n_sa = (N + 32) // 32
     samples = sa[torch.arange(1, n_sa, device=sa.device) * 32].cpu().numpy().astype(np.uint64)
     del sa
-    counts = torch.zeros(4, dtype=torch.int64, device=text.device)
-    for a in range(0, N, piece):
-        counts += torch.bincount(text[a:min(N, a + piece)].to(torch.int64), minlength=4)
+    counts = _histogram(text, 4)
     del text
     L2 = np.zeros(5, dtype=np.uint64)
     L2[1:] = np.cumsum(counts.cpu().numpy()).astype(np.uint64)
