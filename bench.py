@@ -57,7 +57,12 @@ def make_large_codes(length, seed, dev, repeat_frac=0.45):
         ar = torch.arange(fam_len, device=dev)
         # copies of one family sit on distinct slots of a fam_len grid, so the scatter below never writes a
         # position twice (overlapping writes would make the genome depend on the write order)
-        slots = torch.randperm(length // fam_len, generator=g, device=dev)[:n_copies]
+        import math
+        n_slots = length // fam_len
+        stride = int(n_slots * 0.6180339887) | 1
+        while math.gcd(stride, n_slots) != 1:
+            stride += 2
+        slots = (torch.arange(n_copies, device=dev, dtype=torch.int64) * stride + 12345) % n_slots   # a permutation prefix: distinct slots
         for a in range(0, n_copies, per):
             m = min(per, n_copies - a)
             starts = DECOY_LEN + slots[a:a + m] * fam_len
@@ -176,7 +181,7 @@ def main():
     n_reads = 2 * n_pairs
     n_bases = n_reads * READ_LEN
     batches = [gen_reads_device(codes, n_pairs, seed=1000 + 17 * rank + b, err=0.011, dev=dev) for b in range(2)]
-    seed_cap = 6 * n_reads + 1024
+    seed_cap = (32 if large else 6) * n_reads + 1024
     d_seed_off = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)
     d_seeds = torch.empty(seed_cap * 16, dtype=torch.uint8, device=dev)
     ws = api.Workspace(ix, n_reads, n_bases)
