@@ -4,10 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], the largest configuration that can be built on the box in
-the time allowed): an E. coli-sized seeded synthetic genome (one 4,639,675 bp contig behind a 2 kb
-decoy contig), its FM-index built here by kart_amd.index_build, and 10 M read pairs (20 M reads of
-150 bp, 1 % substitution errors + 0.1 % haplotype substitutions) generated directly in HBM.
+Workload = the configuration BASELINE.json's metric is quoted on, 150 bp PE on hg38 (configs[2]): there is no
+network for the real FASTA, so a seeded hg38-SIZED synthetic genome stands in (3.1 Gbp, 45 % of it mutated copies
+of a 300 bp and a 6 kb repeat family, behind a 2 kb decoy contig; generated on the device).  Its FM-index
+(2L = 6.2 G symbols) is built here by kart_amd.index_build on the GPU (~35 s) and loaded with the full suffix
+array (61 GB in HBM); 10 M read pairs (20 M reads of 150 bp, 1 % substitution errors + 0.1 % haplotype
+substitutions) are generated directly in HBM.  If the large index cannot be built on the machine the run falls
+back to configs[1] (E. coli-sized, 4,639,675 bp) and says so in config.fallback; `--genome-len` selects a size.
 One "step" = one pass of the GPU hot path over one batch of 20 M resident reads:
 kg_seed_batch_device = search (FM-index backward search) + scan + locate (SA recovery) + sort.
 Every rank owns one GPU with a replicated index and its own read shard (weak scaling, no data-path
@@ -30,7 +33,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GENOME_LEN = 4_639_675
+GENOME_LEN = 4_639_675            # configs[1]: E. coli-sized
+HG38_LEN = 3_100_000_000          # configs[2]: hg38-sized (synthetic stand-in: there is no network for the real FASTA)
 DECOY_LEN = 2_000
 READ_LEN = 150
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -113,8 +117,30 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded FASTQ->SAM leg")
     ap.add_argument("--bucketed", action="store_true", default=None, help="force the bucketed (large-N) suffix-array builder")
-    ap.add_argument("--genome-len", type=int, default=GENOME_LEN, help="experiment knob: synthetic genome length (default = configs[1])")
+    ap.add_argument("--genome-len", type=int, default=None,
+                    help="synthetic genome length; default = hg38-sized (configs[2], the size BASELINE.json's metric is quoted on), "
+                         "falling back to configs[1] (4,639,675) if the large index cannot be built on this machine")
     args = ap.parse_args()
+    fallback_note = None
+    if args.genome_len is None:
+        args.genome_len = HG38_LEN
+        try:
+            return run(args, None)
+        except Exception as exc:   # large path failed (disk, memory, ...): measure configs[1] instead and say so
+            import traceback
+            traceback.print_exc()
+            fallback_note = "hg38-sized workload failed on this machine (%s: %s); fell back to configs[1]" % (type(exc).__name__, str(exc)[:200])
+            args.genome_len = GENOME_LEN
+            try:
+                import torch.distributed as dist
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+    return run(args, fallback_note)
+
+
+def run(args, fallback_note):
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,7 +207,7 @@ def main():
     n_reads = 2 * n_pairs
     n_bases = n_reads * READ_LEN
     batches = [gen_reads_device(codes, n_pairs, seed=1000 + 17 * rank + b, err=0.011, dev=dev) for b in range(2)]
-    seed_cap = (32 if large else 6) * n_reads + 1024
+    seed_cap = (12 if large else 6) * n_reads + 1024
     d_seed_off = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)
     d_seeds = torch.empty(seed_cap * 16, dtype=torch.uint8, device=dev)
     ws = api.Workspace(ix, n_reads, n_bases)
@@ -196,6 +222,7 @@ def main():
 
     # ---- parity spot check on this very input (not timed) ------------------------------------------
     parity = "skipped"
+    orc = None
     if rank == 0:
         from oracle import oracle as O
         step(0)
@@ -250,13 +277,16 @@ def main():
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": ("configs[1]: E. coli-like 4.64 Mbp" if args.genome_len == GENOME_LEN else "EXPERIMENT: %d bp%s" % (args.genome_len, " hg38-like (45 pct repeats)" if large else "")) + " synthetic genome (seed 2), %d x 150 bp PE reads per GPU per step, "
+        "config": {"workload": ("configs[1]: E. coli-like 4.64 Mbp" if args.genome_len == GENOME_LEN else
+                                "configs[2]: hg38-sized (3.1 Gbp, 45 pct repeat families)" if args.genome_len == HG38_LEN else
+                                "EXPERIMENT: %d bp%s" % (args.genome_len, " hg38-like (45 pct repeats)" if large else "")) + " synthetic genome, %d x 150 bp PE reads per GPU per step, "
                                "1%% substitution errors + 0.1%% haplotype substitutions; step = seeding hot path "
                                "(BWT search + SA locate + sort) on HBM-resident reads" % n_reads,
                    "reads_per_gpu_per_step": n_reads, "sa_mode": args.sa, "index_bytes": int(ix.info.device_bytes),
                    "index_residency": ("index (%.1f MB) fits the 256 MiB Infinity Cache; reads stream from HBM" if ix.info.device_bytes < 256e6
                                        else "index (%.1f MB) exceeds the 256 MiB Infinity Cache: rank gathers are HBM accesses") % (ix.info.device_bytes / 1e6),
                    "parallelism": "read-sharded x%d, index replicated" % world,
+                   "fallback": fallback_note,
                    "index_build_s": round(t_build, 2), "index_build_plus_load_s": round(t_idx, 2), "parity_sample": parity},
         "roofline": {"bound": "hbm", "kernel": "search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -266,12 +296,15 @@ def main():
         "work_per_read": {k2: v / n_reads for k2, v in c.items()},
     }
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(prefix, batches[0][0], READ_LEN)
+        line["cpu_baseline"] = cpu_baseline(orc, batches[0][0], READ_LEN)
     if world == 1 and not args.no_e2e:
         del d_seeds, d_seed_off, batches
+        if orc is not None:
+            orc.close()
+        ws.close()
+        ix.close()                      # the CLI loads its own copy of the index
         torch.cuda.empty_cache()
-        if genome is not None:
-            line["end_to_end"] = end_to_end(prefix, genome, workdir)
+        line["end_to_end"] = end_to_end(prefix, genome, workdir, n_pairs=250_000 if genome is None else 500_000, codes=codes if genome is None else None)
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
@@ -302,12 +335,27 @@ def measured_traffic(n_reads, args):
                 t = json.load(open(os.path.join(ROOT, "profiles", f))).get("_search_traffic")
             except Exception:
                 t = None
-            if t and t.get("reads_per_launch") == n_reads and args.genome_len == GENOME_LEN:
+            if t and t.get("reads_per_launch") == n_reads and t.get("genome_len", GENOME_LEN) == args.genome_len:
                 best = (t["traffic_bytes_per_launch"], "profiles/" + f)
     return best if best else (None, None)
 
 
-def end_to_end(prefix, genome, workdir, n_pairs=500_000):
+def write_fastq_from_codes(codes, n_pairs, seed, f1, f2, dev):
+    """FASTQ pair files from the device read generator (large genomes: no host-side copy of the genome exists)."""
+    enc, _ = gen_reads_device(codes, n_pairs, seed=seed, err=0.011, dev=dev)
+    arr = enc.view(n_pairs, 2, READ_LEN).cpu().numpy()
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.frombuffer(b"TGCA", dtype=np.uint8)
+    r1 = acgt[arr[:, 0, :]]
+    r2 = comp[arr[:, 1, ::-1]]        # the generator holds mate 2 as the mapper does (reverse-complemented): undo that
+    qual = b"5" * READ_LEN
+    for path, rr, mate in ((f1, r1, 1), (f2, r2, 2)):
+        with open(path, "wb") as fh:
+            for i in range(n_pairs):
+                fh.write(b"@r%d\t/%d\n" % (i, mate) + rr[i].tobytes() + b"\n+\n" + qual + b"\n")
+
+
+def end_to_end(prefix, genome, workdir, n_pairs=500_000, codes=None):
     """Bounded FASTQ -> SAM leg (not `value`): kart_amd/bin/kart-amd (host pipeline + the same kernels) on 1 M reads of
     the same genome, and -- when the unmodified reference binary travelled with the snapshot -- oracle/_ref/kart on
     the same files at -t 1 (the byte-identity check) and -t 32 (its best setting on this host class)."""
@@ -317,10 +365,13 @@ def end_to_end(prefix, genome, workdir, n_pairs=500_000):
     ref = os.path.join(ROOT, "oracle", "_ref", "kart")
     if not os.path.exists(exe):
         return None
-    names, r1, r2 = synth.simulate_pairs(genome, n_pairs, seed=5, err=0.01)
     f1, f2 = os.path.join(workdir, "e2e_1.fq"), os.path.join(workdir, "e2e_2.fq")
-    synth.write_fastq(f1, names, r1, mate=1)
-    synth.write_fastq(f2, names, r2, mate=2)
+    if codes is not None:
+        write_fastq_from_codes(codes, n_pairs, 5, f1, f2, codes.device)
+    else:
+        names, r1, r2 = synth.simulate_pairs(genome, n_pairs, seed=5, err=0.01)
+        synth.write_fastq(f1, names, r1, mate=1)
+        synth.write_fastq(f2, names, r2, mate=2)
     common = ["-silent", "-i", prefix, "-f", f1, "-f2", f2]
     out = {"reads": 2 * n_pairs, "unit": "reads/s"}
 
@@ -351,12 +402,10 @@ def end_to_end(prefix, genome, workdir, n_pairs=500_000):
     return out
 
 
-def cpu_baseline(prefix, enc_dev, read_len):
+def cpu_baseline(orc, enc_dev, read_len):
     """The CPU oracle port of the same step (seeding incl. SA locate and sort) on all host cores, on a
     bounded sample of the same reads (sized for roughly 10-20 s of CPU work)."""
-    from oracle import oracle as O
     cores = effective_cores()
-    orc = O.Oracle(prefix)
     k = 20000
     enc = enc_dev[: k * read_len].cpu().numpy()
     off = np.arange(k + 1, dtype=np.int64) * read_len
