@@ -45,6 +45,21 @@ def make_genome(seed, length=GENOME_LEN):
     return synth.make_genome([("decoy", DECOY_LEN), ("chrE", length)], seed=seed, gc=0.508)
 
 
+def contig_table(length):
+    """(name, offset, len) of the sequence contigs behind the decoy: one contig up to 300 Mbp, else 24 equal
+    "chromosomes" (contig lengths are 32-bit in the BWA/Kart index format, reference src/structure.h:44-50)."""
+    if length < 300_000_000:
+        return [("chrE", DECOY_LEN, length)]
+    n = 24
+    part = length // n
+    out, off = [], DECOY_LEN
+    for i in range(n):
+        ln = part if i < n - 1 else length - part * (n - 1)
+        out.append(("chr%d" % (i + 1), off, ln))
+        off += ln
+    return out
+
+
 def make_large_codes(length, seed, dev, repeat_frac=0.45):
     """hg38-like synthetic genome for the large experiments, generated on the device: uniform random bases with
     `repeat_frac` of the positions overwritten by mutated copies of a short (300 bp) and a long (6 kb) repeat
@@ -182,7 +197,7 @@ def run(args, fallback_note):
         codes = make_large_codes(args.genome_len, seed=3, dev=dev)
         genome = None
         if rank == 0 and not have_index:
-            anns = [("decoy", "(null)", 0, DECOY_LEN, 0), ("chrE", "(null)", DECOY_LEN, args.genome_len, 0)]
+            anns = [("decoy", "(null)", 0, DECOY_LEN, 0)] + [(nm, "(null)", off, ln, 0) for nm, off, ln in contig_table(args.genome_len)]
             index_build.build_index_from_codes(codes.cpu().numpy(), anns, [], prefix + ".tmp", device=str(dev), bucketed=args.bucketed, verbose=True)
             for e in (".bwt", ".sa", ".pac", ".ann", ".amb"):
                 os.replace(prefix + ".tmp" + e, prefix + e)
