@@ -188,7 +188,7 @@ def run(args, fallback_note):
     # ---- index (built once by rank 0, replicated per GPU) ------------------------------------------
     workdir = os.environ.get("KART_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "kart_bench_%d" % os.getuid())
     os.makedirs(workdir, exist_ok=True)
-    prefix = os.path.join(workdir, "ecoli_like" if args.genome_len == GENOME_LEN else "synth_%d%s" % (args.genome_len, "_b" if args.bucketed else ""))
+    prefix = os.path.join(workdir, "ecoli_like" if args.genome_len == GENOME_LEN else "synth_v2_%d%s" % (args.genome_len, "_b" if args.bucketed else ""))   # v2: 24 contigs above 300 Mbp
     t_idx = time.time()
     large = args.genome_len >= 300_000_000
     have_index = all(os.path.exists(prefix + e) for e in (".bwt", ".sa", ".pac", ".ann", ".amb"))

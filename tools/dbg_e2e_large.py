@@ -4,7 +4,7 @@ import bench
 dev = torch.device("cuda", 0)
 L = int(sys.argv[1]) if len(sys.argv) > 1 else bench.HG38_LEN
 wd = "/tmp/kart_bench_%d" % os.getuid()
-prefix = os.path.join(wd, "synth_%d" % L)
+prefix = os.path.join(wd, "synth_v2_%d" % L)
 subprocess.run([sys.executable, "bench.py", "--genome-len", str(L), "--pairs", "1000000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e"], stdout=subprocess.DEVNULL)
 codes = bench.make_large_codes(L, 3, dev)
 f1, f2 = os.path.join(wd, "d1.fq"), os.path.join(wd, "d2.fq")
