@@ -15,6 +15,8 @@
  *   IdentifySeedPairs_FastMode / _SensitiveMode                  }   mode KG_MODE_FAST / _SENSITIVE
  *       (src/structure.h:189,191; src/AlignmentCandidates.cpp:49,132)
  *   nw_alignment (src/structure.h:229, src/nw_alignment.cpp:18)  kg_nw_batch (+ _device form)
+ *   GenerateAlignmentCandidateForIlluminaSeq / ForPacBioSeq      kg_candidates_batch
+ *       (src/structure.h:193-194; src/AlignmentCandidates.cpp:82,171)
  *
  * Threading: an index handle is immutable after load and may be shared by any number of host
  * threads; a workspace (kg_workspace) owns the scratch of one in-flight batch and must not be
@@ -125,6 +127,22 @@ int  kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_
                           int64_t n_bases, int64_t *d_seed_offsets, kg_seed *d_seeds,
                           int64_t seed_capacity, void *stream);
 int64_t kg_workspace_overflow(kg_workspace *ws);   /* 0 = fitted, else seeds needed */
+
+/* ---- chaining ----------------------------------------------------------------------------------- */
+/* Candidates of every read of the batch that the LAST kg_seed_batch call on this workspace seeded (its
+ * seeds are still resident on the device).  Per read r: n_cands[r] candidates, stored at
+ * cands[seed_offsets[r] + c]; candidate seeds (re-sorted by (gPos,rPos) for Illumina, in pick order for
+ * PacBio, exactly as the reference leaves AlignmentCandidate_t::SeedVec) at cand_seeds[first .. first+count).
+ * n_reads and n_seeds (= seed_offsets[n_reads]) must be those of that call -- they size the three output
+ * buffers (n_cands: n_reads; cands, cand_seeds: n_seeds) and a mismatch is KG_ERR_ARG. */
+typedef struct {
+	int64_t posDiff;    /* AlignmentCandidate_t::PosDiff (clamped at 0) */
+	int32_t score;      /* sum of seed lengths */
+	int32_t count;      /* seeds in the candidate */
+	int64_t first;      /* index of its first seed in cand_seeds */
+} kg_candidate;
+int  kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_reads, int64_t n_seeds,
+                         int32_t *n_cands, kg_candidate *cands, kg_seed *cand_seeds);
 
 /* ---- Needleman-Wunsch gap closing ----------------------------------------------------------- */
 /* n fragment pairs: frag1 (read side, raw characters) concatenated with offsets off1[n+1], frag2

@@ -29,12 +29,13 @@ KG_OCC_THR_DEFAULT = 50
 KG_OP_DIAG, KG_OP_GAP1, KG_OP_GAP2 = 0, 1, 2
 
 SEED_DT = np.dtype([("gPos", "<i8"), ("rPos", "<i4"), ("len", "<i4")])
+CAND_DT = np.dtype([("posDiff", "<i8"), ("score", "<i4"), ("count", "<i4"), ("first", "<i8")])
 
 # every symbol include/kart_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "kg_last_error", "kg_device_count", "kg_index_load", "kg_index_destroy", "kg_index_info",
     "kg_index_contig", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters",
-    "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
+    "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
 )
 
 
@@ -93,6 +94,7 @@ def load_library() -> C.CDLL:
                                 C.c_void_p, C.POINTER(C.c_void_p)]
     L.kg_seed_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.kg_candidates_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kg_nw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.kg_nw_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
@@ -167,6 +169,23 @@ class Workspace:
             return so, np.zeros(0, dtype=SEED_DT)
         buf = (C.c_char * (total * SEED_DT.itemsize)).from_address(out.value)
         return so, np.frombuffer(buf, dtype=SEED_DT).copy()
+
+    def candidates_batch(self, seed_offsets: np.ndarray, pacbio: bool = False, max_gaps: int = 5):
+        """GenerateAlignmentCandidateFor{Illumina,PacBio}Seq for the batch the last seed_batch() call seeded.
+        Returns one list per read of (score, posDiff, seeds structured array)."""
+        n = len(seed_offsets) - 1
+        total = int(seed_offsets[n])
+        ncand = np.zeros(n, dtype=np.int32)
+        cands = np.zeros(total + 1, dtype=CAND_DT)
+        cseeds = np.zeros(total + 1, dtype=SEED_DT)
+        _check(self.lib.kg_candidates_batch(self.h, int(pacbio), max_gaps, n, total, _ptr(ncand), _ptr(cands), _ptr(cseeds)), "kg_candidates_batch")
+        out = []
+        for r in range(n):
+            lst = []
+            for c in cands[seed_offsets[r]:seed_offsets[r] + ncand[r]]:
+                lst.append((int(c["score"]), int(c["posDiff"]), cseeds[c["first"]:c["first"] + c["count"]].copy()))
+            out.append(lst)
+        return out
 
     def seed_batch_device(self, d_enc, d_offsets, n_reads, n_bases, d_seed_offsets, d_seeds, seed_capacity, mode,
                           min_seed_len=None, occ_thr=KG_OCC_THR_DEFAULT, stream=0):

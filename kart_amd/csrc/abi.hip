@@ -98,6 +98,8 @@ struct kg_index {
 	uint64_t *d_sa = nullptr;
 	void *d_fsa = nullptr;
 	uint8_t *d_pac = nullptr;
+	int64_t *d_contig_end = nullptr;   // ChrLocMap keys, ascending
+	int n_ends = 0;
 	uint64_t device_bytes = 0;
 };
 
@@ -117,6 +119,12 @@ struct kg_workspace {
 	int64_t *d_seed_off = nullptr;
 	kg_seed *d_seeds = nullptr;
 	int64_t seed_capacity = 0;
+	int64_t last_reads = 0, last_seeds = 0;   // batch the staging buffers currently hold (kg_seed_batch)
+	kg_candidate *d_cands = nullptr;
+	kg_seed *d_cand_seeds = nullptr;
+	int32_t *d_n_cands = nullptr;
+	uint8_t *d_taken = nullptr;
+	int64_t cand_capacity = 0, ncand_capacity = 0;
 	kg_seed *h_seeds = nullptr;     // pinned
 	int64_t h_seed_capacity = 0;
 	hipStream_t stream = nullptr;
@@ -219,6 +227,14 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	HIP_TRY(hipMemcpy(ix->d_sa, samples.data(), ix->n_sa * 8, hipMemcpyHostToDevice));
 	HIP_TRY(hipMalloc((void **)&ix->d_pac, pac_bytes));
 	HIP_TRY(hipMemcpy(ix->d_pac, ix->pac.data(), pac_bytes, hipMemcpyHostToDevice));
+	{
+		std::vector<int64_t> ends;
+		for (const ContigRec &c : ix->contigs) { ends.push_back(c.fwd_start + c.len - 1); ends.push_back(c.rev_start + c.len - 1); }
+		std::sort(ends.begin(), ends.end());
+		ix->n_ends = (int)ends.size();
+		HIP_TRY(hipMalloc((void **)&ix->d_contig_end, 8 * ends.size() + 8));
+		HIP_TRY(hipMemcpy(ix->d_contig_end, ends.data(), 8 * ends.size(), hipMemcpyHostToDevice));
+	}
 	ix->device_bytes = occ_bytes + ix->n_sa * 8 + pac_bytes;
 	v.occ = ix->d_occ;
 	v.sa = ix->d_sa;
@@ -284,6 +300,7 @@ void kg_index_destroy(kg_index *ix)
 	if (ix->d_sa) (void)hipFree(ix->d_sa);
 	if (ix->d_fsa) (void)hipFree(ix->d_fsa);
 	if (ix->d_pac) (void)hipFree(ix->d_pac);
+	if (ix->d_contig_end) (void)hipFree(ix->d_contig_end);
 	delete ix;
 }
 
@@ -345,7 +362,7 @@ void kg_workspace_destroy(kg_workspace *ws)
 	if (!ws) return;
 	(void)hipSetDevice(ws->ix->device);
 	if (ws->stream) { (void)hipStreamSynchronize(ws->stream); (void)hipStreamDestroy(ws->stream); }
-	void *ptrs[] = {ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
+	void *ptrs[] = {ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (ws->h_seeds) (void)hipHostFree(ws->h_seeds);
@@ -493,6 +510,53 @@ int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, con
 		HIP_TRY(hipStreamSynchronize(ws->stream));
 	}
 	*seeds = ws->h_seeds;
+	ws->last_reads = n_reads;
+	ws->last_seeds = total;
+	return KG_OK;
+}
+
+// Replaces GenerateAlignmentCandidateForIlluminaSeq / ForPacBioSeq (reference src/AlignmentCandidates.cpp:82-130,
+// 171-224) for every read of the batch the last kg_seed_batch call left on the device.
+int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_reads, int64_t n_seeds,
+                         int32_t *n_cands, kg_candidate *cands, kg_seed *cand_seeds)
+{
+	if (!ws || !n_cands) return fail(KG_ERR_ARG, "kg_candidates_batch: null argument");
+	if (ws->last_reads <= 0) return fail(KG_ERR_ARG, "kg_candidates_batch: no seeded batch on this workspace (call kg_seed_batch first)");
+	if (ws->last_seeds > 0 && (!cands || !cand_seeds)) return fail(KG_ERR_ARG, "kg_candidates_batch: null output buffer");
+	if (max_gaps < 0) return fail(KG_ERR_ARG, "kg_candidates_batch: negative max_gaps");
+	if (n_reads != ws->last_reads || n_seeds != ws->last_seeds)
+		return fail(KG_ERR_ARG, "kg_candidates_batch: batch shape (%lld reads, %lld seeds) is not the one kg_seed_batch left on this workspace (%lld, %lld)",
+		            (long long)n_reads, (long long)n_seeds, (long long)ws->last_reads, (long long)ws->last_seeds);
+	HIP_TRY(hipSetDevice(ws->ix->device));
+	int64_t n = ws->last_reads, m = ws->last_seeds;
+	if (m + 1 > ws->cand_capacity) {
+		for (void *p : {(void *)ws->d_cands, (void *)ws->d_cand_seeds, (void *)ws->d_taken})
+			if (p) HIP_TRY(hipFree(p));
+		ws->d_cands = nullptr; ws->d_cand_seeds = nullptr; ws->d_taken = nullptr;
+		int64_t cap = m + m / 4 + 1024;
+		HIP_TRY(hipMalloc((void **)&ws->d_cands, sizeof(kg_candidate) * (size_t)cap));
+		HIP_TRY(hipMalloc((void **)&ws->d_cand_seeds, sizeof(kg_seed) * (size_t)cap));
+		HIP_TRY(hipMalloc((void **)&ws->d_taken, (size_t)cap));
+		ws->cand_capacity = cap;
+	}
+	if (n > ws->ncand_capacity) {
+		if (ws->d_n_cands) HIP_TRY(hipFree(ws->d_n_cands));
+		ws->d_n_cands = nullptr;
+		HIP_TRY(hipMalloc((void **)&ws->d_n_cands, 4 * (size_t)(n + 1024)));
+		ws->ncand_capacity = n + 1024;
+	}
+	ChainArgs a;
+	a.read_off = ws->d_read_off; a.n_reads = n; a.seed_off = ws->d_seed_off; a.seeds = ws->d_seeds;
+	a.contig_end = ws->ix->d_contig_end; a.n_ends = ws->ix->n_ends;
+	a.pacbio = pacbio ? 1 : 0; a.max_gaps = max_gaps;
+	a.n_cands = ws->d_n_cands; a.cands = ws->d_cands; a.cand_seeds = ws->d_cand_seeds; a.taken = ws->d_taken;
+	HIP_TRY(launch_chain_batch(a, ws->ix->n_cu, ws->stream));
+	HIP_TRY(hipMemcpyAsync(n_cands, ws->d_n_cands, 4 * (size_t)n, hipMemcpyDeviceToHost, ws->stream));
+	if (m > 0) {
+		HIP_TRY(hipMemcpyAsync(cands, ws->d_cands, sizeof(kg_candidate) * (size_t)m, hipMemcpyDeviceToHost, ws->stream));
+		HIP_TRY(hipMemcpyAsync(cand_seeds, ws->d_cand_seeds, sizeof(kg_seed) * (size_t)m, hipMemcpyDeviceToHost, ws->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(ws->stream));
 	return KG_OK;
 }
 

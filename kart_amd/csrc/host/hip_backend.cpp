@@ -47,6 +47,15 @@ public:
 		if (kg_seed_batch(ws_, mode, info_.min_seed_len, KG_OCC_THR_DEFAULT, enc.data(), off.data(), n, seed_off.data(), &out) != KG_OK) die("kg_seed_batch");
 		seeds.assign(out, out + seed_off[(size_t)n]);
 	}
+	void candidates_batch(bool pacbio, int max_gaps, const std::vector<int64_t> &, const std::vector<int64_t> &seed_off,
+	                      const std::vector<kg_seed> &, std::vector<int32_t> &n_cands, std::vector<kg_candidate> &cands,
+	                      std::vector<kg_seed> &cand_seeds) override
+	{
+		// the seeds are still on the device (same workspace, same thread as seed_batch)
+		size_t n = seed_off.size() - 1, m = (size_t)seed_off[n];
+		n_cands.resize(n + 1); cands.resize(m + 1); cand_seeds.resize(m + 1);
+		if (kg_candidates_batch(ws_, pacbio ? 1 : 0, max_gaps, (int64_t)n, (int64_t)m, n_cands.data(), cands.data(), cand_seeds.data()) != KG_OK) die("kg_candidates_batch");
+	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
 	{
 		std::lock_guard<std::mutex> lk(nw_mu_);   // the staging vectors below are shared; calls from the commit path are rare

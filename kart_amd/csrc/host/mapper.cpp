@@ -143,86 +143,15 @@ struct PairStats {
 };
 
 // ----------------------------------------------------------------------------------------------
-// chaining: GenerateAlignmentCandidateForIlluminaSeq / ForPacBioSeq
-// (src/AlignmentCandidates.cpp:82-130, 171-224)
+// chaining (GenerateAlignmentCandidateForIlluminaSeq / ForPacBioSeq, src/AlignmentCandidates.cpp:82-130,
+// 171-224) runs on the device: KernelBackend::candidates_batch -> kg_candidates_batch (chain_kernel in
+// seed_kernels.hip); chunk_stage_a unpacks its output with from_seed()
 // ----------------------------------------------------------------------------------------------
 Pair from_seed(const kg_seed &s)
 {
 	Pair p;
 	p.simple = true; p.rPos = s.rPos; p.gPos = s.gPos; p.rLen = p.gLen = s.len; p.posDiff = s.gPos - s.rPos;
 	return p;
-}
-
-int64_t contig_end_of(const RefData &ref, int64_t g)  // GetAlignmentBoundary, src/tools.cpp:399-404
-{
-	std::map<int64_t, int>::const_iterator it = ref.chr_end.lower_bound(g);
-	return it == ref.chr_end.end() ? ref.two_genome_size - 1 : it->first;
-}
-
-void chain_illumina(const Ctx &cx, int rlen, const kg_seed *s, int num, std::vector<Candidate> &out)
-{
-	out.clear();
-	int thr = (int)(rlen * 0.2);
-	if (thr > 50) thr = 50;
-	int i = 0;
-	while (i < num && s[i].gPos - s[i].rPos < 0) i++;
-	while (i < num) {
-		int score = s[i].len;
-		int64_t g_end = contig_end_of(cx.ref, s[i].gPos);
-		int j = i, k = i + 1;
-		for (; k < num; ++k) {
-			int64_t dk = s[k].gPos - s[k].rPos, dj = s[j].gPos - s[j].rPos;
-			if (s[k].gPos > g_end || dk - dj > cx.opt.max_gaps) break;
-			score += s[k].len;
-			j = k;
-		}
-		if (score > thr) {
-			Candidate c;
-			c.score = score;
-			for (int q = i; q < k; ++q) c.pairs.push_back(from_seed(s[q]));
-			if (score - 50 > thr) thr = score - 50;
-			c.posDiff = c.pairs[0].posDiff < 0 ? 0 : c.pairs[0].posDiff;
-			std::sort(c.pairs.begin(), c.pairs.end(), pair_by_gpos);
-			out.push_back(c);
-		}
-		i = k;
-	}
-}
-
-void chain_pacbio(const kg_seed *s, int num, std::vector<Candidate> &out)
-{
-	out.clear();
-	if (num <= 0) return;
-	int thr = 0;
-	std::vector<char> taken((size_t)num, 0);
-	int i = 0;
-	while (i < num && s[i].gPos - s[i].rPos < 0) i++;
-	for (; i < num; ++i) {
-		if (taken[i]) continue;
-		Candidate c;
-		c.score = s[i].len;
-		taken[i] = 1;
-		c.pairs.push_back(from_seed(s[i]));
-		int j = i;
-		for (int k = i + 1; k < num; ++k) {
-			if (taken[k]) continue;
-			int64_t dk = s[k].gPos - s[k].rPos, dj = s[j].gPos - s[j].rPos;
-			if (std::llabs(dk - dj) < 300) {
-				if (s[k].rPos > s[j].rPos) {
-					c.score += s[k].len;
-					c.pairs.push_back(from_seed(s[k]));
-					taken[k] = 1;
-					j = k;
-				}
-			} else if (s[k].gPos - s[j].gPos > 1000) break;
-		}
-		if (c.score >= thr) {
-			thr = c.score;
-			int64_t d = s[i].gPos - s[i].rPos;
-			c.posDiff = d < 0 ? 0 : d;
-			out.push_back(c);
-		}
-	}
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1717,8 +1646,8 @@ int est_distance(const Ctx &cx, int64_t iPaired, int64_t iDistance)  // src/Mapp
 }
 
 // stage A: chaining, pairing, rescue, filters, report pass 1 (collects the chunk's NW jobs)
-void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<int64_t> &seed_off, const std::vector<kg_seed> &seeds,
-                   ChunkState &ck, int est)
+void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<int64_t> &seed_off, const std::vector<int32_t> &n_cands,
+                   const std::vector<kg_candidate> &dev_cands, const std::vector<kg_seed> &cand_seeds, ChunkState &ck, int est)
 {
 	ck.est_used = est;
 	ck.ps = PairStats();
@@ -1728,10 +1657,17 @@ void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<in
 	ck.jobs.clear();
 	for (int q = 0; q < ck.count; ++q) {
 		size_t ri = (size_t)(ck.begin + q);
-		const kg_seed *s = seeds.data() + seed_off[ri];
-		int ns = (int)(seed_off[ri + 1] - seed_off[ri]);
-		if (cx.opt.pacbio) chain_pacbio(s, ns, ck.cands[(size_t)q]);
-		else chain_illumina(cx, reads[ri].rlen, s, ns, ck.cands[(size_t)q]);
+		// the candidates were chained on the device (kg_candidates_batch); unpack them into the per-read vectors
+		std::vector<Candidate> &out = ck.cands[(size_t)q];
+		out.resize((size_t)n_cands[ri]);
+		for (int c = 0; c < n_cands[ri]; ++c) {
+			const kg_candidate &d = dev_cands[(size_t)seed_off[ri] + (size_t)c];
+			Candidate &o = out[(size_t)c];
+			o.score = d.score;
+			o.posDiff = d.posDiff;
+			o.pairs.resize((size_t)d.count);
+			for (int k = 0; k < d.count; ++k) o.pairs[(size_t)k] = from_seed(cand_seeds[(size_t)d.first + (size_t)k]);
+		}
 	}
 	if (ck.paired) {
 		for (int q = 0; q < ck.count; q += 2) {
@@ -1811,6 +1747,9 @@ struct Batch {
 	std::vector<int64_t> off;
 	std::vector<int64_t> seed_off;                  // per-read seed ranges of this batch (filled by the seeding stage)
 	std::vector<kg_seed> seeds;
+	std::vector<int32_t> n_cands;                   // chaining results of this batch (kg_candidates_batch)
+	std::vector<kg_candidate> cands;
+	std::vector<kg_seed> cand_seeds;
 	std::deque<OwnedRead> owned;                    // storage behind the views (getline()/gzgets() readers)
 	std::vector<std::unique_ptr<char[]>> arenas;    // storage behind reverse-complemented mates (mapped files)
 	bool eof = false;
@@ -1908,7 +1847,10 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	auto fetch = [&](Batch *b, int64_t n_chunks) {
 		read_batch(cx, src, n_chunks, chunk_limit, read_pool, *b);
 		double t = now_s();
-		if (!b->reads.empty()) cx.kern.seed_batch(mode, b->enc, b->off, b->seed_off, b->seeds);
+		if (!b->reads.empty()) {
+			cx.kern.seed_batch(mode, b->enc, b->off, b->seed_off, b->seeds);
+			cx.kern.candidates_batch(cx.opt.pacbio, cx.opt.max_gaps, b->off, b->seed_off, b->seeds, b->n_cands, b->cands, b->cand_seeds);
+		}
 		b->seed_seconds = now_s() - t;
 	};
 	auto commit = [&](Batch &b) {   // in-order: EstDistance feeds forward (src/Mapping.cpp:533-540)
@@ -1922,7 +1864,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 				              (!ck.ps.rescue_used || std::min(est_true, cx.opt.max_insert) == std::min(ck.est_used, cx.opt.max_insert)));
 				if (!valid) {   // mapped under an estimate that would have decided differently: redo with the true one
 					st.respeculated++;
-					chunk_stage_a(cx, b.reads, b.seed_off, b.seeds, ck, est_true);
+					chunk_stage_a(cx, b.reads, b.seed_off, b.n_cands, b.cands, b.cand_seeds, ck, est_true);
 					run_nw(cx, b.chunks, c, c + 1);
 					chunk_stage_c(cx, b.reads, ck);
 				}
@@ -1952,7 +1894,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 		Batch *cp = cur.get(), *pp = prev.get();
 		double t3 = now_s();
 		pool.run2(pp ? (int)pp->chunks.size() : 0, [&](int c) { chunk_stage_c(cx, pp->reads, pp->chunks[(size_t)c]); },
-		          have_cur ? (int)cp->chunks.size() : 0, [&](int c) { chunk_stage_a(cx, cp->reads, cp->seed_off, cp->seeds, cp->chunks[(size_t)c], est_guess); });
+		          have_cur ? (int)cp->chunks.size() : 0, [&](int c) { chunk_stage_a(cx, cp->reads, cp->seed_off, cp->n_cands, cp->cands, cp->cand_seeds, cp->chunks[(size_t)c], est_guess); });
 		double t4 = now_s(); tot.t_a += t4 - t3;
 		if (have_cur) run_nw(cx, cp->chunks, 0, cp->chunks.size());
 		tot.t_nw += now_s() - t4;

@@ -429,6 +429,113 @@ __global__ __launch_bounds__(256) void sort_kernel(SeedArgs a)
 	}
 }
 
+// ---- chaining: GenerateAlignmentCandidateForIlluminaSeq / ForPacBioSeq --------------------------------
+// (reference src/AlignmentCandidates.cpp:82-130, 171-224).  One read per lane; the seed lists are short
+// (2-4 seeds for 150 bp reads, ~170 for a 7 kb PacBio read), the logic is a sequential greedy scan.
+__device__ __forceinline__ int64_t contig_end_of(const ChainArgs &a, int64_t g)   // GetAlignmentBoundary, src/tools.cpp:399-404
+{
+	int lo = 0, hi = a.n_ends - 1;
+	while (lo < hi) {
+		int mid = (lo + hi) >> 1;
+		if (a.contig_end[mid] < g) lo = mid + 1; else hi = mid;
+	}
+	return a.contig_end[lo];
+}
+
+__global__ __launch_bounds__(256) void chain_kernel(ChainArgs a)
+{
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; r < a.n_reads; r += stride) {
+		const int64_t base = a.seed_off[r];
+		const int num = (int)(a.seed_off[r + 1] - base);
+		const int rlen = (int)(a.read_off[r + 1] - a.read_off[r]);
+		const kg_seed *s = a.seeds + base;
+		kg_candidate *out = a.cands + base;
+		kg_seed *cs = a.cand_seeds + base;
+		int nc = 0;
+		int64_t used = 0;
+		int i = 0;
+		while (i < num && s[i].gPos - s[i].rPos < 0) i++;
+		if (!a.pacbio) {
+			int thr = rlen / 5;                       // (int)(rlen*0.2) for non-negative rlen
+			if (thr > 50) thr = 50;
+			while (i < num) {
+				int score = s[i].len;
+				int64_t g_end = contig_end_of(a, s[i].gPos);
+				int j = i, k = i + 1;
+				for (; k < num; ++k) {
+					int64_t dk = s[k].gPos - s[k].rPos, dj = s[j].gPos - s[j].rPos;
+					if (s[k].gPos > g_end || dk - dj > a.max_gaps) break;
+					score += s[k].len;
+					j = k;
+				}
+				if (score > thr) {
+					if (score - 50 > thr) thr = score - 50;
+					int64_t d = s[i].gPos - s[i].rPos;
+					kg_candidate c;
+					c.posDiff = d < 0 ? 0 : d; c.score = score; c.count = k - i; c.first = base + used;
+					// the candidate's seeds, re-sorted by (gPos, rPos) (:118): insertion sort while copying
+					for (int q = i; q < k; ++q) {
+						kg_seed v = s[q];
+						int64_t p = used + (q - i);
+						while (p > used && (cs[p - 1].gPos > v.gPos || (cs[p - 1].gPos == v.gPos && cs[p - 1].rPos > v.rPos))) { cs[p] = cs[p - 1]; --p; }
+						cs[p] = v;
+					}
+					used += k - i;
+					out[nc++] = c;
+				}
+				i = k;
+			}
+		} else {
+			uint8_t *taken = a.taken + base;
+			for (int q = 0; q < num; ++q) taken[q] = 0;
+			int thr = 0;
+			for (; i < num; ++i) {
+				if (taken[i]) continue;
+				int score = s[i].len;
+				taken[i] = 1;
+				int64_t first = used;
+				// tentative: the picked seeds are written at cs[used..]; kept only if the score qualifies.  A seed
+				// is taken at most once whether or not its candidate is kept (reference TakenArr), so the
+				// slots of a rejected candidate are simply reused by the next one.
+				cs[used++] = s[i];
+				int j = i;
+				for (int k = i + 1; k < num; ++k) {
+					if (taken[k]) continue;
+					int64_t dk = s[k].gPos - s[k].rPos, dj = s[j].gPos - s[j].rPos;
+					int64_t dd = dk - dj;
+					if ((dd < 0 ? -dd : dd) < 300) {
+						if (s[k].rPos > s[j].rPos) {
+							score += s[k].len;
+							cs[used++] = s[k];
+							taken[k] = 1;
+							j = k;
+						}
+					} else if (s[k].gPos - s[j].gPos > 1000) break;
+				}
+				if (score >= thr) {
+					thr = score;
+					int64_t d = s[i].gPos - s[i].rPos;
+					kg_candidate c;
+					c.posDiff = d < 0 ? 0 : d; c.score = score; c.count = (int32_t)(used - first); c.first = base + first;
+					out[nc++] = c;
+				} else used = first;
+			}
+		}
+		a.n_cands[r] = nc;
+	}
+}
+
+hipError_t launch_chain_batch(const ChainArgs &a, int n_cu, hipStream_t stream)
+{
+	if (a.n_reads <= 0) return hipSuccess;
+	int64_t g = (a.n_reads + 255) / 256;
+	if (g > (int64_t)n_cu * 16) g = (int64_t)n_cu * 16;
+	hipLaunchKernelGGL(chain_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
 __global__ void finish_offsets_kernel(SeedArgs a)
 {
 	// seed_off[n_reads] = total; record overflow and the output counters

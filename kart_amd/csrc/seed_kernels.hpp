@@ -48,6 +48,21 @@ hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *
 hipError_t launch_build_qtab(const FmView &ix, uint2 *t32, uint4 *t64, hipStream_t stream);
 hipError_t launch_expand_sa(const FmView &ix, uint64_t n_sa, uint32_t *fsa32, uint64_t *fsa64, hipStream_t stream);
 
+struct ChainArgs {
+	const int64_t *read_off;     // for rlen
+	int64_t n_reads;
+	const int64_t *seed_off;
+	const kg_seed *seeds;        // per read sorted by the seeding mode's comparator
+	const int64_t *contig_end;   // ChrLocMap keys (last coordinate of every strand copy), ascending
+	int n_ends;
+	int pacbio, max_gaps;
+	int32_t *n_cands;
+	kg_candidate *cands;
+	kg_seed *cand_seeds;
+	uint8_t *taken;              // PacBio: one flag per seed
+};
+hipError_t launch_chain_batch(const ChainArgs &a, int n_cu, hipStream_t stream);
+
 struct NwArgs {
 	const char *f1;
 	const int64_t *off1;

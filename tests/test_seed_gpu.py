@@ -108,3 +108,65 @@ def test_wide_index_instantiation(golden, built_lib):
     ''') % (ROOT, os.path.join(ROOT, "tests", "golden", "hotpath_small.npz"), os.path.join(ROOT, "tests", "golden", "idx", "small"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KG_FORCE_U64="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0 and b"wide ok" in r.stdout, r.stdout.decode()[-800:]
+
+
+def _check_candidates(got, want_iter):
+    for ri, lst in enumerate(got):
+        want = want_iter(ri)
+        assert len(lst) == len(want), (ri, len(lst), len(want))
+        for (gs, gp, gv), (ws_, wp, wv) in zip(lst, want):
+            assert (gs, gp) == (ws_, wp), ri
+            assert len(gv) == len(wv), ri
+            assert (gv["gPos"] == wv["gPos"]).all() and (gv["rPos"] == wv["rPos"]).all() and (gv["len"] == wv["rLen"]).all(), ri
+
+
+@pytest.mark.parametrize("pacbio", [0, 1])
+def test_candidates_golden(golden, gpu_index, pacbio):
+    """kg_candidates_batch == the candidates the unmodified reference produced (golden cand_rows/cand_pairs)"""
+    key = "sens" if pacbio else "fast"
+    enc, off = golden[key + "_enc"], golden[key + "_off"]
+    rows = golden["cand_rows"]
+    cp_off = np.concatenate([[0], np.cumsum(rows[:, 4])])
+    ws = gpu_index.workspace(len(off) - 1, len(enc))
+    so, _ = ws.seed_batch(enc, off, pacbio)
+    got = ws.candidates_batch(so, bool(pacbio))
+    by_read = {}
+    for gi, row in enumerate(rows):
+        if row[0] == pacbio:
+            by_read.setdefault(int(row[1]), []).append((int(row[2]), int(row[3]), golden["cand_pairs"][cp_off[gi]:cp_off[gi + 1]]))
+    _check_candidates(got, lambda ri: by_read.get(ri, []))
+    assert sum(len(x) for x in got) == sum(1 for r in rows if r[0] == pacbio)
+
+
+def test_candidates_vs_oracle(gpu_index, oracle_small, request):
+    """both chaining modes on 6k simulated reads (Illumina: incl. ragged lengths and max_gaps variants)"""
+    g = {}
+    cur = None
+    for line in open(request.config.rootpath / "tests" / "golden" / "small.fa", "rb"):
+        if line.startswith(b">"):
+            cur = line[1:].strip().decode(); g[cur] = []
+        else:
+            g[cur].append(line.strip())
+    g = {k: np.frombuffer(b"".join(v), dtype=np.uint8) for k, v in g.items()}
+    _, r1, r2 = synth.simulate_pairs(g, 3000, seed=23, err=0.03, n_frac=0.001)
+    reads = [synth.encode(r) for r in r1] + [synth.encode(r) for r in r2]
+    rng = np.random.default_rng(9)
+    for i in rng.integers(0, len(reads), size=300):
+        reads[i] = reads[i][: int(rng.integers(0, 151))]
+    enc, off = api.concat_reads(reads)
+    ws = gpu_index.workspace(len(reads), len(enc))
+    for pacbio, max_gaps in ((0, 5), (0, 0), (0, 30), (1, 5)):
+        so, seeds = ws.seed_batch(enc, off, pacbio)
+        got = ws.candidates_batch(so, bool(pacbio), max_gaps)
+        _check_candidates(got, lambda ri: oracle_small.candidates(len(reads[ri]), seeds[so[ri]:so[ri + 1]], bool(pacbio), max_gaps))
+
+
+def test_candidates_need_the_seeded_batch(golden, gpu_index):
+    ws = api.Workspace(gpu_index, 1024, 1 << 16)
+    with pytest.raises(RuntimeError, match="kg_seed_batch first"):
+        ws.candidates_batch(np.zeros(2, np.int64))
+    so, _ = ws.seed_batch(golden["fast_enc"][: golden["fast_off"][10]], golden["fast_off"][:11], 0)
+    with pytest.raises(RuntimeError, match="batch shape"):
+        ws.candidates_batch(so[:5])          # not the batch that was seeded
+    assert len(ws.candidates_batch(so)) == 10
+    ws.close()
