@@ -97,6 +97,7 @@ struct kg_index {
 	void *d_qtab = nullptr;
 	uint64_t *d_sa = nullptr;
 	void *d_fsa = nullptr;
+	uint8_t *d_text = nullptr;
 	uint8_t *d_pac = nullptr;
 	int64_t *d_contig_end = nullptr;   // ChrLocMap keys, ascending
 	int n_ends = 0;
@@ -248,21 +249,27 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		HIP_TRY(hipDeviceSynchronize());
 		v.planes = ix->d_planes;
 		ix->device_bytes += plane_bytes;
-		// q-mer interval table (4^12 entries)
+		// q-mer interval table: 4^q entries with 4^q ~ text length (12 for E. coli, 16 for hg38), 8 bytes each
 		v.qtab32 = nullptr;
 		v.qtab64 = nullptr;
+		v.qmer = 0;
 		if (!getenv("KG_NO_QTAB")) {
 			bool narrow = v.seq_len < 0xFFFFFF00ull && !getenv("KG_FORCE_U64");
-			size_t tab_bytes = ((size_t)1 << (2 * kQmer)) * (narrow ? 8 : 16);
+			int q = kQmerMin;
+			while (q < kQmerMax && ((uint64_t)1 << (2 * q + 1)) <= v.seq_len) q++;      // round(log4(2L))
+			if (const char *env = getenv("KG_QMER")) { int t = atoi(env); if (t >= kQmerMin && t <= kQmerMax) q = t; }   // tuning knob
+			size_t tab_bytes = ((size_t)1 << (2 * q)) * 8;
 			HIP_TRY(hipMalloc(&ix->d_qtab, tab_bytes));
-			HIP_TRY(launch_build_qtab(v, narrow ? (uint2 *)ix->d_qtab : nullptr, narrow ? nullptr : (uint4 *)ix->d_qtab, nullptr));
+			v.qmer = q;
+			HIP_TRY(launch_build_qtab(v, q, narrow ? (uint2 *)ix->d_qtab : nullptr, narrow ? nullptr : (uint64_t *)ix->d_qtab, nullptr));
 			HIP_TRY(hipDeviceSynchronize());
-			if (narrow) v.qtab32 = (const uint2 *)ix->d_qtab; else v.qtab64 = (const uint4 *)ix->d_qtab;
+			if (narrow) v.qtab32 = (const uint2 *)ix->d_qtab; else v.qtab64 = (const uint64_t *)ix->d_qtab;
 			ix->device_bytes += tab_bytes;
 		}
 	}
 	v.fsa32 = nullptr;
 	v.fsa64 = nullptr;
+	v.text = nullptr;
 
 	if (sa_mode == KG_SA_FULL) {
 		bool narrow = v.seq_len < 0xFFFFFFFFull && !getenv("KG_FORCE_U64");
@@ -275,6 +282,14 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		v.fsa32 = f32;
 		v.fsa64 = f64;
 		ix->device_bytes += fsa_bytes;
+		if (!getenv("KG_NO_DIRECT")) {   // the text, for finishing single-suffix searches by comparison
+			size_t text_bytes = (size_t)(v.seq_len / 4 + 1) + 16;
+			HIP_TRY(hipMalloc((void **)&ix->d_text, text_bytes));
+			HIP_TRY(launch_build_text(ix->d_pac, (uint64_t)ix->l_pac, ix->d_text, text_bytes, nullptr));
+			HIP_TRY(hipDeviceSynchronize());
+			v.text = ix->d_text;
+			ix->device_bytes += text_bytes;
+		}
 	} else if (sa_mode != KG_SA_SAMPLED) {
 		return fail(KG_ERR_ARG, "kg_index_load: unknown sa_mode %d", sa_mode);
 	}
@@ -299,6 +314,7 @@ void kg_index_destroy(kg_index *ix)
 	}
 	if (ix->d_sa) (void)hipFree(ix->d_sa);
 	if (ix->d_fsa) (void)hipFree(ix->d_fsa);
+	if (ix->d_text) (void)hipFree(ix->d_text);
 	if (ix->d_pac) (void)hipFree(ix->d_pac);
 	if (ix->d_contig_end) (void)hipFree(ix->d_contig_end);
 	delete ix;

@@ -29,18 +29,24 @@ struct FmView {
 	const uint64_t *sa;
 	const uint32_t *fsa32;
 	const uint64_t *fsa64;
-	// q-mer interval table (device-private, built at load): for the first kQmer bases of a search,
-	// the interval after kQmer-1 extension steps.  Entry = { k, n | lf2 << 28 } (u32 index) or
-	// { k lo, k hi, n, lf2 } (u64 index); n == 0 means "no such q-mer / not representable": the
-	// search then starts step by step, so results never depend on the table.
+	// q-mer interval table (device-private, built at load): for the first `qmer` bases of a search, the
+	// interval after qmer-1 extension steps.  q grows with the text (4^q ~ 2L: 12 for E. coli, 16 for hg38)
+	// so that the jump lands on intervals of a few suffixes.  Entry = { k, n | lf2 << 28 } (u32 index) or
+	// k | n << 34 | lf2 << 60 (u64 index); n == 0 means "no such q-mer / not representable": the search
+	// then starts step by step, so results never depend on the table.
 	const uint2 *qtab32;
-	const uint4 *qtab64;
+	const uint64_t *qtab64;
+	int qmer;
+	// the indexed text itself (forward strand then reverse complement, 2L bases), 2 bits per base, base i in
+	// bits 2*(i&3) of byte i>>2, built at load from the .pac bases when the full SA is: once a search's interval
+	// has shrunk to ONE suffix the rest of the match is a plain comparison against the text at that suffix
+	const uint8_t *text;
 	uint64_t primary;
 	uint64_t seq_len;
 	uint64_t L2[5];
 };
 
-constexpr int kQmer = 12;
+constexpr int kQmerMin = 8, kQmerMax = 16;
 
 // ---- bit-plane rank structure ---------------------------------------------------------------
 

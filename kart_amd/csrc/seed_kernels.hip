@@ -17,11 +17,16 @@
 //                   is drained.  Only the reverse-complement side of BWA's bi-interval is tracked:
 //                   on a forward+revcomp text it is a plain backward search and needs ONE base's
 //                   rank at two positions per step instead of all four (SURVEY.md App. C check).
+//                   When the interval has shrunk to a single suffix (and the full SA is resident) the
+//                   lane stops ranking: one gather from the SA names the text position, and the
+//                   rest of the match is a 16-bases-per-iteration comparison of the read against
+//                   the 2-bit text -- same match length by construction (an interval of one extends
+//                   iff the next text base equals the next read base), ~4x fewer cache lines.
 //                   Output: a dense list of hits {interval start, size, rPos, len, read, seed slot}.
 //   locate_kernel : persistent lanes over (hit, i) items.  SAMPLED mode walks LF until a sampled
 //                   rank (bwt_sa); FULL mode is one gather from the expanded suffix array.  The
 //                   text position of the pattern is 2L - SA[x1+i] - len.
-//   sort_kernel   : per-read ordering with the mode's comparator (total order, so the result is
+//   sort_*_kernel : per-read ordering with the mode's comparator (total order, so the result is
 //                   unique and equals the reference's std::sort output).
 #include "seed_kernels.hpp"
 
@@ -51,7 +56,7 @@ struct WavePool {
 	unsigned long long next = 0, end = 0;
 };
 
-__device__ __forceinline__ unsigned long long pool_take(WavePool &p, unsigned long long *counter, bool want)
+__device__ __forceinline__ unsigned long long pool_take(WavePool &p, unsigned long long *counter, bool want, unsigned long long chunk = kPoolChunk)
 {
 	uint64_t mask = __ballot(want);
 	if (mask == 0) return 0;
@@ -62,11 +67,11 @@ __device__ __forceinline__ unsigned long long pool_take(WavePool &p, unsigned lo
 	if (cnt > avail) {  // wave-uniform branch
 		unsigned long long base = 0;
 		int leader = __ffsll((unsigned long long)mask) - 1;
-		if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, kPoolChunk);
+		if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, chunk);
 		base = __shfl(base, leader);
 		if (rank >= avail) ticket = base + (rank - avail);
 		p.next = base + (cnt - avail);
-		p.end = base + kPoolChunk;
+		p.end = base + chunk;
 	} else {
 		p.next += cnt;
 	}
@@ -142,6 +147,8 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(SeedArgs a)
 // level some lane always needs the rare path.
 constexpr int kRefill = 8;
 
+struct __attribute__((packed, aligned(1))) U64u { uint64_t v; };
+
 template <typename idx_t>
 __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 {
@@ -154,6 +161,9 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 	const int msl = a.min_seed_len;
 	const idx_t occ_thr = (idx_t)a.occ_thr;
 	const bool have_tab = sizeof(idx_t) == 4 ? ix.qtab32 != nullptr : ix.qtab64 != nullptr;
+	const int q = ix.qmer;
+	const uint64_t qmask = q >= 16 ? ~0ull : (1ull << (4 * q)) - 1;
+	const bool direct = ix.text != nullptr && (ix.fsa32 != nullptr || ix.fsa64 != nullptr);
 
 	bool have_read = false, done = false, active = false, pending = false;
 	int r = 0, rlen = 0, pos = 0, stop_pos = 0, end_pos = 0, seed_cnt = 0;
@@ -161,6 +171,10 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 	const uint64_t *pw = a.packed;
 	uint64_t win = 0x4444444444444444ull, wnext = 0x4444444444444444ull;
 	idx_t k = 0, n = 0;
+	// how the lane extends its match: 0 = rank (LF) steps, 1 = interval of one, fetch its suffix, 2 = compare
+	// the read with the text at tpos (the text position facing read position `cur`)
+	int mode = 0;
+	idx_t tpos = 0;
 	uint32_t c_search = 0, c_lf = 0, c_lf2 = 0;
 	WavePool read_pool, hit_pool;
 
@@ -173,9 +187,10 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 			unsigned long long slot = pool_take(hit_pool, a.hit_count, hit);
 			if (hit) {
 				uint4 *dst = reinterpret_cast<uint4 *>(a.hits + slot);
-				uint64_t k64 = (uint64_t)k;
+				bool at_text = mode == 2;                                   // finished against the text: position known
+				uint64_t k64 = at_text ? (uint64_t)tpos - (uint64_t)len : (uint64_t)k;
 				dst[0] = make_uint4((uint32_t)k64, (uint32_t)(k64 >> 32), (uint32_t)r, (uint32_t)pos);
-				dst[1] = make_uint4((uint32_t)len, (uint32_t)n, (uint32_t)seed_cnt, 0u);
+				dst[1] = make_uint4((uint32_t)len, (uint32_t)n, (uint32_t)seed_cnt, at_text ? 1u : 0u);
 				seed_cnt += (int)n;
 			}
 			if (pending) {
@@ -225,11 +240,11 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 			stop_pos += skip ? 1 : 0;
 			bool go = starting && !skip;
 			if (go) {
-				// the next kQmer codes as a 2-bit packed index (code at pos in the lowest bits)
+				// the next q codes as a 2-bit packed index (code at pos in the lowest bits)
 				int sh = (pos & 15) << 2;
 				uint64_t x = sh ? (win >> sh) | (wnext << (64 - sh)) : win;
-				x &= (1ull << (4 * kQmer)) - 1;
-				bool clean = (x & 0x4444444444444444ull) == 0 && pos + kQmer <= (fast ? rlen : stop_pos) && have_tab;
+				x &= qmask;
+				bool clean = (x & 0x4444444444444444ull) == 0 && pos + q <= (fast ? rlen : stop_pos) && have_tab;
 				uint64_t y = x & 0x3333333333333333ull;
 				y = (y | (y >> 2)) & 0x0F0F0F0F0F0F0F0Full;
 				y = (y | (y >> 4)) & 0x00FF00FF00FF00FFull;
@@ -242,18 +257,19 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 						uint2 e = ix.qtab32[y];
 						tk = (idx_t)e.x; tn = (idx_t)(e.y & 0x0FFFFFFFu); tlf2 = e.y >> 28;
 					} else {
-						uint4 e = ix.qtab64[y];
-						tk = (idx_t)(((uint64_t)e.y << 32) | e.x); tn = (idx_t)e.z; tlf2 = e.w;
+						uint64_t e = ix.qtab64[y];
+						tk = (idx_t)(e & 0x3FFFFFFFFull); tn = (idx_t)((e >> 34) & 0x3FFFFFFull); tlf2 = (uint32_t)(e >> 60);
 					}
 				}
 				bool jump = clean && tn != 0;
 				k = jump ? tk : l2s[3 - code0] + 1;                            // x[1], :149
 				n = jump ? tn : l2s[code0 + 1] - l2s[code0];                  // x[2], :150
-				cur = pos + (jump ? kQmer : 1);
-				// the reference performs these kQmer-1 steps one by one; keep its block accounting
-				c_lf += jump ? (uint32_t)(kQmer - 1) : 0u;
+				cur = pos + (jump ? q : 1);
+				// the reference performs these q-1 steps one by one; keep its block accounting
+				c_lf += jump ? (uint32_t)(q - 1) : 0u;
 				c_lf2 += jump ? tlf2 : 0u;
 				stop = fast ? rlen : stop_pos;
+				mode = direct && n == 1 ? 1 : 0;
 				active = true;
 				c_search++;
 				if ((cur >> 4) != wword) { win = wnext; wword++; wnext = pw[wword + 1]; }
@@ -264,30 +280,74 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 
 		// ================= tight loop =================
 		for (;;) {
-			int code = (int)((win >> ((cur & 15) << 2)) & 15);
-			bool do_step = active && cur < stop && code <= 3;
-			idx_t nn = 0, ok = 0;
+			int sh = (cur & 15) << 2;
+			int code = (int)((win >> sh) & 15);
+			bool alive = active && cur < stop && code <= 3;                 // :153-154; otherwise the search is over
+			bool lf = alive && mode == 0, sa = alive && mode == 1, cmp = alive && mode == 2;
 			int c = 3 - code;
-			if (do_step) {
-				idx_t kk = k - 1, ll = k - 1 + n;                          // bwt_2occ4(x1-1, x1-1+x2), :157
+			// the gathers of this iteration -- issued together, used below
+			idx_t kk = 0, ll = 0;
+			uint4 vk = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+			uint64_t sav = 0, tw = 0;
+			if (lf) {
+				kk = k - 1; ll = k - 1 + n;                                 // bwt_2occ4(x1-1, x1-1+x2), :157
 				kk -= (kk >= primary);
 				ll -= (ll >= primary);
-				uint4 vk = ix.planes[(((uint64_t)(kk >> 6)) << 2) + (uint32_t)c];
-				uint4 vl = ix.planes[(((uint64_t)(ll >> 6)) << 2) + (uint32_t)c];
+				vk = ix.planes[(((uint64_t)(kk >> 6)) << 2) + (uint32_t)c];
+				vl = ix.planes[(((uint64_t)(ll >> 6)) << 2) + (uint32_t)c];
+			}
+			if (sa) sav = ix.fsa32 ? (uint64_t)ix.fsa32[k] : ix.fsa64[k];
+			if (cmp) tw = reinterpret_cast<const U64u *>(ix.text + ((uint64_t)tpos >> 2))->v;
+			bool cont = false;
+			if (lf) {
 				uint64_t mk = (2ull << (kk & 63)) - 1, ml = (2ull << (ll & 63)) - 1;
-				ok = (idx_t)(((uint64_t)vk.w << 32) | vk.z) + (idx_t)__popcll((((uint64_t)vk.y << 32) | vk.x) & mk);
+				idx_t ok = (idx_t)(((uint64_t)vk.w << 32) | vk.z) + (idx_t)__popcll((((uint64_t)vk.y << 32) | vk.x) & mk);
 				idx_t ol = (idx_t)(((uint64_t)vl.w << 32) | vl.z) + (idx_t)__popcll((((uint64_t)vl.y << 32) | vl.x) & ml);
-				nn = ol - ok;
+				idx_t nn = ol - ok;
 				c_lf++;
 				c_lf2 += (kk >> 7) != (ll >> 7) ? 1u : 0u;                 // reference 128-symbol block accounting
+				cont = nn != 0;
+				if (cont) {
+					k = l2s[c] + 1 + ok;
+					n = nn;
+					cur++;
+					mode = direct && nn == 1 ? 1 : 0;
+				}
 			}
-			bool cont = nn != 0;                                            // implies do_step
-			if (cont) {
-				k = l2s[c] + 1 + ok;
-				n = nn;
-				cur++;
-				if ((cur & 15) == 0) { win = wnext; wword++; wnext = pw[wword + 1]; }
+			if (sa) {
+				// SA[k] = where the reverse complement of the match starts; the match itself then ends right
+				// before text position 2L - SA[k], which is the base the next read base must equal
+				tpos = (idx_t)(ix.seq_len - sav);
+				mode = 2;
+				cont = true;
 			}
+			if (cmp) {
+				uint64_t rd = sh ? (win >> sh) | (wnext << (64 - sh)) : win;      // 16 read codes from cur, one per nibble
+				uint64_t x = (uint32_t)(tw >> (((uint32_t)tpos & 3) << 1));      // 16 text bases from tpos, 2 bits each
+				x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+				x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+				x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+				x = (x | (x << 2)) & 0x3333333333333333ull;
+				uint64_t diff = x ^ rd;                                             // an ambiguous read code (>3) always differs
+				int m = diff ? (__ffsll((unsigned long long)diff) - 1) >> 2 : 16;
+				uint64_t left = ix.seq_len - (uint64_t)tpos;                       // the text ends: the reference's step finds nothing
+				m = (uint64_t)m > left ? (int)left : m;
+				int lim = stop - cur < 16 ? stop - cur : 16;
+				if (m < lim) {
+					// the reference extends m times, then either stops at an ambiguous base (no step) or
+					// performs the step that empties the interval
+					int code2 = (int)((rd >> (m << 2)) & 15);
+					c_lf += (uint32_t)m + (code2 <= 3 ? 1u : 0u);
+					cur += m;
+					tpos += (idx_t)m;
+				} else {
+					c_lf += (uint32_t)lim;
+					cur += lim;
+					tpos += (idx_t)lim;
+					cont = cur < stop;
+				}
+			}
+			if (cont && (cur >> 4) != wword) { win = wnext; wword++; wnext = pw[wword + 1]; }
 			pending = pending || (active && !cont);
 			active = cont;
 			uint64_t parked = __ballot(pending);
@@ -380,10 +440,10 @@ __global__ __launch_bounds__(256) void locate_full_kernel(SeedArgs a)
 		Hit h = a.hits[t];
 		int64_t out = hit_out_base(a, h);
 		for (int i = 0; i < h.n; ++i) {
-			uint64_t sa = ix.fsa32 ? (uint64_t)ix.fsa32[h.k + i] : ix.fsa64[h.k + i];
+			uint64_t sa = h.direct ? 0 : ix.fsa32 ? (uint64_t)ix.fsa32[h.k + i] : ix.fsa64[h.k + i];
 			if (out + i < a.seed_capacity) {
 				kg_seed s;
-				s.gPos = (int64_t)(ix.seq_len - sa - (uint64_t)h.len);
+				s.gPos = h.direct ? (int64_t)h.k : (int64_t)(ix.seq_len - sa - (uint64_t)h.len);
 				s.rPos = h.rpos; s.len = h.len;
 				a.seeds[out + i] = s;
 			}
@@ -401,31 +461,200 @@ __device__ __forceinline__ bool seed_less(const kg_seed &x, const kg_seed &y, in
 	return x.gPos == y.gPos ? x.rPos < y.rPos : x.gPos < y.gPos;
 }
 
-__global__ __launch_bounds__(256) void sort_kernel(SeedArgs a)
+// ---- per-read ordering -----------------------------------------------------------------------------
+// Most reads carry 2-4 seeds, reads inside repeat families hundreds (up to 50 per search), long reads
+// more.  Sorting a long list from one lane is a chain of dependent global-memory accesses that holds up
+// its wave, so the work is split by size:
+//   sort_small_kernel : one read per lane; lists of <= 8 are sorted in registers (19-comparator network,
+//                       no dependent memory traffic); longer lists go to one of two work lists (one
+//                       atomic per wave and list)
+//   sort_wave_kernel  : 9..64 seeds, one read per wave: bitonic network across the lanes (shuffles)
+//   sort_lds_kernel   : > 64 seeds, one read per wave: bitonic in LDS, in two size classes (<= 256 seeds with a
+//                       4 KB buffer so that many waves fit a CU, <= kSortLds with 32 KB); Shell sort in
+//                       place beyond (rare)
+// Both comparators are total orders on the data, so any correct sort reproduces std::sort's result.
+constexpr int kSortLds = 2048;
+
+__device__ __forceinline__ kg_seed seed_sentinel()
 {
-	// One read per lane, in place.  Most reads have 2-4 seeds (plain insertion sort = the last gap), but
-	// reads inside repeat families carry hundreds (up to 50 per search), so the passes are Shell's
-	// (Ciura gaps): ~n^1.3 moves instead of n^2/4 for the lane that would otherwise hold up its wave.
-	const int gaps[8] = {701, 301, 132, 57, 23, 10, 4, 1};
-	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	kg_seed s;
+	s.gPos = INT64_MAX; s.rPos = 0; s.len = 0;       // greater than every real seed under both comparators
+	return s;
+}
+
+// work-list append through a wave-local ticket pool (see pool_take: one atomic per 256 tickets -- a plain
+// wave-aggregated atomic per iteration runs into the single-word atomic ceiling); tickets a wave reserved
+// but never used are marked -1 by list_close and skipped by the consumers
+__device__ __forceinline__ void list_append(int32_t *list, WavePool &pool, unsigned long long *count, bool want, int32_t value)
+{
+	unsigned long long t = pool_take(pool, count, want, 64);
+	if (want) list[t] = value;
+}
+
+__device__ __forceinline__ void list_close(int32_t *list, const WavePool &pool)
+{
+	for (unsigned long long x = pool.next + (threadIdx.x & 63); x < pool.end; x += 64) list[x] = -1;
+}
+
+// each work list has room for every read plus one pool chunk per wave of sort_small_kernel's grid
+__device__ __forceinline__ int64_t sort_list_stride(const SeedArgs &a) { return a.max_hits * 2; }
+
+// a seed as the sort sees it: key = PosDiff (FastMode) or gPos (SensitiveMode), then rPos; scalars only, so
+// the networks below stay in registers
+struct SortItem { int64_t key; int32_t rpos, len; };
+
+__device__ __forceinline__ SortItem sort_item(const kg_seed &s, int mode)
+{
+	SortItem t;
+	t.key = mode == KG_MODE_FAST ? s.gPos - s.rPos : s.gPos;
+	t.rpos = s.rPos; t.len = s.len;
+	return t;
+}
+
+__device__ __forceinline__ kg_seed sort_seed(int64_t key, int32_t rpos, int32_t len, int mode)
+{
+	kg_seed s;
+	s.gPos = mode == KG_MODE_FAST ? key + rpos : key;
+	s.rPos = rpos; s.len = len;
+	return s;
+}
+
+#define KG_LOAD(i)                                                                           \
+	int64_t k##i = INT64_MAX; int32_t r##i = 0, l##i = 0;                                    \
+	if (n > i) { SortItem t_ = sort_item(s[i], mode); k##i = t_.key; r##i = t_.rpos; l##i = t_.len; }
+#define KG_STORE(i) if (n > i) s[i] = sort_seed(k##i, r##i, l##i, mode)
+#define KG_CE(i, j)                                                                          \
+	do {                                                                                     \
+		bool sw_ = k##j < k##i || (k##j == k##i && r##j < r##i);                             \
+		int64_t ka_ = sw_ ? k##j : k##i, kb_ = sw_ ? k##i : k##j;                            \
+		int32_t ra_ = sw_ ? r##j : r##i, rb_ = sw_ ? r##i : r##j;                            \
+		int32_t la_ = sw_ ? l##j : l##i, lb_ = sw_ ? l##i : l##j;                            \
+		k##i = ka_; k##j = kb_; r##i = ra_; r##j = rb_; l##i = la_; l##j = lb_;              \
+	} while (0)
+
+__global__ __launch_bounds__(256) void sort_small_kernel(SeedArgs a)
+{
+	int32_t *list_wave = reinterpret_cast<int32_t *>(a.hits);      // the hit records are dead once located
+	const int64_t list_stride = sort_list_stride(a);
+	int32_t *list_lds = list_wave + list_stride;
+	unsigned long long *counts = a.read_queue + 12;
+	WavePool pool0, pool1, pool2;
+	const int mode = a.mode;
+	int64_t r0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	for (; r < a.n_reads; r += stride) {
+	int64_t rounds = (a.n_reads + stride - 1) / stride;          // wave-uniform trip count (ballots below)
+	for (int64_t it = 0; it < rounds; ++it) {
+		int64_t r = r0 + it * stride;
+		int64_t lo = 0;
+		int n = 0;
+		if (r < a.n_reads) {
+			lo = a.seed_off[r];
+			int64_t hi = a.seed_off[r + 1];
+			if (hi > a.seed_capacity) hi = a.seed_capacity;
+			n = (int)(hi - lo);
+		}
+		list_append(list_wave, pool0, counts + 0, n > 8 && n <= 64, (int32_t)r);
+		list_append(list_lds, pool1, counts + 1, n > 64 && n <= 256, (int32_t)r);
+		list_append(list_lds + list_stride, pool2, counts + 2, n > 256, (int32_t)r);
+		if (n < 2 || n > 8) continue;
+		kg_seed *s = a.seeds + lo;
+		KG_LOAD(0) KG_LOAD(1) KG_LOAD(2) KG_LOAD(3) KG_LOAD(4) KG_LOAD(5) KG_LOAD(6) KG_LOAD(7)
+		KG_CE(0, 2); KG_CE(1, 3); KG_CE(4, 6); KG_CE(5, 7);
+		KG_CE(0, 4); KG_CE(1, 5); KG_CE(2, 6); KG_CE(3, 7);
+		KG_CE(0, 1); KG_CE(2, 3); KG_CE(4, 5); KG_CE(6, 7);
+		KG_CE(2, 4); KG_CE(3, 5);
+		KG_CE(1, 4); KG_CE(3, 6);
+		KG_CE(1, 2); KG_CE(3, 4); KG_CE(5, 6);
+		KG_STORE(0); KG_STORE(1); KG_STORE(2); KG_STORE(3); KG_STORE(4); KG_STORE(5); KG_STORE(6); KG_STORE(7);
+	}
+	list_close(list_wave, pool0);
+	list_close(list_lds, pool1);
+	list_close(list_lds + list_stride, pool2);
+}
+
+__global__ __launch_bounds__(256) void sort_wave_kernel(SeedArgs a)
+{
+	const int32_t *list = reinterpret_cast<const int32_t *>(a.hits);
+	const unsigned long long n_list = a.read_queue[12];
+	const int mode = a.mode;
+	const int lane = threadIdx.x & 63;
+	const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+	// 64 list entries per wave at a time (one coalesced load); unused pool tickets are -1
+	for (unsigned long long t0 = wave * 64; t0 < n_list; t0 += n_waves * 64) {
+	int32_t mine = t0 + lane < n_list ? list[t0 + lane] : -1;
+	for (uint64_t todo = __ballot(mine >= 0); todo; todo &= todo - 1) {
+		int64_t r = __shfl(mine, __ffsll((unsigned long long)todo) - 1);
+		int64_t lo = a.seed_off[r], hi = a.seed_off[r + 1];
+		if (hi > a.seed_capacity) hi = a.seed_capacity;
+		int n = (int)(hi - lo);
+		kg_seed *s = a.seeds + lo;
+		int64_t key = INT64_MAX;
+		int32_t rpos = 0, len = 0;
+		if (lane < n) { SortItem t_ = sort_item(s[lane], mode); key = t_.key; rpos = t_.rpos; len = t_.len; }
+#pragma unroll
+		for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+			for (int j = k >> 1; j > 0; j >>= 1) {
+				int64_t okey = (int64_t)(((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)key >> 32), j) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)(uint64_t)key, j));
+				int32_t orpos = __shfl_xor(rpos, j), olen = __shfl_xor(len, j);
+				bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+				bool o_less = okey < key || (okey == key && orpos < rpos);
+				bool take = keep_min == o_less;
+				key = take ? okey : key; rpos = take ? orpos : rpos; len = take ? olen : len;
+			}
+		if (lane < n) s[lane] = sort_seed(key, rpos, len, mode);
+	}
+	}
+}
+
+template <int kCap, int kList>
+__global__ __launch_bounds__(64) void sort_lds_kernel(SeedArgs a)
+{
+	__shared__ kg_seed buf[kCap];
+	const int32_t *list = reinterpret_cast<const int32_t *>(a.hits) + (int64_t)kList * sort_list_stride(a);
+	const unsigned long long n_list = a.read_queue[12 + kList];
+	const int mode = a.mode;
+	const int lane = threadIdx.x;
+	// one read per wave (= block); 64 list entries at a time, unused pool tickets are -1
+	for (unsigned long long t0 = (unsigned long long)blockIdx.x * 64; t0 < n_list; t0 += (unsigned long long)gridDim.x * 64) {
+	int32_t mine = t0 + lane < n_list ? list[t0 + lane] : -1;
+	for (uint64_t todo = __ballot(mine >= 0); todo; todo &= todo - 1) {
+		int64_t r = __shfl(mine, __ffsll((unsigned long long)todo) - 1);
 		int64_t lo = a.seed_off[r], hi = a.seed_off[r + 1];
 		if (hi > a.seed_capacity) hi = a.seed_capacity;
 		int64_t n = hi - lo;
-		if (n < 2) continue;
 		kg_seed *s = a.seeds + lo;
-#pragma unroll 1
-		for (int gi = 0; gi < 8; ++gi) {
-			int64_t gap = gaps[gi];
-			if (gap >= n) continue;
-			for (int64_t i = gap; i < n; ++i) {
-				kg_seed v = s[i];
-				int64_t j = i - gap;
-				while (j >= 0 && seed_less(v, s[j], a.mode)) { s[j + gap] = s[j]; j -= gap; }
-				s[j + gap] = v;
+		if (n <= kCap) {
+			int p = 128;
+			while (p < n) p <<= 1;
+			for (int i = lane; i < p; i += 64) buf[i] = i < n ? s[i] : seed_sentinel();
+			__syncthreads();
+			for (int k = 2; k <= p; k <<= 1)
+				for (int j = k >> 1; j > 0; j >>= 1) {
+					for (int i = lane; i < (p >> 1); i += 64) {
+						int x = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+						int y = x + j;
+						kg_seed u = buf[x], w = buf[y];
+						bool up = (x & k) == 0;
+						if (seed_less(w, u, mode) == up) { buf[x] = w; buf[y] = u; }
+					}
+					__syncthreads();
+				}
+			for (int i = lane; i < n; i += 64) s[i] = buf[i];
+			__syncthreads();
+		} else if (lane == 0) {
+			// Shell's passes (Ciura gaps) in place
+			for (int64_t gap = 1750; gap > 0; gap = gap == 1750 ? 701 : gap == 701 ? 301 : gap == 301 ? 132 : gap == 132 ? 57 : gap == 57 ? 23 : gap == 23 ? 10 : gap == 10 ? 4 : gap == 4 ? 1 : 0) {
+				for (int64_t i = gap; i < n; ++i) {
+					kg_seed v = s[i];
+					int64_t j = i - gap;
+					while (j >= 0 && seed_less(v, s[j], mode)) { s[j + gap] = s[j]; j -= gap; }
+					s[j + gap] = v;
+				}
 			}
 		}
+	}
 	}
 }
 
@@ -591,30 +820,76 @@ __global__ __launch_bounds__(256) void build_planes_kernel(const uint32_t *occ, 
 
 // q-mer table: entry id encodes the codes LSB first (code of the first base in bits 1:0); the value
 // is the state BWT_Search (reference src/bwt_search.cpp:147-168) reaches after those kQmer bases.
-__global__ __launch_bounds__(256) void build_qtab_kernel(FmView ix, uint2 *t32, uint4 *t64)
+// Table construction, level by level: the entry of a j-base prefix y (first base in the lowest bits) is one
+// extension step away from the entry of its first j-1 bases, so level j is built in place from level j-1 --
+// thread y reads its parent T[y] and writes the four children T[y | c << 2(j-1)], its own slot (c = 0) last.
+// Entries are exact while the table is built ({k, n, lf2} in 16 bytes); levels above kQtabWide are finished
+// per entry from the widest exact level and written in the compact search format.
+constexpr int kQtabWide = 12;
+
+struct QEntry { uint64_t k, n; uint32_t lf2; };
+
+__device__ __forceinline__ QEntry qentry_unpack(uint4 v)
+{
+	QEntry e;
+	e.k = (uint64_t)v.x | ((uint64_t)(v.z & 0xFF) << 32);
+	e.n = (uint64_t)v.y | ((uint64_t)((v.z >> 8) & 0xFF) << 32);
+	e.lf2 = v.z >> 16;
+	return e;
+}
+
+__device__ __forceinline__ uint4 qentry_pack(const QEntry &e)
+{
+	return make_uint4((uint32_t)e.k, (uint32_t)e.n, (uint32_t)(e.k >> 32) | ((uint32_t)(e.n >> 32) << 8) | (e.lf2 << 16), 0u);
+}
+
+__device__ __forceinline__ QEntry qentry_step(const FmView &ix, QEntry e, int read_code)   // one BWT_Search extension, :157-168
+{
+	if (e.n == 0) return e;
+	int c = 3 - read_code;
+	uint64_t kk = e.k - 1, ll = e.k - 1 + e.n;
+	kk -= (kk >= ix.primary);
+	ll -= (ll >= ix.primary);
+	e.lf2 += (kk >> 7) != (ll >> 7);
+	uint64_t ok = rank_plane(ix, kk, c), ol = rank_plane(ix, ll, c);
+	e.n = ol - ok;
+	e.k = l2_of(ix, c) + 1 + ok;
+	return e;
+}
+
+__global__ __launch_bounds__(256) void qtab_level_kernel(FmView ix, uint4 *wide, int level)
+{
+	uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	if (level == 1) {
+		if (y < 4) {
+			QEntry e;
+			e.k = l2_of(ix, 3 - (int)y) + 1; e.n = l2_of(ix, (int)y + 1) - l2_of(ix, (int)y); e.lf2 = 0;   // :149-150
+			wide[y] = qentry_pack(e);
+		}
+		return;
+	}
+	for (; y < (1ull << (2 * (level - 1))); y += stride) {
+		QEntry parent = qentry_unpack(wide[y]);
+		for (int c = 3; c >= 0; --c)
+			wide[y | ((uint64_t)c << (2 * (level - 1)))] = qentry_pack(qentry_step(ix, parent, c));
+	}
+}
+
+__global__ __launch_bounds__(256) void qtab_finish_kernel(FmView ix, const uint4 *wide, int q_wide, int q, uint2 *t32, uint64_t *t64)
 {
 	uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	for (; id < (1ull << (2 * kQmer)); id += stride) {
-		int p = (int)(id & 3);
-		uint64_t k = l2_of(ix, 3 - p) + 1, n = l2_of(ix, p + 1) - l2_of(ix, p);
-		uint32_t lf2 = 0;
-		for (int j = 1; j < kQmer && n != 0; ++j) {
-			int c = 3 - (int)((id >> (2 * j)) & 3);
-			uint64_t kk = k - 1, ll = k - 1 + n;
-			kk -= (kk >= ix.primary);
-			ll -= (ll >= ix.primary);
-			lf2 += (kk >> 7) != (ll >> 7);
-			uint64_t ok = rank_plane(ix, kk, c), ol = rank_plane(ix, ll, c);
-			n = ol - ok;
-			k = l2_of(ix, c) + 1 + ok;
-		}
+	for (; id < (1ull << (2 * q)); id += stride) {
+		QEntry e = qentry_unpack(wide[id & ((1ull << (2 * q_wide)) - 1)]);
+		for (int j = q_wide; j < q; ++j) e = qentry_step(ix, e, (int)((id >> (2 * j)) & 3));
+		// not representable in the compact entry: n = 0, the search falls back to single steps
 		if (t32) {
-			if (n >= (1ull << 28)) n = 0;      // not representable: the search falls back to single steps
-			t32[id] = make_uint2((uint32_t)k, (uint32_t)n | (lf2 << 28));
+			if (e.n >= (1ull << 28)) e.n = 0;
+			t32[id] = make_uint2((uint32_t)e.k, (uint32_t)e.n | (e.lf2 << 28));
 		} else {
-			if (n >= (1ull << 32)) n = 0;
-			t64[id] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)n, lf2);
+			if (e.n >= (1ull << 26) || e.k >= (1ull << 34)) e.n = 0;
+			t64[id] = e.k | (e.n << 34) | ((uint64_t)e.lf2 << 60);
 		}
 	}
 }
@@ -638,10 +913,46 @@ hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *
 	return hipGetLastError();
 }
 
-hipError_t launch_build_qtab(const FmView &ix, uint2 *t32, uint4 *t64, hipStream_t stream)
+// the 2L-base text the index was built over, from the forward-strand .pac bases (bwa packing: base i in bits
+// (~i&3)*2 of byte i>>2): T[x] = pac[x] for x < L, 3 - pac[2L-1-x] above
+__global__ __launch_bounds__(256) void build_text_kernel(const uint8_t *pac, uint64_t l_pac, uint8_t *text, uint64_t n_bytes)
 {
-	hipLaunchKernelGGL(build_qtab_kernel, dim3(256 * 32), dim3(256), 0, stream, ix, t32, t64);
+	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; b < n_bytes; b += stride) {
+		uint32_t out = 0;
+		for (int j = 0; j < 4; ++j) {
+			uint64_t x = (b << 2) + (uint64_t)j;
+			uint32_t v = 0;
+			if (x < l_pac) v = (pac[x >> 2] >> ((~x & 3) << 1)) & 3;
+			else if (x < 2 * l_pac) { uint64_t y = 2 * l_pac - 1 - x; v = 3 - ((pac[y >> 2] >> ((~y & 3) << 1)) & 3); }
+			out |= v << (j << 1);
+		}
+		text[b] = (uint8_t)out;
+	}
+}
+
+hipError_t launch_build_text(const uint8_t *pac, uint64_t l_pac, uint8_t *text, uint64_t n_bytes, hipStream_t stream)
+{
+	hipLaunchKernelGGL(build_text_kernel, dim3(grid_for((int64_t)n_bytes, 256, 256 * 64)), dim3(256), 0, stream, pac, l_pac, text, n_bytes);
 	return hipGetLastError();
+}
+
+hipError_t launch_build_qtab(const FmView &ix, int q, uint2 *t32, uint64_t *t64, hipStream_t stream)
+{
+	int q_wide = q < kQtabWide ? q : kQtabWide;
+	uint4 *wide = nullptr;
+	hipError_t e = hipMalloc((void **)&wide, sizeof(uint4) << (2 * q_wide));
+	if (e != hipSuccess) return e;
+	for (int level = 1; level <= q_wide; ++level) {
+		int64_t parents = level == 1 ? 4 : (int64_t)1 << (2 * (level - 1));
+		hipLaunchKernelGGL(qtab_level_kernel, dim3(grid_for(parents, 256, 256 * 32)), dim3(256), 0, stream, ix, wide, level);
+	}
+	hipLaunchKernelGGL(qtab_finish_kernel, dim3(256 * 64), dim3(256), 0, stream, ix, wide, q_wide, q, t32, t64);
+	e = hipGetLastError();
+	hipError_t e2 = hipStreamSynchronize(stream);
+	(void)hipFree(wide);
+	return e != hipSuccess ? e : e2;
 }
 
 hipError_t launch_expand_sa(const FmView &ix, uint64_t n_sa, uint32_t *fsa32, uint64_t *fsa64, hipStream_t stream)
@@ -694,7 +1005,10 @@ hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_tem
 	else
 		hipLaunchKernelGGL(locate_sampled_kernel, dim3(grid_for(a.max_hits, 256, n_cu * 8)), dim3(256), 0, stream, a);
 	if (ev) (void)hipEventRecord(ev[3], stream);
-	hipLaunchKernelGGL(sort_kernel, dim3(grid_for(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(sort_small_kernel, dim3(grid_for(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(sort_wave_kernel, dim3(n_cu * 8), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL((sort_lds_kernel<256, 1>), dim3(n_cu * 32), dim3(64), 0, stream, a);
+	hipLaunchKernelGGL((sort_lds_kernel<kSortLds, 2>), dim3(n_cu * 5), dim3(64), 0, stream, a);
 	if (ev) (void)hipEventRecord(ev[4], stream);
 	return hipGetLastError();
 }

@@ -14,13 +14,14 @@ struct Hit {
 	int32_t len;
 	int32_t n;           // interval size = number of seeds
 	int32_t seed_start;  // running seed count of the read before this hit
-	int32_t pad;
+	int32_t direct;      // 1: k already holds the text position of the pattern (search finished against the text)
 };
 
 // device control block: zeroed by one hipMemsetAsync per batch
 //   [0] read queue head  [1] hit count  [2] locate queue head  [3] unused
 //   [4..11] counters: searches, lf1, lf2, inv, sa, seeds, bases, overflow(needed seeds or 0)
-constexpr int kCtlWords = 12;
+//   [12..14] reads on the sort work lists: 9..64 seeds (wave), 65..256 (small LDS), > 256 (large LDS)
+constexpr int kCtlWords = 15;
 
 struct SeedArgs {
 	FmView ix;
@@ -45,7 +46,8 @@ size_t scan_temp_bytes(int64_t max_reads);
 // ev: optional array of 5 events recorded before/after the four phases (search | scan | locate | sort)
 hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream, hipEvent_t *ev);
 hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *planes, hipStream_t stream);
-hipError_t launch_build_qtab(const FmView &ix, uint2 *t32, uint4 *t64, hipStream_t stream);
+hipError_t launch_build_text(const uint8_t *pac, uint64_t l_pac, uint8_t *text, uint64_t n_bytes, hipStream_t stream);
+hipError_t launch_build_qtab(const FmView &ix, int q, uint2 *t32, uint64_t *t64, hipStream_t stream);
 hipError_t launch_expand_sa(const FmView &ix, uint64_t n_sa, uint32_t *fsa32, uint64_t *fsa64, hipStream_t stream);
 
 struct ChainArgs {

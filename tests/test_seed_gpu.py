@@ -46,6 +46,22 @@ def test_counters_match_oracle(golden, gpu_index, oracle_small):
     assert abs(inv_got - inv_want) < 0.1 * inv_want
 
 
+def test_counters_with_text_comparison(golden, gpu_index_full, oracle_small):
+    """with the full SA resident, single-suffix searches finish by comparing against the text; the
+    kernel still reports the reference's step count (each compared base = one LF step of the reference).
+    Only the one-or-two-blocks split of those steps is not reconstructed (they are booked as one-block
+    steps; a single-suffix step touches two blocks when its rank is a multiple of 128)."""
+    oracle_small.counters(reset=True)
+    oracle_small.seed_batch(golden["fast_enc"], golden["fast_off"], 0)
+    want = oracle_small.counters(reset=True)
+    ws = gpu_index_full.workspace(len(golden["fast_off"]) - 1, len(golden["fast_enc"]))
+    ws.seed_batch(golden["fast_enc"], golden["fast_off"], 0)
+    got = ws.counters().as_dict()
+    assert got["searches"] == want["searches"] and got["seeds"] == want["seeds"] and got["bases"] == want["bases"]
+    assert got["lf1"] + got["lf2"] == want["lf1"] + want["lf2"]
+    assert got["lf2"] <= want["lf2"] and want["lf2"] - got["lf2"] < 0.02 * (want["lf1"] + want["lf2"])
+
+
 def test_empty_and_tiny_batches(gpu_index):
     assert gpu_index.IdentifySeedPairs_FastMode([]) == []
     out = gpu_index.IdentifySeedPairs_FastMode([np.zeros(1, np.uint8), np.zeros(0, np.uint8), np.full(200, 4, np.uint8)])
