@@ -9,6 +9,9 @@
 
 #include "mapper.hpp"
 
+#include <algorithm>
+#include <thread>
+
 namespace kart {
 
 static void usage(const char *prog)
@@ -107,8 +110,14 @@ int cli_main(int argc, char **argv, KernelBackend *(*make_backend)(const Options
 	fprintf(stdout, "Load the genome index files...\n");
 	RefData ref;
 	std::string err;
-	if (!ref.load(opt.index_prefix, err)) { fprintf(stdout, "\n\nError! Index files are corrupt! (%s)\n", err.c_str()); return 1; }
+	// the host copy of the reference (both strands as characters) is decoded while the device index is uploaded and its
+	// rank / q-mer / suffix-array structures are built
+	std::string ref_err;
+	bool ref_ok = false;
+	std::thread ref_loader([&]() { ref_ok = ref.load(opt.index_prefix, ref_err, std::max(1, opt.threads)); });
 	KernelBackend *kern = make_backend(opt, err);
+	ref_loader.join();
+	if (!ref_ok) { fprintf(stdout, "\n\nError! Index files are corrupt! (%s)\n", ref_err.c_str()); delete kern; return 1; }
 	if (!kern) { fprintf(stderr, "Error! %s\n", err.c_str()); return 1; }
 	FILE *out = fopen(opt.out_name.c_str(), "w");
 	if (!out) { fprintf(stderr, "Error! Cannot open file [%s]\n", opt.out_name.c_str()); delete kern; return 1; }

@@ -129,7 +129,7 @@ struct Ctx {
 	KernelBackend &kern;
 	int min_seed_len;
 	bool fastq = true;
-	const char *refseq() const { return ref.seq.data(); }
+	const char *refseq() const { return ref.seq.get(); }
 };
 
 // What one 4000-read chunk contributes to the run-wide pairing statistics (iPaired / iDistance,
@@ -1855,20 +1855,39 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	};
 	auto commit = [&](Batch &b) {   // in-order: EstDistance feeds forward (src/Mapping.cpp:533-540)
 		double t0 = now_s();
+		// A chunk mapped under a speculated EstDistance stands if the true estimate -- a function of the totals of
+		// all chunks before it -- would have decided every pair the same way.  Walk the batch with running totals,
+		// collect the chunks whose speculation does not hold, re-map those together on the pool, and repeat: a
+		// re-mapped chunk can move the estimates after it.  Every round settles at least the first unsettled chunk,
+		// so the fixed point is the sequential result.
+		for (;;) {
+			std::vector<std::pair<size_t, int>> redo;
+			int64_t paired = tot.iPaired, distance = tot.iDistance;
+			for (size_t c = 0; c < b.chunks.size(); ++c) {
+				ChunkState &ck = b.chunks[c];
+				if (ck.paired) {
+					int est_true = est_distance(cx, paired, distance);
+					bool valid = est_true == ck.est_used ||
+					             (ck.ps.lo < est_true && est_true <= ck.ps.hi &&
+					              (!ck.ps.rescue_used || std::min(est_true, cx.opt.max_insert) == std::min(ck.est_used, cx.opt.max_insert)));
+					if (!valid) redo.emplace_back(c, est_true);
+				}
+				paired += ck.ps.paired;
+				distance += ck.ps.distance;
+			}
+			if (redo.empty()) break;
+			st.respeculated += (int64_t)redo.size();
+			pool.run((int)redo.size(), [&](int i) {
+				chunk_stage_a(cx, b.reads, b.seed_off, b.n_cands, b.cands, b.cand_seeds, b.chunks[redo[(size_t)i].first], redo[(size_t)i].second);
+			});
+			std::vector<NwJobs *> parts;
+			for (const std::pair<size_t, int> &r : redo)
+				if (b.chunks[r.first].jobs.size() > 0) parts.push_back(&b.chunks[r.first].jobs);
+			if (!parts.empty()) cx.kern.nw_batch(parts);
+			pool.run((int)redo.size(), [&](int i) { chunk_stage_c(cx, b.reads, b.chunks[redo[(size_t)i].first]); });
+		}
 		for (size_t c = 0; c < b.chunks.size(); ++c) {
 			ChunkState &ck = b.chunks[c];
-			if (ck.paired) {
-				int est_true = est_distance(cx, tot.iPaired, tot.iDistance);
-				bool valid = est_true == ck.est_used ||
-				             (ck.ps.lo < est_true && est_true <= ck.ps.hi &&
-				              (!ck.ps.rescue_used || std::min(est_true, cx.opt.max_insert) == std::min(ck.est_used, cx.opt.max_insert)));
-				if (!valid) {   // mapped under an estimate that would have decided differently: redo with the true one
-					st.respeculated++;
-					chunk_stage_a(cx, b.reads, b.seed_off, b.n_cands, b.cands, b.cand_seeds, ck, est_true);
-					run_nw(cx, b.chunks, c, c + 1);
-					chunk_stage_c(cx, b.reads, ck);
-				}
-			}
 			writer.push(std::move(ck.text));
 			tot.iPaired += ck.ps.paired;
 			tot.iDistance += ck.ps.distance;
@@ -1919,7 +1938,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 // ----------------------------------------------------------------------------------------------
 // public entry points
 // ----------------------------------------------------------------------------------------------
-bool RefData::load(const std::string &prefix, std::string &err)
+bool RefData::load(const std::string &prefix, std::string &err, int threads)
 {
 	FILE *fp = fopen((prefix + ".ann").c_str(), "r");
 	if (!fp) { err = "cannot read " + prefix + ".ann"; return false; }
@@ -1951,9 +1970,35 @@ bool RefData::load(const std::string &prefix, std::string &err)
 	fclose(fp);
 	std::vector<unsigned char> pac;
 	if (!slurp(prefix + ".pac", pac) || (int64_t)pac.size() < genome_size / 4 + 1) { err = "cannot read " + prefix + ".pac"; return false; }
-	seq.assign((size_t)(two_genome_size + 1), '\0');
+	// both strands as characters (src/bwt_index.cpp:242-258), one .pac byte = four bases at a time; the 2L bytes
+	// are first touched by the decoding threads themselves (6.2 GB for hg38)
+	seq.reset(new char[(size_t)(two_genome_size + 1)]);
+	seq[(size_t)two_genome_size] = '\0';
+	std::vector<uint32_t> fw4(256), rc4(256);
+	for (int v = 0; v < 256; ++v) {
+		char f[4], r[4];
+		for (int j = 0; j < 4; ++j) {
+			int b = (v >> ((3 - j) << 1)) & 3;       // base j of the byte (first base in the top bits)
+			f[j] = "ACGT"[b];
+			r[3 - j] = "TGCA"[b];                    // the reverse strand runs the other way
+		}
+		memcpy(&fw4[(size_t)v], f, 4);
+		memcpy(&rc4[(size_t)v], r, 4);
+	}
+	int64_t whole = genome_size >> 2;                // bytes whose four bases all exist
+	int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, whole >> 20));
+	std::vector<std::thread> pool;
+	char *out = seq.get();
+	for (int t = 0; t < nt; ++t)
+		pool.emplace_back([&, t]() {
+			for (int64_t i = whole * t / nt, e = whole * (t + 1) / nt; i < e; ++i) {
+				memcpy(out + (i << 2), &fw4[pac[(size_t)i]], 4);
+				memcpy(out + (two_genome_size - (i << 2) - 4), &rc4[pac[(size_t)i]], 4);
+			}
+		});
+	for (std::thread &th : pool) th.join();
 	static const char fw[4] = {'A', 'C', 'G', 'T'}, rc[4] = {'T', 'G', 'C', 'A'};
-	for (int64_t f = 0; f < genome_size; ++f) {
+	for (int64_t f = whole << 2; f < genome_size; ++f) {
 		int b = pac[(size_t)(f >> 2)] >> ((~f & 3) << 1) & 3;
 		seq[(size_t)f] = fw[b];
 		seq[(size_t)(two_genome_size - 1 - f)] = rc[b];

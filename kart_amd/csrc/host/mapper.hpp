@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -87,8 +88,8 @@ struct RefData {
 	int64_t genome_size = 0, two_genome_size = 0;
 	std::vector<Contig> contigs;
 	std::map<int64_t, int> chr_end;     // last coordinate of each strand copy -> contig index
-	std::vector<char> seq;              // 2L + 1, forward then reverse complement
-	bool load(const std::string &prefix, std::string &err);
+	std::unique_ptr<char[]> seq;        // 2L + 1, forward then reverse complement
+	bool load(const std::string &prefix, std::string &err, int threads = 16);
 };
 
 struct Stats {
