@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 	// the read with the text at tpos (the text position facing read position `cur`)
 	int mode = 0;
 	idx_t tpos = 0;
-	uint32_t c_search = 0, c_lf = 0, c_lf2 = 0;
+	uint32_t c_search = 0, c_lf = 0, c_lf2 = 0, c_sa = 0;
 	WavePool read_pool, hit_pool;
 
 	for (;;) {
@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 				// SA[k] = where the reverse complement of the match starts; the match itself then ends right
 				// before text position 2L - SA[k], which is the base the next read base must equal
 				tpos = (idx_t)(ix.seq_len - sav);
+				c_sa++;
 				mode = 2;
 				cont = true;
 			}
@@ -357,14 +358,15 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 	// the slots this wave reserved but never filled are marked empty for the locate kernel
 	for (unsigned long long x = hit_pool.next + (threadIdx.x & 63); x < hit_pool.end; x += 64) a.hits[x].n = 0;
 	// work counters: one atomic per wave
-	uint64_t s0 = c_search, s1 = c_lf - c_lf2, s2 = c_lf2;
+	uint64_t s0 = c_search, s1 = c_lf - c_lf2, s2 = c_lf2, s3 = c_sa;
 	for (int off = 32; off > 0; off >>= 1) {
-		s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off);
+		s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); s3 += __shfl_down(s3, off);
 	}
 	if ((threadIdx.x & 63) == 0) {
 		atomicAdd(&a.counters[0], (unsigned long long)s0);
 		atomicAdd(&a.counters[1], (unsigned long long)s1);
 		atomicAdd(&a.counters[2], (unsigned long long)s2);
+		if (s3) atomicAdd(&a.counters[4], (unsigned long long)s3);
 	}
 }
 
@@ -430,25 +432,70 @@ __global__ __launch_bounds__(256) void locate_sampled_kernel(SeedArgs a)
 	}
 }
 
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
+{
+	return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src);
+}
+
+// KG_SA_FULL: one gather per seed.  A wave takes 64 hits at a time; hits that were finished against the text
+// carry their position already, the others expand to n seeds each (up to 50): those (hit, i) items are spread
+// over the lanes -- prefix sum of n across the wave, binary search by shuffle -- so that a 50-seed hit costs
+// its wave one round instead of 50, and the suffix-array reads and seed writes of one hit are contiguous.
 __global__ __launch_bounds__(256) void locate_full_kernel(SeedArgs a)
 {
 	const FmView &ix = a.ix;
 	const unsigned long long n_hits = *a.hit_count;
-	unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-	unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-	for (; t < n_hits; t += stride) {
-		Hit h = a.hits[t];
-		int64_t out = hit_out_base(a, h);
-		for (int i = 0; i < h.n; ++i) {
-			uint64_t sa = h.direct ? 0 : ix.fsa32 ? (uint64_t)ix.fsa32[h.k + i] : ix.fsa64[h.k + i];
-			if (out + i < a.seed_capacity) {
-				kg_seed s;
-				s.gPos = h.direct ? (int64_t)h.k : (int64_t)(ix.seq_len - sa - (uint64_t)h.len);
-				s.rPos = h.rpos; s.len = h.len;
-				a.seeds[out + i] = s;
+	const int lane = threadIdx.x & 63;
+	const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
+	uint32_t c_sa = 0;
+	for (unsigned long long t0 = wave * 64; t0 < n_hits; t0 += n_waves * 64) {
+		Hit h;
+		h.n = 0; h.k = 0; h.len = 0; h.rpos = 0; h.direct = 0; h.read = 0; h.seed_start = 0;
+		if (t0 + lane < n_hits) h = a.hits[t0 + lane];
+		int64_t out = h.n ? hit_out_base(a, h) : 0;
+		if (h.n && h.direct && out < a.seed_capacity) {
+			kg_seed s;
+			s.gPos = (int64_t)h.k; s.rPos = h.rpos; s.len = h.len;
+			a.seeds[out] = s;
+		}
+		int cnt = (h.n && !h.direct) ? h.n : 0;
+		int incl = cnt;
+		for (int d = 1; d < 64; d <<= 1) {
+			int v = __shfl_up(incl, d);
+			if (lane >= d) incl += v;
+		}
+		const int total = __shfl(incl, 63);
+		for (int base = 0; base < total; base += 64) {
+			int t = base + lane;
+			int lo = 0, hi = 63;                                  // smallest lane whose inclusive prefix exceeds t
+#pragma unroll
+			for (int step = 0; step < 6; ++step) {
+				int mid = (lo + hi) >> 1;
+				int v = __shfl(incl, mid);
+				if (v > t) hi = mid; else lo = mid + 1;
+			}
+			int src = lo > 63 ? 63 : lo;
+			int s_incl = __shfl(incl, src), s_cnt = __shfl(cnt, src);
+			uint64_t s_k = shfl_u64(h.k, src);
+			int64_t s_out = (int64_t)shfl_u64((uint64_t)out, src);
+			int s_len = __shfl(h.len, src), s_rpos = __shfl(h.rpos, src);
+			int i = t - (s_incl - s_cnt);
+			if (t < total) {
+				uint64_t sa = ix.fsa32 ? (uint64_t)ix.fsa32[s_k + (uint64_t)i] : ix.fsa64[s_k + (uint64_t)i];
+				c_sa++;
+				if (s_out + i < a.seed_capacity) {
+					kg_seed s;
+					s.gPos = (int64_t)(ix.seq_len - sa - (uint64_t)s_len);
+					s.rPos = s_rpos; s.len = s_len;
+					a.seeds[s_out + i] = s;
+				}
 			}
 		}
 	}
+	uint64_t s1 = c_sa;
+	for (int off = 32; off > 0; off >>= 1) s1 += __shfl_down(s1, off);
+	if (lane == 0 && s1) atomicAdd(&a.counters[4], (unsigned long long)s1);
 }
 
 // comparators of the two seeding modes (reference src/AlignmentCandidates.cpp:11-21)
