@@ -249,27 +249,13 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		HIP_TRY(hipDeviceSynchronize());
 		v.planes = ix->d_planes;
 		ix->device_bytes += plane_bytes;
-		// q-mer interval table: 4^q entries with 4^q ~ text length (12 for E. coli, 16 for hg38), 8 bytes each
-		v.qtab32 = nullptr;
-		v.qtab64 = nullptr;
-		v.qmer = 0;
-		if (!getenv("KG_NO_QTAB")) {
-			bool narrow = v.seq_len < 0xFFFFFF00ull && !getenv("KG_FORCE_U64");
-			int q = kQmerMin;
-			while (q < kQmerMax && ((uint64_t)1 << (2 * q + 1)) <= v.seq_len) q++;      // round(log4(2L))
-			if (const char *env = getenv("KG_QMER")) { int t = atoi(env); if (t >= kQmerMin && t <= kQmerMax) q = t; }   // tuning knob
-			size_t tab_bytes = ((size_t)1 << (2 * q)) * 8;
-			HIP_TRY(hipMalloc(&ix->d_qtab, tab_bytes));
-			v.qmer = q;
-			HIP_TRY(launch_build_qtab(v, q, narrow ? (uint2 *)ix->d_qtab : nullptr, narrow ? nullptr : (uint64_t *)ix->d_qtab, nullptr));
-			HIP_TRY(hipDeviceSynchronize());
-			if (narrow) v.qtab32 = (const uint2 *)ix->d_qtab; else v.qtab64 = (const uint64_t *)ix->d_qtab;
-			ix->device_bytes += tab_bytes;
-		}
 	}
 	v.fsa32 = nullptr;
 	v.fsa64 = nullptr;
 	v.text = nullptr;
+	v.qtab32 = nullptr;
+	v.qtab64 = nullptr;
+	v.qmer = 0;
 
 	if (sa_mode == KG_SA_FULL) {
 		bool narrow = v.seq_len < 0xFFFFFFFFull && !getenv("KG_FORCE_U64");
@@ -292,6 +278,21 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		}
 	} else if (sa_mode != KG_SA_SAMPLED) {
 		return fail(KG_ERR_ARG, "kg_index_load: unknown sa_mode %d", sa_mode);
+	}
+	// q-mer interval table: 4^q entries with 4^q ~ text length (12 for E. coli, 16 for hg38), 8 bytes each; built
+	// last because entries of a single suffix hold that suffix (needs the full SA)
+	if (!getenv("KG_NO_QTAB")) {
+		bool narrow = v.seq_len < 0xFFFFFF00ull && !getenv("KG_FORCE_U64");
+		int q = kQmerMin;
+		while (q < kQmerMax && ((uint64_t)1 << (2 * q + 1)) <= v.seq_len) q++;      // round(log4(2L))
+		if (const char *env = getenv("KG_QMER")) { int t = atoi(env); if (t >= kQmerMin && t <= kQmerMax) q = t; }   // tuning knob
+		size_t tab_bytes = ((size_t)1 << (2 * q)) * 8;
+		HIP_TRY(hipMalloc(&ix->d_qtab, tab_bytes));
+		v.qmer = q;
+		HIP_TRY(launch_build_qtab(v, q, narrow ? (uint2 *)ix->d_qtab : nullptr, narrow ? nullptr : (uint64_t *)ix->d_qtab, nullptr));
+		HIP_TRY(hipDeviceSynchronize());
+		if (narrow) v.qtab32 = (const uint2 *)ix->d_qtab; else v.qtab64 = (const uint64_t *)ix->d_qtab;
+		ix->device_bytes += tab_bytes;
 	}
 	*out = ix.release();
 	return KG_OK;

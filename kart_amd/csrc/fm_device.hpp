@@ -31,9 +31,10 @@ struct FmView {
 	const uint64_t *fsa64;
 	// q-mer interval table (device-private, built at load): for the first `qmer` bases of a search, the
 	// interval after qmer-1 extension steps.  q grows with the text (4^q ~ 2L: 12 for E. coli, 16 for hg38)
-	// so that the jump lands on intervals of a few suffixes.  Entry = { k, n | lf2 << 28 } (u32 index) or
-	// k | n << 34 | lf2 << 60 (u64 index); n == 0 means "no such q-mer / not representable": the search
-	// then starts step by step, so results never depend on the table.
+	// so that the jump lands on intervals of a few suffixes.  Entry = { k, n | sa << 27 | lf2 << 28 } (u32
+	// index) or k | n << 34 | sa << 59 | lf2 << 60 (u64 index); n == 0 means "no such q-mer / not
+	// representable": the search then starts step by step, so results never depend on the table.  sa = 1
+	// (n == 1 and the full SA resident): k is SA[k] already, the search continues against the text.
 	const uint2 *qtab32;
 	const uint64_t *qtab64;
 	int qmer;

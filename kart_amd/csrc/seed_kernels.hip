@@ -252,13 +252,14 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 				y = (y | (y >> 16)) & 0x00000000FFFFFFFFull;
 				idx_t tk = 0, tn = 0;
 				uint32_t tlf2 = 0;
+				bool tsa = false;                              // the entry names the suffix itself (interval of one)
 				if (clean) {
 					if (sizeof(idx_t) == 4) {
 						uint2 e = ix.qtab32[y];
-						tk = (idx_t)e.x; tn = (idx_t)(e.y & 0x0FFFFFFFu); tlf2 = e.y >> 28;
+						tk = (idx_t)e.x; tn = (idx_t)(e.y & 0x07FFFFFFu); tsa = (e.y >> 27) & 1; tlf2 = e.y >> 28;
 					} else {
 						uint64_t e = ix.qtab64[y];
-						tk = (idx_t)(e & 0x3FFFFFFFFull); tn = (idx_t)((e >> 34) & 0x3FFFFFFull); tlf2 = (uint32_t)(e >> 60);
+						tk = (idx_t)(e & 0x3FFFFFFFFull); tn = (idx_t)((e >> 34) & 0x1FFFFFFull); tsa = (e >> 59) & 1; tlf2 = (uint32_t)(e >> 60);
 					}
 				}
 				bool jump = clean && tn != 0;
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 				c_lf2 += jump ? tlf2 : 0u;
 				stop = fast ? rlen : stop_pos;
 				mode = direct && n == 1 ? 1 : 0;
+				if (jump && tsa) { tpos = (idx_t)(ix.seq_len - (uint64_t)tk); mode = 2; }
 				active = true;
 				c_search++;
 				if ((cur >> 4) != wword) { win = wnext; wword++; wnext = pw[wword + 1]; }
@@ -930,13 +932,20 @@ __global__ __launch_bounds__(256) void qtab_finish_kernel(FmView ix, const uint4
 	for (; id < (1ull << (2 * q)); id += stride) {
 		QEntry e = qentry_unpack(wide[id & ((1ull << (2 * q_wide)) - 1)]);
 		for (int j = q_wide; j < q; ++j) e = qentry_step(ix, e, (int)((id >> (2 * j)) & 3));
+		// an interval of one suffix: store the suffix itself (SA[k]) when the full SA is resident -- the search
+		// then goes straight to comparing against the text, without the SA gather
+		uint64_t flag = 0;
+		if (e.n == 1 && ix.text != nullptr && (ix.fsa32 || ix.fsa64)) {
+			e.k = ix.fsa32 ? (uint64_t)ix.fsa32[e.k] : ix.fsa64[e.k];
+			flag = 1;
+		}
 		// not representable in the compact entry: n = 0, the search falls back to single steps
 		if (t32) {
-			if (e.n >= (1ull << 28)) e.n = 0;
-			t32[id] = make_uint2((uint32_t)e.k, (uint32_t)e.n | (e.lf2 << 28));
+			if (e.n >= (1ull << 27)) e.n = 0;
+			t32[id] = make_uint2((uint32_t)e.k, (uint32_t)e.n | ((uint32_t)flag << 27) | (e.lf2 << 28));
 		} else {
-			if (e.n >= (1ull << 26) || e.k >= (1ull << 34)) e.n = 0;
-			t64[id] = e.k | (e.n << 34) | ((uint64_t)e.lf2 << 60);
+			if (e.n >= (1ull << 25) || e.k >= (1ull << 34)) e.n = 0;
+			t64[id] = e.k | (e.n << 34) | (flag << 59) | ((uint64_t)e.lf2 << 60);
 		}
 	}
 }
