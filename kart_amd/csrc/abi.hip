@@ -161,7 +161,8 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	if (!read_file(pre + ".sa", sa) || sa.size() < 56) return fail(KG_ERR_IO, "cannot read %s.sa", prefix);
 	if (!read_file(pre + ".pac", pac) || pac.empty()) return fail(KG_ERR_IO, "cannot read %s.pac", prefix);
 
-	std::unique_ptr<kg_index> ix(new kg_index());
+	// every early return below releases what was uploaded so far
+	std::unique_ptr<kg_index, void (*)(kg_index *)> ix(new kg_index(), kg_index_destroy);
 	ix->device = device;
 	ix->sa_mode = sa_mode;
 	hipDeviceProp_t prop;
@@ -355,7 +356,7 @@ int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_w
 	if (!ix || !out || max_reads <= 0 || max_bases <= 0) return fail(KG_ERR_ARG, "kg_workspace_create: bad argument");
 	*out = nullptr;
 	HIP_TRY(hipSetDevice(ix->device));
-	std::unique_ptr<kg_workspace> ws(new kg_workspace());
+	std::unique_ptr<kg_workspace, void (*)(kg_workspace *)> ws(new kg_workspace(), kg_workspace_destroy);
 	ws->ix = ix;
 	ws->max_reads = max_reads;
 	ws->max_bases = max_bases;

@@ -1972,7 +1972,14 @@ bool RefData::load(const std::string &prefix, std::string &err, int threads)
 	if (!slurp(prefix + ".pac", pac) || (int64_t)pac.size() < genome_size / 4 + 1) { err = "cannot read " + prefix + ".pac"; return false; }
 	// both strands as characters (src/bwt_index.cpp:242-258), one .pac byte = four bases at a time; the 2L bytes
 	// are first touched by the decoding threads themselves (6.2 GB for hg38)
-	seq.reset(new char[(size_t)(two_genome_size + 1)]);
+	// random access all over 6.2 GB (hg38): transparent huge pages keep the report stage out of the page walker
+	{
+		void *mem = nullptr;
+		size_t bytes = (((size_t)two_genome_size + 1) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+		if (posix_memalign(&mem, (size_t)2 << 20, bytes) != 0) { err = "out of memory for the reference sequence"; return false; }
+		madvise(mem, bytes, MADV_HUGEPAGE);
+		seq.reset((char *)mem);
+	}
 	seq[(size_t)two_genome_size] = '\0';
 	std::vector<uint32_t> fw4(256), rc4(256);
 	for (int v = 0; v < 256; ++v) {

@@ -13,6 +13,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -88,7 +89,7 @@ struct RefData {
 	int64_t genome_size = 0, two_genome_size = 0;
 	std::vector<Contig> contigs;
 	std::map<int64_t, int> chr_end;     // last coordinate of each strand copy -> contig index
-	std::unique_ptr<char[]> seq;        // 2L + 1, forward then reverse complement
+	std::unique_ptr<char[], void (*)(void *)> seq{nullptr, free};   // 2L + 1, forward then reverse complement (2 MB-aligned, huge pages)
 	bool load(const std::string &prefix, std::string &err, int threads = 16);
 };
 
