@@ -1645,6 +1645,23 @@ int est_distance(const Ctx &cx, int64_t iPaired, int64_t iDistance)  // src/Mapp
 	return est + (est >> 1);
 }
 
+// KART_AMD_VERBOSE: thread-seconds per section of the two chunk stages (summed over all workers)
+std::atomic<int64_t> g_sec_ns[6];
+const char *const g_sec_name[6] = {"unpack candidates", "pair+rescue+filters", "report plan", "report finish", "pair check+flags+mapq", "sam text"};
+bool g_sections = false;
+struct Section {
+	int id;
+	timespec t0;
+	explicit Section(int i) : id(i) { if (g_sections) clock_gettime(CLOCK_MONOTONIC, &t0); }
+	~Section()
+	{
+		if (!g_sections) return;
+		timespec t1;
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		g_sec_ns[id] += (int64_t)(t1.tv_sec - t0.tv_sec) * 1000000000 + (t1.tv_nsec - t0.tv_nsec);
+	}
+};
+
 // stage A: chaining, pairing, rescue, filters, report pass 1 (collects the chunk's NW jobs)
 void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<int64_t> &seed_off, const std::vector<int32_t> &n_cands,
                    const std::vector<kg_candidate> &dev_cands, const std::vector<kg_seed> &cand_seeds, ChunkState &ck, int est)
@@ -1655,6 +1672,7 @@ void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<in
 	ck.cands.assign((size_t)ck.count, std::vector<Candidate>());
 	ck.work.assign((size_t)ck.count, std::vector<CandWork>());
 	ck.jobs.clear();
+	{ Section sec(0);
 	for (int q = 0; q < ck.count; ++q) {
 		size_t ri = (size_t)(ck.begin + q);
 		// the candidates were chained on the device (kg_candidates_batch); unpack them into the per-read vectors
@@ -1669,6 +1687,8 @@ void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<in
 			for (int k = 0; k < d.count; ++k) o.pairs[(size_t)k] = from_seed(cand_seeds[(size_t)d.first + (size_t)k]);
 		}
 	}
+	}
+	{ Section sec(1);
 	if (ck.paired) {
 		for (int q = 0; q < ck.count; q += 2) {
 			std::vector<Candidate> &v1 = ck.cands[(size_t)q], &v2 = ck.cands[(size_t)q + 1];
@@ -1685,19 +1705,24 @@ void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<in
 	} else {
 		for (int q = 0; q < ck.count; ++q) remove_redundant(cx, ck.cands[(size_t)q]);
 	}
+	}
+	Section sec(2);
 	for (int q = 0; q < ck.count; ++q) report_plan(cx, reads[(size_t)(ck.begin + q)], ck.cands[(size_t)q], ck.work[(size_t)q], ck.jobs);
 }
 
 // stage C: report pass 2, final pair check, flags, MAPQ, SAM text
 void chunk_stage_c(const Ctx &cx, std::vector<Read> &reads, ChunkState &ck)
 {
+	{ Section sec(3);
 	for (int q = 0; q < ck.count; ++q) {
 		bool first = ck.paired ? (q % 2 == 0) : true;
 		report_finish(cx, first, reads[(size_t)(ck.begin + q)], ck.cands[(size_t)q], ck.work[(size_t)q], ck.jobs);
 	}
+	}
 	ck.text.clear();
 	ck.text.reserve((size_t)ck.count * 400);
 	if (ck.paired) {
+		{ Section sec(4);
 		for (int q = 0; q < ck.count; q += 2) {
 			Read &r1 = reads[(size_t)(ck.begin + q)], &r2 = reads[(size_t)(ck.begin + q + 1)];
 			check_final_pair(cx, r1, r2);
@@ -1705,6 +1730,8 @@ void chunk_stage_c(const Ctx &cx, std::vector<Read> &reads, ChunkState &ck)
 			evaluate_mapq(cx, r1);
 			evaluate_mapq(cx, r2);
 		}
+		}
+		Section sec(5);
 		for (int q = 0; q < ck.count; q += 2)
 			output_pair(cx, reads[(size_t)(ck.begin + q)], reads[(size_t)(ck.begin + q + 1)], ck.st, ck.ps, ck.text);
 	} else {
@@ -2021,6 +2048,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	mallopt(M_TRIM_THRESHOLD, -1);
 	mallopt(M_TOP_PAD, 64 << 20);
 	double t_begin = now_s();
+	g_sections = getenv("KART_AMD_VERBOSE") != nullptr;
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	Options &o = const_cast<Options &>(opt);
 	RunTotals tot;
@@ -2058,6 +2086,10 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	if (getenv("KART_AMD_VERBOSE"))
 		fprintf(stdout, "stage seconds: unhidden read+encode+seed %.2f (seed calls %.2f) | finish+format(k-1) with chain+pair+plan(k) %.2f | nw %.2f | commit %.2f\n",
 		        tot.t_read, tot.t_seed, tot.t_a, tot.t_nw, tot.t_commit);
+	if (g_sections) {
+		fprintf(stdout, "worker thread-seconds:");
+		for (int i = 0; i < 6; ++i) fprintf(stdout, " %s %.2f%s", g_sec_name[i], 1e-9 * (double)g_sec_ns[i].load(), i < 5 ? " |" : "\n");
+	}
 	return 0;
 }
 
