@@ -336,7 +336,7 @@ def run(args, fallback_note):
         "work_per_read": {k2: v / n_reads for k2, v in c.items()},
     }
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(orc, batches[0][0], READ_LEN)
+        line["cpu_baseline"] = cpu_baseline(orc, batches[0][0], READ_LEN, prefix, workdir)
     if world == 1 and not args.no_e2e:
         del d_seeds, d_seed_off, batches
         if orc is not None:
@@ -442,9 +442,52 @@ def end_to_end(prefix, genome, workdir, n_pairs=500_000, codes=None):
     return out
 
 
-def cpu_baseline(orc, enc_dev, read_len):
-    """The CPU oracle port of the same step (seeding incl. SA locate and sort) on all host cores, on a
-    bounded sample of the same reads (sized for roughly 10-20 s of CPU work)."""
+_REF_CHILD = r"""
+import json, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle as O
+prefix, npy, threads = sys.argv[2], sys.argv[3], int(sys.argv[4])
+enc = np.load(npy)
+n = len(enc) // 150
+off = np.arange(n + 1, dtype=np.int64) * 150
+sh = O.RefShim(prefix, threads=threads)
+k = min(n, 20000)
+t = time.perf_counter(); sh.seed_batch_count(enc[: k * 150], off[: k + 1], 0, threads); rate = k / (time.perf_counter() - t)
+m = int(min(n, max(k, rate * 12)))
+t = time.perf_counter(); seeds = sh.seed_batch_count(enc[: m * 150], off[: m + 1], 0, threads); dt = time.perf_counter() - t
+print("REFJSON " + json.dumps({"reads": m, "seconds": dt, "seeds": seeds}))
+"""
+
+
+def reference_baseline(prefix, enc_host, cores, workdir):
+    """The reference's own object code (oracle/_ref/libkartref_shim.so: IdentifySeedPairs_FastMode -> BWT_Search -> bwt_sa, built
+    from the sources where they lie) on the same reads, `cores` threads, in a child process (it keeps its index in
+    process globals and exits on errors).  None when oracle/_ref did not travel."""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libkartref_shim.so")):
+        return None
+    npy = os.path.join(workdir, "cpu_baseline_sample.npy")
+    np.save(npy, enc_host)
+    try:
+        r = subprocess.run([sys.executable, "-c", _REF_CHILD, ROOT, prefix, npy, str(cores)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+        for line in r.stdout.decode().splitlines():
+            if line.startswith("REFJSON "):
+                return json.loads(line[8:])
+    except Exception:
+        pass
+    finally:
+        try:
+            os.remove(npy)
+        except OSError:
+            pass
+    return None
+
+
+def cpu_baseline(orc, enc_dev, read_len, prefix=None, workdir=None):
+    """The same step (seeding incl. SA locate and sort) on the host cores, on a bounded sample of the same reads (sized
+    for roughly 10-20 s of CPU work): the reference's own object code when oracle/_ref travelled with the repository
+    ("reference"), and this repository's CPU restatement of it ("port")."""
     cores = effective_cores()
     k = 20000
     enc = enc_dev[: k * read_len].cpu().numpy()
@@ -458,9 +501,16 @@ def cpu_baseline(orc, enc_dev, read_len):
     t = time.perf_counter()
     orc.seed_batch(enc, off, 0, threads=cores)
     dt = time.perf_counter() - t
-    return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+    port = {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
             "sample": "%d reads of the same batch, oracle/liboracle.so seed_batch (FM search + SA locate + sort), %d threads = the cgroup CPU quota "
                       "(%d logical CPUs visible), %.1f s" % (n, cores, os.cpu_count() or 1, dt)}
+    ref = reference_baseline(prefix, enc, cores, workdir) if prefix and workdir else None
+    if not ref:
+        return port
+    return {"value": ref["reads"] / ref["seconds"], "unit": "reads/s", "cores": cores, "kind": "reference",
+            "sample": "%d reads of the same batch through the reference's own IdentifySeedPairs_FastMode (oracle/_ref/libkartref_shim.so, compiled from "
+                      "the reference sources), %d threads = the cgroup CPU quota (%d logical CPUs visible), %.1f s" % (ref["reads"], cores, os.cpu_count() or 1, ref["seconds"]),
+            "port": port}
 
 
 if __name__ == "__main__":

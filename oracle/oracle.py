@@ -197,6 +197,9 @@ class RefShim:
         L.shim_bwt_search.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.shim_seed_read.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.shim_nw.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p]
+        if hasattr(L, "shim_seed_batch"):
+            L.shim_seed_batch.restype = C.c_int64
+            L.shim_seed_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.shim_candidates.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int]
         L.shim_identify_normal_pairs.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         self.min_seed_len = L.shim_init(prefix.encode(), threads, int(pacbio), max_gaps)
@@ -208,6 +211,12 @@ class RefShim:
 
     def set_mode(self, pacbio: bool, max_gaps: int = 5):
         self.lib.shim_set_mode(int(pacbio), max_gaps)
+
+    def seed_batch_count(self, enc: np.ndarray, offsets: np.ndarray, mode: int = 0, threads: int = 1) -> int:
+        """IdentifySeedPairs_* of the reference over a batch on `threads` threads; returns the number of seeds (timing aid)."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        return int(self.lib.shim_seed_batch(mode, _ptr(enc), _ptr(offsets), len(offsets) - 1, threads))
 
     def ref_sequence(self) -> np.ndarray:
         p = self.lib.shim_ref_sequence()

@@ -9,6 +9,8 @@
 #include "structure.h"  // reference src/structure.h (included in place, not copied)
 
 #include <cstring>
+#include <thread>
+#include <vector>
 
 // exported (non-static) functions of src/bwt_search.cpp:44,68,128 that structure.h does not declare
 extern bwtint_t bwt_occ(const bwt_t *bwt, bwtint_t k, ubyte_t c);
@@ -60,6 +62,28 @@ int shim_seed_read(int mode, uint8_t *enc, int rlen, shim_seed *out, int cap)
 	if ((int)v.size() > cap) return -(int)v.size();
 	for (size_t i = 0; i < v.size(); i++) { out[i].gPos = v[i].gPos; out[i].rPos = v[i].rPos; out[i].len = v[i].rLen; }
 	return (int)v.size();
+}
+
+// IdentifySeedPairs_* (the reference's own object code) over a batch of reads on `threads` threads, the way its workers call
+// it (src/Mapping.cpp:546-551): the CPU baseline of bench.py.  Returns the number of seeds found.
+int64_t shim_seed_batch(int mode, uint8_t *enc, const int64_t *off, int64_t n, int threads)
+{
+	std::vector<std::thread> pool;
+	std::vector<int64_t> found((size_t)threads, 0);
+	for (int t = 0; t < threads; ++t)
+		pool.emplace_back([&, t]() {
+			int64_t cnt = 0;
+			for (int64_t i = n * t / threads, e = n * (t + 1) / threads; i < e; ++i) {
+				int rlen = (int)(off[i + 1] - off[i]);
+				vector<SeedPair_t> v = mode == 0 ? IdentifySeedPairs_FastMode(rlen, enc + off[i]) : IdentifySeedPairs_SensitiveMode(rlen, enc + off[i]);
+				cnt += (int64_t)v.size();
+			}
+			found[(size_t)t] = cnt;
+		});
+	for (std::thread &th : pool) th.join();
+	int64_t total = 0;
+	for (int64_t c : found) total += c;
+	return total;
 }
 
 int shim_nw(const char *s1, int m, const char *s2, int n, char *out1, char *out2)
