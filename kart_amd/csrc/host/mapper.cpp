@@ -384,6 +384,73 @@ void common_kmers(int max_shift, const std::vector<Kmer> &v1, const std::vector<
 	});
 }
 
+// Mate rescue joins the 8-mers of one read with those of many reference windows (src/AlignmentRescue.cpp:108-111,
+// 142-145 -> CreateKmerVecFromReadSeq + IdentifyCommonKmers).  The reference sorts every window's k-mers to
+// binary-search them; the join itself is just "all (rPos, gPos) with equal k-mers", and the hit list is sorted by a
+// total order afterwards, so here the READ's k-mers go into a direct-address table once and each window is streamed
+// past it: same hits, no per-window sort.
+struct KmerTable {
+	std::vector<uint16_t> first;     // k-mer id -> 1 + index of its first entry in the read's (id-sorted) k-mer vector
+	KmerTable() : first((size_t)1 << 16, 0) {}
+	void set(const std::vector<Kmer> &kr)
+	{
+		if (kr.size() >= 65535) return;
+		for (size_t i = kr.size(); i-- > 0;) first[kr[i].wid] = (uint16_t)(i + 1);
+	}
+	void clear(const std::vector<Kmer> &kr)
+	{
+		if (kr.size() >= 65535) return;
+		for (size_t i = 0; i < kr.size(); ++i) first[kr[i].wid] = 0;
+	}
+};
+
+void window_hits(int max_shift, const std::vector<Kmer> &kr, const KmerTable &tab, int len, const char *seq, std::vector<KmerHit> &out)
+{
+	out.clear();
+	auto probe = [&](uint32_t wid, uint32_t gpos) {
+		for (size_t i = tab.first[wid]; i != 0 && i <= kr.size() && kr[i - 1].wid == wid; ++i) {
+			uint32_t rpos = kr[i - 1].pos;
+			if ((gpos >= rpos && gpos - rpos < (uint32_t)max_shift) || (gpos < rpos && rpos - gpos < (uint32_t)max_shift)) {
+				KmerHit h;
+				h.rPos = rpos;
+				h.gPos = gpos;
+				h.posDiff = (int)(gpos - rpos);
+				out.push_back(h);
+			}
+		}
+	};
+	// the window's k-mers in position order, with CreateKmerVecFromReadSeq's treatment of 'N' (see kmers_of)
+	uint32_t count = 0, head, tail = 0, ulen = (uint32_t)(len < 0 ? 0 : len);
+	while (count < 8 && tail < ulen) {
+		if (seq[tail++] != 'N') count++;
+		else count = 0;
+	}
+	if (count == 8) {
+		uint32_t wid = kmer_id(seq, head = tail - 8);
+		probe(wid, head);
+		for (head += 1; tail < ulen; head++, tail++) {
+			if (seq[tail] != 'N') {
+				wid = ((wid & 0x3FFF) << 2) + (uint32_t)nt4((unsigned char)seq[tail]);
+				probe(wid, head);
+			} else {
+				count = 0;
+				tail++;
+				while (count < 8 && tail < ulen) {
+					if (seq[tail++] != 'N') count++;
+					else count = 0;
+				}
+				if (count != 8) break;
+				wid = kmer_id(seq, head = tail - 8);
+				probe(wid, head);
+			}
+		}
+	}
+	std::sort(out.begin(), out.end(), [](const KmerHit &a, const KmerHit &b) {
+		if (a.posDiff == b.posDiff) return a.rPos < b.rPos;
+		return a.posDiff < b.posDiff;
+	});
+}
+
 void simple_pairs_from_kmers(int min_len, const std::vector<KmerHit> &hits, std::vector<Pair> &out)  // :132-162
 {
 	out.clear();
@@ -900,6 +967,18 @@ int max_score(const std::vector<Candidate> &v)
 	return s;
 }
 
+// the k-mer hits between a read (k-mers `kr`, registered in `tab`) and a reference window
+void rescue_hits(int slen, const std::vector<Kmer> &kr, const KmerTable &tab, const char *window, std::vector<KmerHit> &hits)
+{
+	if (kr.size() < 65535) {
+		window_hits(slen, kr, tab, slen, window, hits);
+	} else {            // more k-mers than the table's 16-bit links address: the reference's sort-and-search join
+		std::vector<Kmer> kg;
+		kmers_of(slen, window, kg);
+		common_kmers(slen, kr, kg, hits);
+	}
+}
+
 // IdnetifyRescueCandidate, src/AlignmentRescue.cpp:24-69
 Candidate rescue_candidate(const Ctx &cx, int64_t gPos, std::vector<Pair> &vec)
 {
@@ -947,13 +1026,15 @@ bool rescue_unpaired(const Ctx &cx, int est, const Read &r1, const Read &r2, std
 	if (est > cx.opt.max_insert) est = cx.opt.max_insert;
 	bool mated = false;
 	int num1 = (int)v1.size(), num2 = (int)v2.size();
-	std::vector<Kmer> kr, kg;
+	std::vector<Kmer> kr;
 	std::vector<KmerHit> hits;
 	std::vector<Pair> sp;
+	static thread_local KmerTable tab;
 	if (strategy == 1 || strategy == 3) {
 		int thr = max_score(v1) - 30;
 		if (thr < 50) thr = 50;
 		kmers_of(r2.rlen, r2.seq.data(), kr);
+		tab.set(kr);
 		for (int j = num2, i = 0; i < num1; ++i) {
 			if (v1[i].score < thr) continue;
 			int64_t left = v1[i].posDiff, right = v1[i].posDiff + est + r2.rlen;
@@ -965,8 +1046,7 @@ bool rescue_unpaired(const Ctx &cx, int est, const Read &r1, const Read &r2, std
 			int slen = (int)(right - left);
 			if (slen < r2.rlen) continue;
 			if (left < 0 || right > ref.two_genome_size) continue;
-			kmers_of(slen, cx.refseq() + left, kg);
-			common_kmers(slen, kr, kg, hits);
+			rescue_hits(slen, kr, tab, cx.refseq() + left, hits);
 			simple_pairs_from_kmers(10, hits, sp);
 			Candidate c = rescue_candidate(cx, left, sp);
 			if (c.score > score2) {
@@ -976,11 +1056,13 @@ bool rescue_unpaired(const Ctx &cx, int est, const Read &r1, const Read &r2, std
 				v2.push_back(c);
 			}
 		}
+		tab.clear(kr);
 	}
 	if (strategy == 2 || strategy == 3) {
 		int thr = max_score(v2) - 30;   // the rescued entries appended above are included, as in the reference
 		if (thr < 50) thr = 50;
 		kmers_of(r1.rlen, r1.seq.data(), kr);
+		tab.set(kr);
 		for (int i = num1, j = 0; j < num2; ++j) {
 			if (v2[j].score < thr) continue;
 			int64_t left = v2[j].posDiff - est, right = v2[j].posDiff + r2.rlen;
@@ -994,8 +1076,7 @@ bool rescue_unpaired(const Ctx &cx, int est, const Read &r1, const Read &r2, std
 			if (slen < r1.rlen) continue;
 			if (left < 0) { left = 0; slen = (int)(right - left); if (slen < r1.rlen) continue; }
 			if (right > ref.two_genome_size) continue;
-			kmers_of(slen, cx.refseq() + left, kg);
-			common_kmers(slen, kr, kg, hits);
+			rescue_hits(slen, kr, tab, cx.refseq() + left, hits);
 			simple_pairs_from_kmers(10, hits, sp);
 			Candidate c = rescue_candidate(cx, left, sp);
 			if (c.score > score1) {
@@ -1005,6 +1086,7 @@ bool rescue_unpaired(const Ctx &cx, int est, const Read &r1, const Read &r2, std
 				v1.push_back(c);
 			}
 		}
+		tab.clear(kr);
 	}
 	return mated;
 }

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""End-to-end (FASTQ -> SAM) on the hg38-sized synthetic genome of bench.py: kart-amd vs the unmodified reference binary at
+-t <threads>, same files.  MEASUREMENT TOOL (GPU box).  usage: python tools/e2e_large.py [genome_len] [pairs] [check_t1_pairs]"""
+import json, os, subprocess, sys, time
+import torch
+sys.path.insert(0, ".")
+import bench
+dev = torch.device("cuda", 0)
+L = int(sys.argv[1]) if len(sys.argv) > 1 else bench.HG38_LEN
+pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
+wd = "/tmp/kart_bench_%d" % os.getuid()
+prefix = os.path.join(wd, "synth_v2_%d" % L)
+subprocess.run([sys.executable, "bench.py", "--genome-len", str(L), "--pairs", "1000000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e"], stdout=subprocess.DEVNULL)
+codes = bench.make_large_codes(L, 3, dev)
+f1, f2 = os.path.join(wd, "l1.fq"), os.path.join(wd, "l2.fq")
+bench.write_fastq_from_codes(codes, pairs, 5, f1, f2, dev)
+del codes; torch.cuda.empty_cache()
+threads = min(32, 2 * bench.effective_cores())
+res = {"genome_len": L, "reads": 2 * pairs, "threads": threads}
+def run(tag, exe, t):
+    t0 = time.time()
+    r = subprocess.run([exe, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-o", os.path.join(wd, tag + ".sam"), "-t", str(t)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, KART_AMD_VERBOSE="1"))
+    dt = time.time() - t0
+    res[tag] = {"rc": r.returncode, "process_seconds": round(dt, 2), "reads_per_s_process": round(2 * pairs / dt)}
+    for line in r.stdout.decode().splitlines():
+        if line.startswith("mapping seconds"):
+            ms = float(line.split(":")[1]); res[tag]["mapping_seconds"] = ms; res[tag]["reads_per_s_mapping_phase"] = round(2 * pairs / ms)
+        if line.startswith("stage seconds") or line.startswith("worker thread-seconds") or line.startswith("All the"):
+            res[tag].setdefault("log", []).append(line.strip())
+run("kart_amd", "kart_amd/bin/kart-amd", threads)
+if os.path.exists("oracle/_ref/kart"):
+    run("reference_kart", "oracle/_ref/kart", threads)
+    # the reference prints its own mapping time ("... processed in N seconds"), which excludes its index load
+print(json.dumps(res))
