@@ -646,9 +646,8 @@ void plan_pair(const Ctx &cx, const Read &rd, const Pair &sp, int role, PairWork
 		else if (sp.gLen > 0) w.ops.push_back(std::make_pair(sp.gLen, 'D'));
 		return;
 	}
-	std::string f1(rd.seq.data() + sp.rPos, (size_t)sp.rLen), f2(cx.refseq() + sp.gPos, (size_t)sp.gLen);
 	int n = 0;
-	bool shortcut = (role == 1 || !cx.opt.pacbio) && quick_match(sp, f1.c_str(), f2.c_str(), n);
+	bool shortcut = (role == 1 || !cx.opt.pacbio) && quick_match(sp, rd.seq.data() + sp.rPos, cx.refseq() + sp.gPos, n);
 	if (shortcut) {
 		w.kind = PairWork::IMMEDIATE;
 		w.score = sp.rLen - n;
@@ -662,6 +661,7 @@ void plan_pair(const Ctx &cx, const Read &rd, const Pair &sp, int role, PairWork
 		return;
 	}
 	w.kind = PairWork::PLANNED;
+	std::string f1(rd.seq.data() + sp.rPos, (size_t)sp.rLen), f2(cx.refseq() + sp.gPos, (size_t)sp.gLen);
 	plan_alignment(cx, sp.rLen, f1, sp.gLen, f2, w.plan, jobs);
 }
 
