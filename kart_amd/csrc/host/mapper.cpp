@@ -478,11 +478,19 @@ void simple_pairs_from_kmers(int min_len, const std::vector<KmerHit> &hits, std:
 
 void simple_pairs_from_fragments(int max_dist, int len1, const char *f1, int len2, const char *f2, std::vector<Pair> &out)  // :164-179
 {
-	std::vector<Kmer> k1, k2;
-	std::vector<KmerHit> hits;
+	static thread_local std::vector<Kmer> k1;
+	static thread_local std::vector<KmerHit> hits;
+	static thread_local KmerTable tab;
 	kmers_of(len1, f1, k1);
-	kmers_of(len2, f2, k2);
-	common_kmers(max_dist, k1, k2, hits);
+	if (k1.size() < 65535) {         // same hits as the reference's two sorted vectors + binary search (see window_hits)
+		tab.set(k1);
+		window_hits(max_dist, k1, tab, len2, f2, hits);
+		tab.clear(k1);
+	} else {
+		std::vector<Kmer> k2;
+		kmers_of(len2, f2, k2);
+		common_kmers(max_dist, k1, k2, hits);
+	}
 	simple_pairs_from_kmers(8, hits, out);
 	std::sort(out.begin(), out.end(), pair_by_gpos);
 }

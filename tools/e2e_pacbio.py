@@ -17,7 +17,7 @@ def run(tag, cmd):
     res[tag] = {"rc": r.returncode, "seconds": round(dt, 2), "reads_per_s": round(n / dt, 1)}
     for line in r.stdout.decode().splitlines():
         if line.startswith("mapping seconds"): res[tag]["mapping_seconds"] = float(line.split(":")[1])
-        if line.startswith("stage seconds"): res[tag]["stages"] = line
+        if line.startswith("stage seconds") or line.startswith("worker thread-seconds"): res[tag].setdefault("stages", []).append(line)
 common = ["-silent", "-i", os.path.join(d, "idx"), "-f", fq, "-pacbio"]
 for t_ in (8, 32):
     run("kart_amd_t%d" % t_, ["kart_amd/bin/kart-amd"] + common + ["-t", str(t_), "-o", os.path.join(d, "amd.sam")])
