@@ -326,7 +326,7 @@ uint32_t kmer_id(const char *seq, uint32_t pos)  // CreateKmerID, :25-32
 	return id;
 }
 
-void kmers_of(int len, const char *seq, std::vector<Kmer> &vec)  // CreateKmerVecFromReadSeq, :56-102
+void kmers_of(int len, const char *seq, std::vector<Kmer> &vec, bool sorted = true)  // CreateKmerVecFromReadSeq, :56-102
 {
 	vec.clear();
 	uint32_t count = 0, head, tail = 0, ulen = (uint32_t)(len < 0 ? 0 : len);
@@ -357,7 +357,7 @@ void kmers_of(int len, const char *seq, std::vector<Kmer> &vec)  // CreateKmerVe
 			vec.push_back(km);
 		}
 	}
-	std::sort(vec.begin(), vec.end(), [](const Kmer &a, const Kmer &b) { return a.wid < b.wid; });
+	if (sorted) std::sort(vec.begin(), vec.end(), [](const Kmer &a, const Kmer &b) { return a.wid < b.wid; });
 }
 
 void common_kmers(int max_shift, const std::vector<Kmer> &v1, const std::vector<Kmer> &v2, std::vector<KmerHit> &out)  // :104-130
@@ -390,12 +390,17 @@ void common_kmers(int max_shift, const std::vector<Kmer> &v1, const std::vector<
 // total order afterwards, so here the READ's k-mers go into a direct-address table once and each window is streamed
 // past it: same hits, no per-window sort.
 struct KmerTable {
-	std::vector<uint16_t> first;     // k-mer id -> 1 + index of its first entry in the read's (id-sorted) k-mer vector
+	std::vector<uint16_t> first;     // k-mer id -> 1 + index of the last read k-mer with that id (0 = none)
+	std::vector<uint16_t> next;      // read k-mer -> 1 + index of the previous one with the same id
 	KmerTable() : first((size_t)1 << 16, 0) {}
-	void set(const std::vector<Kmer> &kr)
+	void set(const std::vector<Kmer> &kr)      // kr in any order
 	{
 		if (kr.size() >= 65535) return;
-		for (size_t i = kr.size(); i-- > 0;) first[kr[i].wid] = (uint16_t)(i + 1);
+		next.resize(kr.size());
+		for (size_t i = 0; i < kr.size(); ++i) {
+			next[i] = first[kr[i].wid];
+			first[kr[i].wid] = (uint16_t)(i + 1);
+		}
 	}
 	void clear(const std::vector<Kmer> &kr)
 	{
@@ -408,7 +413,7 @@ void window_hits(int max_shift, const std::vector<Kmer> &kr, const KmerTable &ta
 {
 	out.clear();
 	auto probe = [&](uint32_t wid, uint32_t gpos) {
-		for (size_t i = tab.first[wid]; i != 0 && i <= kr.size() && kr[i - 1].wid == wid; ++i) {
+		for (size_t i = tab.first[wid]; i != 0; i = tab.next[i - 1]) {
 			uint32_t rpos = kr[i - 1].pos;
 			if ((gpos >= rpos && gpos - rpos < (uint32_t)max_shift) || (gpos < rpos && rpos - gpos < (uint32_t)max_shift)) {
 				KmerHit h;
@@ -481,13 +486,14 @@ void simple_pairs_from_fragments(int max_dist, int len1, const char *f1, int len
 	static thread_local std::vector<Kmer> k1;
 	static thread_local std::vector<KmerHit> hits;
 	static thread_local KmerTable tab;
-	kmers_of(len1, f1, k1);
+	kmers_of(len1, f1, k1, false);
 	if (k1.size() < 65535) {         // same hits as the reference's two sorted vectors + binary search (see window_hits)
 		tab.set(k1);
 		window_hits(max_dist, k1, tab, len2, f2, hits);
 		tab.clear(k1);
 	} else {
 		std::vector<Kmer> k2;
+		std::sort(k1.begin(), k1.end(), [](const Kmer &a, const Kmer &b) { return a.wid < b.wid; });
 		kmers_of(len2, f2, k2);
 		common_kmers(max_dist, k1, k2, hits);
 	}
