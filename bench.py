@@ -422,7 +422,7 @@ def end_to_end(prefix, genome, workdir, n_pairs=500_000, codes=None):
         ms = [float(l.split(":")[1]) for l in r.stdout.decode().splitlines() if l.startswith("mapping seconds")]
         return r.returncode, dt, (ms[0] if ms else None)
 
-    threads = min(32, 2 * effective_cores())
+    threads = effective_cores()          # more workers than the CPU quota only adds context switches
     rc, dt, ms = run([exe] + common + ["-t", str(threads), "-o", os.path.join(workdir, "e2e_amd.sam")])
     if rc != 0:
         return {"error": "kart-amd failed"}

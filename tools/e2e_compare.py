@@ -24,6 +24,8 @@ def run(tag, cmd):
             ms = float(line.split(":")[1])
             res[tag]["mapping_seconds"] = ms
             res[tag]["mapping_reads_per_s"] = round(2 * n_pairs / ms)
+        if line.startswith("stage seconds") or line.startswith("worker thread-seconds"):
+            res[tag].setdefault("log", []).append(line.strip())
 common = ["-silent", "-i", os.path.join(d, "idx"), "-f", f1, "-f2", f2]
 for t_ in ((32, 64) if skip_t1 else (8, 32, 64, 128)):
     run("kart_amd_t%d" % t_, ["kart_amd/bin/kart-amd"] + common + ["-t", str(t_), "-o", os.path.join(d, "amd.sam")])
