@@ -186,3 +186,35 @@ def test_candidates_need_the_seeded_batch(golden, gpu_index):
         ws.candidates_batch(so[:5])          # not the batch that was seeded
     assert len(ws.candidates_batch(so)) == 10
     ws.close()
+
+
+def test_long_reads_cover_every_sort_class(gpu_index_full, gpu_index, oracle_small, request):
+    """reads of 200 bp .. 60 kb in SensitiveMode give seed lists of a handful up to several thousand per read: the register
+    network, the wave bitonic, both LDS classes and the in-place Shell pass of the sort, and multi-round expansion in locate"""
+    g = {}
+    cur = None
+    for line in open(request.config.rootpath / "tests" / "golden" / "small.fa", "rb"):
+        if line.startswith(b">"):
+            cur = line[1:].strip().decode(); g[cur] = []
+        else:
+            g[cur].append(line.strip())
+    g = {k: np.frombuffer(b"".join(v), dtype=np.uint8) for k, v in g.items()}
+    big = max(g.values(), key=len)
+    rng = np.random.default_rng(31)
+    reads = []
+    for ln in (200, 900, 2500, 7000, 20000, min(60000, len(big) - 10)):
+        for rep in range(3):
+            p = int(rng.integers(0, len(big) - ln))
+            r = big[p:p + ln].copy()
+            e = rng.random(ln) < 0.04
+            r[e] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(e.sum()))]
+            reads.append(synth.encode(r if rep != 1 else synth.revcomp(r)))
+    enc, off = api.concat_reads(reads)
+    so_o, s_o = oracle_small.seed_batch(enc, off, 1, threads=4)
+    sizes = np.diff(so_o)
+    assert sizes.max() > 2048 and ((sizes > 256) & (sizes <= 2048)).any() and ((sizes > 64) & (sizes <= 256)).any() and (sizes <= 64).any()
+    for ix in (gpu_index_full, gpu_index):
+        ws = ix.workspace(len(reads), len(enc))
+        so_g, s_g = ws.seed_batch(enc, off, 1)
+        assert (so_g == so_o).all()
+        assert (s_g == s_o.astype(api.SEED_DT)).all()
