@@ -170,11 +170,21 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
 	FmView &v = ix->view;
+	if (bwt.size() < 40) return fail(KG_ERR_IO, "%s.bwt is truncated", prefix);
+	if (sa.size() < 56) return fail(KG_ERR_IO, "%s.sa is truncated", prefix);
 	memcpy(&v.primary, bwt.data(), 8);
 	v.L2[0] = 0;
 	memcpy(&v.L2[1], bwt.data() + 8, 32);
 	v.seq_len = v.L2[4];
 	size_t n_words = (bwt.size() - 40) / 4;
+	{
+		// 16 symbols per word, 8 count words in front of every 128-symbol block, one trailing count record
+		// (reference src/BWT_Index/bwtindex.c:51-75)
+		uint64_t need = (v.seq_len + 15) / 16 + 8 * ((v.seq_len + 127) / 128) + 8;
+		if (v.seq_len == 0 || v.primary > v.seq_len || (uint64_t)n_words < need)
+			return fail(KG_ERR_IO, "%s.bwt is truncated or malformed (%llu words for %llu symbols, need %llu)", prefix, (unsigned long long)n_words,
+			            (unsigned long long)v.seq_len, (unsigned long long)need);
+	}
 	uint64_t sa_intv = 0, sa_len = 0;
 	memcpy(&sa_intv, sa.data() + 40, 8);
 	memcpy(&sa_len, sa.data() + 48, 8);
