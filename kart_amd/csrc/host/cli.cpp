@@ -72,7 +72,11 @@ int parse_cli(int argc, char **argv, Options &opt)
 		return -2;
 	}
 	if (!opt.files2.empty() && opt.files1.size() != opt.files2.size()) {
-		fprintf(stdout, "Error! Paired-end reads input numbers do not match!\n");
+		fprintf(stdout, "Error! Paired-end reads input numbers do not match!\n");   // reference src/main.cpp:184-190: lists both sets
+		fprintf(stdout, "Read1:\n");
+		for (const std::string &f : opt.files1) fprintf(stdout, "\t%s\n", f.c_str());
+		fprintf(stdout, "Read2:\n");
+		for (const std::string &f : opt.files2) fprintf(stdout, "\t%s\n", f.c_str());
 		return -2;
 	}
 	struct stat s;

@@ -94,3 +94,28 @@ def test_speculative_chunks_match_live_reference(ins_mean, threads, host_oracle_
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1]
+
+
+def test_cli_error_behaviour(host_oracle_binary, tmp_path):
+    """exit codes and messages of the command line for bad invocations -- the values below are what the unmodified
+    reference binary prints/returns for the same arguments (src/main.cpp:106-207); only the banner line differs"""
+    fq = materialise(str(tmp_path), "pe_1.fq")
+
+    def run(*args):
+        r = subprocess.run([host_oracle_binary] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=str(tmp_path))
+        return r.returncode, r.stdout.decode(), r.stderr.decode()
+
+    rc, out, _ = run()
+    assert rc == 0 and "Usage:" in out and "-i Index_Prefix" in out
+    rc, out, _ = run("-v")
+    assert rc == 0 and out == "kart v2.5.6\n\n"
+    rc, out, _ = run("-i", "/nonexistent/idx", "-f", fq)
+    assert rc == 1 and out.startswith("Error! Please specify a valid reference index!\n") and "Usage:" in out
+    rc, out, _ = run("-i", SMALL_PREFIX)
+    assert rc == 1 and "Usage:" in out
+    rc, out, _ = run("-i", SMALL_PREFIX, "-f", "/nonexistent.fq", "-o", str(tmp_path / "x.sam"))
+    assert rc == 0 and out == "Cannot access file:[/nonexistent.fq]\n"
+    rc, out, _ = run("-i", SMALL_PREFIX, "-f", fq, "-f2", fq, "-f2", fq, "-o", str(tmp_path / "x.sam"))
+    assert rc == 1 and out == "Error! Paired-end reads input numbers do not match!\nRead1:\n\t%s\nRead2:\n\t%s\n\t%s\n" % (fq, fq, fq)
+    rc, out, err = run("-i", SMALL_PREFIX, "-f", fq, "-o", "/nonexistent_dir/x.sam")
+    assert "Cannot open file [/nonexistent_dir/x.sam]" in err
