@@ -103,25 +103,40 @@ def test_occ_threshold_and_min_seed_len_parameters(golden, gpu_index, oracle_sma
         assert (so_g == so_o).all() and (s_g == s_o.astype(api.SEED_DT)).all()
 
 
-def test_wide_index_instantiation(golden, built_lib):
-    """search_kernel<uint64_t>, the 16-byte q-mer table and the u64 full SA -- the variants an hg38-sized index
-    (2L > 2^32) selects -- forced onto the small index (KG_FORCE_U64) in a child process; results must not change."""
+def test_wide_index_instantiation(golden, built_lib, gpu_index_full, tmp_path, request):
+    """search_kernel<uint64_t>, the 8-byte q-mer entries and the u64 full SA -- the variants an hg38-sized index
+    (2L > 2^32) selects -- forced onto the small index (KG_FORCE_U64) in a child process; results must not change
+    (golden reads, plus reads at the ends of the text whose expected seeds come from the narrow kernels)."""
     import os, subprocess, sys, textwrap
     from conftest import ROOT
+    chunks = [l.strip() for l in open(request.config.rootpath / "tests" / "golden" / "small.fa", "rb") if not l.startswith(b">")]
+    fwd = np.frombuffer(b"".join(chunks), dtype=np.uint8)
+    raw = [fwd[:150], fwd[-150:], fwd[1:40], fwd[-41:-1], np.concatenate([fwd[-100:], fwd[:50]]), synth.revcomp(fwd[:150]), synth.revcomp(fwd[-150:])]
+    reads = [synth.encode(r) for r in raw]
+    enc, off = api.concat_reads(reads)
+    exp = {}
+    for mode in (0, 1):
+        so, seeds = gpu_index_full.workspace(len(reads), len(enc)).seed_batch(enc, off, mode)
+        exp["so%d" % mode], exp["s%d" % mode] = so, seeds
+    edge = str(tmp_path / "edge.npz")
+    np.savez(edge, enc=enc, off=off, **exp)
     code = textwrap.dedent('''
         import sys, numpy as np
         sys.path.insert(0, %r)
         from kart_amd import api
         g = np.load(%r, allow_pickle=True)
+        e = np.load(%r)
         for sa_mode in (api.KG_SA_SAMPLED, api.KG_SA_FULL):
             ix = api.Index(%r, 0, sa_mode)
             for mode, key in ((0, "fast"), (1, "sens")):
                 ws = ix.workspace(len(g[key + "_off"]) - 1, len(g[key + "_enc"]))
                 so, seeds = ws.seed_batch(g[key + "_enc"], g[key + "_off"], mode)
                 assert (so == g[key + "_seed_off"]).all() and (seeds == g[key + "_seeds"].astype(api.SEED_DT)).all(), (sa_mode, key)
+                so, seeds = ix.workspace(len(e["off"]) - 1, len(e["enc"])).seed_batch(e["enc"], e["off"], mode)
+                assert (so == e["so%%d" %% mode]).all() and (seeds == e["s%%d" %% mode]).all(), ("edge", sa_mode, mode)
             ix.close()
         print("wide ok")
-    ''') % (ROOT, os.path.join(ROOT, "tests", "golden", "hotpath_small.npz"), os.path.join(ROOT, "tests", "golden", "idx", "small"))
+    ''') % (ROOT, os.path.join(ROOT, "tests", "golden", "hotpath_small.npz"), edge, os.path.join(ROOT, "tests", "golden", "idx", "small"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KG_FORCE_U64="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0 and b"wide ok" in r.stdout, r.stdout.decode()[-800:]
 
@@ -218,3 +233,40 @@ def test_long_reads_cover_every_sort_class(gpu_index_full, gpu_index, oracle_sma
         so_g, s_g = ws.seed_batch(enc, off, 1)
         assert (so_g == so_o).all()
         assert (s_g == s_o.astype(api.SEED_DT)).all()
+
+
+def test_reads_at_the_ends_of_the_text(gpu_index_full, gpu_index, oracle_small, request):
+    """matches that run into the first / last base of the forward strand (= the last / first base of the indexed text
+    on the other strand), across contig junctions and across the forward/reverse seam, with and without tails that
+    cannot match: the text-comparison path must stop exactly where the reference's interval empties"""
+    chunks = []
+    for line in open(request.config.rootpath / "tests" / "golden" / "small.fa", "rb"):
+        if not line.startswith(b">"):
+            chunks.append(line.strip())
+    fwd = np.frombuffer(b"".join(chunks), dtype=np.uint8)          # all contigs, as the index concatenates them
+    L = len(fwd)
+    rng = np.random.default_rng(77)
+    rnd = lambda n: np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)]
+    raw = []
+    for ln in (20, 40, 150, 151, 300):
+        for a in (0, 1, 2, 3, 17):
+            raw.append(fwd[a:a + ln])                               # starts at / near the first base
+            raw.append(fwd[L - ln - a:L - a])                       # ends at / near the last base
+            raw.append(np.concatenate([rnd(30), fwd[a:a + ln]]))    # unmatchable head, then the text start
+            raw.append(np.concatenate([fwd[L - ln - a:L - a], rnd(30)]))   # runs off the end of the strand
+            raw.append(np.concatenate([synth.revcomp(fwd[:ln]), fwd[:ln]]))   # the seam: revcomp(end of text) + start
+    for edge in (3000, 63000, 93000):                               # contig junctions of small.fa
+        for ln in (60, 150):
+            raw.append(fwd[edge - ln // 2:edge + ln // 2])
+    reads = []
+    for r in raw:
+        reads.append(synth.encode(r))
+        reads.append(synth.encode(synth.revcomp(r)))
+    enc, off = api.concat_reads(reads)
+    for mode in (0, 1):
+        so_o, s_o = oracle_small.seed_batch(enc, off, mode)
+        assert so_o[-1] > 0
+        for ix in (gpu_index_full, gpu_index):
+            ws = ix.workspace(len(reads), len(enc))
+            so_g, s_g = ws.seed_batch(enc, off, mode)
+            assert (so_g == so_o).all() and (s_g == s_o.astype(api.SEED_DT)).all(), mode
