@@ -517,7 +517,8 @@ __device__ __forceinline__ bool seed_less(const kg_seed &x, const kg_seed &y, in
 //   sort_small_kernel : one read per lane; lists of <= 8 are sorted in registers (19-comparator network,
 //                       no dependent memory traffic); longer lists go to one of two work lists (one
 //                       atomic per wave and list)
-//   sort_wave_kernel  : 9..64 seeds, one read per wave: bitonic network across the lanes (shuffles)
+//   sort_wave_kernel  : 9..64 seeds: bitonic network across 16, 32 or 64 lanes by shuffle, i.e. four, two or one
+//                       list(s) per wave
 //   sort_lds_kernel   : > 64 seeds, one read per wave: bitonic in LDS, in two size classes (<= 256 seeds with a
 //                       4 KB buffer so that many waves fit a CU, <= kSortLds with 32 KB); Shell sort in
 //                       place beyond (rare)
@@ -545,8 +546,9 @@ __device__ __forceinline__ void list_close(int32_t *list, const WavePool &pool)
 	for (unsigned long long x = pool.next + (threadIdx.x & 63); x < pool.end; x += 64) list[x] = -1;
 }
 
-// each work list has room for every read plus one pool chunk per wave of sort_small_kernel's grid
-__device__ __forceinline__ int64_t sort_list_stride(const SeedArgs &a) { return a.max_hits * 2; }
+// each of the five work lists has room for every read plus one 64-ticket pool chunk per wave of sort_small_kernel's
+// grid (max_hits >= max_reads + 8192 per CU; the lists share the 32-byte hit records' memory: 5 x 4 bytes each)
+__device__ __forceinline__ int64_t sort_list_stride(const SeedArgs &a) { return a.max_hits; }
 
 // a seed as the sort sees it: key = PosDiff (FastMode) or gPos (SensitiveMode), then rPos; scalars only, so
 // the networks below stay in registers
@@ -583,11 +585,10 @@ __device__ __forceinline__ kg_seed sort_seed(int64_t key, int32_t rpos, int32_t 
 
 __global__ __launch_bounds__(256) void sort_small_kernel(SeedArgs a)
 {
-	int32_t *list_wave = reinterpret_cast<int32_t *>(a.hits);      // the hit records are dead once located
+	int32_t *lists = reinterpret_cast<int32_t *>(a.hits);          // the hit records are dead once located
 	const int64_t list_stride = sort_list_stride(a);
-	int32_t *list_lds = list_wave + list_stride;
 	unsigned long long *counts = a.read_queue + 12;
-	WavePool pool0, pool1, pool2;
+	WavePool pool0, pool1, pool2, pool3, pool4;
 	const int mode = a.mode;
 	int64_t r0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -602,9 +603,11 @@ __global__ __launch_bounds__(256) void sort_small_kernel(SeedArgs a)
 			if (hi > a.seed_capacity) hi = a.seed_capacity;
 			n = (int)(hi - lo);
 		}
-		list_append(list_wave, pool0, counts + 0, n > 8 && n <= 64, (int32_t)r);
-		list_append(list_lds, pool1, counts + 1, n > 64 && n <= 256, (int32_t)r);
-		list_append(list_lds + list_stride, pool2, counts + 2, n > 256, (int32_t)r);
+		list_append(lists, pool0, counts + 0, n > 8 && n <= 16, (int32_t)r);
+		list_append(lists + list_stride, pool1, counts + 1, n > 16 && n <= 32, (int32_t)r);
+		list_append(lists + 2 * list_stride, pool2, counts + 2, n > 32 && n <= 64, (int32_t)r);
+		list_append(lists + 3 * list_stride, pool3, counts + 3, n > 64 && n <= 256, (int32_t)r);
+		list_append(lists + 4 * list_stride, pool4, counts + 4, n > 256, (int32_t)r);
 		if (n < 2 || n > 8) continue;
 		kg_seed *s = a.seeds + lo;
 		KG_LOAD(0) KG_LOAD(1) KG_LOAD(2) KG_LOAD(3) KG_LOAD(4) KG_LOAD(5) KG_LOAD(6) KG_LOAD(7)
@@ -616,44 +619,55 @@ __global__ __launch_bounds__(256) void sort_small_kernel(SeedArgs a)
 		KG_CE(1, 2); KG_CE(3, 4); KG_CE(5, 6);
 		KG_STORE(0); KG_STORE(1); KG_STORE(2); KG_STORE(3); KG_STORE(4); KG_STORE(5); KG_STORE(6); KG_STORE(7);
 	}
-	list_close(list_wave, pool0);
-	list_close(list_lds, pool1);
-	list_close(list_lds + list_stride, pool2);
+	list_close(lists, pool0);
+	list_close(lists + list_stride, pool1);
+	list_close(lists + 2 * list_stride, pool2);
+	list_close(lists + 3 * list_stride, pool3);
+	list_close(lists + 4 * list_stride, pool4);
 }
 
+// kGroup lanes per list: 64 / kGroup lists are sorted side by side in one wave
+template <int kGroup, int kList>
 __global__ __launch_bounds__(256) void sort_wave_kernel(SeedArgs a)
 {
-	const int32_t *list = reinterpret_cast<const int32_t *>(a.hits);
-	const unsigned long long n_list = a.read_queue[12];
+	const int32_t *list = reinterpret_cast<const int32_t *>(a.hits) + (int64_t)kList * sort_list_stride(a);
+	const unsigned long long n_list = a.read_queue[12 + kList];
 	const int mode = a.mode;
 	const int lane = threadIdx.x & 63;
+	const int sub = lane & (kGroup - 1), grp = lane / kGroup;
+	constexpr int kPer = 64 / kGroup;
 	const unsigned long long wave = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const unsigned long long n_waves = ((unsigned long long)gridDim.x * blockDim.x) >> 6;
 	// 64 list entries per wave at a time (one coalesced load); unused pool tickets are -1
 	for (unsigned long long t0 = wave * 64; t0 < n_list; t0 += n_waves * 64) {
-	int32_t mine = t0 + lane < n_list ? list[t0 + lane] : -1;
-	for (uint64_t todo = __ballot(mine >= 0); todo; todo &= todo - 1) {
-		int64_t r = __shfl(mine, __ffsll((unsigned long long)todo) - 1);
-		int64_t lo = a.seed_off[r], hi = a.seed_off[r + 1];
-		if (hi > a.seed_capacity) hi = a.seed_capacity;
-		int n = (int)(hi - lo);
-		kg_seed *s = a.seeds + lo;
-		int64_t key = INT64_MAX;
-		int32_t rpos = 0, len = 0;
-		if (lane < n) { SortItem t_ = sort_item(s[lane], mode); key = t_.key; rpos = t_.rpos; len = t_.len; }
-#pragma unroll
-		for (int k = 2; k <= 64; k <<= 1)
-#pragma unroll
-			for (int j = k >> 1; j > 0; j >>= 1) {
-				int64_t okey = (int64_t)(((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)key >> 32), j) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)(uint64_t)key, j));
-				int32_t orpos = __shfl_xor(rpos, j), olen = __shfl_xor(len, j);
-				bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-				bool o_less = okey < key || (okey == key && orpos < rpos);
-				bool take = keep_min == o_less;
-				key = take ? okey : key; rpos = take ? orpos : rpos; len = take ? olen : len;
+		int32_t mine = t0 + lane < n_list ? list[t0 + lane] : -1;
+		for (int base = 0; base < 64; base += kPer) {
+			int64_t r = __shfl(mine, base + grp);
+			if (__ballot(r >= 0) == 0) continue;
+			int n = 0;
+			kg_seed *s = a.seeds;
+			if (r >= 0) {
+				int64_t lo = a.seed_off[r], hi = a.seed_off[r + 1];
+				if (hi > a.seed_capacity) hi = a.seed_capacity;
+				n = (int)(hi - lo);
+				s += lo;
 			}
-		if (lane < n) s[lane] = sort_seed(key, rpos, len, mode);
-	}
+			int64_t key = INT64_MAX;
+			int32_t rpos = 0, len = 0;
+			if (sub < n) { SortItem t_ = sort_item(s[sub], mode); key = t_.key; rpos = t_.rpos; len = t_.len; }
+#pragma unroll
+			for (int k = 2; k <= kGroup; k <<= 1)
+#pragma unroll
+				for (int j = k >> 1; j > 0; j >>= 1) {
+					int64_t okey = (int64_t)(((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)key >> 32), j) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)(uint64_t)key, j));
+					int32_t orpos = __shfl_xor(rpos, j), olen = __shfl_xor(len, j);
+					bool keep_min = ((sub & j) == 0) == ((sub & k) == 0);
+					bool o_less = okey < key || (okey == key && orpos < rpos);
+					bool take = keep_min == o_less;
+					key = take ? okey : key; rpos = take ? orpos : rpos; len = take ? olen : len;
+				}
+			if (sub < n) s[sub] = sort_seed(key, rpos, len, mode);
+		}
 	}
 }
 
@@ -1062,9 +1076,11 @@ hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_tem
 		hipLaunchKernelGGL(locate_sampled_kernel, dim3(grid_for(a.max_hits, 256, n_cu * 8)), dim3(256), 0, stream, a);
 	if (ev) (void)hipEventRecord(ev[3], stream);
 	hipLaunchKernelGGL(sort_small_kernel, dim3(grid_for(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
-	hipLaunchKernelGGL(sort_wave_kernel, dim3(n_cu * 8), dim3(256), 0, stream, a);
-	hipLaunchKernelGGL((sort_lds_kernel<256, 1>), dim3(n_cu * 32), dim3(64), 0, stream, a);
-	hipLaunchKernelGGL((sort_lds_kernel<kSortLds, 2>), dim3(n_cu * 5), dim3(64), 0, stream, a);
+	hipLaunchKernelGGL((sort_wave_kernel<16, 0>), dim3(n_cu * 8), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL((sort_wave_kernel<32, 1>), dim3(n_cu * 8), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL((sort_wave_kernel<64, 2>), dim3(n_cu * 8), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL((sort_lds_kernel<256, 3>), dim3(n_cu * 32), dim3(64), 0, stream, a);
+	hipLaunchKernelGGL((sort_lds_kernel<kSortLds, 4>), dim3(n_cu * 5), dim3(64), 0, stream, a);
 	if (ev) (void)hipEventRecord(ev[4], stream);
 	return hipGetLastError();
 }

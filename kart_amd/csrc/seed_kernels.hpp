@@ -20,8 +20,9 @@ struct Hit {
 // device control block: zeroed by one hipMemsetAsync per batch
 //   [0] read queue head  [1] hit count  [2] locate queue head  [3] unused
 //   [4..11] counters: searches, lf1, lf2, inv, sa, seeds, bases, overflow(needed seeds or 0)
-//   [12..14] reads on the sort work lists: 9..64 seeds (wave), 65..256 (small LDS), > 256 (large LDS)
-constexpr int kCtlWords = 15;
+//   [12..16] reads on the sort work lists: 9..16, 17..32, 33..64 seeds (4 / 2 / 1 lists per wave), 65..256 (small LDS),
+//            > 256 (large LDS)
+constexpr int kCtlWords = 17;
 
 struct SeedArgs {
 	FmView ix;
