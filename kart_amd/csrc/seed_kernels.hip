@@ -1040,7 +1040,7 @@ size_t scan_temp_bytes(int64_t max_reads)
 {
 	size_t bytes = 0;
 	WideIter it((const int32_t *)nullptr, WidenOp());
-	hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, (int64_t *)nullptr, (int)max_reads);
+	(void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, (int64_t *)nullptr, (int)max_reads);   // size query only
 	return bytes;
 }
 
