@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 	int r = 0, rlen = 0, pos = 0, stop_pos = 0, end_pos = 0, seed_cnt = 0;
 	int cur = 0, stop = 0, wword = 0;
 	const uint64_t *pw = a.packed;
+	int64_t rbase = 0;                    // raw-code variant (a.packed == nullptr): window words are made on the fly
+	const bool raw = a.packed == nullptr;
+#define KG_WORD(w) (raw ? window_word(a.enc, a.n_bases, rbase, rlen, (w)) : pw[(w)])
 	uint64_t win = 0x4444444444444444ull, wnext = 0x4444444444444444ull;
 	idx_t k = 0, n = 0;
 	// how the lane extends its match: 0 = rank (LF) steps, 1 = interval of one, fetch its suffix, 2 = compare
@@ -213,8 +216,9 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 						int64_t base = a.read_off[t];
 						rlen = (int)(a.read_off[t + 1] - base);
 						pw = a.packed + (base >> 4) + 3 * (int64_t)t;
-						win = pw[0];
-						wnext = pw[1];
+						rbase = base;
+						win = KG_WORD(0);
+						wnext = KG_WORD(1);
 						wword = 0;
 						pos = 0; stop_pos = 30; end_pos = rlen - msl; seed_cnt = 0;
 						have_read = true;
@@ -230,8 +234,8 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 			bool starting = idle && !finished;
 			int w = pos >> 4;
 			if (starting && w != wword) {           // the new start lies outside the window's first word
-				if (w == wword + 1) win = wnext; else win = pw[w];
-				wnext = pw[w + 1];
+				if (w == wword + 1) win = wnext; else win = KG_WORD(w);
+				wnext = KG_WORD(w + 1);
 				wword = w;
 			}
 			int code0 = (int)((win >> ((pos & 15) << 2)) & 15);
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 				if (jump && tsa) { tpos = (idx_t)(ix.seq_len - (uint64_t)tk); mode = 2; }
 				active = true;
 				c_search++;
-				if ((cur >> 4) != wword) { win = wnext; wword++; wnext = pw[wword + 1]; }
+				if ((cur >> 4) != wword) { win = wnext; wword++; wnext = KG_WORD(wword + 1); }
 			}
 			if (__ballot(!done && !active) == 0) break;
 		}
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 					cont = cur < stop;
 				}
 			}
-			if (cont && (cur >> 4) != wword) { win = wnext; wword++; wnext = pw[wword + 1]; }
+			if (cont && (cur >> 4) != wword) { win = wnext; wword++; wnext = KG_WORD(wword + 1); }
 			pending = pending || (active && !cont);
 			active = cont;
 			uint64_t parked = __ballot(pending);
@@ -1055,15 +1059,18 @@ hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_tem
 	int per_cu = 8;
 	if (const char *env = getenv("KG_SEARCH_BLOCKS_PER_CU")) per_cu = atoi(env) > 0 ? atoi(env) : 8;  // tuning knob
 	int blocks = grid_for(a.n_reads, 256, n_cu * per_cu);
-	hipLaunchKernelGGL(pack_reads_kernel, dim3(grid_for(a.n_reads * 16, 256, n_cu * 32)), dim3(256), 0, stream, a);
+	static const bool fused_pack = getenv("KG_FUSED_PACK") != nullptr;      // experiment: no pack pre-pass, raw codes read in the search
+	SeedArgs a2 = a;
+	if (fused_pack) a2.packed = nullptr;
+	else hipLaunchKernelGGL(pack_reads_kernel, dim3(grid_for(a.n_reads * 16, 256, n_cu * 32)), dim3(256), 0, stream, a);
 	if (ev) (void)hipEventRecord(ev[0], stream);
 	// 32-bit interval arithmetic whenever the text allows it; KG_FORCE_U64 exercises the wide instantiation
 	// (the one hg38-sized indexes use) on small test indexes
 	static const bool force_wide = getenv("KG_FORCE_U64") != nullptr;
 	if (a.ix.seq_len < 0xFFFFFF00ull && !(force_wide && a.ix.qtab64))
-		hipLaunchKernelGGL(search_kernel<uint32_t>, dim3(blocks), dim3(256), 0, stream, a);
+		hipLaunchKernelGGL(search_kernel<uint32_t>, dim3(blocks), dim3(256), 0, stream, a2);
 	else
-		hipLaunchKernelGGL(search_kernel<uint64_t>, dim3(blocks), dim3(256), 0, stream, a);
+		hipLaunchKernelGGL(search_kernel<uint64_t>, dim3(blocks), dim3(256), 0, stream, a2);
 	if (ev) (void)hipEventRecord(ev[1], stream);
 	size_t tb = scan_temp_bytes;
 	WideIter it(a.seeds_per_read, WidenOp());

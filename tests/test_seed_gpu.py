@@ -137,8 +137,10 @@ def test_wide_index_instantiation(golden, built_lib, gpu_index_full, tmp_path, r
             ix.close()
         print("wide ok")
     ''') % (ROOT, os.path.join(ROOT, "tests", "golden", "hotpath_small.npz"), edge, os.path.join(ROOT, "tests", "golden", "idx", "small"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KG_FORCE_U64="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    assert r.returncode == 0 and b"wide ok" in r.stdout, r.stdout.decode()[-800:]
+    # ... and the same checks for the variant that reads the raw read codes in the search kernel (no pack pre-pass)
+    for env in ({"KG_FORCE_U64": "1"}, {"KG_FUSED_PACK": "1"}, {"KG_FORCE_U64": "1", "KG_FUSED_PACK": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0 and b"wide ok" in r.stdout, (env, r.stdout.decode()[-800:])
 
 
 def _check_candidates(got, want_iter):
