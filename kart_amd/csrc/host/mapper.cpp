@@ -674,6 +674,16 @@ void plan_pair(const Ctx &cx, const Read &rd, const Pair &sp, int role, PairWork
 		w.ops.push_back(std::make_pair(sp.rLen, 'S'));
 		return;
 	}
+	if (sp.rLen == 1 && sp.gLen == 1) {
+		// one base against one base -- the mismatch right next to a maximal exact match, by far the most common gap:
+		// nw_alignment can only answer with the diagonal (+-1.5 against -3 for two gaps), the quality check passes a
+		// single column, nothing is trimmed, and AddNewCigarElements (src/tools.cpp:49-104) books 1M with one
+		// identical base iff the raw characters are equal -- no job for the kernel
+		w.kind = PairWork::IMMEDIATE;
+		w.score = rd.seq[(size_t)sp.rPos] == cx.refseq()[sp.gPos] ? 1 : 0;
+		w.ops.push_back(std::make_pair(1, 'M'));
+		return;
+	}
 	w.kind = PairWork::PLANNED;
 	std::string f1(rd.seq.data() + sp.rPos, (size_t)sp.rLen), f2(cx.refseq() + sp.gPos, (size_t)sp.gLen);
 	plan_alignment(cx, sp.rLen, f1, sp.gLen, f2, w.plan, jobs);
