@@ -1995,7 +1995,9 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	// small batches first: the estimate moves fastest while the totals are small
 	int64_t batch_chunks = 1;
 	// enough chunks per batch to keep every worker busy (static chunk -> worker assignment)
-	const int64_t max_batch_chunks = std::max<int64_t>(std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit), cx.opt.pacbio ? 64 * nthreads : 4 * nthreads);
+	// ... and a whole number of chunks per worker, so that the last round of a phase is not half empty
+	int64_t want_chunks = std::max<int64_t>(std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit), cx.opt.pacbio ? 64 * nthreads : 4 * nthreads);
+	const int64_t max_batch_chunks = (want_chunks + nthreads - 1) / nthreads * nthreads;
 	if (!cx.opt.paired || cx.opt.pacbio) batch_chunks = max_batch_chunks;   // no EstDistance feedback to settle: full batches at once
 	std::unique_ptr<Batch> cur(new Batch()), nxt(new Batch()), prev;
 
