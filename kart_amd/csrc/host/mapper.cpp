@@ -1990,7 +1990,8 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	//   main thread     : NW kernel call of batch k, then the in-order commit of batch k-1
 	// The speculated EstDistance therefore lags the committed totals by up to two batches; the commit's
 	// validity check absorbs that.
-	Pool pool(nthreads), read_pool(nthreads);
+	// parsing + encoding costs ~0.4x what the mapping stages cost per read: half as many reader threads keep up
+	Pool pool(nthreads), read_pool((nthreads + 1) / 2);
 	Writer writer(out);
 	// small batches first: the estimate moves fastest while the totals are small
 	int64_t batch_chunks = 1;
