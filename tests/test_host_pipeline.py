@@ -43,10 +43,10 @@ def materialise(tmp, name):
     return dst
 
 
-def run_case(binary, case, tmp):
+def run_case(binary, case, tmp, extra=()):
     args = [materialise(tmp, a) if (a.endswith((".fq", ".fa", ".gz"))) else a for a in CASES[case]]
     out = os.path.join(tmp, case + ".sam")
-    r = subprocess.run([binary, "-silent", "-i", SMALL_PREFIX] + args + ["-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    r = subprocess.run([binary, "-silent", "-i", SMALL_PREFIX] + args + list(extra) + ["-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-500:]
     got = open(out, "rb").read()
     want = gzip.open(os.path.join(SAM, GOLD_OF.get(case, case) + ".sam.gz")).read()
@@ -94,6 +94,13 @@ def test_speculative_chunks_match_live_reference(ins_mean, threads, host_oracle_
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("threads", [1, 3, 16])
+def test_output_does_not_depend_on_the_thread_count(threads, host_oracle_binary, tmp_path):
+    for case in ("pe", "edge_pe", "pacbio"):
+        got, want, _ = run_case(host_oracle_binary, case, str(tmp_path), ["-t", str(threads)])
+        assert got == want, (case, threads)
 
 
 def test_cli_error_behaviour(host_oracle_binary, tmp_path):

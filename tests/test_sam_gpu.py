@@ -83,6 +83,13 @@ def test_live_reference_pacbio_7kb(product_binary, tmp_path):
     assert outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("threads", [1, 3, 16, 64])
+def test_output_does_not_depend_on_the_thread_count(threads, product_binary, tmp_path):
+    for case in ("pe", "pe_m", "pacbio"):
+        got, want, _ = run_case(product_binary, case, str(tmp_path), ["-t", str(threads)])
+        assert got == want, (case, threads)
+
+
 def test_repeated_runs_are_deterministic(product_binary, tmp_path):
     """Regression test for an intermittent race (NW work lists emptied by a late memset of recycled
     stream-ordered pool memory): the same paired-end input mapped 12 times must give the golden SAM every time."""
