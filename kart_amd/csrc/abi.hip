@@ -298,7 +298,14 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		while (q < kQmerMax && ((uint64_t)1 << (2 * q + 1)) <= v.seq_len) q++;      // round(log4(2L))
 		if (const char *env = getenv("KG_QMER")) { int t = atoi(env); if (t >= kQmerMin && t <= kQmerMax) q = t; }   // tuning knob
 		size_t tab_bytes = ((size_t)1 << (2 * q)) * 8;
-		HIP_TRY(hipMalloc(&ix->d_qtab, tab_bytes));
+		// the table is an accelerator, not a requirement: when the device cannot hold 4^q entries (34 GB at q = 16) take a smaller q
+		while (hipMalloc(&ix->d_qtab, tab_bytes) != hipSuccess) {
+			(void)hipGetLastError();
+			ix->d_qtab = nullptr;
+			if (q <= kQmerMin) return fail(KG_ERR_NOMEM, "kg_index_load: no device memory for the q-mer table");
+			q--;
+			tab_bytes >>= 2;
+		}
 		v.qmer = q;
 		HIP_TRY(launch_build_qtab(v, q, narrow ? (uint2 *)ix->d_qtab : nullptr, narrow ? nullptr : (uint64_t *)ix->d_qtab, nullptr));
 		HIP_TRY(hipDeviceSynchronize());
