@@ -19,7 +19,7 @@
 //                   rank at two positions per step instead of all four (SURVEY.md App. C check).
 //                   When the interval has shrunk to a single suffix (and the full SA is resident) the
 //                   lane stops ranking: one gather from the SA names the text position, and the
-//                   rest of the match is a 16-bases-per-iteration comparison of the read against
+//                   rest of the match is a 48-bases-per-iteration comparison of the read against
 //                   the 2-bit text -- same match length by construction (an interval of one extends
 //                   iff the next text base equals the next read base), ~4x fewer cache lines.
 //                   Output: a dense list of hits {interval start, size, rPos, len, read, seed slot}.
@@ -148,6 +148,17 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(SeedArgs a)
 constexpr int kRefill = 8;
 
 struct __attribute__((packed, aligned(1))) U64u { uint64_t v; };
+
+// 16 bases of 2 bits -> 16 nibbles (the base in the low bits of its nibble)
+__device__ __forceinline__ uint64_t spread_2bit(uint32_t v)
+{
+	uint64_t x = v;
+	x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+	x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+	x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+	x = (x | (x << 2)) & 0x3333333333333333ull;
+	return x;
+}
 
 template <typename idx_t>
 __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
@@ -288,13 +299,15 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 		for (;;) {
 			int sh = (cur & 15) << 2;
 			int code = (int)((win >> sh) & 15);
-			bool alive = active && cur < stop && code <= 3;                 // :153-154; otherwise the search is over
+			// :153-154; otherwise the search is over.  In text-comparison mode the window registers are not kept
+			// in step with cur (the comparison loads its own read words, and an ambiguous code simply differs)
+			bool alive = active && cur < stop && (mode == 2 || code <= 3);
 			bool lf = alive && mode == 0, sa = alive && mode == 1, cmp = alive && mode == 2;
 			int c = 3 - code;
 			// the gathers of this iteration -- issued together, used below
 			idx_t kk = 0, ll = 0;
 			uint4 vk = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
-			uint64_t sav = 0, tw = 0;
+			uint64_t sav = 0, t0 = 0, t1 = 0, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
 			if (lf) {
 				kk = k - 1; ll = k - 1 + n;                                 // bwt_2occ4(x1-1, x1-1+x2), :157
 				kk -= (kk >= primary);
@@ -303,7 +316,12 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 				vl = ix.planes[(((uint64_t)(ll >> 6)) << 2) + (uint32_t)c];
 			}
 			if (sa) sav = ix.fsa32 ? (uint64_t)ix.fsa32[k] : ix.fsa64[k];
-			if (cmp) tw = reinterpret_cast<const U64u *>(ix.text + ((uint64_t)tpos >> 2))->v;
+			if (cmp) {
+				const U64u *tp = reinterpret_cast<const U64u *>(ix.text + ((uint64_t)tpos >> 2));
+				t0 = tp[0].v; t1 = tp[1].v;                                   // 64 text bases from the byte holding tpos
+				int w = cur >> 4;
+				r0 = KG_WORD(w); r1 = KG_WORD(w + 1); r2 = KG_WORD(w + 2); r3 = KG_WORD(w + 3);   // 64 read codes from the word holding cur
+			}
 			bool cont = false;
 			if (lf) {
 				uint64_t mk = (2ull << (kk & 63)) - 1, ml = (2ull << (ll & 63)) - 1;
@@ -329,21 +347,26 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 				cont = true;
 			}
 			if (cmp) {
-				uint64_t rd = sh ? (win >> sh) | (wnext << (64 - sh)) : win;      // 16 read codes from cur, one per nibble
-				uint64_t x = (uint32_t)(tw >> (((uint32_t)tpos & 3) << 1));      // 16 text bases from tpos, 2 bits each
-				x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-				x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-				x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-				x = (x | (x << 2)) & 0x3333333333333333ull;
-				uint64_t diff = x ^ rd;                                             // an ambiguous read code (>3) always differs
-				int m = diff ? (__ffsll((unsigned long long)diff) - 1) >> 2 : 16;
+				// 48 bases per round: read codes (one per nibble) against text bases (2 bits each, spread to nibbles);
+				// an ambiguous read code (> 3) always differs
+				uint64_t q0 = sh ? (r0 >> sh) | (r1 << (64 - sh)) : r0;
+				uint64_t q1 = sh ? (r1 >> sh) | (r2 << (64 - sh)) : r1;
+				uint64_t q2 = sh ? (r2 >> sh) | (r3 << (64 - sh)) : r2;
+				int ts = ((int)((uint32_t)tpos & 3)) << 1;
+				uint64_t ta = ts ? (t0 >> ts) | (t1 << (64 - ts)) : t0;           // text bases 0..31 from tpos
+				uint64_t tb = t1 >> ts;                                            // bases 32..(63 - ts/2)
+				uint64_t d0 = spread_2bit((uint32_t)ta) ^ q0, d1 = spread_2bit((uint32_t)(ta >> 32)) ^ q1, d2 = spread_2bit((uint32_t)tb) ^ q2;
+				int m = d0 ? (__ffsll((unsigned long long)d0) - 1) >> 2
+				      : d1 ? 16 + ((__ffsll((unsigned long long)d1) - 1) >> 2)
+				      : d2 ? 32 + ((__ffsll((unsigned long long)d2) - 1) >> 2) : 48;
 				uint64_t left = ix.seq_len - (uint64_t)tpos;                       // the text ends: the reference's step finds nothing
 				m = (uint64_t)m > left ? (int)left : m;
-				int lim = stop - cur < 16 ? stop - cur : 16;
+				int lim = stop - cur < 48 ? stop - cur : 48;
 				if (m < lim) {
 					// the reference extends m times, then either stops at an ambiguous base (no step) or
 					// performs the step that empties the interval
-					int code2 = (int)((rd >> (m << 2)) & 15);
+					uint64_t qw = m < 16 ? q0 : m < 32 ? q1 : q2;
+					int code2 = (int)((qw >> ((m & 15) << 2)) & 15);
 					c_lf += (uint32_t)m + (code2 <= 3 ? 1u : 0u);
 					cur += m;
 					tpos += (idx_t)m;
@@ -354,7 +377,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 					cont = cur < stop;
 				}
 			}
-			if (cont && (cur >> 4) != wword) { win = wnext; wword++; wnext = KG_WORD(wword + 1); }
+			if (cont && mode != 2 && (cur >> 4) != wword) { win = wnext; wword++; wnext = KG_WORD(wword + 1); }
 			pending = pending || (active && !cont);
 			active = cont;
 			uint64_t parked = __ballot(pending);
