@@ -482,6 +482,7 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.min_seed_len = min_seed_len;
 	a.occ_thr = occ_thr;
 	a.packed = ws->d_packed;
+	{ static const int dbg = getenv("KG_DEBUG_COUNT") ? atoi(getenv("KG_DEBUG_COUNT")) : 0; a.debug_count = dbg; }
 	a.hits = ws->d_hits;
 	a.max_hits = ws->max_hits;
 	a.seeds_per_read = ws->d_seeds_per_read;

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 	// the read with the text at tpos (the text position facing read position `cur`)
 	int mode = 0;
 	idx_t tpos = 0;
-	uint32_t c_search = 0, c_lf = 0, c_lf2 = 0, c_sa = 0;
+	uint32_t c_search = 0, c_lf = 0, c_lf2 = 0, c_sa = 0, c_dbg = 0;
+	const int dbg = a.debug_count;        // 1 table lookups, 2 LF steps executed, 3 of them with kk/ll in different 128-byte lines, 4 text rounds
 	WavePool read_pool, hit_pool;
 
 	for (;;) {
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 						tk = (idx_t)(e & 0x3FFFFFFFFull); tn = (idx_t)((e >> 34) & 0x1FFFFFFull); tsa = (e >> 59) & 1; tlf2 = (uint32_t)(e >> 60);
 					}
 				}
+				c_dbg += (dbg == 1 && clean) ? 1u : 0u;
 				bool jump = clean && tn != 0;
 				k = jump ? tk : l2s[3 - code0] + 1;                            // x[1], :149
 				n = jump ? tn : l2s[code0 + 1] - l2s[code0];                  // x[2], :150
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 				idx_t nn = ol - ok;
 				c_lf++;
 				c_lf2 += (kk >> 7) != (ll >> 7) ? 1u : 0u;                 // reference 128-symbol block accounting
+				c_dbg += (dbg == 2 || (dbg == 3 && (kk >> 7) != (ll >> 7))) ? 1u : 0u;
 				cont = nn != 0;
 				if (cont) {
 					k = l2s[c] + 1 + ok;
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 			if (cmp) {
 				// 48 bases per round: read codes (one per nibble) against text bases (2 bits each, spread to nibbles);
 				// an ambiguous read code (> 3) always differs
+				c_dbg += dbg == 4 ? 1u : 0u;
 				uint64_t q0 = sh ? (r0 >> sh) | (r1 << (64 - sh)) : r0;
 				uint64_t q1 = sh ? (r1 >> sh) | (r2 << (64 - sh)) : r1;
 				uint64_t q2 = sh ? (r2 >> sh) | (r3 << (64 - sh)) : r2;
@@ -396,6 +400,11 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 		atomicAdd(&a.counters[1], (unsigned long long)s1);
 		atomicAdd(&a.counters[2], (unsigned long long)s2);
 		if (s3) atomicAdd(&a.counters[4], (unsigned long long)s3);
+	}
+	if (dbg) {
+		uint64_t s4 = c_dbg;
+		for (int off = 32; off > 0; off >>= 1) s4 += __shfl_down(s4, off);
+		if ((threadIdx.x & 63) == 0 && s4) atomicAdd(&a.counters[3], (unsigned long long)s4);
 	}
 }
 
