@@ -1087,9 +1087,11 @@ hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_tem
 	// queue heads, hit count and counters are zeroed on the stream every call
 	hipLaunchKernelGGL(seed_reset_kernel, dim3(1), dim3(64), 0, stream, a.read_queue);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	// persistent lanes: 8 blocks of 256 threads per CU (= 32 waves/CU) unless the batch is smaller
-	int per_cu = 8;
-	if (const char *env = getenv("KG_SEARCH_BLOCKS_PER_CU")) per_cu = atoi(env) > 0 ? atoi(env) : 8;  // tuning knob
+	// persistent lanes: 4 blocks of 256 threads per CU (= 16 waves/CU, all resident from the first cycle: with ~90 VGPRs a
+	// SIMD holds 5 waves, and blocks that only start when others retire find the read queue nearly drained) unless the
+	// batch is smaller.  Sweep on both workloads: 3 / 4 / 5 / 6 / 8 blocks -> 22.9 / 20.2 / 22.0 / 22.3 / 22.6 ms (hg38-sized)
+	int per_cu = 4;
+	if (const char *env = getenv("KG_SEARCH_BLOCKS_PER_CU")) per_cu = atoi(env) > 0 ? atoi(env) : 4;  // tuning knob
 	int blocks = grid_for(a.n_reads, 256, n_cu * per_cu);
 	static const bool fused_pack = getenv("KG_FUSED_PACK") != nullptr;      // experiment: no pack pre-pass, raw codes read in the search
 	SeedArgs a2 = a;
