@@ -1087,9 +1087,9 @@ hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_tem
 	// queue heads, hit count and counters are zeroed on the stream every call
 	hipLaunchKernelGGL(seed_reset_kernel, dim3(1), dim3(64), 0, stream, a.read_queue);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	// persistent lanes: 4 blocks of 256 threads per CU (= 16 waves/CU, all resident from the first cycle: with ~90 VGPRs a
-	// SIMD holds 5 waves, and blocks that only start when others retire find the read queue nearly drained) unless the
-	// batch is smaller.  Sweep on both workloads: 3 / 4 / 5 / 6 / 8 blocks -> 22.9 / 20.2 / 22.0 / 22.3 / 22.6 ms (hg38-sized)
+	// persistent lanes: 4 blocks of 256 threads per CU (= 16 waves/CU, all resident: with ~90 VGPRs a SIMD holds 5 waves)
+	// unless the batch is smaller.  More blocks change nothing (alternating A/B of 4 / 6 / 8 per CU: 22.0-22.6 ms each on
+	// the hg38-sized workload, tools/ab_blocks.sh): the kernel is bound by the fabric, not by the number of waves in flight.
 	int per_cu = 4;
 	if (const char *env = getenv("KG_SEARCH_BLOCKS_PER_CU")) per_cu = atoi(env) > 0 ? atoi(env) : 4;  // tuning knob
 	int blocks = grid_for(a.n_reads, 256, n_cu * per_cu);
