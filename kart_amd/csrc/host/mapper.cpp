@@ -1832,7 +1832,18 @@ void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<in
 	}
 	}
 	Section sec(2);
-	for (int q = 0; q < ck.count; ++q) report_plan(cx, reads[(size_t)(ck.begin + q)], ck.cands[(size_t)q], ck.work[(size_t)q], ck.jobs);
+	// the plan compares read fragments with the reference at the candidates' positions -- random addresses in 6.2 GB for
+	// hg38: ask for the lines of the reads a few places ahead while this one is being planned
+	auto prefetch_ref = [&](int q) {
+		if (q >= ck.count) return;
+		for (const Candidate &c : ck.cands[(size_t)q])
+			for (const Pair &p : c.pairs) {
+				__builtin_prefetch(cx.refseq() + p.gPos);
+				__builtin_prefetch(cx.refseq() + p.gPos + p.gLen + 64);
+			}
+	};
+	for (int q = 0; q < 6 && q < ck.count; ++q) prefetch_ref(q);
+	for (int q = 0; q < ck.count; ++q) { prefetch_ref(q + 6); report_plan(cx, reads[(size_t)(ck.begin + q)], ck.cands[(size_t)q], ck.work[(size_t)q], ck.jobs); }
 }
 
 // stage C: report pass 2, final pair check, flags, MAPQ, SAM text
