@@ -1237,8 +1237,9 @@ void sam_unmapped(const Ctx &cx, const Read &rd, std::string &out)
 	out += "\tAS:i:0\tXS:i:0\n";
 }
 
-void sam_mapped(const Ctx &cx, const Read &rd, const Report &rp, bool has_mate, long long mate_pos, int tlen,
-                std::string_view seq, std::string_view qual, std::string &out)
+// flip: the record shows the reverse complement of the read as it is held (and its qualities reversed); written straight
+// into the chunk's text, no temporaries
+void sam_mapped(const Ctx &cx, const Read &rd, const Report &rp, bool has_mate, long long mate_pos, int tlen, bool flip, std::string &out)
 {
 	out += rd.name; out += '\t';
 	append_int(out, rp.flag); out += '\t';
@@ -1248,8 +1249,24 @@ void sam_mapped(const Ctx &cx, const Read &rd, const Report &rp, bool has_mate, 
 	out += rp.cigar;
 	if (has_mate) { out += "\t=\t"; append_int(out, mate_pos); out += '\t'; append_int(out, tlen); out += '\t'; }
 	else out += "\t*\t0\t0\t";
-	out += seq; out += '\t';
-	if (cx.fastq) out += qual; else out += '*';
+	if (!flip) out += rd.seq;
+	else {
+		size_t at = out.size(), n = rd.seq.size();
+		out.resize(at + n);
+		char *d = &out[at];
+		const char *sq = rd.seq.data();
+		for (size_t i = 0; i < n; ++i) d[i] = comp_base(sq[n - 1 - i]);      // GetComplementarySeq, src/tools.cpp:19-29
+	}
+	out += '\t';
+	if (!cx.fastq) out += '*';
+	else if (!flip) out += rd.qual;
+	else {
+		size_t at = out.size(), n = rd.qual.size();
+		out.resize(at + n);
+		char *d = &out[at];
+		const char *ql = rd.qual.data();
+		for (size_t i = 0; i < n; ++i) d[i] = ql[n - 1 - i];
+	}
 	out += "\tNM:i:"; append_int(out, rd.rlen - rd.score);
 	out += "\tAS:i:"; append_int(out, rd.score);
 	out += "\tXS:i:"; append_int(out, rd.sub_score);
@@ -1262,16 +1279,9 @@ void output_pair(const Ctx &cx, const Read &r1, const Read &r2, Stats &st, PairS
 	if (r1.score == 0) { st.unmapped++; sam_unmapped(cx, r1, out); }
 	else {
 		if (r1.mapq == 60) st.unique++;
-		std::string rseq, rqual;
-		bool have_rev = false;
 		for (int i = r1.best; i < r1.can_num; ++i) {
 			const Report &rp = r1.rep[(size_t)i];
 			if (rp.score > 0) {
-				if (!rp.fwd && !have_rev) {
-					rseq = revcomp(r1.seq);
-					if (cx.fastq) { rqual.assign(r1.qual); std::reverse(rqual.begin(), rqual.end()); }
-					have_rev = true;
-				}
 				int j = rp.mate;
 				if (j != -1 && r2.rep[(size_t)j].score > 0) {
 					int dist = (int)(r2.rep[(size_t)j].gPos - rp.gPos + (rp.fwd ? r2.rlen : 0 - r1.rlen));
@@ -1279,8 +1289,8 @@ void output_pair(const Ctx &cx, const Read &r1, const Read &r2, Stats &st, PairS
 						ps.paired += 2;
 						if (abs(dist) < 10000) ps.distance += abs(dist);
 					}
-					sam_mapped(cx, r1, rp, true, (long long)r2.rep[(size_t)j].gPos, dist, rp.fwd ? r1.seq : std::string_view(rseq), rp.fwd ? r1.qual : std::string_view(rqual), out);
-				} else sam_mapped(cx, r1, rp, false, 0, 0, rp.fwd ? r1.seq : std::string_view(rseq), rp.fwd ? r1.qual : std::string_view(rqual), out);
+					sam_mapped(cx, r1, rp, true, (long long)r2.rep[(size_t)j].gPos, dist, !rp.fwd, out);
+				} else sam_mapped(cx, r1, rp, false, 0, 0, !rp.fwd, out);
 			}
 			if (!cx.opt.multi_hit) break;
 		}
@@ -1288,21 +1298,15 @@ void output_pair(const Ctx &cx, const Read &r1, const Read &r2, Stats &st, PairS
 	if (r2.score == 0) { st.unmapped++; sam_unmapped(cx, r2, out); }
 	else {
 		if (r2.mapq == 60) st.unique++;
-		std::string fseq, rqual;
-		bool have_fwd = false;
+		// mate 2 is held reverse-complemented (src/GetData.cpp:125-135): a forward report shows it flipped back
 		for (int j = r2.best; j < r2.can_num; ++j) {
 			const Report &rp = r2.rep[(size_t)j];
 			if (rp.score > 0) {
-				if (rp.fwd && !have_fwd) {
-					fseq = revcomp(r2.seq);
-					if (cx.fastq) { rqual.assign(r2.qual); std::reverse(rqual.begin(), rqual.end()); }
-					have_fwd = true;
-				}
 				int i = rp.mate;
 				if (i != -1 && r1.rep[(size_t)i].score > 0) {
 					int dist = 0 - (int)(rp.gPos - r1.rep[(size_t)i].gPos + (r1.rep[(size_t)i].fwd ? r2.rlen : 0 - r1.rlen));
-					sam_mapped(cx, r2, rp, true, (long long)r1.rep[(size_t)i].gPos, dist, rp.fwd ? std::string_view(fseq) : r2.seq, rp.fwd ? std::string_view(rqual) : r2.qual, out);
-				} else sam_mapped(cx, r2, rp, false, 0, 0, rp.fwd ? std::string_view(fseq) : r2.seq, rp.fwd ? std::string_view(rqual) : r2.qual, out);
+					sam_mapped(cx, r2, rp, true, (long long)r1.rep[(size_t)i].gPos, dist, rp.fwd, out);
+				} else sam_mapped(cx, r2, rp, false, 0, 0, rp.fwd, out);
 			}
 			if (!cx.opt.multi_hit) break;
 		}
@@ -1313,17 +1317,10 @@ void output_single(const Ctx &cx, const Read &rd, Stats &st, std::string &out)  
 {
 	if (rd.score == 0) { st.unmapped++; sam_unmapped(cx, rd, out); return; }
 	if (rd.mapq == 60) st.unique++;
-	std::string rseq, rqual;
-	bool have_rev = false;
 	for (int i = rd.best; i < rd.can_num; ++i) {
 		const Report &rp = rd.rep[(size_t)i];
 		if (rp.score == rd.score) {
-			if (!rp.fwd && !have_rev) {
-				rseq = revcomp(rd.seq);
-				if (cx.fastq) { rqual.assign(rd.qual); std::reverse(rqual.begin(), rqual.end()); }
-				have_rev = true;
-			}
-			sam_mapped(cx, rd, rp, false, 0, 0, rp.fwd ? rd.seq : std::string_view(rseq), rp.fwd ? rd.qual : std::string_view(rqual), out);
+			sam_mapped(cx, rd, rp, false, 0, 0, !rp.fwd, out);
 			if (!cx.opt.multi_hit) break;
 		}
 	}
