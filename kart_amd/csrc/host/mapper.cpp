@@ -634,7 +634,7 @@ bool local_quality_ok(const std::string &a1, const std::string &a2)  // CheckLoc
 // what pass 1 decided for one pair of a candidate
 struct PairWork {
 	enum Kind { NONE, SIMPLE, IMMEDIATE, PLANNED } kind = NONE;
-	CigarVec ops;     // IMMEDIATE
+	std::pair<int, char> op{0, '\0'};   // IMMEDIATE: always exactly one CIGAR element (or none)
 	int score = 0;    // IMMEDIATE
 	Plan plan;        // PLANNED
 };
@@ -656,8 +656,8 @@ void plan_pair(const Ctx &cx, const Read &rd, const Pair &sp, int role, PairWork
 {
 	if (role == 1 && (sp.rLen == 0 || sp.gLen == 0)) {   // ProcessNormalSequencePair :229-233
 		w.kind = PairWork::IMMEDIATE;
-		if (sp.rLen > 0) w.ops.push_back(std::make_pair(sp.rLen, 'I'));
-		else if (sp.gLen > 0) w.ops.push_back(std::make_pair(sp.gLen, 'D'));
+		if (sp.rLen > 0) w.op = std::make_pair(sp.rLen, 'I');
+		else if (sp.gLen > 0) w.op = std::make_pair(sp.gLen, 'D');
 		return;
 	}
 	int n = 0;
@@ -665,13 +665,13 @@ void plan_pair(const Ctx &cx, const Read &rd, const Pair &sp, int role, PairWork
 	if (shortcut) {
 		w.kind = PairWork::IMMEDIATE;
 		w.score = sp.rLen - n;
-		w.ops.push_back(std::make_pair(sp.rLen, 'M'));
+		w.op = std::make_pair(sp.rLen, 'M');
 		return;
 	}
 	if (!cx.opt.pacbio && ((role == 0 && sp.rLen > 50) || (role == 2 && sp.rLen > 100))) {   // :307-311, :358-362
 		w.kind = PairWork::IMMEDIATE;
 		w.score = 0;
-		w.ops.push_back(std::make_pair(sp.rLen, 'S'));
+		w.op = std::make_pair(sp.rLen, 'S');
 		return;
 	}
 	if (sp.rLen == 1 && sp.gLen == 1) {
@@ -681,7 +681,7 @@ void plan_pair(const Ctx &cx, const Read &rd, const Pair &sp, int role, PairWork
 		// identical base iff the raw characters are equal -- no job for the kernel
 		w.kind = PairWork::IMMEDIATE;
 		w.score = rd.seq[(size_t)sp.rPos] == cx.refseq()[sp.gPos] ? 1 : 0;
-		w.ops.push_back(std::make_pair(1, 'M'));
+		w.op = std::make_pair(1, 'M');
 		return;
 	}
 	w.kind = PairWork::PLANNED;
@@ -831,7 +831,7 @@ void report_plan(const Ctx &cx, Read &rd, std::vector<Candidate> &cands, std::ve
 			if (j == 0 || j == num - 1) {
 				if (v[j].rLen > 3000) {               // :671-676, :690-695
 					w.kind = PairWork::IMMEDIATE;
-					w.ops.push_back(std::make_pair(v[j].rLen, 'S'));
+					w.op = std::make_pair(v[j].rLen, 'S');
 					w.score = -1;                     // marks the long soft clip (handled like s == 0 but unconditionally)
 					continue;
 				}
@@ -877,7 +877,7 @@ void report_finish(const Ctx &cx, bool first, Read &rd, std::vector<Candidate> &
 			bool head = j == 0, tail = j == num - 1 && !head;
 			int s;
 			if (w.kind == PairWork::IMMEDIATE) {
-				cig.insert(cig.end(), w.ops.begin(), w.ops.end());
+				if (w.op.second != '\0') cig.push_back(w.op);
 				s = w.score;
 			} else {
 				stitch(w.plan, jobs, a1, a2);
