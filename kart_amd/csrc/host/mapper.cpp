@@ -866,6 +866,7 @@ void report_finish(const Ctx &cx, bool first, Read &rd, std::vector<Candidate> &
 		std::vector<Pair> &v = cands[(size_t)i].pairs;
 		int num = (int)v.size();
 		CigarVec cig;
+		cig.reserve((size_t)num + 4);
 		for (int j = 0; j < num; ++j) {
 			PairWork &w = cw.pairs[(size_t)j];
 			if (w.kind == PairWork::NONE) continue;
