@@ -1238,40 +1238,57 @@ void sam_unmapped(const Ctx &cx, const Read &rd, std::string &out)
 	out += "\tAS:i:0\tXS:i:0\n";
 }
 
+// raw-pointer writers for the record below: one capacity check per record instead of one per field
+inline char *put(char *p, std::string_view v) { memcpy(p, v.data(), v.size()); return p + v.size(); }
+inline char *put(char *p, const char *lit, size_t n) { memcpy(p, lit, n); return p + n; }
+inline char *put_int(char *p, long long v)   // what "%d" / "%lld" print
+{
+	char buf[24];
+	int n = 0;
+	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+	do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+	if (v < 0) buf[n++] = '-';
+	while (n) *p++ = buf[--n];
+	return p;
+}
+
 // flip: the record shows the reverse complement of the read as it is held (and its qualities reversed); written straight
 // into the chunk's text, no temporaries
 void sam_mapped(const Ctx &cx, const Read &rd, const Report &rp, bool has_mate, long long mate_pos, int tlen, bool flip, std::string &out)
 {
-	out += rd.name; out += '\t';
-	append_int(out, rp.flag); out += '\t';
-	out += cx.ref.contigs[(size_t)rp.chr].name; out += '\t';
-	append_int(out, (long long)rp.gPos); out += '\t';
-	append_int(out, rd.mapq); out += '\t';
-	out += rp.cigar;
-	if (has_mate) { out += "\t=\t"; append_int(out, mate_pos); out += '\t'; append_int(out, tlen); out += '\t'; }
-	else out += "\t*\t0\t0\t";
-	if (!flip) out += rd.seq;
+	const std::string &chr = cx.ref.contigs[(size_t)rp.chr].name;
+	size_t at = out.size();
+	out.resize(at + rd.name.size() + chr.size() + rp.cigar.size() + rd.seq.size() + rd.qual.size() + 192);
+	char *p = &out[at];
+	p = put(p, rd.name); *p++ = '\t';
+	p = put_int(p, rp.flag); *p++ = '\t';
+	p = put(p, chr); *p++ = '\t';
+	p = put_int(p, (long long)rp.gPos); *p++ = '\t';
+	p = put_int(p, rd.mapq); *p++ = '\t';
+	p = put(p, rp.cigar);
+	if (has_mate) { p = put(p, "\t=\t", 3); p = put_int(p, mate_pos); *p++ = '\t'; p = put_int(p, tlen); *p++ = '\t'; }
+	else p = put(p, "\t*\t0\t0\t", 7);
+	size_t n = rd.seq.size();
+	if (!flip) p = put(p, rd.seq);
 	else {
-		size_t at = out.size(), n = rd.seq.size();
-		out.resize(at + n);
-		char *d = &out[at];
 		const char *sq = rd.seq.data();
-		for (size_t i = 0; i < n; ++i) d[i] = comp_base(sq[n - 1 - i]);      // GetComplementarySeq, src/tools.cpp:19-29
+		for (size_t i = 0; i < n; ++i) p[i] = comp_base(sq[n - 1 - i]);      // GetComplementarySeq, src/tools.cpp:19-29
+		p += n;
 	}
-	out += '\t';
-	if (!cx.fastq) out += '*';
-	else if (!flip) out += rd.qual;
+	*p++ = '\t';
+	if (!cx.fastq) *p++ = '*';
+	else if (!flip) p = put(p, rd.qual);
 	else {
-		size_t at = out.size(), n = rd.qual.size();
-		out.resize(at + n);
-		char *d = &out[at];
+		n = rd.qual.size();
 		const char *ql = rd.qual.data();
-		for (size_t i = 0; i < n; ++i) d[i] = ql[n - 1 - i];
+		for (size_t i = 0; i < n; ++i) p[i] = ql[n - 1 - i];
+		p += n;
 	}
-	out += "\tNM:i:"; append_int(out, rd.rlen - rd.score);
-	out += "\tAS:i:"; append_int(out, rd.score);
-	out += "\tXS:i:"; append_int(out, rd.sub_score);
-	out += '\n';
+	p = put(p, "\tNM:i:", 6); p = put_int(p, rd.rlen - rd.score);
+	p = put(p, "\tAS:i:", 6); p = put_int(p, rd.score);
+	p = put(p, "\tXS:i:", 6); p = put_int(p, rd.sub_score);
+	*p++ = '\n';
+	out.resize((size_t)(p - out.data()));
 }
 
 // OutputPairedAlignments, src/Mapping.cpp:177-270.  Mate 2 is held reverse-complemented (App. B-2).
