@@ -286,7 +286,18 @@ void identify_normal_pairs(int rlen, int glen, std::vector<Pair> &v)  // :420-49
 				v.push_back(np);
 			}
 		}
-		if ((int)v.size() > num) std::inplace_merge(v.begin(), v.begin() + num, v.end(), pair_by_gpos);
+		if ((int)v.size() > num) {
+			// the appended gap pairs go between the seeds in (gPos, rPos) order (keys are distinct); a handful per read:
+			// insert them by hand, std::inplace_merge allocates a scratch buffer every time
+			if (v.size() - (size_t)num <= 8) {
+				for (size_t t = (size_t)num; t < v.size(); ++t) {
+					Pair x = v[t];
+					size_t p = t;
+					while (p > 0 && pair_by_gpos(x, v[p - 1])) { v[p] = v[p - 1]; --p; }
+					v[p] = x;
+				}
+			} else std::inplace_merge(v.begin(), v.begin() + num, v.end(), pair_by_gpos);
+		}
 	}
 	if (!v.empty()) {
 		int r_gap = v[0].rPos > 0 ? v[0].rPos : 0;
