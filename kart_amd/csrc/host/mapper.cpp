@@ -1834,6 +1834,7 @@ void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<in
 			Candidate &o = out[(size_t)c];
 			o.score = d.score;
 			o.posDiff = d.posDiff;
+			o.pairs.reserve((size_t)d.count * 2 + 3);     // room for the gap pairs identify_normal_pairs adds later
 			o.pairs.resize((size_t)d.count);
 			for (int k = 0; k < d.count; ++k) o.pairs[(size_t)k] = from_seed(cand_seeds[(size_t)d.first + (size_t)k]);
 		}
