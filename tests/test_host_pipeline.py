@@ -126,3 +126,18 @@ def test_cli_error_behaviour(host_oracle_binary, tmp_path):
     assert rc == 1 and out == "Error! Paired-end reads input numbers do not match!\nRead1:\n\t%s\nRead2:\n\t%s\n\t%s\n" % (fq, fq, fq)
     rc, out, err = run("-i", SMALL_PREFIX, "-f", fq, "-o", "/nonexistent_dir/x.sam")
     assert "Cannot open file [/nonexistent_dir/x.sam]" in err
+
+
+def test_output_to_a_pipe(host_oracle_binary, tmp_path):
+    """a FIFO cannot be seeked: the writer must fall back from parallel pwrite to one sequential stream"""
+    import threading
+    fifo = str(tmp_path / "out.fifo")
+    os.mkfifo(fifo)
+    got = []
+    t = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()))
+    t.start()
+    args = [materialise(str(tmp_path), a) if a.endswith((".fq", ".fa", ".gz")) else a for a in CASES["pe"]]
+    r = subprocess.run([host_oracle_binary, "-silent", "-t", "4", "-i", SMALL_PREFIX] + args + ["-o", fifo], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    t.join(60)
+    assert r.returncode == 0, r.stdout.decode()[-500:]
+    assert got and got[0] == gzip.open(os.path.join(SAM, "pe.sam.gz")).read()
