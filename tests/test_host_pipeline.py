@@ -96,6 +96,46 @@ def test_speculative_chunks_match_live_reference(ins_mean, threads, host_oracle_
     assert outs[0] == outs[1]
 
 
+def test_odd_input_files_match_live_reference(host_oracle_binary, tmp_path):
+    """inputs the readers must treat exactly like the reference's getline()/gzgets() loops: a second file shorter than the
+    first, CRLF line ends, no newline at the end of the file, empty files, an interleaved file with an odd number of records,
+    one gz and one plain mate file.  Needs oracle/_ref/kart (live comparison)."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "kart")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/kart not present")
+    src1 = open(materialise(str(tmp_path), "pe_1.fq"), "rb").read().split(b"\n")
+    src2 = open(materialise(str(tmp_path), "pe_2.fq"), "rb").read().split(b"\n")
+
+    def make(name, lines, n, eol=b"\n", trail=True, gz=False):
+        data = eol.join(lines[: 4 * n]) + (eol if trail else b"")
+        path = str(tmp_path / name)
+        if gz:
+            with gzip.open(path, "wb") as fh:
+                fh.write(data)
+        else:
+            open(path, "wb").write(data)
+        return path
+
+    a1, a2 = make("a1.fq", src1, 3000), make("a2.fq", src2, 3000)
+    cases = {
+        "short_r2": ["-f", a1, "-f2", make("short2.fq", src2, 2500)],
+        "crlf": ["-f", make("crlf1.fq", src1, 3000, b"\r\n"), "-f2", make("crlf2.fq", src2, 3000, b"\r\n")],
+        "no_final_newline": ["-f", make("nt1.fq", src1, 3000, trail=False), "-f2", make("nt2.fq", src2, 3000, trail=False)],
+        "empty": ["-f", make("empty.fq", [], 0, trail=False)],
+        "interleaved_odd": ["-f", make("odd.fq", src1, 2999), "-p"],
+        "gz_crlf": ["-f", make("crlf1.fq.gz", src1, 3000, b"\r\n", gz=True), "-f2", make("crlf2.fq.gz", src2, 3000, b"\r\n", gz=True)],
+        "gz_short_r2": ["-f", make("a1.fq.gz", src1, 3000, gz=True), "-f2", make("short2.fq.gz", src2, 2500, gz=True)],
+        "gz_and_plain": ["-f", make("b1.fq.gz", src1, 3000, gz=True), "-f2", a2],
+    }
+    for name, args in cases.items():
+        outs = []
+        for binary, extra in ((ref_bin, ["-t", "1"]), (host_oracle_binary, ["-t", "4"])):
+            out = str(tmp_path / (name + "_" + os.path.basename(binary) + ".sam"))
+            r = subprocess.run([binary, "-silent", "-i", SMALL_PREFIX] + args + ["-o", out] + extra, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            outs.append((r.returncode, open(out, "rb").read()))
+        assert outs[0] == outs[1], name
+
+
 @pytest.mark.parametrize("threads", [1, 3, 16])
 def test_output_does_not_depend_on_the_thread_count(threads, host_oracle_binary, tmp_path):
     for case in ("pe", "edge_pe", "pacbio"):
