@@ -403,7 +403,9 @@ void common_kmers(int max_shift, const std::vector<Kmer> &v1, const std::vector<
 struct KmerTable {
 	std::vector<uint16_t> first;     // k-mer id -> 1 + index of the last read k-mer with that id (0 = none)
 	std::vector<uint16_t> next;      // read k-mer -> 1 + index of the previous one with the same id
-	KmerTable() : first((size_t)1 << 16, 0) {}
+	// ids are sums of eight codes 0..4 (a lower-case 'n' is not skipped like 'N' and encodes as 4, as in the reference):
+	// up to 4 * (4^8 - 1) / 3 = 87380, so 2^17 slots
+	KmerTable() : first((size_t)1 << 17, 0) {}
 	void set(const std::vector<Kmer> &kr)      // kr in any order
 	{
 		if (kr.size() >= 65535) return;

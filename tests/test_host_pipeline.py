@@ -127,6 +127,26 @@ def test_odd_input_files_match_live_reference(host_oracle_binary, tmp_path):
         "gz_short_r2": ["-f", make("a1.fq.gz", src1, 3000, gz=True), "-f2", make("short2.fq.gz", src2, 2500, gz=True)],
         "gz_and_plain": ["-f", make("b1.fq.gz", src1, 3000, gz=True), "-f2", a2],
     }
+
+    def fasta(name, lines, n, wrap=None, lower=False, gz=False):
+        rec = []
+        for i in range(n):
+            seq = lines[4 * i + 1]
+            if i % 50 == 7:
+                seq = seq[:17] + b"N" * 40 + seq[57:]              # an ambiguity run inside the read
+            if lower:
+                seq = seq.lower()                                   # ... 'n' is NOT skipped by the 8-mer code, unlike 'N'
+            rec.append(b">" + lines[4 * i][1:])
+            rec += [seq[a:a + wrap] for a in range(0, len(seq), wrap)] if wrap else [seq]
+        return make(name, rec, len(rec), gz=gz)
+
+    cases.update({
+        "fasta_pe": ["-f", fasta("s1.fa", src1, 2000), "-f2", fasta("s2.fa", src2, 2000)],
+        "fasta_wrapped_pe": ["-f", fasta("w1.fa", src1, 2000, wrap=60), "-f2", fasta("w2.fa", src2, 2000, wrap=60)],
+        "fasta_lower_case_with_n_runs": ["-f", fasta("l1.fa", src1, 2000, lower=True), "-f2", fasta("l2.fa", src2, 2000, lower=True)],
+        "fasta_gz_pe": ["-f", fasta("g1.fa.gz", src1, 2000, gz=True), "-f2", fasta("g2.fa.gz", src2, 2000, gz=True)],
+        "fasta_and_fastq": ["-f", fasta("m1.fa", src1, 2000), "-f2", a2],
+    })
     for name, args in cases.items():
         outs = []
         for binary, extra in ((ref_bin, ["-t", "1"]), (host_oracle_binary, ["-t", "4"])):
