@@ -687,7 +687,7 @@ void plan_pair(const Ctx &cx, const Read &rd, const Pair &sp, int role, PairWork
 		w.op = std::make_pair(sp.rLen, 'S');
 		return;
 	}
-	if (sp.rLen == 1 && sp.gLen == 1) {
+	if (sp.rLen == 1 && sp.gLen == 1 && rd.seq[(size_t)sp.rPos] != '-') {   // (a literal '-' in a read is booked as a deletion by the reference's CIGAR scan)
 		// one base against one base -- the mismatch right next to a maximal exact match, by far the most common gap:
 		// nw_alignment can only answer with the diagonal (+-1.5 against -3 for two gaps), the quality check passes a
 		// single column, nothing is trimmed, and AddNewCigarElements (src/tools.cpp:49-104) books 1M with one
