@@ -2,7 +2,8 @@
 """Long-read (-pacbio) counterpart of tools/fuzz_vs_reference.py: 60 reads of 300..9000 bases at 5..25 % error per seed, IUPAC codes,
 lower case, N / n runs; host pipeline (CPU oracle backend) vs oracle/_ref/kart -t 1.  usage: python tools/fuzz_pacbio_vs_reference.py <first> <last>"""
 import subprocess, os, sys, numpy as np
-R='/root/repo'
+R=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AMD=os.environ.get('KART_FUZZ_BIN', R+'/tests/_build/kart-host-oracle')   # KART_FUZZ_BIN=<repo>/kart_amd/bin/kart-amd on a GPU box
 sys.path.insert(0,R)
 from kart_amd import synth
 from kart_amd.index_build import read_fasta
@@ -27,7 +28,7 @@ for seed in range(int(sys.argv[1]),int(sys.argv[2])):
     if fasta: synth.write_fasta(fn,{n:r for n,r in zip(names,out)}) if hasattr(synth,'write_fasta') else None
     else: synth.write_fastq(fn,names,out)
     res=[]
-    for exe,t in ((R+'/oracle/_ref/kart','1'),(R+'/tests/_build/kart-host-oracle','3')):
+    for exe,t in ((R+'/oracle/_ref/kart','1'),(AMD,'3')):
         o='pb_%s.sam'%os.path.basename(exe)
         if os.path.exists(o): os.remove(o)
         try:

@@ -4,7 +4,8 @@
 SE / FASTA / -m.  VALIDATION TOOL (needs oracle/_ref).  usage: python tools/fuzz_vs_reference.py <first_seed> <last_seed>
 Run from a scratch directory; prints every differing case."""
 import subprocess, os, sys, numpy as np
-R='/root/repo'
+R=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AMD=os.environ.get('KART_FUZZ_BIN', R+'/tests/_build/kart-host-oracle')   # KART_FUZZ_BIN=<repo>/kart_amd/bin/kart-amd on a GPU box
 sys.path.insert(0,R)
 from kart_amd.index_build import read_fasta
 g={n:s for n,_,s in read_fasta(R+'/tests/golden/small.fa')}
@@ -42,7 +43,7 @@ def run(seed, mode):
     wr('z1.'+ext,r1,1,fasta); wr('z2.'+ext,r2,2,fasta)
     args={'pe':['-f','z1.fq','-f2','z2.fq'],'se':['-f','z1.fq'],'fa':['-f','z1.fa','-f2','z2.fa'],'pe_m':['-f','z1.fq','-f2','z2.fq','-m']}[mode]
     outs=[]
-    for exe,t in ((R+'/oracle/_ref/kart','1'),(R+'/tests/_build/kart-host-oracle','3')):
+    for exe,t in ((R+'/oracle/_ref/kart','1'),(AMD,'3')):
         out='z_%s.sam'%os.path.basename(exe)
         if os.path.exists(out): os.remove(out)
         try:
