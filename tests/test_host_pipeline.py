@@ -126,6 +126,8 @@ def test_odd_input_files_match_live_reference(host_oracle_binary, tmp_path):
         "gz_crlf": ["-f", make("crlf1.fq.gz", src1, 3000, b"\r\n", gz=True), "-f2", make("crlf2.fq.gz", src2, 3000, b"\r\n", gz=True)],
         "gz_short_r2": ["-f", make("a1.fq.gz", src1, 3000, gz=True), "-f2", make("short2.fq.gz", src2, 2500, gz=True)],
         "gz_and_plain": ["-f", make("b1.fq.gz", src1, 3000, gz=True), "-f2", a2],
+        # several libraries in one run: the pairing statistics carry over from one to the next
+        "two_pe_libraries": ["-f", a1, make("c1.fq.gz", src1[12000:], 1500, gz=True), "-f2", a2, make("c2.fq.gz", src2[12000:], 1500, gz=True)],
     }
 
     def fasta(name, lines, n, wrap=None, lower=False, gz=False):
