@@ -1483,7 +1483,10 @@ int next_chunk(const Ctx &cx, bool sep, Input &in1, Input &in2, std::deque<Owned
 struct MappedFile {
 	const char *data = nullptr;
 	size_t size = 0, pos = 0;
-	~MappedFile() { if (data) munmap(const_cast<char *>(data), size); }
+	bool mapped = false;
+	~MappedFile() { if (data && mapped) munmap(const_cast<char *>(data), size); }
+	// a block of text owned by someone else (the inflated part of a gz file that a batch holds)
+	void attach(const char *text, size_t n) { data = text; size = n; pos = 0; line_end.clear(); next_line = 0; }
 	bool open(const std::string &path)
 	{
 		int fd = ::open(path.c_str(), O_RDONLY);
@@ -1496,6 +1499,7 @@ struct MappedFile {
 		madvise(p, (size_t)sb.st_size, MADV_SEQUENTIAL);
 		data = (const char *)p;
 		size = (size_t)sb.st_size;
+		mapped = true;
 		return true;
 	}
 	// getline(): returns the line length including the newline when there is one, -1 at end of file
@@ -1947,14 +1951,36 @@ struct Batch {
 	std::vector<kg_seed> cand_seeds;
 	std::deque<OwnedRead> owned;                    // storage behind the views (getline()/gzgets() readers)
 	std::vector<std::unique_ptr<char[]>> arenas;    // storage behind reverse-complemented mates (mapped files)
+	std::vector<char> text1, text2;                 // inflated FASTQ text behind the views (gz files)
 	bool eof = false;
 	double seconds = 0, seed_seconds = 0;
 };
 
+// gzipped FASTQ: the text is inflated a batch at a time (both mate files in parallel) into buffers the batch owns and then
+// parsed by the same view code as a mapped file; what is left after the last whole chunk is carried into the next batch
+struct GzText {
+	gzFile f = nullptr;
+	std::vector<char> carry;
+	bool eof = false;
+	double bytes_per_record = 0;
+	void fill(std::vector<char> &buf, size_t want)
+	{
+		size_t at = buf.size(), got = 0;
+		buf.resize(at + want);
+		while (got < want) {
+			int n = gzread(f, buf.data() + at + got, (unsigned)std::min<size_t>(want - got, (size_t)1 << 30));
+			if (n <= 0) { eof = true; break; }
+			got += (size_t)n;
+		}
+		buf.resize(at + got);
+	}
+};
+
 struct Source {
-	bool sep = false, fast = false;
+	bool sep = false, fast = false, gzfast = false;
 	Input in1, in2;            // getline()/gzgets() readers (FASTA, gz)
-	MappedFile m1, m2;         // mapped plain FASTQ
+	MappedFile m1, m2;         // mapped plain FASTQ, or the inflated text of the current batch
+	GzText g1, g2;
 };
 
 // reads `batch_chunks` whole chunks (GetNextChunk each); runs on the prefetch thread
@@ -1963,22 +1989,67 @@ void read_batch(const Ctx &cx, Source &src, int64_t batch_chunks, int chunk_limi
 	double t0 = now_s();
 	b.reads.clear(); b.chunks.clear(); b.owned.clear(); b.arenas.clear(); b.eof = false;
 	std::vector<RecView> views;
+	int64_t parse_chunks = batch_chunks;
+	if (src.gzfast) {
+		const size_t recs_per_file = (size_t)batch_chunks * (size_t)chunk_limit / (src.sep ? 2 : 1);
+		b.text1.swap(src.g1.carry); src.g1.carry.clear();
+		b.text2.swap(src.g2.carry); src.g2.carry.clear();
+		auto want = [&](const GzText &g, const std::vector<char> &t) {
+			size_t est = (size_t)((double)recs_per_file * (g.bytes_per_record > 0 ? g.bytes_per_record * 1.03 : 360.0)) + (1 << 16);
+			return est > t.size() ? est - t.size() : (size_t)0;
+		};
+		size_t need1 = want(src.g1, b.text1), need2 = src.sep ? want(src.g2, b.text2) : 0;
+		for (;;) {
+			std::future<void> other;
+			if (src.sep && !src.g2.eof && need2) other = std::async(std::launch::async, [&]() { src.g2.fill(b.text2, need2); });
+			if (!src.g1.eof && need1) src.g1.fill(b.text1, need1);
+			if (other.valid()) other.get();
+			// the mate files end together or not at all: once one is exhausted the rest of the other is needed
+			if (src.sep && src.g1.eof != src.g2.eof) {
+				GzText &g = src.g1.eof ? src.g2 : src.g1;
+				std::vector<char> &t = src.g1.eof ? b.text2 : b.text1;
+				while (!g.eof) g.fill(t, (size_t)64 << 20);
+			}
+			src.m1.attach(b.text1.data(), b.text1.size());
+			src.m1.index_ahead(pool, b.text1.size());
+			size_t recs1 = src.m1.line_end.size() / 4, recs2 = 0;
+			if (src.sep) {
+				src.m2.attach(b.text2.data(), b.text2.size());
+				src.m2.index_ahead(pool, b.text2.size());
+				recs2 = src.m2.line_end.size() / 4;
+			}
+			bool final = src.g1.eof && (!src.sep || src.g2.eof);
+			if (final) break;                               // everything is in memory: parse to the end
+			size_t reads_avail = src.sep ? 2 * std::min(recs1, recs2) : (recs1 & ~(size_t)1);
+			parse_chunks = std::min<int64_t>(batch_chunks, (int64_t)(reads_avail / (size_t)chunk_limit));
+			if (parse_chunks >= 1) break;
+			need1 = need2 = std::max<size_t>((size_t)1 << 20, recs_per_file * 64);   // not even one whole chunk yet: more text
+		}
+	}
 	if (src.fast) {
-		// roughly the bytes this batch will consume (header + 2 x read + "+"), indexed in parallel
+		// roughly the bytes this batch will consume(header + 2 x read + "+"), indexed in parallel
 		size_t per_file = (size_t)batch_chunks * (size_t)chunk_limit * 400 / (src.sep ? 2 : 1) + (1 << 20);
 		src.m1.index_ahead(pool, per_file);
 		if (src.sep) src.m2.index_ahead(pool, per_file);
 	}
-	while ((int64_t)b.chunks.size() < batch_chunks) {
+	const bool by_views = src.fast || src.gzfast;
+	while ((int64_t)b.chunks.size() < parse_chunks) {
 		ChunkState ck;
-		ck.begin = src.fast ? (int)views.size() : (int)b.owned.size();
-		ck.count = src.fast ? next_chunk_views(cx, src.sep, src.m1, src.m2, views, chunk_limit)
+		ck.begin = by_views ? (int)views.size() : (int)b.owned.size();
+		ck.count = by_views ? next_chunk_views(cx, src.sep, src.m1, src.m2, views, chunk_limit)
 		                    : next_chunk(cx, src.sep, src.in1, src.in2, b.owned, chunk_limit);
 		if (ck.count == 0) { b.eof = true; break; }
 		ck.paired = cx.opt.paired && ck.count % 2 == 0 && !cx.opt.pacbio;
 		b.chunks.push_back(std::move(ck));
 	}
-	if (src.fast) {
+	if (src.gzfast) {   // what the parser did not reach belongs to the next batch
+		size_t n1 = views.size() / (src.sep ? 2 : 1);
+		if (n1 > 0) src.g1.bytes_per_record = (double)src.m1.pos / (double)((views.size() + (src.sep ? 1 : 0)) / (src.sep ? 2 : 1));
+		if (src.sep && views.size() > 1) src.g2.bytes_per_record = (double)src.m2.pos / (double)(views.size() / 2);
+		src.g1.carry.assign(b.text1.begin() + (std::ptrdiff_t)src.m1.pos, b.text1.end());
+		if (src.sep) src.g2.carry.assign(b.text2.begin() + (std::ptrdiff_t)src.m2.pos, b.text2.end());
+	}
+	if (by_views) {
 		b.reads.resize(views.size());
 		int blocks = (int)((views.size() + 2047) / 2048);
 		b.arenas.resize((size_t)blocks);
@@ -2251,6 +2322,8 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		if (sep && !in2.fp && !in2.gz) continue;
 		src.sep = sep;
 		src.fast = want_fast && src.m1.open(f1) && (!sep || src.m2.open(opt.files2[lib]));
+		src.gzfast = gz && cx.fastq && !getenv("KART_AMD_NO_MMAP");
+		if (src.gzfast) { src.g1.f = in1.gz; src.g2.f = in2.gz; gzbuffer(in1.gz, 1 << 20); if (in2.gz) gzbuffer(in2.gz, 1 << 20); }
 		double tl = now_s();
 		map_library(cx, src, out, stats, tot);
 		tot.t_lib += now_s() - tl;
