@@ -2108,7 +2108,10 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	int64_t batch_chunks = 1;
 	// enough chunks per batch to keep every worker busy (static chunk -> worker assignment)
 	// ... and a whole number of chunks per worker, so that the last round of a phase is not half empty
-	int64_t want_chunks = std::max<int64_t>(std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit), cx.opt.pacbio ? 64 * nthreads : 4 * nthreads);
+	// batches are sized in bases: 400 k short reads, or ~10 k long reads (1024 chunks of 10) -- enough to fill the GPU and the
+	// workers, small enough that three batches in flight stay within a few GB and that seeding overlaps the mapping
+	int64_t want_chunks = cx.opt.pacbio ? std::max<int64_t>(1024, 8 * nthreads)
+	                                     : std::max<int64_t>(std::max<int64_t>(1, cx.opt.batch_reads / chunk_limit), 4 * nthreads);
 	const int64_t max_batch_chunks = (want_chunks + nthreads - 1) / nthreads * nthreads;
 	if (!cx.opt.paired || cx.opt.pacbio) batch_chunks = max_batch_chunks;   // no EstDistance feedback to settle: full batches at once
 	std::unique_ptr<Batch> cur(new Batch()), nxt(new Batch()), prev;
