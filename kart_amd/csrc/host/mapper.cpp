@@ -1674,6 +1674,18 @@ public:
 			if (i < n_b) fb(i);
 		});
 	}
+	// the same two sets, but every worker first does ALL its items of the first set, then calls `between` (which may
+	// block), then does its items of the second set
+	void run_ordered(int n_first, const std::function<void(int)> &f_first, const std::function<void()> &between, int n_second,
+	                 const std::function<void(int)> &f_second)
+	{
+		if (n_first <= 0 && n_second <= 0) return;
+		run(n_, [&](int w) {
+			for (int i = w; i < n_first; i += n_) f_first(i);
+			between();
+			for (int i = w; i < n_second; i += n_) f_second(i);
+		});
+	}
 	void run(int n_items, const std::function<void(int)> &fn)
 	{
 		if (n_items <= 0) return;
@@ -2095,10 +2107,11 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	const int nthreads = std::max(1, cx.opt.threads);
 	// Three batches in flight:
 	//   prefetch thread : read + encode + seed (GPU) of batch k+1
-	//   worker pool     : ONE combined phase -- finish/format the chunks of batch k-1 and chain/pair/plan the
-	//                     chunks of batch k, chunk c of either batch on worker c mod n, so whatever a worker
-	//                     allocates for a chunk it also frees (no cross-thread frees)
-	//   main thread     : NW kernel call of batch k, then the in-order commit of batch k-1
+	//   worker pool     : ONE combined phase -- chain/pair/plan the chunks of batch k, then finish/format the chunks of
+	//                     batch k-1, chunk c of either batch on worker c mod n, so whatever a worker allocates for a
+	//                     chunk it also frees (no cross-thread frees)
+	//   helper thread   : NW kernel call of batch k, overlapping the commit of k-1 and the planning of k+1
+	//   main thread     : the in-order commit of batch k-1
 	// The speculated EstDistance therefore lags the committed totals by up to two batches; the commit's
 	// validity check absorbs that.
 	// parsing + encoding costs ~0.4x what the mapping stages cost per read: half as many reader threads keep up
@@ -2115,6 +2128,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 	const int64_t max_batch_chunks = (want_chunks + nthreads - 1) / nthreads * nthreads;
 	if (!cx.opt.paired || cx.opt.pacbio) batch_chunks = max_batch_chunks;   // no EstDistance feedback to settle: full batches at once
 	std::unique_ptr<Batch> cur(new Batch()), nxt(new Batch()), prev;
+	std::shared_future<void> nw_prev;      // the gap-closing kernel call of `prev`, running on its own thread
 
 	auto fetch = [&](Batch *b, int64_t n_chunks) {
 		read_batch(cx, src, n_chunks, chunk_limit, read_pool, *b);
@@ -2184,11 +2198,24 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 		int est_guess = est_distance(cx, tot.iPaired, tot.iDistance);
 		Batch *cp = cur.get(), *pp = prev.get();
 		double t3 = now_s();
-		pool.run2(pp ? (int)pp->chunks.size() : 0, [&](int c) { chunk_stage_c(cx, pp->reads, pp->chunks[(size_t)c]); },
-		          have_cur ? (int)cp->chunks.size() : 0, [&](int c) { chunk_stage_a(cx, cp->reads, cp->seed_off, cp->n_cands, cp->cands, cp->cand_seeds, cp->chunks[(size_t)c], est_guess); });
-		double t4 = now_s(); tot.t_a += t4 - t3;
-		if (have_cur) run_nw(cx, cp->chunks, 0, cp->chunks.size());
-		tot.t_nw += now_s() - t4;
+		// one phase on the pool: plan the chunks of batch k, then -- once the gap-closing kernel call of batch k-1, which has
+		// been running on its own thread since the last phase, is back -- finish and format the chunks of batch k-1
+		std::atomic<int64_t> nw_wait_ns{0};
+		pool.run_ordered(have_cur ? (int)cp->chunks.size() : 0,
+		                 [&](int c) { chunk_stage_a(cx, cp->reads, cp->seed_off, cp->n_cands, cp->cands, cp->cand_seeds, cp->chunks[(size_t)c], est_guess); },
+		                 [&]() {
+			                 if (!nw_prev.valid()) return;
+			                 double tw = now_s();
+			                 nw_prev.wait();
+			                 nw_wait_ns += (int64_t)((now_s() - tw) * 1e9);
+		                 },
+		                 pp ? (int)pp->chunks.size() : 0, [&](int c) { chunk_stage_c(cx, pp->reads, pp->chunks[(size_t)c]); });
+		if (nw_prev.valid()) nw_prev.get();
+		double t4 = now_s();
+		tot.t_nw += 1e-9 * (double)nw_wait_ns.load() / (double)nthreads;   // average time a worker stood waiting for the kernel call
+		tot.t_a += t4 - t3;
+		if (have_cur) nw_prev = std::async(std::launch::async, [&cx, cp]() { run_nw(cx, cp->chunks, 0, cp->chunks.size()); }).share();
+		else nw_prev = std::shared_future<void>();
 		if (pp) commit(*pp);
 		prev = have_cur ? std::move(cur) : nullptr;
 		if (more) {
