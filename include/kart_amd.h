@@ -111,7 +111,8 @@ int  kg_workspace_kernel_ms(kg_workspace *ws, float ms[4]);
 /* Host-buffer form.  enc_bases: concatenated reads, 1 byte/base, codes 0..3 = ACGT, >3 = ambiguous
  * (EnCodeReadSeq, src/Mapping.cpp:482-485); read_offsets[n_reads+1].  On return
  * seed_offsets[n_reads+1] is filled and *seeds points at a library-owned pinned array of
- * seed_offsets[n_reads] entries, valid until the next call on the same workspace.  Per read the
+ * seed_offsets[n_reads] entries, valid until the next call on the same workspace (seeds may be NULL when only
+ * kg_candidates_batch is going to look at them: they then stay on the device).  Per read the
  * entries equal what IdentifySeedPairs_{Fast,Sensitive}Mode returns, in the same order
  * (sorted by (PosDiff,rPos) resp. (gPos,rPos)). */
 int  kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr,
@@ -130,19 +131,20 @@ int64_t kg_workspace_overflow(kg_workspace *ws);   /* 0 = fitted, else seeds nee
 
 /* ---- chaining ----------------------------------------------------------------------------------- */
 /* Candidates of every read of the batch that the LAST kg_seed_batch call on this workspace seeded (its
- * seeds are still resident on the device).  Per read r: n_cands[r] candidates, stored at
- * cands[seed_offsets[r] + c]; candidate seeds (re-sorted by (gPos,rPos) for Illumina, in pick order for
- * PacBio, exactly as the reference leaves AlignmentCandidate_t::SeedVec) at cand_seeds[first .. first+count).
- * n_reads and n_seeds (= seed_offsets[n_reads]) must be those of that call -- they size the three output
- * buffers (n_cands: n_reads; cands, cand_seeds: n_seeds) and a mismatch is KG_ERR_ARG. */
+ * seeds are still resident on the device).  Per read r: n_cands[r] candidates, stored densely in read order --
+ * those of read r are (*cands)[o .. o + n_cands[r]) with o = n_cands[0] + ... + n_cands[r-1] -- and their seeds
+ * (re-sorted by (gPos,rPos) for Illumina, in pick order for PacBio, exactly as the reference leaves
+ * AlignmentCandidate_t::SeedVec) at (*cand_seeds)[first .. first+count).  *cands and *cand_seeds point at library-owned
+ * pinned arrays of *n_cands_total / *n_cand_seeds_total entries, valid until the next call on the same workspace.
+ * n_reads and n_seeds (= seed_offsets[n_reads]) must be those of the seeding call; a mismatch is KG_ERR_ARG. */
 typedef struct {
 	int64_t posDiff;    /* AlignmentCandidate_t::PosDiff (clamped at 0) */
 	int32_t score;      /* sum of seed lengths */
 	int32_t count;      /* seeds in the candidate */
 	int64_t first;      /* index of its first seed in cand_seeds */
 } kg_candidate;
-int  kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_reads, int64_t n_seeds,
-                         int32_t *n_cands, kg_candidate *cands, kg_seed *cand_seeds);
+int  kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_reads, int64_t n_seeds, int32_t *n_cands,
+                         const kg_candidate **cands, int64_t *n_cands_total, const kg_seed **cand_seeds, int64_t *n_cand_seeds_total);
 
 /* ---- Needleman-Wunsch gap closing ----------------------------------------------------------- */
 /* n fragment pairs: frag1 (read side, raw characters) concatenated with offsets off1[n+1], frag2

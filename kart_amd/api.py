@@ -94,7 +94,8 @@ def load_library() -> C.CDLL:
                                 C.c_void_p, C.POINTER(C.c_void_p)]
     L.kg_seed_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
-    L.kg_candidates_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kg_candidates_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.kg_nw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.kg_nw_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
@@ -175,15 +176,18 @@ class Workspace:
         Returns one list per read of (score, posDiff, seeds structured array)."""
         n = len(seed_offsets) - 1
         total = int(seed_offsets[n])
-        ncand = np.zeros(n, dtype=np.int32)
-        cands = np.zeros(total + 1, dtype=CAND_DT)
-        cseeds = np.zeros(total + 1, dtype=SEED_DT)
-        _check(self.lib.kg_candidates_batch(self.h, int(pacbio), max_gaps, n, total, _ptr(ncand), _ptr(cands), _ptr(cseeds)), "kg_candidates_batch")
-        out = []
+        ncand = np.zeros(n + 1, dtype=np.int32)
+        pc, ps, nc, ns = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
+        _check(self.lib.kg_candidates_batch(self.h, int(pacbio), max_gaps, n, total, _ptr(ncand), C.byref(pc), C.byref(nc), C.byref(ps), C.byref(ns)),
+               "kg_candidates_batch")
+        cands = np.frombuffer((C.c_char * (nc.value * CAND_DT.itemsize)).from_address(pc.value), dtype=CAND_DT).copy() if nc.value else np.zeros(0, CAND_DT)
+        cseeds = np.frombuffer((C.c_char * (ns.value * SEED_DT.itemsize)).from_address(ps.value), dtype=SEED_DT).copy() if ns.value else np.zeros(0, SEED_DT)
+        out, at = [], 0
         for r in range(n):
             lst = []
-            for c in cands[seed_offsets[r]:seed_offsets[r] + ncand[r]]:
+            for c in cands[at:at + ncand[r]]:
                 lst.append((int(c["score"]), int(c["posDiff"]), cseeds[c["first"]:c["first"] + c["count"]].copy()))
+            at += int(ncand[r])
             out.append(lst)
         return out
 

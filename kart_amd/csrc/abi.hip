@@ -125,6 +125,11 @@ struct kg_workspace {
 	kg_seed *d_cand_seeds = nullptr;
 	int32_t *d_n_cands = nullptr;
 	uint8_t *d_taken = nullptr;
+	int32_t *d_used = nullptr;
+	int64_t *d_cand_off = nullptr, *d_cseed_off = nullptr;
+	kg_candidate *d_dense_cands = nullptr, *h_cands = nullptr;
+	kg_seed *d_dense_seeds = nullptr, *h_cand_seeds = nullptr;
+	int64_t h_cand_capacity = 0;
 	int64_t cand_capacity = 0, ncand_capacity = 0;
 	kg_seed *h_seeds = nullptr;     // pinned
 	int64_t h_seed_capacity = 0;
@@ -385,7 +390,7 @@ int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_w
 	HIP_TRY(hipMalloc((void **)&ws->d_seeds_per_read, 4 * (size_t)max_reads));
 	HIP_TRY(hipMalloc((void **)&ws->d_ctl, 8 * kCtlWords));
 	HIP_TRY(hipMemset(ws->d_ctl, 0, 8 * kCtlWords));
-	ws->scan_bytes = scan_temp_bytes(max_reads);
+	ws->scan_bytes = scan_temp_bytes(max_reads + 1);
 	HIP_TRY(hipMalloc(&ws->d_scan_temp, ws->scan_bytes ? ws->scan_bytes : 256));
 	HIP_TRY(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
 	*out = ws.release();
@@ -397,7 +402,9 @@ void kg_workspace_destroy(kg_workspace *ws)
 	if (!ws) return;
 	(void)hipSetDevice(ws->ix->device);
 	if (ws->stream) { (void)hipStreamSynchronize(ws->stream); (void)hipStreamDestroy(ws->stream); }
-	void *ptrs[] = {ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
+	if (ws->h_cands) (void)hipHostFree(ws->h_cands);
+	if (ws->h_cand_seeds) (void)hipHostFree(ws->h_cand_seeds);
+	void *ptrs[] = {ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (ws->h_seeds) (void)hipHostFree(ws->h_seeds);
@@ -500,8 +507,8 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, const uint8_t *enc_bases,
                   const int64_t *read_offsets, int64_t n_reads, int64_t *seed_offsets, const kg_seed **seeds)
 {
-	if (!ws || !read_offsets || !seed_offsets || !seeds) return fail(KG_ERR_ARG, "kg_seed_batch: null argument");
-	*seeds = nullptr;
+	if (!ws || !read_offsets || !seed_offsets) return fail(KG_ERR_ARG, "kg_seed_batch: null argument");
+	if (seeds) *seeds = nullptr;
 	int64_t n_bases = n_reads > 0 ? read_offsets[n_reads] - read_offsets[0] : 0;
 	if (n_reads > 0 && read_offsets[0] != 0) return fail(KG_ERR_ARG, "kg_seed_batch: read_offsets[0] must be 0");
 	int rc = check_seed_args(ws, mode, min_seed_len, occ_thr, n_reads, n_bases);
@@ -534,6 +541,9 @@ int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, con
 		if (attempt == 1) return fail(KG_ERR_CAPACITY, "kg_seed_batch: seed buffer overflow persisted");
 	}
 	int64_t total = seed_offsets[n_reads];
+	ws->last_reads = n_reads;
+	ws->last_seeds = total;
+	if (!seeds) return KG_OK;             // the caller only wants the candidates: the seeds stay on the device
 	if (total > ws->h_seed_capacity) {
 		if (ws->h_seeds) HIP_TRY(hipHostFree(ws->h_seeds));
 		ws->h_seeds = nullptr;
@@ -553,12 +563,12 @@ int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, con
 
 // Replaces GenerateAlignmentCandidateForIlluminaSeq / ForPacBioSeq (reference src/AlignmentCandidates.cpp:82-130,
 // 171-224) for every read of the batch the last kg_seed_batch call left on the device.
-int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_reads, int64_t n_seeds,
-                         int32_t *n_cands, kg_candidate *cands, kg_seed *cand_seeds)
+int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_reads, int64_t n_seeds, int32_t *n_cands,
+                         const kg_candidate **cands, int64_t *n_cands_total, const kg_seed **cand_seeds, int64_t *n_cand_seeds_total)
 {
-	if (!ws || !n_cands) return fail(KG_ERR_ARG, "kg_candidates_batch: null argument");
+	if (!ws || !n_cands || !cands || !n_cands_total || !cand_seeds || !n_cand_seeds_total) return fail(KG_ERR_ARG, "kg_candidates_batch: null argument");
+	*cands = nullptr; *cand_seeds = nullptr; *n_cands_total = 0; *n_cand_seeds_total = 0;
 	if (ws->last_reads <= 0) return fail(KG_ERR_ARG, "kg_candidates_batch: no seeded batch on this workspace (call kg_seed_batch first)");
-	if (ws->last_seeds > 0 && (!cands || !cand_seeds)) return fail(KG_ERR_ARG, "kg_candidates_batch: null output buffer");
 	if (max_gaps < 0) return fail(KG_ERR_ARG, "kg_candidates_batch: negative max_gaps");
 	if (n_reads != ws->last_reads || n_seeds != ws->last_seeds)
 		return fail(KG_ERR_ARG, "kg_candidates_batch: batch shape (%lld reads, %lld seeds) is not the one kg_seed_batch left on this workspace (%lld, %lld)",
@@ -566,33 +576,55 @@ int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_re
 	HIP_TRY(hipSetDevice(ws->ix->device));
 	int64_t n = ws->last_reads, m = ws->last_seeds;
 	if (m + 1 > ws->cand_capacity) {
-		for (void *p : {(void *)ws->d_cands, (void *)ws->d_cand_seeds, (void *)ws->d_taken})
+		for (void *p : {(void *)ws->d_cands, (void *)ws->d_cand_seeds, (void *)ws->d_taken, (void *)ws->d_dense_cands, (void *)ws->d_dense_seeds})
 			if (p) HIP_TRY(hipFree(p));
-		ws->d_cands = nullptr; ws->d_cand_seeds = nullptr; ws->d_taken = nullptr;
+		ws->d_cands = nullptr; ws->d_cand_seeds = nullptr; ws->d_taken = nullptr; ws->d_dense_cands = nullptr; ws->d_dense_seeds = nullptr;
 		int64_t cap = m + m / 4 + 1024;
 		HIP_TRY(hipMalloc((void **)&ws->d_cands, sizeof(kg_candidate) * (size_t)cap));
 		HIP_TRY(hipMalloc((void **)&ws->d_cand_seeds, sizeof(kg_seed) * (size_t)cap));
 		HIP_TRY(hipMalloc((void **)&ws->d_taken, (size_t)cap));
+		HIP_TRY(hipMalloc((void **)&ws->d_dense_cands, sizeof(kg_candidate) * (size_t)cap));
+		HIP_TRY(hipMalloc((void **)&ws->d_dense_seeds, sizeof(kg_seed) * (size_t)cap));
 		ws->cand_capacity = cap;
 	}
-	if (n > ws->ncand_capacity) {
-		if (ws->d_n_cands) HIP_TRY(hipFree(ws->d_n_cands));
-		ws->d_n_cands = nullptr;
-		HIP_TRY(hipMalloc((void **)&ws->d_n_cands, 4 * (size_t)(n + 1024)));
-		ws->ncand_capacity = n + 1024;
+	if (n + 1 > ws->ncand_capacity) {
+		for (void *p : {(void *)ws->d_n_cands, (void *)ws->d_used, (void *)ws->d_cand_off, (void *)ws->d_cseed_off})
+			if (p) HIP_TRY(hipFree(p));
+		ws->d_n_cands = nullptr; ws->d_used = nullptr; ws->d_cand_off = nullptr; ws->d_cseed_off = nullptr;
+		int64_t cap = n + 1024;
+		HIP_TRY(hipMalloc((void **)&ws->d_n_cands, 4 * (size_t)cap));
+		HIP_TRY(hipMalloc((void **)&ws->d_used, 4 * (size_t)cap));
+		HIP_TRY(hipMalloc((void **)&ws->d_cand_off, 8 * (size_t)cap));
+		HIP_TRY(hipMalloc((void **)&ws->d_cseed_off, 8 * (size_t)cap));
+		ws->ncand_capacity = cap;
 	}
 	ChainArgs a;
 	a.read_off = ws->d_read_off; a.n_reads = n; a.seed_off = ws->d_seed_off; a.seeds = ws->d_seeds;
 	a.contig_end = ws->ix->d_contig_end; a.n_ends = ws->ix->n_ends;
 	a.pacbio = pacbio ? 1 : 0; a.max_gaps = max_gaps;
-	a.n_cands = ws->d_n_cands; a.cands = ws->d_cands; a.cand_seeds = ws->d_cand_seeds; a.taken = ws->d_taken;
-	HIP_TRY(launch_chain_batch(a, ws->ix->n_cu, ws->stream));
+	a.n_cands = ws->d_n_cands; a.used = ws->d_used; a.cands = ws->d_cands; a.cand_seeds = ws->d_cand_seeds; a.taken = ws->d_taken;
+	a.cand_off = ws->d_cand_off; a.cseed_off = ws->d_cseed_off; a.dense_cands = ws->d_dense_cands; a.dense_seeds = ws->d_dense_seeds;
+	HIP_TRY(launch_chain_batch(a, ws->d_scan_temp, ws->scan_bytes, ws->ix->n_cu, ws->stream));
+	int64_t totals[2] = {0, 0};
 	HIP_TRY(hipMemcpyAsync(n_cands, ws->d_n_cands, 4 * (size_t)n, hipMemcpyDeviceToHost, ws->stream));
-	if (m > 0) {
-		HIP_TRY(hipMemcpyAsync(cands, ws->d_cands, sizeof(kg_candidate) * (size_t)m, hipMemcpyDeviceToHost, ws->stream));
-		HIP_TRY(hipMemcpyAsync(cand_seeds, ws->d_cand_seeds, sizeof(kg_seed) * (size_t)m, hipMemcpyDeviceToHost, ws->stream));
-	}
+	HIP_TRY(hipMemcpyAsync(&totals[0], ws->d_cand_off + n, 8, hipMemcpyDeviceToHost, ws->stream));
+	HIP_TRY(hipMemcpyAsync(&totals[1], ws->d_cseed_off + n, 8, hipMemcpyDeviceToHost, ws->stream));
 	HIP_TRY(hipStreamSynchronize(ws->stream));
+	int64_t need = std::max(totals[0], totals[1]);
+	if (need > ws->h_cand_capacity) {
+		if (ws->h_cands) HIP_TRY(hipHostFree(ws->h_cands));
+		if (ws->h_cand_seeds) HIP_TRY(hipHostFree(ws->h_cand_seeds));
+		ws->h_cands = nullptr; ws->h_cand_seeds = nullptr;
+		int64_t cap = need + need / 4 + 1024;
+		HIP_TRY(hipHostMalloc((void **)&ws->h_cands, sizeof(kg_candidate) * (size_t)cap, hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void **)&ws->h_cand_seeds, sizeof(kg_seed) * (size_t)cap, hipHostMallocDefault));
+		ws->h_cand_capacity = cap;
+	}
+	if (totals[0] > 0) HIP_TRY(hipMemcpyAsync(ws->h_cands, ws->d_dense_cands, sizeof(kg_candidate) * (size_t)totals[0], hipMemcpyDeviceToHost, ws->stream));
+	if (totals[1] > 0) HIP_TRY(hipMemcpyAsync(ws->h_cand_seeds, ws->d_dense_seeds, sizeof(kg_seed) * (size_t)totals[1], hipMemcpyDeviceToHost, ws->stream));
+	HIP_TRY(hipStreamSynchronize(ws->stream));
+	*cands = ws->h_cands; *cand_seeds = ws->h_cand_seeds;
+	*n_cands_total = totals[0]; *n_cand_seeds_total = totals[1];
 	return KG_OK;
 }
 

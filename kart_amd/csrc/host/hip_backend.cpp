@@ -37,24 +37,26 @@ public:
 		kg_index_destroy(ix_);
 	}
 	int min_seed_len() const override { return info_.min_seed_len; }
-	void seed_batch(int mode, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off, std::vector<int64_t> &seed_off,
-	                std::vector<kg_seed> &seeds) override
+	void seed_and_chain(int mode, bool pacbio, int max_gaps, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off,
+	                    std::vector<int32_t> &n_cands, std::vector<int64_t> &cand_off, std::vector<kg_candidate> &cands,
+	                    std::vector<kg_seed> &cand_seeds) override
 	{
 		int64_t n = (int64_t)off.size() - 1;
 		reserve(n, off[(size_t)n]);
-		seed_off.assign(off.size(), 0);
-		const kg_seed *out = nullptr;
-		if (kg_seed_batch(ws_, mode, info_.min_seed_len, KG_OCC_THR_DEFAULT, enc.data(), off.data(), n, seed_off.data(), &out) != KG_OK) die("kg_seed_batch");
-		seeds.assign(out, out + seed_off[(size_t)n]);
-	}
-	void candidates_batch(bool pacbio, int max_gaps, const std::vector<int64_t> &, const std::vector<int64_t> &seed_off,
-	                      const std::vector<kg_seed> &, std::vector<int32_t> &n_cands, std::vector<kg_candidate> &cands,
-	                      std::vector<kg_seed> &cand_seeds) override
-	{
-		// the seeds are still on the device (same workspace, same thread as seed_batch)
-		size_t n = seed_off.size() - 1, m = (size_t)seed_off[n];
-		n_cands.resize(n + 1); cands.resize(m + 1); cand_seeds.resize(m + 1);
-		if (kg_candidates_batch(ws_, pacbio ? 1 : 0, max_gaps, (int64_t)n, (int64_t)m, n_cands.data(), cands.data(), cand_seeds.data()) != KG_OK) die("kg_candidates_batch");
+		seed_off_.assign(off.size(), 0);
+		// the seeds stay on the device (seeds = NULL); only the chained candidates come back, packed
+		if (kg_seed_batch(ws_, mode, info_.min_seed_len, KG_OCC_THR_DEFAULT, enc.data(), off.data(), n, seed_off_.data(), nullptr) != KG_OK) die("kg_seed_batch");
+		n_cands.assign((size_t)n + 1, 0);
+		const kg_candidate *c = nullptr;
+		const kg_seed *cs = nullptr;
+		int64_t nc = 0, ns = 0;
+		if (kg_candidates_batch(ws_, pacbio ? 1 : 0, max_gaps, n, seed_off_[(size_t)n], n_cands.data(), &c, &nc, &cs, &ns) != KG_OK) die("kg_candidates_batch");
+		cands.assign(c, c + nc);          // the library's pinned arrays are overwritten by the next batch
+		cand_seeds.assign(cs, cs + ns);
+		cand_off.resize((size_t)n + 1);
+		int64_t at = 0;
+		for (int64_t r = 0; r < n; ++r) { cand_off[(size_t)r] = at; at += n_cands[(size_t)r]; }
+		cand_off[(size_t)n] = at;
 	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
 	{
@@ -102,6 +104,7 @@ private:
 	std::vector<int64_t> o1_, o2_;
 	std::vector<uint8_t> ops_;
 	std::vector<int32_t> len_;
+	std::vector<int64_t> seed_off_;
 	kg_workspace *ws_ = nullptr;
 	kg_index_info_t info_;
 };

@@ -1832,7 +1832,7 @@ struct Section {
 };
 
 // stage A: chaining, pairing, rescue, filters, report pass 1 (collects the chunk's NW jobs)
-void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<int64_t> &seed_off, const std::vector<int32_t> &n_cands,
+void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<int64_t> &cand_off, const std::vector<int32_t> &n_cands,
                    const std::vector<kg_candidate> &dev_cands, const std::vector<kg_seed> &cand_seeds, ChunkState &ck, int est)
 {
 	ck.est_used = est;
@@ -1848,7 +1848,7 @@ void chunk_stage_a(const Ctx &cx, std::vector<Read> &reads, const std::vector<in
 		std::vector<Candidate> &out = ck.cands[(size_t)q];
 		out.resize((size_t)n_cands[ri]);
 		for (int c = 0; c < n_cands[ri]; ++c) {
-			const kg_candidate &d = dev_cands[(size_t)seed_off[ri] + (size_t)c];
+			const kg_candidate &d = dev_cands[(size_t)cand_off[ri] + (size_t)c];
 			Candidate &o = out[(size_t)c];
 			o.score = d.score;
 			o.posDiff = d.posDiff;
@@ -1956,8 +1956,7 @@ struct Batch {
 	std::vector<ChunkState> chunks;
 	std::vector<uint8_t> enc;                       // EnCodeReadSeq output, concatenated
 	std::vector<int64_t> off;
-	std::vector<int64_t> seed_off;                  // per-read seed ranges of this batch (filled by the seeding stage)
-	std::vector<kg_seed> seeds;
+	std::vector<int64_t> cand_off;                  // per-read candidate ranges of this batch (filled by the seeding + chaining stage)
 	std::vector<int32_t> n_cands;                   // chaining results of this batch (kg_candidates_batch)
 	std::vector<kg_candidate> cands;
 	std::vector<kg_seed> cand_seeds;
@@ -2134,8 +2133,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 		read_batch(cx, src, n_chunks, chunk_limit, read_pool, *b);
 		double t = now_s();
 		if (!b->reads.empty()) {
-			cx.kern.seed_batch(mode, b->enc, b->off, b->seed_off, b->seeds);
-			cx.kern.candidates_batch(cx.opt.pacbio, cx.opt.max_gaps, b->off, b->seed_off, b->seeds, b->n_cands, b->cands, b->cand_seeds);
+			cx.kern.seed_and_chain(mode, cx.opt.pacbio, cx.opt.max_gaps, b->enc, b->off, b->n_cands, b->cand_off, b->cands, b->cand_seeds);
 		}
 		b->seed_seconds = now_s() - t;
 	};
@@ -2164,7 +2162,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 			if (redo.empty()) break;
 			st.respeculated += (int64_t)redo.size();
 			pool.run((int)redo.size(), [&](int i) {
-				chunk_stage_a(cx, b.reads, b.seed_off, b.n_cands, b.cands, b.cand_seeds, b.chunks[redo[(size_t)i].first], redo[(size_t)i].second);
+				chunk_stage_a(cx, b.reads, b.cand_off, b.n_cands, b.cands, b.cand_seeds, b.chunks[redo[(size_t)i].first], redo[(size_t)i].second);
 			});
 			std::vector<NwJobs *> parts;
 			for (const std::pair<size_t, int> &r : redo)
@@ -2202,7 +2200,7 @@ void map_library(Ctx &cx, Source &src, FILE *out, Stats &st, RunTotals &tot)
 		// been running on its own thread since the last phase, is back -- finish and format the chunks of batch k-1
 		std::atomic<int64_t> nw_wait_ns{0};
 		pool.run_ordered(have_cur ? (int)cp->chunks.size() : 0,
-		                 [&](int c) { chunk_stage_a(cx, cp->reads, cp->seed_off, cp->n_cands, cp->cands, cp->cand_seeds, cp->chunks[(size_t)c], est_guess); },
+		                 [&](int c) { chunk_stage_a(cx, cp->reads, cp->cand_off, cp->n_cands, cp->cands, cp->cand_seeds, cp->chunks[(size_t)c], est_guess); },
 		                 [&]() {
 			                 if (!nw_prev.valid()) return;
 			                 double tw = now_s();

@@ -2,8 +2,7 @@
 //
 // Mirrors the reference's driver (reference src/Mapping.cpp, src/GetData.cpp, src/main.cpp) above
 // the C ABI of include/kart_amd.h.  The three hot-path stages are batched:
-//     seeding      -> KernelBackend::seed_batch        (kg_seed_batch,        HIP)
-//     chaining     -> KernelBackend::candidates_batch  (kg_candidates_batch,  HIP)
+//     seeding + chaining -> KernelBackend::seed_and_chain  (kg_seed_batch + kg_candidates_batch, HIP)
 //     gap closing  -> KernelBackend::nw_batch    (kg_nw_batch,     HIP)
 // everything else here is the reference's per-read control flow restated on the host (chaining,
 // pairing with the EstDistance feedback, mate rescue, report, flags, MAPQ, SAM text), written to
@@ -67,14 +66,12 @@ struct KernelBackend {
 	virtual ~KernelBackend() {}
 	// index constants the host needs
 	virtual int min_seed_len() const = 0;
-	// IdentifySeedPairs_{Fast,Sensitive}Mode for a batch: enc = concatenated codes, off[n+1]
-	virtual void seed_batch(int mode, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off,
-	                        std::vector<int64_t> &seed_off, std::vector<kg_seed> &seeds) = 0;
-	// GenerateAlignmentCandidateFor{Illumina,PacBio}Seq for the batch the last seed_batch call seeded:
-	// n_cands[r] candidates at cands[seed_off[r] ...], their seeds at cand_seeds[cands[].first ...]
-	virtual void candidates_batch(bool pacbio, int max_gaps, const std::vector<int64_t> &off, const std::vector<int64_t> &seed_off,
-	                              const std::vector<kg_seed> &seeds, std::vector<int32_t> &n_cands, std::vector<kg_candidate> &cands,
-	                              std::vector<kg_seed> &cand_seeds) = 0;
+	// IdentifySeedPairs_{Fast,Sensitive}Mode + GenerateAlignmentCandidateFor{Illumina,PacBio}Seq for a batch: enc = concatenated
+	// codes, off[n+1].  Out: n_cands[r] candidates per read, stored densely in read order (those of read r start at
+	// cand_off[r]), their seeds at cand_seeds[cands[].first ...].  The seeds themselves never leave the device.
+	virtual void seed_and_chain(int mode, bool pacbio, int max_gaps, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off,
+	                            std::vector<int32_t> &n_cands, std::vector<int64_t> &cand_off, std::vector<kg_candidate> &cands,
+	                            std::vector<kg_seed> &cand_seeds) = 0;
 	// nw_alignment for the jobs of several chunks in one call (fills ops/len of every part)
 	virtual void nw_batch(std::vector<NwJobs *> &parts) = 0;
 };

@@ -852,17 +852,29 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a)
 			}
 		}
 		a.n_cands[r] = nc;
+		a.used[r] = (int32_t)used;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) { a.n_cands[a.n_reads] = 0; a.used[a.n_reads] = 0; }
+}
+
+// the candidates and their seeds, packed in read order (what goes back to the host)
+__global__ __launch_bounds__(256) void compact_cands_kernel(ChainArgs a)
+{
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; r < a.n_reads; r += stride) {
+		const int64_t base = a.seed_off[r], co = a.cand_off[r], so = a.cseed_off[r];
+		const int nc = a.n_cands[r], ns = a.used[r];
+		for (int c = 0; c < nc; ++c) {
+			kg_candidate v = a.cands[base + c];
+			v.first = so + (v.first - base);
+			a.dense_cands[co + c] = v;
+		}
+		for (int i = 0; i < ns; ++i) a.dense_seeds[so + i] = a.cand_seeds[base + i];
 	}
 }
 
-hipError_t launch_chain_batch(const ChainArgs &a, int n_cu, hipStream_t stream)
-{
-	if (a.n_reads <= 0) return hipSuccess;
-	int64_t g = (a.n_reads + 255) / 256;
-	if (g > (int64_t)n_cu * 16) g = (int64_t)n_cu * 16;
-	hipLaunchKernelGGL(chain_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
-	return hipGetLastError();
-}
+hipError_t launch_chain_batch(const ChainArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream);
 
 __global__ void finish_offsets_kernel(SeedArgs a)
 {
@@ -1078,6 +1090,23 @@ size_t scan_temp_bytes(int64_t max_reads)
 	WideIter it((const int32_t *)nullptr, WidenOp());
 	(void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, (int64_t *)nullptr, (int)max_reads);   // size query only
 	return bytes;
+}
+
+hipError_t launch_chain_batch(const ChainArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream)
+{
+	if (a.n_reads <= 0) return hipSuccess;
+	int64_t g = (a.n_reads + 255) / 256;
+	if (g > (int64_t)n_cu * 16) g = (int64_t)n_cu * 16;
+	hipLaunchKernelGGL(chain_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
+	hipError_t e;
+	size_t tb = scan_temp_bytes;
+	WideIter it1(a.n_cands, WidenOp());
+	if ((e = hipcub::DeviceScan::ExclusiveSum(scan_temp, tb, it1, a.cand_off, (int)(a.n_reads + 1), stream)) != hipSuccess) return e;
+	tb = scan_temp_bytes;
+	WideIter it2(a.used, WidenOp());
+	if ((e = hipcub::DeviceScan::ExclusiveSum(scan_temp, tb, it2, a.cseed_off, (int)(a.n_reads + 1), stream)) != hipSuccess) return e;
+	hipLaunchKernelGGL(compact_cands_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
+	return hipGetLastError();
 }
 
 hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream, hipEvent_t *ev)

@@ -60,12 +60,17 @@ struct ChainArgs {
 	const int64_t *contig_end;   // ChrLocMap keys (last coordinate of every strand copy), ascending
 	int n_ends;
 	int pacbio, max_gaps;
-	int32_t *n_cands;
-	kg_candidate *cands;
+	int32_t *n_cands;            // [n_reads + 1], the last entry stays 0 (scan tail)
+	int32_t *used;               // [n_reads + 1] candidate seeds written per read
+	kg_candidate *cands;         // sparse: candidate c of read r at seed_off[r] + c
 	kg_seed *cand_seeds;
 	uint8_t *taken;              // PacBio: one flag per seed
+	// dense outputs (read order), filled by the compaction pass
+	int64_t *cand_off, *cseed_off;   // [n_reads + 1] exclusive scans of n_cands / used
+	kg_candidate *dense_cands;
+	kg_seed *dense_seeds;
 };
-hipError_t launch_chain_batch(const ChainArgs &a, int n_cu, hipStream_t stream);
+hipError_t launch_chain_batch(const ChainArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream);
 
 struct NwArgs {
 	const char *f1;

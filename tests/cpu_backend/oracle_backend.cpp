@@ -19,48 +19,46 @@ public:
 	explicit OracleBackend(ko_index *ix) : ix_(ix) {}
 	~OracleBackend() override { ko_index_free(ix_); }
 	int min_seed_len() const override { return ko_min_seed_len(ix_); }
-	void seed_batch(int mode, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off, std::vector<int64_t> &seed_off,
-	                std::vector<kg_seed> &seeds) override
+	void seed_and_chain(int mode, bool pacbio, int max_gaps, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off,
+	                    std::vector<int32_t> &n_cands, std::vector<int64_t> &cand_off, std::vector<kg_candidate> &cands,
+	                    std::vector<kg_seed> &cand_seeds) override
 	{
 		int64_t n = (int64_t)off.size() - 1;
-		seed_off.assign(off.size(), 0);
+		std::vector<int64_t> seed_off(off.size(), 0);
 		std::vector<ko_seed> buf((size_t)(64 * n + 65536));
 		int64_t t = ko_seed_batch(ix_, mode, ko_min_seed_len(ix_), enc.data(), off.data(), n, seed_off.data(), buf.data(), (int64_t)buf.size(), 4);
 		if (t < 0) {
 			buf.resize((size_t)(-t));
 			t = ko_seed_batch(ix_, mode, ko_min_seed_len(ix_), enc.data(), off.data(), n, seed_off.data(), buf.data(), (int64_t)buf.size(), 4);
 		}
-		seeds.resize((size_t)t);
-		for (int64_t i = 0; i < t; ++i) { seeds[(size_t)i].gPos = buf[(size_t)i].gPos; seeds[(size_t)i].rPos = buf[(size_t)i].rPos; seeds[(size_t)i].len = buf[(size_t)i].len; }
-	}
-	void candidates_batch(bool pacbio, int max_gaps, const std::vector<int64_t> &off, const std::vector<int64_t> &seed_off,
-	                      const std::vector<kg_seed> &seeds, std::vector<int32_t> &n_cands, std::vector<kg_candidate> &cands,
-	                      std::vector<kg_seed> &cand_seeds) override
-	{
-		size_t n = seed_off.size() - 1, m = (size_t)seed_off[n];
-		n_cands.assign(n + 1, 0); cands.assign(m + 1, kg_candidate()); cand_seeds.assign(m + 1, kg_seed());
-		for (size_t r = 0; r < n; ++r) {
-			int ns = (int)(seed_off[r + 1] - seed_off[r]);
+		n_cands.assign((size_t)n + 1, 0);
+		cand_off.assign((size_t)n + 1, 0);
+		cands.clear(); cand_seeds.clear();
+		for (int64_t r = 0; r < n; ++r) {
+			cand_off[(size_t)r] = (int64_t)cands.size();
+			int ns = (int)(seed_off[(size_t)r + 1] - seed_off[(size_t)r]);
 			if (ns == 0) continue;
-			std::vector<ko_seed> in((size_t)ns);
-			for (int i = 0; i < ns; ++i) { const kg_seed &s = seeds[(size_t)seed_off[r] + (size_t)i]; in[(size_t)i].gPos = s.gPos; in[(size_t)i].rPos = s.rPos; in[(size_t)i].len = s.len; }
+			const ko_seed *in = buf.data() + seed_off[(size_t)r];
 			std::vector<int> coff((size_t)ns + 2), score((size_t)ns + 1);
 			std::vector<int64_t> pd((size_t)ns + 1);
 			std::vector<ko_pair> pairs((size_t)ns + 1);
-			int rlen = (int)(off[r + 1] - off[r]);
-			int nc = pacbio ? ko_candidates_pacbio(ix_, rlen, in.data(), ns, coff.data(), score.data(), pd.data(), pairs.data(), ns + 1, ns + 1)
-			                : ko_candidates_illumina(ix_, rlen, max_gaps, in.data(), ns, coff.data(), score.data(), pd.data(), pairs.data(), ns + 1, ns + 1);
+			int rlen = (int)(off[(size_t)r + 1] - off[(size_t)r]);
+			int nc = pacbio ? ko_candidates_pacbio(ix_, rlen, in, ns, coff.data(), score.data(), pd.data(), pairs.data(), ns + 1, ns + 1)
+			                : ko_candidates_illumina(ix_, rlen, max_gaps, in, ns, coff.data(), score.data(), pd.data(), pairs.data(), ns + 1, ns + 1);
 			if (nc < 0) { fprintf(stderr, "oracle backend: candidate buffers too small\n"); exit(1); }
-			n_cands[r] = nc;
+			n_cands[(size_t)r] = nc;
 			for (int c = 0; c < nc; ++c) {
-				kg_candidate &o = cands[(size_t)seed_off[r] + (size_t)c];
-				o.posDiff = pd[(size_t)c]; o.score = score[(size_t)c]; o.count = coff[(size_t)c + 1] - coff[(size_t)c]; o.first = seed_off[r] + coff[(size_t)c];
+				kg_candidate o;
+				o.posDiff = pd[(size_t)c]; o.score = score[(size_t)c]; o.count = coff[(size_t)c + 1] - coff[(size_t)c]; o.first = (int64_t)cand_seeds.size();
 				for (int q = coff[(size_t)c]; q < coff[(size_t)c + 1]; ++q) {
-					kg_seed &d = cand_seeds[(size_t)seed_off[r] + (size_t)q];
+					kg_seed d;
 					d.gPos = pairs[(size_t)q].gPos; d.rPos = pairs[(size_t)q].rPos; d.len = pairs[(size_t)q].rLen;
+					cand_seeds.push_back(d);
 				}
+				cands.push_back(o);
 			}
 		}
+		cand_off[(size_t)n] = (int64_t)cands.size();
 	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
 	{

@@ -18,7 +18,8 @@ ws.set_profiling(True)
 for it in range(3):
     t = time.time(); so, seeds = ws.seed_batch(enc, off, 1); t1 = time.time() - t
     ms = ws.kernel_ms()
-    t = time.time(); c = ws.lib.kg_candidates_batch  # timing of the chaining call through the python wrapper includes the unpacking; use raw call
-    ncand = np.zeros(len(off) - 1, dtype=np.int32); cands = np.zeros(int(so[-1]) + 1, dtype=api.CAND_DT); cs = np.zeros(int(so[-1]) + 1, dtype=api.SEED_DT)
-    t = time.time(); rc = c(ws.h, 1, 5, len(off) - 1, int(so[-1]), ncand.ctypes.data, cands.ctypes.data, cs.ctypes.data); t2 = time.time() - t
+    import ctypes as C
+    ncand = np.zeros(len(off), dtype=np.int32)
+    pc, ps, nc, ns = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
+    t = time.time(); rc = ws.lib.kg_candidates_batch(ws.h, 1, 5, len(off) - 1, int(so[-1]), ncand.ctypes.data, C.byref(pc), C.byref(nc), C.byref(ps), C.byref(ns)); t2 = time.time() - t
     print("seed_batch %.3f s (kernels ms: %s) | candidates_batch %.3f s rc=%d | seeds/read %.1f cands/read %.2f" % (t1, ms, t2, rc, so[-1] / (len(off) - 1), ncand.mean()))
