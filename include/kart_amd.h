@@ -42,6 +42,8 @@ extern "C" {
 
 #define KG_MODE_FAST         0   /* IdentifySeedPairs_FastMode      (Illumina) */
 #define KG_MODE_SENSITIVE    1   /* IdentifySeedPairs_SensitiveMode (-pacbio)  */
+#define KG_INPUT_ASCII    0x100   /* OR into mode: the read bytes are the characters themselves; the library applies
+                                     nst_nt4_table (EnCodeReadSeq, src/Mapping.cpp:482-485) on the device */
 
 #define KG_OCC_THR_DEFAULT   50  /* OCC_Thr, src/bwt_search.cpp:3 */
 

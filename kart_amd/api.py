@@ -24,6 +24,7 @@ LIB_PATH = os.path.join(_HERE, "libkart_amd.so")
 
 KG_OK = 0
 KG_MODE_FAST, KG_MODE_SENSITIVE = 0, 1
+KG_INPUT_ASCII = 0x100   # OR into mode: reads are given as characters, encoded on the device
 KG_SA_SAMPLED, KG_SA_FULL = 0, 1
 KG_OCC_THR_DEFAULT = 50
 KG_OP_DIAG, KG_OP_GAP1, KG_OP_GAP2 = 0, 1, 2

@@ -457,7 +457,7 @@ int64_t kg_workspace_overflow(kg_workspace *ws)
 static int check_seed_args(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, int64_t n_reads, int64_t n_bases)
 {
 	if (!ws) return fail(KG_ERR_ARG, "kg_seed_batch: null workspace");
-	if (mode != KG_MODE_FAST && mode != KG_MODE_SENSITIVE) return fail(KG_ERR_ARG, "kg_seed_batch: unknown mode %d", mode);
+	if ((mode & ~KG_INPUT_ASCII) != KG_MODE_FAST && (mode & ~KG_INPUT_ASCII) != KG_MODE_SENSITIVE) return fail(KG_ERR_ARG, "kg_seed_batch: unknown mode %d", mode);
 	if (min_seed_len < 13 || min_seed_len > 16) return fail(KG_ERR_ARG, "kg_seed_batch: min_seed_len %d outside 13..16", min_seed_len);
 	if (occ_thr < 1 || occ_thr > 1000000) return fail(KG_ERR_ARG, "kg_seed_batch: occ_thr %d out of range", occ_thr);
 	if (n_reads < 0 || n_reads > ws->max_reads) return fail(KG_ERR_CAPACITY, "kg_seed_batch: %lld reads exceed the workspace (%lld)", (long long)n_reads, (long long)ws->max_reads);
@@ -485,7 +485,8 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.read_off = d_read_offsets;
 	a.n_reads = n_reads;
 	a.n_bases = n_bases;
-	a.mode = mode;
+	a.mode = mode & ~KG_INPUT_ASCII;
+	a.ascii = (mode & KG_INPUT_ASCII) ? 1 : 0;
 	a.min_seed_len = min_seed_len;
 	a.occ_thr = occ_thr;
 	a.packed = ws->d_packed;

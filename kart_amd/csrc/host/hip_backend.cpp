@@ -45,7 +45,7 @@ public:
 		reserve(n, off[(size_t)n]);
 		seed_off_.assign(off.size(), 0);
 		// the seeds stay on the device (seeds = NULL); only the chained candidates come back, packed
-		if (kg_seed_batch(ws_, mode, info_.min_seed_len, KG_OCC_THR_DEFAULT, enc.data(), off.data(), n, seed_off_.data(), nullptr) != KG_OK) die("kg_seed_batch");
+		if (kg_seed_batch(ws_, mode | KG_INPUT_ASCII, info_.min_seed_len, KG_OCC_THR_DEFAULT, enc.data(), off.data(), n, seed_off_.data(), nullptr) != KG_OK) die("kg_seed_batch");
 		n_cands.assign((size_t)n + 1, 0);
 		const kg_candidate *c = nullptr;
 		const kg_seed *cs = nullptr;

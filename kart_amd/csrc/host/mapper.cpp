@@ -1954,7 +1954,7 @@ double now_s()
 struct Batch {
 	std::vector<Read> reads;
 	std::vector<ChunkState> chunks;
-	std::vector<uint8_t> enc;                       // EnCodeReadSeq output, concatenated
+	std::vector<uint8_t> enc;                       // the read characters, concatenated (encoded on the device)
 	std::vector<int64_t> off;
 	std::vector<int64_t> cand_off;                  // per-read candidate ranges of this batch (filled by the seeding + chaining stage)
 	std::vector<int32_t> n_cands;                   // chaining results of this batch (kg_candidates_batch)
@@ -2081,20 +2081,16 @@ void read_batch(const Ctx &cx, Source &src, int64_t batch_chunks, int chunk_limi
 			rd.name = o.name; rd.seq = o.seq; rd.qual = o.qual; rd.rlen = o.rlen;
 		}
 	}
-	// EnCodeReadSeq (src/Mapping.cpp:482-485).  The reference encodes mate 2 with mate 1's length (:550,
-	// App. B-5); with equal-length mates that is the same thing, otherwise it reads or leaves
-	// uninitialised bytes -- here every read is encoded over its own length.
+	// The reads of the batch, concatenated, as characters: EnCodeReadSeq (src/Mapping.cpp:482-485) itself runs on the device
+	// (KG_INPUT_ASCII).  The reference encodes mate 2 with mate 1's length (:550, App. B-5); with equal-length mates that is the
+	// same thing, otherwise it reads or leaves uninitialised bytes -- here every read is taken over its own length.
 	std::vector<Read> &reads = b.reads;
 	b.off.assign(reads.size() + 1, 0);
 	for (size_t i = 0; i < reads.size(); ++i) b.off[i + 1] = b.off[i] + reads[i].rlen;
 	b.enc.resize((size_t)b.off[reads.size()]);
 	pool.run((int)((reads.size() + 4095) / 4096), [&](int blk) {
 		size_t lo = (size_t)blk * 4096, hi = std::min(reads.size(), lo + 4096);
-		for (size_t i = lo; i < hi; ++i) {
-			uint8_t *dst = b.enc.data() + b.off[i];
-			std::string_view sq = reads[i].seq;
-			for (int p = 0; p < reads[i].rlen; ++p) dst[p] = (uint8_t)nt4((unsigned char)sq[(size_t)p]);
-		}
+		for (size_t i = lo; i < hi; ++i) memcpy(b.enc.data() + b.off[i], reads[i].seq.data(), (size_t)reads[i].rlen);
 	});
 	b.seconds = now_s() - t0;
 }

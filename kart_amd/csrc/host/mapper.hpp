@@ -66,8 +66,8 @@ struct KernelBackend {
 	virtual ~KernelBackend() {}
 	// index constants the host needs
 	virtual int min_seed_len() const = 0;
-	// IdentifySeedPairs_{Fast,Sensitive}Mode + GenerateAlignmentCandidateFor{Illumina,PacBio}Seq for a batch: enc = concatenated
-	// codes, off[n+1].  Out: n_cands[r] candidates per read, stored densely in read order (those of read r start at
+	// IdentifySeedPairs_{Fast,Sensitive}Mode + GenerateAlignmentCandidateFor{Illumina,PacBio}Seq for a batch: enc = the concatenated
+	// read CHARACTERS (the backend applies EnCodeReadSeq), off[n+1].  Out: n_cands[r] candidates per read, stored densely in read order (those of read r start at
 	// cand_off[r]), their seeds at cand_seeds[cands[].first ...].  The seeds themselves never leave the device.
 	virtual void seed_and_chain(int mode, bool pacbio, int max_gaps, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off,
 	                            std::vector<int32_t> &n_cands, std::vector<int64_t> &cand_off, std::vector<kg_candidate> &cands,

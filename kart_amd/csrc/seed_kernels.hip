@@ -95,7 +95,20 @@ __device__ __forceinline__ uint32_t nibbles_of(uint32_t x)   // 4 bytes -> 4 nib
 	return (nib | (nib >> 8)) & 0x0000FFFFu;
 }
 
-__device__ __forceinline__ uint64_t window_word(const uint8_t *enc, int64_t n_bases, int64_t base, int rlen, int w)
+// nst_nt4_table on four characters at once: A/C/G/T in either case carry their code in bits 2:1 (00, 01, 11, 10 -- one
+// Gray-to-binary step away), everything else becomes 4
+__device__ __forceinline__ uint32_t ascii_to_codes(uint32_t x)
+{
+	uint32_t g = (x >> 1) & 0x03030303u;
+	uint32_t code = g ^ ((g >> 1) & 0x01010101u);
+	uint32_t u = x & 0xDFDFDFDFu;
+	auto nonzero = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };   // 0x80 per non-zero byte
+	uint32_t other = nonzero(u ^ 0x41414141u) & nonzero(u ^ 0x43434343u) & nonzero(u ^ 0x47474747u) & nonzero(u ^ 0x54545454u);   // 0x80: none of ACGT
+	uint32_t m = (other >> 7) * 0xFFu;                                         // 0xFF per such byte
+	return (code & ~m) | (0x04040404u & m);
+}
+
+__device__ __forceinline__ uint64_t window_word(const uint8_t *enc, int64_t n_bases, int64_t base, int rlen, int w, bool ascii = false)
 {
 	int64_t at = base + ((int64_t)w << 4);
 	int valid = rlen - (w << 4);                  // positions of this word that exist
@@ -109,6 +122,7 @@ __device__ __forceinline__ uint64_t window_word(const uint8_t *enc, int64_t n_ba
 			if (at + j < n_bases) t[j >> 2] |= (uint32_t)enc[at + j] << ((j & 3) << 3);
 		a = t[0]; b = t[1]; c = t[2]; d = t[3];
 	}
+	if (ascii) { a = ascii_to_codes(a); b = ascii_to_codes(b); c = ascii_to_codes(c); d = ascii_to_codes(d); }
 	uint64_t word = (uint64_t)(nibbles_of(a) | (nibbles_of(b) << 16)) | ((uint64_t)(nibbles_of(c) | (nibbles_of(d) << 16)) << 32);
 	uint64_t keep = valid >= 16 ? ~0ull : valid <= 0 ? 0ull : ((1ull << (valid << 2)) - 1);
 	return (word & keep) | (0x4444444444444444ull & ~keep);
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(SeedArgs a)
 		int rlen = (int)(a.read_off[r + 1] - base);
 		uint64_t *out = a.packed + (base >> 4) + 3 * r;
 		int words = (rlen >> 4) + 3;
-		for (int w = w0; w < words; w += 16) out[w] = window_word(a.enc, a.n_bases, base, rlen, w);
+		for (int w = w0; w < words; w += 16) out[w] = window_word(a.enc, a.n_bases, base, rlen, w, a.ascii != 0);
 	}
 }
 
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(256) void search_kernel(SeedArgs a)
 	const uint64_t *pw = a.packed;
 	int64_t rbase = 0;                    // raw-code variant (a.packed == nullptr): window words are made on the fly
 	const bool raw = a.packed == nullptr;
-#define KG_WORD(w) (raw ? window_word(a.enc, a.n_bases, rbase, rlen, (w)) : pw[(w)])
+#define KG_WORD(w) (raw ? window_word(a.enc, a.n_bases, rbase, rlen, (w), a.ascii != 0) : pw[(w)])
 	uint64_t win = 0x4444444444444444ull, wnext = 0x4444444444444444ull;
 	idx_t k = 0, n = 0;
 	// how the lane extends its match: 0 = rank (LF) steps, 1 = interval of one, fetch its suffix, 2 = compare

@@ -31,6 +31,7 @@ struct SeedArgs {
 	int64_t n_reads;
 	int64_t n_bases;
 	int mode, min_seed_len, occ_thr;
+	int ascii;           // the read bytes are characters, not codes (KG_INPUT_ASCII)
 	int debug_count;     // KG_DEBUG_COUNT: which kind of gather the search kernel tallies into the (otherwise unused) inv counter
 	// scratch
 	uint64_t *packed;    // 4-bit read codes, 16 per word, read r at word (read_off[r] >> 4) + 3 r

@@ -26,10 +26,20 @@ public:
 		int64_t n = (int64_t)off.size() - 1;
 		std::vector<int64_t> seed_off(off.size(), 0);
 		std::vector<ko_seed> buf((size_t)(64 * n + 65536));
-		int64_t t = ko_seed_batch(ix_, mode, ko_min_seed_len(ix_), enc.data(), off.data(), n, seed_off.data(), buf.data(), (int64_t)buf.size(), 4);
+		std::vector<uint8_t> codes(enc.size());          // EnCodeReadSeq (src/Mapping.cpp:482-485): nst_nt4_table
+		for (size_t i = 0; i < enc.size(); ++i) {
+			switch (enc[i]) {
+			case 'A': case 'a': codes[i] = 0; break;
+			case 'C': case 'c': codes[i] = 1; break;
+			case 'G': case 'g': codes[i] = 2; break;
+			case 'T': case 't': codes[i] = 3; break;
+			default: codes[i] = 4;
+			}
+		}
+		int64_t t = ko_seed_batch(ix_, mode, ko_min_seed_len(ix_), codes.data(), off.data(), n, seed_off.data(), buf.data(), (int64_t)buf.size(), 4);
 		if (t < 0) {
 			buf.resize((size_t)(-t));
-			t = ko_seed_batch(ix_, mode, ko_min_seed_len(ix_), enc.data(), off.data(), n, seed_off.data(), buf.data(), (int64_t)buf.size(), 4);
+			t = ko_seed_batch(ix_, mode, ko_min_seed_len(ix_), codes.data(), off.data(), n, seed_off.data(), buf.data(), (int64_t)buf.size(), 4);
 		}
 		n_cands.assign((size_t)n + 1, 0);
 		cand_off.assign((size_t)n + 1, 0);

@@ -272,3 +272,33 @@ def test_reads_at_the_ends_of_the_text(gpu_index_full, gpu_index, oracle_small, 
             ws = ix.workspace(len(reads), len(enc))
             so_g, s_g = ws.seed_batch(enc, off, mode)
             assert (so_g == so_o).all() and (s_g == s_o.astype(api.SEED_DT)).all(), mode
+
+
+def test_character_input_is_encoded_on_the_device(gpu_index_full, gpu_index, oracle_small, request):
+    """KG_INPUT_ASCII: the same reads given as characters (upper and lower case, N, n, IUPAC codes, other bytes) must seed
+    exactly like their nst_nt4_table codes"""
+    chunks = [l.strip() for l in open(request.config.rootpath / "tests" / "golden" / "small.fa", "rb") if not l.startswith(b">")]
+    fwd = np.frombuffer(b"".join(chunks), dtype=np.uint8)
+    rng = np.random.default_rng(123)
+    odd = np.frombuffer(b"NnRYKMSWacgtACGT.-*@\x00\xff", dtype=np.uint8)
+    texts = []
+    for i in range(3000):
+        ln = int(rng.integers(0, 400))
+        p = int(rng.integers(0, len(fwd) - ln - 1))
+        r = fwd[p:p + ln].copy()
+        if i % 3 == 0:
+            r = np.frombuffer(r.tobytes().lower(), np.uint8).copy()
+        m = rng.random(ln) < 0.03
+        r[m] = odd[rng.integers(0, len(odd), int(m.sum()))]
+        texts.append(r)
+    txt, off = api.concat_reads(texts)
+    enc, _ = api.concat_reads([synth.encode(t) for t in texts])
+    assert (enc <= 4).all()
+    for mode in (0, 1):
+        for ix in (gpu_index_full, gpu_index):
+            ws = ix.workspace(len(texts), max(1, len(txt)))
+            so_c, s_c = ws.seed_batch(enc, off, mode)
+            so_a, s_a = ws.seed_batch(txt, off, mode | api.KG_INPUT_ASCII)
+            assert (so_a == so_c).all() and (s_a == s_c).all(), mode
+    so_o, s_o = oracle_small.seed_batch(enc, off, 0)
+    assert (so_a[-1] >= 0) and (gpu_index_full.workspace(len(texts), len(txt)).seed_batch(txt, off, api.KG_INPUT_ASCII)[1] == s_o.astype(api.SEED_DT)).all()
