@@ -46,16 +46,18 @@ inline int nt4(unsigned char ch)  // nst_nt4_table, src/BWT_Index/bntseq.c:40-57
 	}
 }
 
-inline char comp_base(char c)  // GetComplementaryBase, src/tools.cpp:3-17
-{
-	switch (c) {
-	case 'A': case 'a': return 'T';
-	case 'C': case 'c': return 'G';
-	case 'G': case 'g': return 'C';
-	case 'T': case 't': return 'A';
-	default: return 'N';
+// GetComplementaryBase, src/tools.cpp:3-17, as a table (it runs over every base of every mate 2 and of every reverse-strand
+// record): A/a -> T, C/c -> G, G/g -> C, T/t -> A, anything else -> N
+struct CompTable {
+	char t[256];
+	constexpr CompTable() : t()
+	{
+		for (int i = 0; i < 256; ++i) t[i] = 'N';
+		t['A'] = t['a'] = 'T'; t['C'] = t['c'] = 'G'; t['G'] = t['g'] = 'C'; t['T'] = t['t'] = 'A';
 	}
-}
+};
+constexpr CompTable kComp;
+inline char comp_base(char c) { return kComp.t[(unsigned char)c]; }
 
 std::string revcomp(std::string_view s)  // GetComplementarySeq, src/tools.cpp:19-29
 {
