@@ -434,7 +434,29 @@ def end_to_end(prefix, genome, workdir, n_pairs=500_000, codes=None):
         if rc1 == 0 and rcn == 0:
             out["reference_kart"] = {"t1_reads_per_s": round(2 * n_pairs / dt1), "t%d_reads_per_s" % threads: round(2 * n_pairs / dtn)}
             out["sam_identical_to_reference_t1"] = open(os.path.join(workdir, "e2e_amd.sam"), "rb").read() == open(os.path.join(workdir, "e2e_ref1.sam"), "rb").read()
-    for f in (f1, f2, "e2e_amd.sam", "e2e_ref1.sam", "e2e_refn.sam"):
+    # a larger sample for steady-state rates (the small one above is dominated by the batch ramp and the index load; it is
+    # small because the reference's -t 1 run, the identity check, maps ~10 k reads/s); reference at -t <threads> only
+    big = 4 * n_pairs if codes is not None else 8 * n_pairs
+    g1, g2 = os.path.join(workdir, "e2e_big_1.fq"), os.path.join(workdir, "e2e_big_2.fq")
+    try:
+        if codes is not None:
+            write_fastq_from_codes(codes, big, 6, g1, g2, codes.device)
+        else:
+            names, r1, r2 = synth.simulate_pairs(genome, big, seed=6, err=0.01)
+            synth.write_fastq(g1, names, r1, mate=1)
+            synth.write_fastq(g2, names, r2, mate=2)
+        bigc = ["-silent", "-i", prefix, "-f", g1, "-f2", g2]
+        rc, dt, ms = run([exe] + bigc + ["-t", str(threads), "-o", os.path.join(workdir, "e2e_big_amd.sam")])
+        if rc == 0:
+            out["steady_state"] = {"reads": 2 * big, "kart_amd": {"process_seconds": round(dt, 3), "mapping_seconds": ms,
+                                                                  "reads_per_s_mapping_phase": round(2 * big / ms) if ms else None, "reads_per_s_process": round(2 * big / dt)}}
+            if os.path.exists(ref):
+                rcn, dtn, _ = run([ref] + bigc + ["-t", str(threads), "-o", os.path.join(workdir, "e2e_big_ref.sam")])
+                if rcn == 0:
+                    out["steady_state"]["reference_kart_t%d" % threads] = {"process_seconds": round(dtn, 3), "reads_per_s_process": round(2 * big / dtn)}
+    except Exception as exc:      # the extra sample must never cost the line
+        out["steady_state"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:120])}
+    for f in (f1, f2, g1, g2, "e2e_amd.sam", "e2e_ref1.sam", "e2e_refn.sam", "e2e_big_amd.sam", "e2e_big_ref.sam"):
         try:
             os.remove(f if os.path.isabs(f) else os.path.join(workdir, f))
         except OSError:
