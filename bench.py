@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded FASTQ->SAM leg")
     ap.add_argument("--bucketed", action="store_true", default=None, help="force the bucketed (large-N) suffix-array builder")
+    ap.add_argument("--repeat-frac", type=float, default=0.45, help="EXPERIMENT: share of the large synthetic genome covered by the two repeat families (default 0.45 = configs[2])")
     ap.add_argument("--genome-len", type=int, default=None,
                     help="synthetic genome length; default = hg38-sized (configs[2], the size BASELINE.json's metric is quoted on), "
                          "falling back to configs[1] (4,639,675) if the large index cannot be built on this machine")
@@ -189,7 +190,7 @@ def run(args, fallback_note):
     # ---- index (built once by rank 0, replicated per GPU) ------------------------------------------
     workdir = os.environ.get("KART_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "kart_bench_%d" % os.getuid())
     os.makedirs(workdir, exist_ok=True)
-    prefix = os.path.join(workdir, "ecoli_like" if args.genome_len == GENOME_LEN else "synth_v2_%d%s" % (args.genome_len, "_b" if args.bucketed else ""))   # v2: 24 contigs above 300 Mbp
+    prefix = os.path.join(workdir, "ecoli_like" if args.genome_len == GENOME_LEN else "synth_v2_%d%s%s" % (args.genome_len, "_b" if args.bucketed else "", "" if args.repeat_frac == 0.45 else "_r%g" % args.repeat_frac))   # v2: 24 contigs above 300 Mbp
     t_idx = time.time()
     large = args.genome_len >= 300_000_000
     ref_fa = os.environ.get("KART_REF_FASTA")
@@ -214,7 +215,7 @@ def run(args, fallback_note):
         del fwd
     elif large:
         # large experiments: hg38-like codes made on the device, no FASTA round trip
-        codes = make_large_codes(args.genome_len, seed=3, dev=dev)
+        codes = make_large_codes(args.genome_len, seed=3, dev=dev, repeat_frac=args.repeat_frac)
         genome = None
         if rank == 0 and not have_index:
             anns = [("decoy", "(null)", 0, DECOY_LEN, 0)] + [(nm, "(null)", off, ln, 0) for nm, off, ln in contig_table(args.genome_len)]
@@ -314,7 +315,8 @@ def run(args, fallback_note):
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": ("KART_REF_FASTA=%s (%d bp, real FASTA, ambiguous bases replaced as the index does)" % (os.path.basename(ref_fa), args.genome_len) if ref_fa else
                                 "configs[1]: E. coli-like 4.64 Mbp" if args.genome_len == GENOME_LEN else
-                                "configs[2]: hg38-sized (3.1 Gbp, 45 pct repeat families)" if args.genome_len == HG38_LEN else
+                                "configs[2]: hg38-sized (3.1 Gbp, 45 pct repeat families)" if args.genome_len == HG38_LEN and args.repeat_frac == 0.45 else
+                                "EXPERIMENT: hg38-sized (3.1 Gbp), %g pct repeat families" % (100 * args.repeat_frac) if args.genome_len == HG38_LEN else
                                 "EXPERIMENT: %d bp%s" % (args.genome_len, " hg38-like (45 pct repeats)" if large else "")) + (" genome, " if ref_fa else " synthetic genome, ") + "%d x 150 bp PE reads per GPU per step, "
                                "1%% substitution errors + 0.1%% haplotype substitutions; step = seeding hot path "
                                "(BWT search + SA locate + sort) on HBM-resident reads" % n_reads,
@@ -369,6 +371,8 @@ def measured_traffic(n_reads, args):
     MI355X_MICROARCH.md prescribes).  bench.py cannot run the profiler on itself, so the figure is
     only reported when the workload matches the profiled one; otherwise null."""
     best = None
+    if getattr(args, "repeat_frac", 0.45) != 0.45 or os.environ.get("KART_REF_FASTA"):
+        return None, None          # the profiled workload is the default one
     for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         if f.endswith("_pmc_summary.json"):
             try:
