@@ -50,11 +50,9 @@ int parse_cli(int argc, char **argv, Options &opt)
 			}
 		} else if (p == "-g" && i + 1 < argc) {
 			if ((opt.max_gaps = atoi(argv[++i])) < 0) opt.max_gaps = 0;
-		} else if (p == "-o" && i + 1 < argc) opt.out_name = argv[++i];
-		else if (p == "-bo") {
-			fprintf(stdout, "Error! BAM output (-bo) is not part of this build; use -o for SAM\n");
-			return -2;
-		} else if (p == "-gpu" && i + 1 < argc) opt.device = atoi(argv[++i]);
+		} else if (p == "-o" && i + 1 < argc) { opt.bam = false; opt.out_name = argv[++i]; }
+		else if (p == "-bo" && i + 1 < argc) { opt.bam = true; opt.out_name = argv[++i]; }
+		else if (p == "-gpu" && i + 1 < argc) opt.device = atoi(argv[++i]);
 		else if (p == "-silent") opt.silent = true;
 		else if (p == "-pacbio") opt.pacbio = true;
 		else if (p == "-m") opt.multi_hit = true;

@@ -41,6 +41,7 @@ namespace {
 #include "detail/report.inc"
 #include "detail/pairing.inc"
 #include "detail/sam.inc"
+#include "detail/bam.inc"
 #include "detail/reader.inc"
 #include "detail/pipeline.inc"
 
@@ -137,8 +138,16 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	Options &o = const_cast<Options &>(opt);
 	RunTotals tot;
 	// header: @PG first, then @SQ, no @HD (src/Mapping.cpp:664-675)
-	fprintf(out, "@PG\tID:kart\tPN:Kart\tVN:%s\n", "2.5.6");
-	for (size_t i = 0; i < ref.contigs.size(); ++i) fprintf(out, "@SQ\tSN:%s\tLN:%lld\n", ref.contigs[i].name.c_str(), (long long)ref.contigs[i].len);
+	{
+		std::string header = "@PG\tID:kart\tPN:Kart\tVN:2.5.6\n";
+		for (size_t i = 0; i < ref.contigs.size(); ++i) header += "@SQ\tSN:" + ref.contigs[i].name + "\tLN:" + std::to_string((long long)ref.contigs[i].len) + "\n";
+		if (opt.bam) {                                  // src/Mapping.cpp:676-680: the same text, as the BAM header
+			for (size_t i = 0; i < ref.contigs.size(); ++i) cx.bam_ref_id[ref.contigs[i].name] = (int)i;
+			std::string blocks;
+			bgzf_append(bam_header(ref, header), blocks);
+			fwrite(blocks.data(), 1, blocks.size(), out);
+		} else fwrite(header.data(), 1, header.size(), out);
+	}
 	for (size_t lib = 0; lib < opt.files1.size(); ++lib) {
 		const std::string &f1 = opt.files1[lib];
 		bool gz = f1.size() >= 2 && f1.substr(f1.find_last_of('.') + 1) == "gz";   // src/Mapping.cpp:688
@@ -167,6 +176,11 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		double tl = now_s();
 		map_library(cx, src, out, stats, tot);
 		tot.t_lib += now_s() - tl;
+	}
+	if (opt.bam) {                                      // the empty BGZF block that marks the end of the file (SAMv1 4.1.2)
+		std::string eof_block;
+		bgzf_append_block((const unsigned char *)"", 0, eof_block);
+		fwrite(eof_block.data(), 1, eof_block.size(), out);
 	}
 	stats.paired = tot.iPaired;
 	stats.distance = tot.iDistance;

@@ -34,6 +34,7 @@ struct Options {
 	bool pacbio = false;      // -pacbio
 	bool multi_hit = false;   // -m
 	bool silent = false;      // -silent
+	bool bam = false;         // -bo: BAM instead of SAM (src/main.cpp:155-158)
 	int device = 0;
 	int sa_mode = KG_SA_FULL;
 	int64_t batch_reads = 400000;   // reads seeded per GPU call (a whole number of 4000-read chunks)
