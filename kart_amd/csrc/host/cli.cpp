@@ -22,6 +22,7 @@ static void usage(const char *prog)
 	fprintf(stdout, "         -f            files with #1 mates reads (format:fa, fq, fq.gz)\n");
 	fprintf(stdout, "         -f2           files with #2 mates reads (format:fa, fq, fq.gz)\n");
 	fprintf(stdout, "         -o            alignment filename in SAM format [output.sam]\n");
+	fprintf(stdout, "         -bo           alignment filename in BAM format\n");
 	fprintf(stdout, "         -m            output multiple alignments\n");
 	fprintf(stdout, "         -g INT        max gaps (indels) [5]\n");
 	fprintf(stdout, "         -p            paired-end reads are interlaced in the same file\n");
