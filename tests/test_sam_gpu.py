@@ -96,3 +96,17 @@ def test_repeated_runs_are_deterministic(product_binary, tmp_path):
     for it in range(12):
         got, want, _ = run_case(product_binary, "pe_g2" if it % 2 else "pe", str(tmp_path))
         assert got == want, "run %d differs" % it
+
+
+def test_bam_output_of_the_product_binary(product_binary, tmp_path):
+    """-bo through the HIP-backed binary: decodes to the golden SAM records"""
+    from test_bam_output import decode_bam, sam_records
+    from test_host_pipeline import materialise
+    args = [materialise(str(tmp_path), a) if a.endswith((".fq", ".fa", ".gz")) else a for a in CASES["pe"]]
+    bam, sam = str(tmp_path / "o.bam"), str(tmp_path / "gold.sam")
+    r = subprocess.run([product_binary, "-silent", "-t", "8", "-i", SMALL_PREFIX] + args + ["-bo", bam], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-400:]
+    open(sam, "wb").write(gzip.open(os.path.join(GOLDEN, "sam", "pe.sam.gz")).read())
+    head, want = sam_records(sam)
+    text, _, got = decode_bam(bam)
+    assert text == head and got == want
