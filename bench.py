@@ -338,6 +338,10 @@ def run(args, fallback_note):
         "work_per_read": {k2: v / n_reads for k2, v in c.items()},
     }
     if world == 1 and not args.no_cpu_baseline:
+        try:
+            line["nw_kernels"] = nw_leg(ix, dev)
+        except Exception as exc:      # a side measurement must never cost the line
+            line["nw_kernels"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:120])}
         line["cpu_baseline"] = cpu_baseline(orc, batches[0][0], READ_LEN, prefix, workdir)
     if world == 1 and not args.no_e2e:
         del d_seeds, d_seed_off, batches
@@ -397,6 +401,38 @@ def write_fastq_from_codes(codes, n_pairs, seed, f1, f2, dev):
         with open(path, "wb") as fh:
             for i in range(n_pairs):
                 fh.write(b"@r%d\t/%d\n" % (i, mate) + rr[i].tobytes() + b"\n+\n" + qual + b"\n")
+
+
+def nw_leg(ix, dev):
+    """Gap-closing kernels on device-resident fragment batches (not `value`): pairs/s and GCUPS (DP cells per second) per size
+    class -- integer DP is bound by VALU/LDS throughput, not by memory.  1-8 bases is the 97 % case of 150 bp reads."""
+    rng = np.random.default_rng(0)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    for name, n, lo, hi in (("1-8", 4_000_000, 1, 9), ("9-32", 1_000_000, 9, 33), ("33-128", 100_000, 33, 129), ("300-1100", 2_000, 300, 1101)):
+        m = rng.integers(lo, hi, size=n)
+        k = np.clip(m + rng.integers(-3, 4, size=n), lo, hi - 1)
+        o1 = np.zeros(n + 1, np.int64); o2 = np.zeros(n + 1, np.int64)
+        np.cumsum(m, out=o1[1:]); np.cumsum(k, out=o2[1:])
+        f1 = lut[torch.randint(0, 4, (int(o1[-1]) + 16,), device=dev).long()]
+        f2 = lut[torch.randint(0, 4, (int(o2[-1]) + 16,), device=dev).long()]
+        d1, d2 = torch.from_numpy(o1).to(dev), torch.from_numpy(o2).to(dev)
+        ops = torch.empty(int(o1[-1] + o2[-1]) + 16, dtype=torch.uint8, device=dev)
+        ln = torch.empty(n, dtype=torch.int32, device=dev)
+
+        def call():
+            rc = ix.lib.kg_nw_batch_device(ix.h, f1.data_ptr(), d1.data_ptr(), f2.data_ptr(), d2.data_ptr(), n, int(max(m.max(), k.max())), ops.data_ptr(), ln.data_ptr(), stream)
+            assert rc == 0, ix.lib.kg_last_error()
+        call(); torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t) / 3
+        out[name] = {"pairs_per_s": round(n / dt), "GCUPS": round(float((m.astype(np.float64) * k).sum()) / dt / 1e9, 1)}
+        del f1, f2, ops, ln
+    return out
 
 
 def end_to_end(prefix, genome, workdir, n_pairs=500_000, codes=None):
