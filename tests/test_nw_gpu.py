@@ -63,3 +63,28 @@ def test_nw_properties_large_batch(gpu_index):
 
 def test_nw_empty_batch(gpu_index):
     assert gpu_index.nw_ops([]) == []
+
+
+def test_nw_long_fragments_up_to_the_limit(gpu_index, oracle_small):
+    """wave-per-pair kernel over many 64-column stripes, direction words in the HBM slab: 2.5 k, 5 k and the 7000-base limit,
+    related sequences with indels (the long-read case) and one unrelated pair"""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    pairs = []
+    for m in (2500, 5000, 7000):
+        a = alpha[rng.integers(0, 4, size=m)]
+        b = list(a)
+        for _ in range(m // 12):
+            p = int(rng.integers(0, len(b)))
+            r = rng.random()
+            if r < 0.35 and len(b) > 1:
+                del b[p]
+            elif r < 0.7 and len(b) < 6999:
+                b.insert(p, int(alpha[rng.integers(0, 4)]))
+            else:
+                b[p] = int(alpha[rng.integers(0, 4)])
+        pairs.append((a.tobytes(), np.array(b[:7000], dtype=np.uint8).tobytes()))
+    pairs.append((alpha[rng.integers(0, 4, size=3000)].tobytes(), alpha[rng.integers(0, 4, size=2700)].tobytes()))
+    got = gpu_index.nw_alignment(pairs)
+    for (a, b), g in zip(pairs, got):
+        assert g == oracle_small.nw(a, b), (len(a), len(b))
