@@ -11,6 +11,7 @@
  *   bwa_idx_load + RestoreReferenceInfo (src/bwt_index.cpp:148,230; src/main.cpp:192-207)
  *                                                                kg_index_load / kg_index_destroy
  *   Mapping(): MinSeedLength choice (src/Mapping.cpp:645)        kg_index_info().min_seed_len
+ *   bwt_occ4 / bwt_sa (src/bwt_search.cpp:68-85,128-138)         kg_rank_sa_batch
  *   BWT_Search (src/structure.h:178, src/bwt_search.cpp:140)     } kg_seed_batch (+ _device form)
  *   IdentifySeedPairs_FastMode / _SensitiveMode                  }   mode KG_MODE_FAST / _SENSITIVE
  *       (src/structure.h:189,191; src/AlignmentCandidates.cpp:49,132)
@@ -97,6 +98,13 @@ int  kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out);
 void kg_index_destroy(kg_index *ix);
 int  kg_index_info(const kg_index *ix, kg_index_info_t *info);
 int  kg_index_contig(const kg_index *ix, int i, kg_contig_t *out);
+
+/* bwt_occ4 (src/bwt_search.cpp:68-85) and bwt_sa (src/bwt_search.cpp:128-138) for n ranks k[i] in [0, 2L] (k = (uint64_t)-1
+ * is accepted by the rank part, as in the reference), on the device's own rank / suffix-array layouts.  Host buffers.
+ * occ4[4n] (may be NULL): occurrences of A,C,G,T in BWT[0..k].  sa_walk[n] (may be NULL): the reference's sampled walk.
+ * sa_full[n] (may be NULL): the expanded suffix array's entry when the index was loaded with KG_SA_FULL (there SA[0] = 2L,
+ * where the reference's sa[0] = -1 yields 2^64-1), else (uint64_t)-1. */
+int  kg_rank_sa_batch(kg_index *ix, const uint64_t *k, int64_t n, uint64_t *occ4, uint64_t *sa_walk, uint64_t *sa_full);
 
 /* ---- workspace ---------------------------------------------------------------------------- */
 /* Scratch for batches of up to max_reads reads / max_bases bases on the index's device. */

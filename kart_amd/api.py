@@ -35,7 +35,7 @@ CAND_DT = np.dtype([("posDiff", "<i8"), ("score", "<i4"), ("count", "<i4"), ("fi
 # every symbol include/kart_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "kg_last_error", "kg_device_count", "kg_index_load", "kg_index_destroy", "kg_index_info",
-    "kg_index_contig", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters",
+    "kg_index_contig", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters",
     "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
 )
 
@@ -83,6 +83,7 @@ def load_library() -> C.CDLL:
     L.kg_index_destroy.restype = None
     L.kg_index_info.argtypes = [C.c_void_p, C.POINTER(IndexInfo)]
     L.kg_index_contig.argtypes = [C.c_void_p, C.c_int, C.POINTER(Contig)]
+    L.kg_rank_sa_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kg_workspace_create.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]
     L.kg_workspace_destroy.argtypes = [C.c_void_p]
     L.kg_workspace_destroy.restype = None
@@ -237,6 +238,17 @@ class Index:
                 ws.close()
             ws = self._ws = Workspace(self, max(n_reads, 1024), max(n_bases, 1 << 16))
         return ws
+
+    # -- rank / suffix array (bwt_occ4, bwt_sa) ------------------------------------------------------
+    def rank_sa(self, ks):
+        """(occ4[n,4], sa_walk[n], sa_full[n]) for ranks ks: bwt_occ4 / bwt_sa of the reference on the device layouts."""
+        ks = np.ascontiguousarray(ks, dtype=np.uint64)
+        n = len(ks)
+        occ4 = np.zeros((n, 4), dtype=np.uint64)
+        walk = np.zeros(n, dtype=np.uint64)
+        full = np.zeros(n, dtype=np.uint64)
+        _check(self.lib.kg_rank_sa_batch(self.h, _ptr(ks), n, _ptr(occ4), _ptr(walk), _ptr(full)), "kg_rank_sa_batch")
+        return occ4, walk, full
 
     # -- seeding ------------------------------------------------------------------------------
     def _seed(self, reads, mode, min_seed_len, occ_thr):

@@ -390,6 +390,25 @@ int kg_index_contig(const kg_index *ix, int i, kg_contig_t *out)
 	return KG_OK;
 }
 
+int kg_rank_sa_batch(kg_index *ix, const uint64_t *k, int64_t n, uint64_t *occ4, uint64_t *sa_walk, uint64_t *sa_full)
+{
+	if (!ix || !k || n < 0) return fail(KG_ERR_ARG, "kg_rank_sa_batch: bad argument");
+	if (n == 0) return KG_OK;
+	HIP_TRY(hipSetDevice(ix->device));
+	uint64_t *d = nullptr;
+	HIP_TRY(hipMalloc((void **)&d, 8 * (size_t)n * 7));
+	uint64_t *d_k = d, *d_occ = d + n, *d_walk = d + 5 * n, *d_full = d + 6 * n;
+	hipError_t e = hipMemcpy(d_k, k, 8 * (size_t)n, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = launch_rank_sa(ix->view, d_k, n, occ4 ? d_occ : nullptr, sa_walk ? d_walk : nullptr, sa_full ? d_full : nullptr, nullptr);
+	if (e == hipSuccess) e = hipDeviceSynchronize();
+	if (e == hipSuccess && occ4) e = hipMemcpy(occ4, d_occ, 32 * (size_t)n, hipMemcpyDeviceToHost);
+	if (e == hipSuccess && sa_walk) e = hipMemcpy(sa_walk, d_walk, 8 * (size_t)n, hipMemcpyDeviceToHost);
+	if (e == hipSuccess && sa_full) e = hipMemcpy(sa_full, d_full, 8 * (size_t)n, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_rank_sa_batch: %s", hipGetErrorString(e));
+	return KG_OK;
+}
+
 int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_workspace **out)
 {
 	if (!ix || !out || max_reads <= 0 || max_bases <= 0) return fail(KG_ERR_ARG, "kg_workspace_create: bad argument");
@@ -553,7 +572,10 @@ int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, con
 		                          ws->d_seed_off, ws->d_seeds, ws->seed_capacity, ws->stream);
 		if (rc != KG_OK) return rc;
 		HIP_TRY(hipMemcpyAsync(seed_offsets, ws->d_seed_off, 8 * (size_t)(n_reads + 1), hipMemcpyDeviceToHost, ws->stream));
+		unsigned long long over = 0;
+		HIP_TRY(hipMemcpyAsync(&over, ws->d_ctl + 11, 8, hipMemcpyDeviceToHost, ws->stream));
 		HIP_TRY(hipStreamSynchronize(ws->stream));
+		if (over == (~0ull >> 1)) return fail(KG_ERR_CAPACITY, "kg_seed_batch: the hit list of the workspace overflowed");
 		if (seed_offsets[n_reads] <= ws->seed_capacity) break;
 		want = seed_offsets[n_reads];
 		if (attempt == 1) return fail(KG_ERR_CAPACITY, "kg_seed_batch: seed buffer overflow persisted");
@@ -691,13 +713,22 @@ static int nw_run(kg_index *ix, const char *d_frag1, const int64_t *d_off1, cons
 	a.dir_words_per_wave = 0;
 	a.big_waves = 0;
 	a.big_lds_bytes = 0;
+	a.gb_offset_words = 0;
 	size_t dir_words = 0;
 	if (max_len > 32) {
 		a.big_lds_bytes = nw_big_lds_bytes((int)max_len);
 		int per_cu = std::max(1, std::min(16, (160 * 1024) / std::max(a.big_lds_bytes, 1024)));
 		int64_t waves = std::min<int64_t>((int64_t)ix->n_cu * per_cu, n);
 		a.dir_words_per_wave = nw_dir_words((int)max_len);
-		while (waves > 1 && waves * a.dir_words_per_wave * 4 > (8ll << 30)) waves /= 2;   // slab pool <= 8 GiB
+		if (max_len > kNwMaxLen) {
+			// beyond what the LDS holds: boundary column + codes behind the direction words of the wave's slab
+			a.gb_offset_words = a.dir_words_per_wave;
+			a.dir_words_per_wave += (nw_big_lds_bytes((int)max_len) + 3) / 4 + 16;
+			a.big_lds_bytes = 0;
+			waves = std::min<int64_t>(waves, 64);        // such fragments are rare and each slab is large
+			if (a.dir_words_per_wave * 4 > (64ll << 30)) return fail(KG_ERR_CAPACITY, "kg_nw_batch: a fragment of %lld bases needs more than 64 GiB of traceback words", (long long)max_len);
+		}
+		while (waves > 1 && waves * a.dir_words_per_wave * 4 > (8ll << 30)) waves /= 2;   // slab pool <= 8 GiB (one slab may exceed it)
 		a.big_waves = (int)waves;
 		dir_words = (size_t)(waves * a.dir_words_per_wave);
 	}
@@ -720,7 +751,7 @@ int kg_nw_batch_device(kg_index *ix, const char *d_frag1, const int64_t *d_off1,
 	if (n < 0 || n > 0x7fffffff) return fail(KG_ERR_ARG, "kg_nw_batch_device: bad pair count");
 	if (n == 0) return KG_OK;
 	if (!d_frag1 || !d_off1 || !d_frag2 || !d_off2 || !d_ops || !d_aln_len) return fail(KG_ERR_ARG, "kg_nw_batch_device: null buffer");
-	if (max_len > kNwMaxLen) return fail(KG_ERR_ARG, "kg_nw_batch_device: fragment of %lld bases exceeds the supported %d", (long long)max_len, kNwMaxLen);
+	if (max_len < 0 || max_len > 0x3fffffff) return fail(KG_ERR_ARG, "kg_nw_batch_device: bad max_len");
 	HIP_TRY(hipSetDevice(ix->device));
 	return nw_run(ix, d_frag1, d_off1, d_frag2, d_off2, n, max_len, d_ops, d_aln_len, (hipStream_t)stream);
 }
@@ -740,7 +771,6 @@ int kg_nw_batch(kg_index *ix, const char *frag1, const int64_t *off1, const char
 		max_len = std::max(max_len, std::max(m, q));
 	}
 	HIP_TRY(hipSetDevice(ix->device));
-	if (max_len > kNwMaxLen) return fail(KG_ERR_ARG, "kg_nw_batch: fragment of %lld bases exceeds the supported %d", (long long)max_len, kNwMaxLen);
 	// one cached device block per call: [frag1 | frag2 | off1 | off2 | ops | aln_len], 256-byte aligned parts
 	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	size_t p_f1 = 0, p_f2 = p_f1 + up((size_t)b1 + 16), p_o1 = p_f2 + up((size_t)b2 + 16), p_o2 = p_o1 + up(8 * (size_t)(n + 1)),

@@ -134,6 +134,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	mallopt(M_TOP_PAD, 64 << 20);
 	double t_begin = now_s();
 	g_sections = getenv("KART_AMD_VERBOSE") != nullptr;
+	if (const char *uf = getenv("KART_AMD_UNSET_FLAG")) g_unset_flag = atoi(uf);
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	Options &o = const_cast<Options &>(opt);
 	RunTotals tot;

@@ -187,9 +187,13 @@ __global__ __launch_bounds__(256) void nw_small32_kernel(NwArgs a)
 // LDS per wave: boundary column S,R for rows 0..m (column 64*stripe), updated in place: lane 63
 // rewrites row i 63 steps after lane 0 consumed it.
 
+// kGlobal: fragments longer than kNwMaxLen -- the boundary column and the sequence-1 codes no longer fit the LDS and
+// live in a per-wave HBM slab behind the direction words instead (same sweep; the reference's nw_alignment has no length
+// limit, src/nw_alignment.cpp:24-33, so neither has this path).
+template <bool kGlobal>
 __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 {
-	extern __shared__ int lds[];
+	extern __shared__ int lds_dyn[];
 	const int lane = threadIdx.x;
 	const unsigned long long count = a.queue[2];
 	const int32_t *list = a.big_list + 2 * a.n;
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 		int64_t p = list[t];
 		int64_t o1 = a.off1[p], o2 = a.off2[p];
 		int m = (int)(a.off1[p + 1] - o1), n = (int)(a.off2[p + 1] - o2);
+		int *lds = kGlobal ? reinterpret_cast<int *>(dir + a.gb_offset_words) : lds_dyn;
 		int *bS = lds, *bR = lds + (m + 1);
 		unsigned char *s1c = reinterpret_cast<unsigned char *>(lds + 2 * (m + 1));  // fits: see nw_big_lds_bytes()
 		for (int i = lane; i <= m; i += 64) { bS[i] = i == 0 ? 0 : -2 - i; bR[i] = i == 0 ? 0 : NEG; }
@@ -308,10 +313,14 @@ hipError_t launch_nw_batch(const NwArgs &a, int n_cu, hipStream_t stream)
 	hipLaunchKernelGGL(nw_small32_kernel, dim3(grid_for_nw(a.n, 256, n_cu * 2)), dim3(256), 0, stream, a);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	if (a.dir_scratch && a.big_waves > 0) {
+		if (a.gb_offset_words > 0) {
+			hipLaunchKernelGGL(nw_big_kernel<true>, dim3(a.big_waves), dim3(64), 0, stream, a);
+			return hipGetLastError();
+		}
 		if (a.big_lds_bytes > 48 * 1024 &&
-		    (e = hipFuncSetAttribute(reinterpret_cast<const void *>(nw_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, a.big_lds_bytes)) != hipSuccess)
+		    (e = hipFuncSetAttribute(reinterpret_cast<const void *>(nw_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, a.big_lds_bytes)) != hipSuccess)
 			return e;
-		hipLaunchKernelGGL(nw_big_kernel, dim3(a.big_waves), dim3(64), a.big_lds_bytes, stream, a);
+		hipLaunchKernelGGL(nw_big_kernel<false>, dim3(a.big_waves), dim3(64), a.big_lds_bytes, stream, a);
 	}
 	return hipGetLastError();
 }

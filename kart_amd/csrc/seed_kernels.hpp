@@ -51,6 +51,7 @@ hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_tem
 hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *planes, hipStream_t stream);
 hipError_t launch_build_text(const uint8_t *pac, uint64_t l_pac, uint8_t *text, uint64_t n_bytes, hipStream_t stream);
 hipError_t launch_build_qtab(const FmView &ix, int q, uint2 *t32, uint64_t *t64, hipStream_t stream);
+hipError_t launch_rank_sa(const FmView &ix, const uint64_t *ks, int64_t n, uint64_t *occ4, uint64_t *sa_walk, uint64_t *sa_full, hipStream_t stream);
 hipError_t launch_expand_sa(const FmView &ix, uint64_t n_sa, uint32_t *fsa32, uint64_t *fsa64, hipStream_t stream);
 
 struct ChainArgs {
@@ -89,6 +90,7 @@ struct NwArgs {
 	int64_t dir_words_per_wave;
 	int big_waves;               // number of slabs = grid of the wave-per-pair kernel
 	int big_lds_bytes;           // boundary column + sequence-1 codes for the longest pair
+	int64_t gb_offset_words;     // > 0: fragments beyond kNwMaxLen -- boundary column and codes at this word offset of the wave's slab instead of the LDS
 };
 
 constexpr int kNwMaxLen = 7000;  // longest fragment the wave-per-pair kernel's 64 KB LDS holds

@@ -29,6 +29,6 @@ def test_no_cpu_fallback_without_device(built_lib):
 def test_product_does_not_import_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "kart_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".inc", ".c", ".cc")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", ""), f

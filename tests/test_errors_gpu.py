@@ -58,7 +58,9 @@ def test_seed_batch_capacity_errors(golden, gpu_index):
     ws.close()
 
 
-def test_nw_fragment_too_long(gpu_index):
-    with pytest.raises(api.KartAmdError, match=r"status 3.*exceeds the supported"):
-        gpu_index.nw_alignment([(b"A" * 7001, b"A" * 10)])
+def test_nw_fragment_beyond_the_lds_limit_is_not_an_error(gpu_index, oracle_small):
+    """fragments longer than 7000 bases used to be rejected (and the host pipeline then exited); the reference's
+    nw_alignment has no limit, and neither has the kernel path with the boundary column in HBM"""
+    a, b = b"A" * 7001, b"A" * 10
+    assert gpu_index.nw_alignment([(a, b)]) == [oracle_small.nw(a, b)]
     assert gpu_index.nw_alignment([(b"ACGT", b"ACGT")]) == [(b"ACGT", b"ACGT")]

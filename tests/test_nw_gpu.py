@@ -88,3 +88,32 @@ def test_nw_long_fragments_up_to_the_limit(gpu_index, oracle_small):
     got = gpu_index.nw_alignment(pairs)
     for (a, b), g in zip(pairs, got):
         assert g == oracle_small.nw(a, b), (len(a), len(b))
+
+
+def test_nw_fragments_longer_than_the_lds_holds(gpu_index, oracle_small):
+    """> 7000 bases: the wave-per-pair sweep with its boundary column and sequence codes in the wave's HBM slab instead of the
+    LDS (the reference allocates full matrices of any size, src/nw_alignment.cpp:24-33): 7001 x 7001 related, 9000 x 8200
+    with indels, a long fragment against a short one and the reverse, mixed with small pairs of the other size classes"""
+    rng = np.random.default_rng(79)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def mutate(a, k):
+        b = list(a)
+        for _ in range(k):
+            p = int(rng.integers(0, len(b)))
+            r = rng.random()
+            if r < 0.35 and len(b) > 1:
+                del b[p]
+            elif r < 0.7:
+                b.insert(p, int(alpha[rng.integers(0, 4)]))
+            else:
+                b[p] = int(alpha[rng.integers(0, 4)])
+        return np.array(b, dtype=np.uint8).tobytes()
+
+    a1 = alpha[rng.integers(0, 4, size=7001)]
+    a2 = alpha[rng.integers(0, 4, size=9000)]
+    pairs = [(a1.tobytes(), mutate(a1, 300)[:7001]), (a2.tobytes(), mutate(a2[:8200], 500)), (a2.tobytes()[:7500], b"ACGTTGCA" * 5),
+             (b"ACGTTGCAAC" * 4, a2.tobytes()[:7300]), (b"ACGT", b"ACT"), (b"ACGTACGTACGTACGTAAAC", b"ACGTACGTCGTACGTAAAC"), (a1.tobytes()[:100], a1.tobytes()[3:90])]
+    got = gpu_index.nw_alignment(pairs)
+    for (a, b), g in zip(pairs, got):
+        assert g == oracle_small.nw(a, b), (len(a), len(b))

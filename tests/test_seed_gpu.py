@@ -302,3 +302,39 @@ def test_character_input_is_encoded_on_the_device(gpu_index_full, gpu_index, ora
             assert (so_a == so_c).all() and (s_a == s_c).all(), mode
     so_o, s_o = oracle_small.seed_batch(enc, off, 0)
     assert (so_a[-1] >= 0) and (gpu_index_full.workspace(len(texts), len(txt)).seed_batch(txt, off, api.KG_INPUT_ASCII)[1] == s_o.astype(api.SEED_DT)).all()
+
+
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full"])
+def test_rank_and_sa_kats_on_the_device(golden, which, request):
+    """the reference's own bwt_occ4 / bwt_sa answers (tests/golden/hotpath_small.npz: kat_k, kat_occ4, kat_sa, written by
+    oracle/pin_against_ref.py from the reference's object code; reference src/bwt_search.cpp:35-138) against the device's
+    rank_plane / lf_step_plane walk / expanded suffix array, through kg_rank_sa_batch"""
+    ix = request.getfixturevalue(which)
+    ks = golden["kat_k"]
+    occ4, walk, full = ix.rank_sa(ks)
+    assert (occ4 == golden["kat_occ4"]).all()
+    assert (walk == golden["kat_sa"]).all()
+    if which == "gpu_index_full":
+        # SA[0] is the sentinel suffix: 2L in the expanded array, sa[0] = -1 (wrapping) in the reference's samples
+        want = np.where(ks == 0, np.uint64(ix.seq_len), golden["kat_sa"])
+        assert (full == want).all()
+    else:
+        assert (full == np.uint64(2**64 - 1)).all()
+    # k = (bwtint_t)-1 is legal for the rank part (src/bwt_search.cpp:72-75)
+    occ4, _, _ = ix.rank_sa(np.array([2**64 - 1], dtype=np.uint64))
+    assert (occ4 == 0).all()
+
+
+def test_rank_and_sa_every_rank_of_the_small_index(gpu_index_full, oracle_small):
+    """all 2L+1 ranks: device occ4 against the oracle's, and walk == expanded suffix array (a permutation of 0..2L)"""
+    n = gpu_index_full.seq_len
+    ks = np.arange(n + 1, dtype=np.uint64)
+    occ4, walk, full = gpu_index_full.rank_sa(ks)
+    assert (walk[1:] == full[1:]).all() and full[0] == n and walk[0] == 2**64 - 1
+    assert (np.sort(full) == ks).all()
+    for k in range(0, n + 1, 997):
+        assert (oracle_small.occ4(k) == occ4[k]).all(), k
+    # ranks are monotone and sum to the position
+    tot = occ4.sum(axis=1)
+    kk = ks - (ks >= np.uint64(gpu_index_full.info.primary))
+    assert (tot == kk + 1).all()
