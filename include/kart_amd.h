@@ -88,6 +88,16 @@ typedef struct {
 	uint64_t searches, lf1, lf2, inv, sa, seeds, bases;
 } kg_counters_t;
 
+/* What the search kernel of the last kg_seed_batch* call itself fetched (the IMPLEMENTED algorithm: q-mer table jump, rank
+ * steps on the bit-plane layout, one suffix-array gather and text comparison once an interval is a single suffix), as opposed
+ * to kg_counters_t's reference-algorithm accounting.  Useful bytes per launch =
+ *   8*table_lookups + 32*rank_steps (two 16-byte rank segments) + sa_entry_bytes*sa_gathers + 48*text_rounds (16 B of text +
+ *   32 B of read words) + 8*window_words + 20*reads (offsets, seed count) + 32*hits (hit records written). */
+typedef struct {
+	uint64_t table_lookups, rank_steps, rank_steps_two_lines, sa_gathers, text_rounds, window_words, hits, searches;
+	uint64_t sa_entry_bytes;
+} kg_traffic_t;
+
 const char *kg_last_error(void);            /* thread-local message of the last failure */
 int  kg_device_count(void);                 /* number of usable HIP devices (0 if none) */
 
@@ -111,6 +121,7 @@ int  kg_rank_sa_batch(kg_index *ix, const uint64_t *k, int64_t n, uint64_t *occ4
 int  kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_workspace **out);
 void kg_workspace_destroy(kg_workspace *ws);
 int  kg_workspace_counters(kg_workspace *ws, kg_counters_t *out);   /* synchronises the device */
+int  kg_workspace_traffic(kg_workspace *ws, kg_traffic_t *out);     /* synchronises the device */
 /* Per-kernel timing: when enabled, every kg_seed_batch* call brackets its kernels with HIP events
  * on the launch stream; kg_workspace_kernel_ms() synchronises and returns the durations of the
  * last call in milliseconds: ms[0] search, ms[1] scan+offsets, ms[2] locate, ms[3] sort. */

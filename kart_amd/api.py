@@ -35,7 +35,7 @@ CAND_DT = np.dtype([("posDiff", "<i8"), ("score", "<i4"), ("count", "<i4"), ("fi
 # every symbol include/kart_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "kg_last_error", "kg_device_count", "kg_index_load", "kg_index_destroy", "kg_index_info",
-    "kg_index_contig", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters",
+    "kg_index_contig", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters", "kg_workspace_traffic",
     "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
 )
 
@@ -65,6 +65,27 @@ class Counters(C.Structure):
         return 64 * (self.lf1 + 2 * self.lf2 + self.inv) + 8 * self.sa + self.bases + 16 * self.seeds
 
 
+class Traffic(C.Structure):
+    """kg_traffic_t: what the search kernel itself fetched in the last batch (the implemented algorithm)."""
+    _fields_ = [(n, C.c_uint64) for n in ("table_lookups", "rank_steps", "rank_steps_two_lines", "sa_gathers", "text_rounds", "window_words",
+                                          "hits", "searches", "sa_entry_bytes")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+    def useful_bytes(self, n_reads: int) -> int:
+        """bytes the implemented search needs per launch (see include/kart_amd.h, kg_traffic_t)"""
+        return (8 * self.table_lookups + 32 * self.rank_steps + self.sa_entry_bytes * self.sa_gathers + 48 * self.text_rounds
+                + 8 * self.window_words + 20 * n_reads + 32 * self.hits)
+
+    def min_lines(self, n_reads: int) -> int:
+        """128-byte lines a launch cannot avoid touching with this layout: one per table lookup / SA gather, one or two per rank
+        step, the text and read lines of a comparison round (a 16-byte text window straddles a line boundary 1 time in 8, a
+        32-byte read window 1 in 4), the hit records and per-read words (dense)"""
+        return int(self.table_lookups + self.rank_steps + self.rank_steps_two_lines + self.sa_gathers + self.text_rounds * (1.125 + 1.25)
+                   + (8 * self.window_words + 20 * n_reads + 32 * self.hits) / 128)
+
+
 _lib = None
 
 
@@ -88,6 +109,7 @@ def load_library() -> C.CDLL:
     L.kg_workspace_destroy.argtypes = [C.c_void_p]
     L.kg_workspace_destroy.restype = None
     L.kg_workspace_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+    L.kg_workspace_traffic.argtypes = [C.c_void_p, C.POINTER(Traffic)]
     L.kg_workspace_overflow.argtypes = [C.c_void_p]
     L.kg_workspace_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.kg_workspace_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float * 4)]
@@ -145,6 +167,11 @@ class Workspace:
         c = Counters()
         _check(self.lib.kg_workspace_counters(self.h, C.byref(c)), "kg_workspace_counters")
         return c
+
+    def traffic(self) -> Traffic:
+        t = Traffic()
+        _check(self.lib.kg_workspace_traffic(self.h, C.byref(t)), "kg_workspace_traffic")
+        return t
 
     def overflow(self) -> int:
         return int(self.lib.kg_workspace_overflow(self.h))

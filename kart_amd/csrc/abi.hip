@@ -461,6 +461,20 @@ int kg_workspace_counters(kg_workspace *ws, kg_counters_t *out)
 	return KG_OK;
 }
 
+int kg_workspace_traffic(kg_workspace *ws, kg_traffic_t *out)
+{
+	if (!ws || !out) return fail(KG_ERR_ARG, "kg_workspace_traffic: null argument");
+	HIP_TRY(hipSetDevice(ws->ix->device));
+	HIP_TRY(hipDeviceSynchronize());
+	unsigned long long ctl[kCtlWords];
+	HIP_TRY(hipMemcpy(ctl, ws->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+	out->table_lookups = ctl[17]; out->rank_steps = ctl[18]; out->rank_steps_two_lines = ctl[19];
+	out->text_rounds = ctl[20]; out->window_words = ctl[21];
+	out->sa_gathers = ctl[8]; out->hits = ctl[1]; out->searches = ctl[4];
+	out->sa_entry_bytes = (ws->ix->view.fsa32 ? 4 : 8);
+	return KG_OK;
+}
+
 int kg_workspace_set_profiling(kg_workspace *ws, int enabled)
 {
 	if (!ws) return fail(KG_ERR_ARG, "kg_workspace_set_profiling: null workspace");
@@ -526,7 +540,6 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.min_seed_len = min_seed_len;
 	a.occ_thr = occ_thr;
 	a.packed = ws->d_packed;
-	{ static const int dbg = getenv("KG_DEBUG_COUNT") ? atoi(getenv("KG_DEBUG_COUNT")) : 0; a.debug_count = dbg; }
 	a.hits = ws->d_hits;
 	a.max_hits = ws->max_hits;
 	a.seeds_per_read = ws->d_seeds_per_read;
@@ -534,6 +547,7 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.hit_count = ws->d_ctl + 1;
 	a.locate_queue = ws->d_ctl + 2;
 	a.counters = ws->d_ctl + 4;
+	a.traffic = ws->d_ctl + 17;
 	a.seed_off = d_seed_offsets;
 	a.seeds = d_seeds;
 	a.seed_capacity = seed_capacity;

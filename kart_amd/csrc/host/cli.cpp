@@ -9,7 +9,11 @@
 
 #include "mapper.hpp"
 
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <ctime>
 #include <thread>
 
 namespace kart {
@@ -27,7 +31,7 @@ static void usage(const char *prog)
 	fprintf(stdout, "         -g INT        max gaps (indels) [5]\n");
 	fprintf(stdout, "         -p            paired-end reads are interlaced in the same file\n");
 	fprintf(stdout, "         -pacbio       pacbio data\n");
-	fprintf(stdout, "         -gpu INT      HIP device [0]\n");
+	fprintf(stdout, "         -gpu INT[,INT..] HIP device [0]; a list runs one process per device on contiguous parts of the input\n");
 	fprintf(stdout, "         -v            version\n\n");
 }
 
@@ -53,7 +57,21 @@ int parse_cli(int argc, char **argv, Options &opt)
 			if ((opt.max_gaps = atoi(argv[++i])) < 0) opt.max_gaps = 0;
 		} else if (p == "-o" && i + 1 < argc) { opt.bam = false; opt.out_name = argv[++i]; }
 		else if (p == "-bo" && i + 1 < argc) { opt.bam = true; opt.out_name = argv[++i]; }
-		else if (p == "-gpu" && i + 1 < argc) opt.device = atoi(argv[++i]);
+		else if (p == "-gpu" && i + 1 < argc) {          // one device, or a list a,b,c: one process per device, the input sharded
+			opt.devices.clear();
+			for (const char *q = argv[++i]; *q;) {
+				opt.devices.push_back(atoi(q));
+				while (*q && *q != ',') q++;
+				if (*q == ',') q++;
+			}
+			if (opt.devices.empty()) opt.devices.push_back(0);
+			opt.device = opt.devices[0];
+		} else if (p == "-shard" && i + 1 < argc) {      // r/N: this process maps chunk range r of N (set by the launcher / bench.py)
+			if (sscanf(argv[++i], "%d/%d", &opt.shard_rank, &opt.shard_count) != 2 || opt.shard_count < 1 || opt.shard_rank < 0 || opt.shard_rank >= opt.shard_count) {
+				fprintf(stdout, "Error! -shard expects r/N with 0 <= r < N\n");
+				return -2;
+			}
+		} else if (p == "-rendezvous" && i + 1 < argc) opt.rendezvous = argv[++i];
 		else if (p == "-silent") opt.silent = true;
 		else if (p == "-pacbio") opt.pacbio = true;
 		else if (p == "-m") opt.multi_hit = true;
@@ -105,12 +123,10 @@ int parse_cli(int argc, char **argv, Options &opt)
 	return 0;
 }
 
-int cli_main(int argc, char **argv, KernelBackend *(*make_backend)(const Options &, std::string &))
+// one process: index + reference in, one shard (or all) of the input mapped, SAM out
+static int run_one(const Options &opt, KernelBackend *(*make_backend)(const Options &, std::string &), Stats &st, bool quiet)
 {
-	Options opt;
-	int rc = parse_cli(argc, argv, opt);
-	if (rc < 0) return -rc - 1;
-	fprintf(stdout, "Load the genome index files...\n");
+	if (!quiet) fprintf(stdout, "Load the genome index files...\n");
 	RefData ref;
 	std::string err;
 	// the host copy of the reference (both strands as characters) is decoded while the device index is uploaded and its
@@ -122,14 +138,73 @@ int cli_main(int argc, char **argv, KernelBackend *(*make_backend)(const Options
 	ref_loader.join();
 	if (!ref_ok) { fprintf(stdout, "\n\nError! Index files are corrupt! (%s)\n", ref_err.c_str()); delete kern; return 1; }
 	if (!kern) { fprintf(stderr, "Error! %s\n", err.c_str()); return 1; }
-	FILE *out = fopen(opt.out_name.c_str(), "w");
-	if (!out) { fprintf(stderr, "Error! Cannot open file [%s]\n", opt.out_name.c_str()); delete kern; return 1; }
+	FILE *out = nullptr;
+	if (opt.shard_rank == 0) {                               // later shards open the file once shard 0 has created it
+		out = fopen(opt.out_name.c_str(), "w");
+		if (!out) { fprintf(stderr, "Error! Cannot open file [%s]\n", opt.out_name.c_str()); delete kern; return 1; }
+	}
+	if (opt.silent && !quiet) fprintf(stdout, "Start read mapping...\n");
+	int rc = run_mapping(opt, ref, *kern, out, st);
+	if (out) fclose(out);
+	delete kern;
+	return rc;
+}
+
+// -gpu a,b,c: one child process per device (forked before anything touches HIP), each mapping its shard; see detail/shard.inc
+static int run_sharded(const Options &opt, KernelBackend *(*make_backend)(const Options &, std::string &), Stats &st)
+{
+	const int n = (int)opt.devices.size();
+	char path[128];
+	snprintf(path, sizeof(path), "/dev/shm/kart-amd-rdv-%d-%lld", (int)getpid(), (long long)time(NULL));
+	unlink(path);
+	fprintf(stdout, "Load the genome index files...\n");
+	fflush(stdout);
+	std::vector<pid_t> kids;
+	for (int r = 0; r < n; ++r) {
+		pid_t pid = fork();
+		if (pid < 0) { perror("fork"); shard_mark_failed(path); break; }
+		if (pid == 0) {
+			Options o = opt;
+			o.device = opt.devices[(size_t)r];
+			o.devices.assign(1, o.device);
+			o.shard_rank = r; o.shard_count = n; o.rendezvous = path;
+			o.threads = std::max(1, opt.threads / n);        // -t is the budget of the whole run
+			Stats s;
+			int rc = run_one(o, make_backend, s, true);
+			fflush(stdout);
+			_exit(rc);
+		}
+		kids.push_back(pid);
+	}
 	if (opt.silent) fprintf(stdout, "Start read mapping...\n");
+	int rc = (int)kids.size() == n ? 0 : 1;
+	for (size_t left = kids.size(); left > 0; --left) {
+		int status = 0;
+		pid_t pid = wait(&status);
+		if (pid < 0) break;
+		if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) { rc = 1; shard_mark_failed(path); }   // the others stop waiting for it
+	}
+	if (rc == 0 && !shard_totals(path, n, st)) rc = 1;
+	unlink(path);
+	return rc;
+}
+
+int cli_main(int argc, char **argv, KernelBackend *(*make_backend)(const Options &, std::string &))
+{
+	Options opt;
+	int rc = parse_cli(argc, argv, opt);
+	if (rc < 0) return -rc - 1;
+	if (opt.shard_count > 1 && opt.rendezvous.empty()) { fprintf(stdout, "Error! -shard needs -rendezvous FILE\n"); return 1; }
 	time_t t0 = time(NULL);
 	Stats st;
-	run_mapping(opt, ref, *kern, out, st);
-	fclose(out);
+	const bool launcher = opt.devices.size() > 1 && opt.shard_count == 1;
+	rc = launcher ? run_sharded(opt, make_backend, st) : run_one(opt, make_backend, st, false);
+	if (rc != 0) return rc;
 	bool paired = opt.paired || !opt.files2.empty();
+	if (opt.shard_count > 1) {     // one shard of a run someone else coordinates: that process reports the totals
+		if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "shard %d/%d: %lld reads, mapping seconds %.3f, re-mapped chunks %lld\n", opt.shard_rank, opt.shard_count, (long long)st.total_reads, st.map_seconds, (long long)st.respeculated);
+		return 0;
+	}
 	fprintf(stdout, "\rAll the %lld %s reads have been processed in %lld seconds.\n", (long long)st.total_reads, paired ? "paired-end" : "single-end", (long long)(time(NULL) - t0));
 	if (st.total_reads > 0) {   // src/Mapping.cpp:736-741
 		long long mapped = st.total_reads - st.unmapped;
@@ -140,10 +215,9 @@ int cli_main(int argc, char **argv, KernelBackend *(*make_backend)(const Options
 		else
 			fprintf(stdout, "\t# of total mapped sequences = %lld (sensitivity = %.2f%%)\n", mapped, (int)(10000 * (1.0 * mapped / st.total_reads) + 0.5) / 100.0);
 		fprintf(stdout, "Alignment output: %s\n", opt.out_name.c_str());
-		if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "mapping seconds (index load excluded): %.3f\n", st.map_seconds);
+		if (getenv("KART_AMD_VERBOSE") && !launcher) fprintf(stdout, "mapping seconds (index load excluded): %.3f\n", st.map_seconds);
 		if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "chunks re-mapped after EstDistance speculation: %lld\n", (long long)st.respeculated);
 	}
-	delete kern;
 	return 0;
 }
 

@@ -43,6 +43,7 @@ namespace {
 #include "detail/sam.inc"
 #include "detail/bam.inc"
 #include "detail/reader.inc"
+#include "detail/shard.inc"
 #include "detail/pipeline.inc"
 
 }  // namespace
@@ -138,12 +139,23 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	Options &o = const_cast<Options &>(opt);
 	RunTotals tot;
+	// one process per GPU (shard.inc): this process maps shard_rank of shard_count chunk ranges of the library
+	Shard shard;
+	shard.rank = opt.shard_rank; shard.count = std::max(1, opt.shard_count);
+	if (shard.active()) {
+		if (shard.rank < 0 || shard.rank >= shard.count || shard.count > Rendezvous::kMaxRanks) { fprintf(stderr, "Error! bad shard %d/%d\n", shard.rank, shard.count); return 1; }
+		shard.rdv = rendezvous_open(opt.rendezvous);
+		if (!shard.rdv) { fprintf(stderr, "Error! cannot map the rendezvous file [%s]\n", opt.rendezvous.c_str()); return 1; }
+		stats.sharded = true;
+	}
+	FILE *shard_out = nullptr;                           // the output file as a later shard opens it
 	// header: @PG first, then @SQ, no @HD (src/Mapping.cpp:664-675)
-	{
+	if (opt.bam)
+		for (size_t i = 0; i < ref.contigs.size(); ++i) cx.bam_ref_id[ref.contigs[i].name] = (int)i;
+	if (shard.rank == 0) {
 		std::string header = "@PG\tID:kart\tPN:Kart\tVN:2.5.6\n";
 		for (size_t i = 0; i < ref.contigs.size(); ++i) header += "@SQ\tSN:" + ref.contigs[i].name + "\tLN:" + std::to_string((long long)ref.contigs[i].len) + "\n";
 		if (opt.bam) {                                  // src/Mapping.cpp:676-680: the same text, as the BAM header
-			for (size_t i = 0; i < ref.contigs.size(); ++i) cx.bam_ref_id[ref.contigs[i].name] = (int)i;
 			std::string blocks;
 			bgzf_append(bam_header(ref, header), blocks);
 			fwrite(blocks.data(), 1, blocks.size(), out);
@@ -174,14 +186,36 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		src.fast = want_fast && src.m1.open(f1) && (!sep || src.m2.open(opt.files2[lib]));
 		src.gzfast = gz && cx.fastq && !getenv("KART_AMD_NO_MMAP");
 		if (src.gzfast) { src.g1.f = in1.gz; src.g2.f = in2.gz; gzbuffer(in1.gz, 1 << 20); if (in2.gz) gzbuffer(in2.gz, 1 << 20); }
+		if (shard.active()) {
+			// only a single library of plain 4-line FASTQ is split; anything else is mapped by shard 0 alone
+			bool splittable = src.fast && opt.files1.size() == 1;
+			plan_shard(cx, src, shard, splittable);
+			if (shard.solo && shard.rank > 0) {          // nothing to map here: publish an empty shard once its predecessor is done
+				Rendezvous *rv = shard.rdv;
+				shard.wait([&]() { return rv->done[shard.rank - 1].load() != 0; }, "waiting for the previous shard");
+				rv->paired_end[shard.rank].store(rv->paired_end[shard.rank - 1].load());
+				rv->distance_end[shard.rank].store(rv->distance_end[shard.rank - 1].load());
+				rv->done[shard.rank].store(1);
+				rv->written[shard.rank].store(1);
+				continue;
+			}
+		}
 		double tl = now_s();
-		map_library(cx, src, out, stats, tot);
+		map_library(cx, src, out, stats, tot, shard, shard_out);
 		tot.t_lib += now_s() - tl;
 	}
-	if (opt.bam) {                                      // the empty BGZF block that marks the end of the file (SAMv1 4.1.2)
+	const bool last_writer = !shard.active() || (shard.solo ? shard.rank == 0 : shard.rank == shard.count - 1);
+	if (opt.bam && last_writer) {                       // the empty BGZF block that marks the end of the file (SAMv1 4.1.2)
 		std::string eof_block;
 		bgzf_append_block((const unsigned char *)"", 0, eof_block);
-		fwrite(eof_block.data(), 1, eof_block.size(), out);
+		FILE *to = shard_out ? shard_out : out;          // (a later shard's stream stands right behind its own text)
+		if (to) fwrite(eof_block.data(), 1, eof_block.size(), to);
+	}
+	if (shard_out) fclose(shard_out);
+	if (shard.active()) {
+		// the run is complete when every shard's text is in the file
+		Rendezvous *rv = shard.rdv;
+		if (shard.rank == 0) shard.wait([&]() { for (int q = 0; q < shard.count; ++q) if (!rv->written[q].load()) return false; return true; }, "waiting for the other shards");
 	}
 	stats.paired = tot.iPaired;
 	stats.distance = tot.iDistance;
@@ -194,6 +228,29 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		for (int i = 0; i < 6; ++i) fprintf(stdout, " %s %.2f%s", g_sec_name[i], 1e-9 * (double)g_sec_ns[i].load(), i < 5 ? " |" : "\n");
 	}
 	return 0;
+}
+
+bool shard_totals(const std::string &rendezvous, int shard_count, Stats &sum)
+{
+	Rendezvous *rv = rendezvous_open(rendezvous);
+	if (!rv) return false;
+	sum = Stats();
+	bool ok = rv->failed.load() == 0;
+	for (int q = 0; q < shard_count && q < Rendezvous::kMaxRanks; ++q) {
+		if (!rv->done[q].load()) ok = false;
+		sum.total_reads += rv->total_reads[q].load(); sum.unmapped += rv->unmapped[q].load(); sum.unique += rv->unique[q].load();
+		sum.respeculated += rv->respec[q].load();
+	}
+	// iPaired / iDistance are running totals: the last shard's end values are the run's
+	sum.paired = rv->paired_end[shard_count - 1].load();
+	sum.distance = rv->distance_end[shard_count - 1].load();
+	munmap(rv, sizeof(Rendezvous));
+	return ok;
+}
+
+void shard_mark_failed(const std::string &rendezvous)
+{
+	if (Rendezvous *rv = rendezvous_open(rendezvous)) { rv->failed.store(1); munmap(rv, sizeof(Rendezvous)); }
 }
 
 }  // namespace kart

@@ -36,6 +36,9 @@ struct Options {
 	bool silent = false;      // -silent
 	bool bam = false;         // -bo: BAM instead of SAM (src/main.cpp:155-158)
 	int device = 0;
+	std::vector<int> devices;       // -gpu a,b,c: one process per listed device, the input sharded between them
+	int shard_rank = 0, shard_count = 1;   // this process maps shard_rank of shard_count contiguous chunk ranges of the library ...
+	std::string rendezvous;         // ... coordinating with the other processes through this shared-memory file
 	int sa_mode = KG_SA_FULL;
 	int64_t batch_reads = 400000;   // reads seeded per GPU call (a whole number of 4000-read chunks)
 };
@@ -95,7 +98,12 @@ struct Stats {
 	int64_t total_reads = 0, unmapped = 0, unique = 0, paired = 0, distance = 0;
 	double map_seconds = 0;     // first read in -> last SAM byte handed to the writer (index load excluded)
 	int64_t respeculated = 0;   // chunks re-mapped because their speculated EstDistance did not hold
+	bool sharded = false;       // the totals above are this process's shard only (kart::shard_totals() gives the run's)
 };
+
+// the run-wide totals of a sharded run, summed from the rendezvous block once every shard has finished
+bool shard_totals(const std::string &rendezvous, int shard_count, Stats &sum);
+void shard_mark_failed(const std::string &rendezvous);
 
 // Mapping() of the reference: maps every input library and writes SAM to `out`.
 // Returns 0 on success; `summary` receives the reference's end-of-run statistics.

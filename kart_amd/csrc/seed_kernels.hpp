@@ -22,7 +22,9 @@ struct Hit {
 //   [4..11] counters: searches, lf1, lf2, inv, sa, seeds, bases, overflow(needed seeds or 0)
 //   [12..16] reads on the sort work lists: 9..16, 17..32, 33..64 seeds (4 / 2 / 1 lists per wave), 65..256 (small LDS),
 //            > 256 (large LDS)
-constexpr int kCtlWords = 17;
+//   [17..21] what the search kernel itself fetched: q-mer table lookups, rank steps executed, those touching two 128-byte
+//            lines, text-comparison rounds, packed window words (kg_workspace_traffic)
+constexpr int kCtlWords = 22;
 
 struct SeedArgs {
 	FmView ix;
@@ -32,13 +34,12 @@ struct SeedArgs {
 	int64_t n_bases;
 	int mode, min_seed_len, occ_thr;
 	int ascii;           // the read bytes are characters, not codes (KG_INPUT_ASCII)
-	int debug_count;     // KG_DEBUG_COUNT: which kind of gather the search kernel tallies into the (otherwise unused) inv counter
 	// scratch
 	uint64_t *packed;    // 4-bit read codes, 16 per word, read r at word (read_off[r] >> 4) + 3 r
 	Hit *hits;
 	int64_t max_hits;
 	int32_t *seeds_per_read;
-	unsigned long long *read_queue, *hit_count, *locate_queue, *counters;
+	unsigned long long *read_queue, *hit_count, *locate_queue, *counters, *traffic;
 	// outputs
 	int64_t *seed_off;
 	kg_seed *seeds;

@@ -133,3 +133,51 @@ def test_bam_output_of_the_product_binary(product_binary, tmp_path):
     head, want = sam_records(sam)
     text, _, got = decode_bam(bam)
     assert text == head and got == want
+
+
+def _device_lists():
+    """device lists for the sharded runs: several processes on device 0 always (a 1-GPU box exercises the whole mechanism
+    that way), plus every real multi-device split the box offers"""
+    from kart_amd import api
+    n = api.device_count()
+    lists = ["0,0", "0,0,0"]
+    for k in (2, 4, 8):
+        if n >= k:
+            lists.append(",".join(str(i) for i in range(k)))
+    return lists
+
+
+@pytest.mark.parametrize("case", ["pe_plain", "pe_interleaved", "edge_se", "pe"])
+def test_sharded_golden_sam(case, product_binary, tmp_path):
+    """one process per listed device, contiguous chunk ranges of the library (detail/shard.inc): byte-identical SAM"""
+    for devices in _device_lists():
+        got, want, _ = run_case(product_binary, case, str(tmp_path), ["-gpu", devices, "-t", "8"])
+        assert got == want, (case, devices)
+
+
+def test_sharded_live_reference_160k_reads(product_binary, tmp_path):
+    """40 chunks with drifting insert sizes (the estimate keeps moving): 1, 2, 3 processes -- and 2/4/8 real devices where the
+    box has them -- all equal to the reference's -t 1"""
+    if not os.path.exists(KART_REF):
+        pytest.skip("oracle/_ref/kart not present on this machine")
+    from kart_amd import synth
+    from kart_amd.index_build import read_fasta
+    genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
+    f1, f2 = str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")
+    with open(f1, "wb") as o1, open(f2, "wb") as o2:
+        for part, ins in enumerate((300, 260, 220, 180)):
+            names, r1, r2 = synth.simulate_pairs(genome, 20000, seed=950 + part, err=0.02, mut=0.002, indel_frac=0.3, ins_mean=float(ins), ins_sd=ins / 8.0)
+            names = ["p%d_%s" % (part, n) for n in names]
+            p1, p2 = str(tmp_path / "t1.fq"), str(tmp_path / "t2.fq")
+            synth.write_fastq(p1, names, r1, mate=1)
+            synth.write_fastq(p2, names, r2, mate=2)
+            o1.write(open(p1, "rb").read())
+            o2.write(open(p2, "rb").read())
+    ref = str(tmp_path / "ref.sam")
+    subprocess.run([KART_REF, "-silent", "-i", SMALL_PREFIX, "-f", f1, "-f2", f2, "-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    want = open(ref, "rb").read()
+    for devices in ["0"] + _device_lists():
+        out = str(tmp_path / "o.sam")
+        r = subprocess.run([product_binary, "-silent", "-i", SMALL_PREFIX, "-f", f1, "-f2", f2, "-o", out, "-gpu", devices, "-t", "8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0, (devices, r.stdout.decode()[-600:])
+        assert open(out, "rb").read() == want, devices
