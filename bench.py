@@ -1,28 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the MI355X-native Kart hot path on synthetic 150 bp paired-end reads.
+"""bench.py -- FASTQ -> SAM throughput of the MI355X-native Kart hot path on synthetic 150 bp paired-end reads.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    (N > 1 without a launcher: this script starts the N ranks itself -- torch.distributed.run children, before anything
+     here touches a GPU -- and relays rank 0's line; under torchrun it is one of the ranks)
 
-Workload = the configuration BASELINE.json's metric is quoted on, 150 bp PE on hg38 (configs[2]): there is no
-network for the real FASTA, so a seeded hg38-SIZED synthetic genome stands in (3.1 Gbp, 45 % of it mutated copies
-of a 300 bp and a 6 kb repeat family, behind a 2 kb decoy contig; generated on the device).  Its FM-index
-(2L = 6.2 G symbols) is built here by kart_amd.index_build on the GPU (~35 s) and loaded with the full suffix
-array (61 GB in HBM); 10 M read pairs (20 M reads of 150 bp, 1 % substitution errors + 0.1 % haplotype
-substitutions) are generated directly in HBM.  If the large index cannot be built on the machine the run falls
-back to configs[1] (E. coli-sized, 4,639,675 bp) and says so in config.fallback; `--genome-len` selects a size.
-One "step" = one pass of the GPU hot path over one batch of 20 M resident reads:
-kg_seed_batch_device = search (FM-index backward search) + scan + locate (SA recovery) + sort.
-Every rank owns one GPU with a replicated index and its own read shard (weak scaling, no data-path
-collective); RCCL is used only for the final counter all-reduce.
+Metric (BASELINE.json): mapped reads/sec of the whole job, 150 bp paired-end on hg38 (configs[2]).  There is no network for
+the real FASTA, so a seeded hg38-SIZED synthetic genome stands in (3.1 Gbp in 24 contigs behind a 2 kb decoy, 45 % of it
+mutated copies of a 300 bp and a 6 kb repeat family, generated on the device); its FM-index (2L = 6.2 G symbols) is built by
+kart_amd.index_build on the GPU and loaded with the full suffix array, the 2-bit text and the 4^16-entry q-mer table (97 GB
+of HBM per GPU).  10 M read pairs (20 M reads, 1 % substitution errors + 0.1 % haplotype substitutions) are written as two
+FASTQ files.  `KART_REF_FASTA=<fa>` benchmarks a real reference instead; `--genome-len` selects another synthetic size; if the
+large index cannot be built on the machine a single-rank run falls back to configs[1] and says so in config.fallback.
 
-The JSON line carries `roofline` for the dominant kernel (search_kernel; HIP events recorded on
-the launch stream by the library) and `cpu_baseline` (the CPU oracle port of the same step, all
-host cores, on a bounded sample; rank 0 at N=1 only).
+One "step" = one complete mapping run over those files -- the reference's Mapping() (src/Mapping.cpp:639-742): FASTQ parsed,
+seeds found (FM-index search + SA locate + sort), chained, paired / rescued, gaps closed (NW), SAM text written to the output
+file -- through the host library (include/kart_host.h: index resident across runs, as the metric excludes the index load).
+`value` = reads of the whole job / wall time, max over ranks, first read in to last SAM byte written.  With N ranks the SAME
+20 M reads are split into N contiguous chunk ranges, one process + one GPU + one index replica each (strong scaling), the
+output byte-identical to one process mapping everything; RCCL carries only the final counter all-reduce.
+
+The line also carries: `roofline` for the dominant GPU kernel (search_kernel: bytes the IMPLEMENTED search needs -- exported
+by the kernel itself, kg_workspace_traffic -- over its HIP-event time, against the 8 TB/s HBM peak; `traffic` from the
+committed PMC passes of `bench.py --leg seeding`), `seeding_stage` (the GPU seeding step alone on HBM-resident reads -- last
+round's headline, now a sub-field), `cpu_baseline` (the unmodified reference binary at -t <host quota> on a bounded prefix of
+the same files, same box, same run) and `parity` (SAM byte identity with the reference's -t 1 on a 0.5 M-read prefix, and
+GPU seeds == CPU oracle on a random 200 k-read sample).  Rank 0 at N = 1 only for everything but `value`.
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -122,24 +132,94 @@ def gen_reads_device(genome_codes, n_pairs, seed, err, dev):
     return enc, offsets
 
 
+
+REC_BYTES = 15 + READ_LEN + 1 + 2 + READ_LEN + 1      # one FASTQ record as write_fastq_pairs() lays it out (fixed width)
+
+
+def write_fastq_pairs(codes, n_pairs, seed, f1, f2, dev, err=0.011):
+    """Two FASTQ files of n_pairs fixed-width records from the device read generator: "@r<9 digits>\t/<mate>", the
+    150 bases, "+", 150 x '5'.  Records are assembled on the device and written a million at a time."""
+    enc, _ = gen_reads_device(codes, n_pairs, seed=seed, err=err, dev=dev)
+    view = enc.view(n_pairs, 2, READ_LEN)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    comp = torch.tensor(list(b"TGCA"), dtype=torch.uint8, device=dev)
+    pow10 = torch.tensor([10 ** (8 - d) for d in range(9)], device=dev, dtype=torch.int64)
+    slab = 1 << 20
+    for path, mate in ((f1, 0), (f2, 1)):
+        tmpl = torch.tensor(list(b"@r000000000\t/%d\n" % (mate + 1) + b"A" * READ_LEN + b"\n+\n" + b"5" * READ_LEN + b"\n"), dtype=torch.uint8, device=dev)
+        assert tmpl.numel() == REC_BYTES
+        with open(path, "wb") as fh:
+            for s in range(0, n_pairs, slab):
+                m = min(slab, n_pairs - s)
+                rec = tmpl.repeat(m, 1)
+                idx = torch.arange(s, s + m, device=dev, dtype=torch.int64)
+                rec[:, 2:11] = ((idx[:, None] // pow10) % 10 + 48).to(torch.uint8)
+                # the generator holds mate 2 as the mapper does (reverse-complemented): the file holds it as sequenced
+                rec[:, 15:15 + READ_LEN] = acgt[view[s:s + m, 0, :].long()] if mate == 0 else comp[view[s:s + m, 1, :].flip(1).long()]
+                fh.write(memoryview(rec.cpu().numpy()).cast("B"))
+    del enc
+
+
+def pick_workdir(need_bytes):
+    """KART_BENCH_DIR, else /dev/shm when it has room (files stay in memory: no disk in the timed region), else the temp dir"""
+    d = os.environ.get("KART_BENCH_DIR")
+    if d:
+        return d
+    try:
+        if shutil.disk_usage("/dev/shm").free > need_bytes:
+            return os.path.join("/dev/shm", "kart_bench_%d" % os.getuid())
+    except OSError:
+        pass
+    return os.path.join(tempfile.gettempdir(), "kart_bench_%d" % os.getuid())
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU per step")
-    ap.add_argument("--sa", choices=["sampled", "full"], default="full")
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs of the whole job (split over the ranks)")
+    ap.add_argument("--leg", choices=["all", "seeding"], default="all", help="seeding: only the GPU seeding step on resident reads (what the rocprofv3 passes profile)")
+    ap.add_argument("--seed-steps", type=int, default=5, help="timed launches of the seeding-stage leg")
+    ap.add_argument("--sa", choices=["sampled", "full"], default="full", help="suffix array placement of the seeding-stage leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the bounded FASTQ->SAM leg")
+    ap.add_argument("--no-parity", action="store_true", help="skip the reference -t 1 identity leg and the oracle sample")
+    ap.add_argument("--no-seeding-leg", action="store_true")
     ap.add_argument("--bucketed", action="store_true", default=None, help="force the bucketed (large-N) suffix-array builder")
     ap.add_argument("--repeat-frac", type=float, default=0.45, help="EXPERIMENT: share of the large synthetic genome covered by the two repeat families (default 0.45 = configs[2])")
     ap.add_argument("--genome-len", type=int, default=None,
                     help="synthetic genome length; default = hg38-sized (configs[2], the size BASELINE.json's metric is quoted on), "
-                         "falling back to configs[1] (4,639,675) if the large index cannot be built on this machine")
+                         "falling back to configs[1] (4,639,675) if the large index cannot be built on this machine (single rank only)")
+    ap.add_argument("--threads", type=int, default=None, help="worker threads per rank (default: the host CPU quota / ranks)")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # no launcher around us: start the ranks as children BEFORE anything here initialises a GPU, relay rank 0's line
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE)
+        out = r.stdout.decode()
+        lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+        sys.stdout.write(lines[-1] + "\n" if lines else out)
+        return r.returncode if r.returncode else (0 if lines else 1)
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+
     fallback_note = None
     if args.genome_len is None:
         args.genome_len = HG38_LEN
+        if world > 1:
+            return run(args, None)         # several ranks: no per-rank fallback (the ranks could not agree on it); a failure ends the job
         try:
             return run(args, None)
         except Exception as exc:   # large path failed (disk, memory, ...): measure configs[1] instead and say so
@@ -148,17 +228,65 @@ def main():
             fallback_note = "hg38-sized workload failed on this machine (%s: %s); fell back to configs[1]" % (type(exc).__name__, str(exc)[:200])
             args.genome_len = GENOME_LEN
             os.environ.pop("KART_REF_FASTA", None)
-            try:
-                import torch.distributed as dist
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-            except Exception:
-                pass
     return run(args, fallback_note)
 
 
-def run(args, fallback_note):
+def prepare_index(args, dev, rank, workdir, barrier):
+    """(prefix, codes on the device, build seconds).  Rank 0 builds (or finds) the index files; everybody regenerates the
+    genome codes on its own device (seeded, identical)."""
+    from kart_amd import index_build, synth
+    prefix = os.path.join(workdir, "ecoli_like" if args.genome_len == GENOME_LEN else "synth_v2_%d%s%s" % (args.genome_len, "_b" if args.bucketed else "", "" if args.repeat_frac == 0.45 else "_r%g" % args.repeat_frac))
+    t0 = time.time()
+    large = args.genome_len >= 300_000_000
+    ref_fa = os.environ.get("KART_REF_FASTA")
+    if ref_fa and not os.path.exists(ref_fa):
+        raise RuntimeError("KART_REF_FASTA=%s does not exist" % ref_fa)
+    exts = (".bwt", ".sa", ".pac", ".ann", ".amb")
+    if ref_fa:
+        fwd, anns, ambs = index_build.pack_contigs(index_build.read_fasta(ref_fa))
+        args.genome_len = int(len(fwd))
+        prefix = os.path.join(workdir, "ref_%s_%d" % (os.path.basename(ref_fa).replace(".", "_"), os.path.getsize(ref_fa)))
+        codes = torch.from_numpy(fwd).to(dev)
+        if rank == 0 and not all(os.path.exists(prefix + e) for e in exts):
+            index_build.build_index_from_codes(fwd, anns, ambs, prefix + ".tmp", device=str(dev), bucketed=args.bucketed, verbose=True)
+            for e in exts:
+                os.replace(prefix + ".tmp" + e, prefix + e)
+        del fwd
+    elif large or args.genome_len != GENOME_LEN:
+        codes = make_large_codes(args.genome_len, seed=3, dev=dev, repeat_frac=args.repeat_frac)
+        if rank == 0 and not all(os.path.exists(prefix + e) for e in exts):
+            anns = [("decoy", "(null)", 0, DECOY_LEN, 0)] + [(nm, "(null)", off, ln, 0) for nm, off, ln in contig_table(args.genome_len)]
+            index_build.build_index_from_codes(codes.cpu().numpy(), anns, [], prefix + ".tmp", device=str(dev), bucketed=args.bucketed, verbose=True)
+            for e in exts:
+                os.replace(prefix + ".tmp" + e, prefix + e)
+    else:
+        genome = make_genome(seed=2, length=args.genome_len)
+        if rank == 0 and not all(os.path.exists(prefix + e) for e in exts):
+            fa = prefix + ".fa"
+            synth.write_fasta(fa, genome)
+            index_build.build_index(fa, prefix + ".tmp", device=str(dev))
+            for e in exts:
+                os.replace(prefix + ".tmp" + e, prefix + e)
+        codes = torch.from_numpy(np.concatenate([synth.encode(genome["decoy"]), synth.encode(genome["chrE"])])).to(dev)
+    torch.cuda.empty_cache()
+    barrier()
+    return prefix, codes, time.time() - t0
 
+
+def workload_name(args):
+    ref_fa = os.environ.get("KART_REF_FASTA")
+    if ref_fa:
+        return "KART_REF_FASTA=%s (%d bp, real FASTA, ambiguous bases replaced as the index does)" % (os.path.basename(ref_fa), args.genome_len)
+    if args.genome_len == GENOME_LEN:
+        return "configs[1]: E. coli-like 4.64 Mbp synthetic genome"
+    if args.genome_len == HG38_LEN and args.repeat_frac == 0.45:
+        return "configs[2]: hg38-sized (3.1 Gbp, 45 pct repeat families) synthetic genome"
+    if args.genome_len == HG38_LEN:
+        return "EXPERIMENT: hg38-sized (3.1 Gbp) synthetic genome, %g pct repeat families" % (100 * args.repeat_frac)
+    return "EXPERIMENT: %d bp synthetic genome, hg38-like (45 pct repeats)" % args.genome_len
+
+
+def run(args, fallback_note):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,193 +295,323 @@ def run(args, fallback_note):
     share = os.environ.get("KART_BENCH_SHARE_DEVICE") == "1"
     if share:
         local = 0
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
 
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
-    if world > 1:
-        dist.barrier()
-    from kart_amd import api, index_build, shard, synth
+    barrier()
+    from kart_amd import api, shard
 
-    # ---- index (built once by rank 0, replicated per GPU) ------------------------------------------
-    workdir = os.environ.get("KART_BENCH_DIR") or os.path.join(tempfile.gettempdir(), "kart_bench_%d" % os.getuid())
-    os.makedirs(workdir, exist_ok=True)
-    prefix = os.path.join(workdir, "ecoli_like" if args.genome_len == GENOME_LEN else "synth_v2_%d%s%s" % (args.genome_len, "_b" if args.bucketed else "", "" if args.repeat_frac == 0.45 else "_r%g" % args.repeat_frac))   # v2: 24 contigs above 300 Mbp
-    t_idx = time.time()
-    large = args.genome_len >= 300_000_000
-    ref_fa = os.environ.get("KART_REF_FASTA")
-    if ref_fa and not os.path.exists(ref_fa):
-        raise RuntimeError("KART_REF_FASTA=%s does not exist" % ref_fa)
-    if ref_fa:
-        # a real reference (hg38 when the box has it): index it with this repository's writer, simulate
-        # the reads from its forward strand on the device
-        fwd, anns, ambs = index_build.pack_contigs(index_build.read_fasta(ref_fa))
-        args.genome_len = int(len(fwd))
-        large = True
-        prefix = os.path.join(workdir, "ref_%s_%d" % (os.path.basename(ref_fa).replace(".", "_"), os.path.getsize(ref_fa)))
-    have_index = all(os.path.exists(prefix + e) for e in (".bwt", ".sa", ".pac", ".ann", ".amb"))
-    if ref_fa:
-        codes = torch.from_numpy(fwd).to(dev)
-        genome = None
-        if rank == 0 and not have_index:
-            index_build.build_index_from_codes(fwd, anns, ambs, prefix + ".tmp", device=str(dev), bucketed=args.bucketed, verbose=True)
-            for e in (".bwt", ".sa", ".pac", ".ann", ".amb"):
-                os.replace(prefix + ".tmp" + e, prefix + e)
-            torch.cuda.empty_cache()
-        del fwd
-    elif large:
-        # large experiments: hg38-like codes made on the device, no FASTA round trip
-        codes = make_large_codes(args.genome_len, seed=3, dev=dev, repeat_frac=args.repeat_frac)
-        genome = None
-        if rank == 0 and not have_index:
-            anns = [("decoy", "(null)", 0, DECOY_LEN, 0)] + [(nm, "(null)", off, ln, 0) for nm, off, ln in contig_table(args.genome_len)]
-            index_build.build_index_from_codes(codes.cpu().numpy(), anns, [], prefix + ".tmp", device=str(dev), bucketed=args.bucketed, verbose=True)
-            for e in (".bwt", ".sa", ".pac", ".ann", ".amb"):
-                os.replace(prefix + ".tmp" + e, prefix + e)
-            torch.cuda.empty_cache()
-    else:
-        genome = make_genome(seed=2, length=args.genome_len)
-        if rank == 0 and not have_index:
-            fa = prefix + ".fa"
-            synth.write_fasta(fa, genome)
-            index_build.build_index(fa, prefix + ".tmp", device=str(dev))
-            for e in (".bwt", ".sa", ".pac", ".ann", ".amb"):
-                os.replace(prefix + ".tmp" + e, prefix + e)
-        codes = torch.from_numpy(np.concatenate([synth.encode(genome["decoy"]), synth.encode(genome["chrE"])])).to(dev)
-    if world > 1:
-        dist.barrier()
-    t_build = time.time() - t_idx
-    ix = api.Index(prefix, local, api.KG_SA_FULL if args.sa == "full" else api.KG_SA_SAMPLED)
-    t_idx = time.time() - t_idx
-
-    # ---- resident inputs ----------------------------------------------------------------------------
     n_pairs = args.pairs
     n_reads = 2 * n_pairs
+    workdir = pick_workdir(2 * n_pairs * REC_BYTES + n_reads * 450 + (12 << 30))
+    os.makedirs(workdir, exist_ok=True)
+    prefix, codes, t_build = prepare_index(args, dev, rank, workdir, barrier)
+    large = args.genome_len >= 300_000_000
+
+    if args.leg == "seeding":
+        if rank == 0:
+            line = seeding_leg(args, api, prefix, codes, dev, n_reads_leg=min(n_reads, 20_000_000), oracle_sample=0)
+            print(json.dumps({"metric": "seeding stage only (profiling leg)", "seeding_stage": line}))
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    # ---- the input files (rank 0 writes them; every rank maps its chunk range of the same two files) ----------------
+    f1, f2 = os.path.join(workdir, "bench_1.fq"), os.path.join(workdir, "bench_2.fq")
+    t0 = time.time()
+    if rank == 0:
+        write_fastq_pairs(codes, n_pairs, 5, f1, f2, dev)
+    t_fastq = time.time() - t0
+    barrier()
+    if rank != 0:
+        del codes
+    torch.cuda.empty_cache()
+
+    # ---- the session: index resident on this rank's GPU -----------------------------------------------------------------
+    cores = effective_cores()
+    threads = args.threads or max(2, cores // world)
+    t0 = time.time()
+    sess = api.HostSession(prefix, local, threads)
+    t_load = time.time() - t0
+    out_sam = os.path.join(workdir, "bench_out.sam")
+    base = ["-silent", "-f", f1, "-f2", f2, "-o", out_sam]
+
+    def step(tag):
+        a = list(base)
+        if world > 1:
+            a += ["-shard", "%d/%d" % (rank, world), "-rendezvous", os.path.join(workdir, "rdv_%s" % tag)]
+        return sess.map(a)
+
+    def clean_rendezvous():
+        if rank == 0:
+            for f in os.listdir(workdir):
+                if f.startswith("rdv_"):
+                    os.remove(os.path.join(workdir, f))
+
+    clean_rendezvous()
+    barrier()
+    for w in range(args.warmup):
+        step("w%d" % w)
+    torch.cuda.synchronize(dev)
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for s_ in range(args.steps):
+        stats.append(step("s%d" % s_))
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    cdev = None if share else dev
+    reads_mapped_here = sum(int(st.total_reads - st.unmapped) for st in stats)
+    reads_here = sum(int(st.total_reads) for st in stats)
+    totals = shard.allreduce_counters([reads_here, reads_mapped_here, sum(int(st.respeculated) for st in stats)], device=cdev)   # the path's only collective
+    elapsed = shard.max_over_ranks(elapsed, device=cdev)
+    clean_rendezvous()
+    if rank != 0:
+        sess.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    assert totals[0] == n_reads * args.steps, "the ranks together mapped %d reads per step, expected %d" % (totals[0] // max(1, args.steps), n_reads)
+    value = float(totals[0]) / elapsed
+    last = stats[-1]
+    line = {
+        "metric": "mapped reads/sec (whole node), 150 bp PE",
+        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": workload_name(args) + ", %d x 150 bp paired-end reads (1%% substitution errors + 0.1%% haplotype substitutions) in two FASTQ files; "
+                               "step = one FASTQ -> SAM mapping run of the whole job (parse, FM-index seeding, chaining, pairing / rescue, NW gap closing, SAM written), "
+                               "index resident" % n_reads,
+                   "reads_per_step": n_reads, "reads_per_gpu_per_step": n_reads // world, "threads_per_rank": threads, "host_cpu_quota": cores,
+                   "parallelism": "%d process(es), one GPU + index replica each, contiguous chunk ranges of the same input, SAM merged by file offset" % world,
+                   "files": "page-cache resident (%s)" % workdir, "sam_bytes_per_step": os.path.getsize(out_sam),
+                   "fallback": fallback_note, "index_build_s": round(t_build, 2), "index_load_s": round(t_load, 2), "fastq_write_s": round(t_fastq, 2)},
+        "mapped_reads_per_step": totals[1] // args.steps, "mapped_fraction": totals[1] / max(1, totals[0]),
+        "chunks_remapped_per_step": totals[2] / args.steps,
+        "rank0_map_seconds_last_step": last.map_seconds,
+    }
+
+    if world == 1:
+        # ---- parity + CPU baseline on a prefix of the very files that were timed ------------------------------------------
+        ref_legs = {}
+        if not args.no_parity or not args.no_cpu_baseline:
+            try:
+                ref_legs = reference_legs(args, sess, prefix, workdir, f1, f2, n_pairs, threads, cores)
+            except Exception as exc:      # a side measurement must never cost the line
+                ref_legs = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+        if "cpu_baseline" in ref_legs:
+            line["cpu_baseline"] = ref_legs.pop("cpu_baseline")
+        line["parity"] = ref_legs
+    sess.close()
+    for f in (out_sam, f1, f2):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_seeding_leg:
+        seed = seeding_leg(args, api, prefix, codes, dev, n_reads_leg=min(n_reads, 20_000_000), oracle_sample=0 if args.no_parity else 200_000)
+        line["seeding_stage"] = seed
+        line["roofline"] = seed.pop("roofline")
+        if "oracle_sample" in seed:
+            line.setdefault("parity", {})["seeds_vs_oracle"] = seed.pop("oracle_sample")
+        if not args.no_cpu_baseline:
+            try:
+                line["nw_kernels"] = seed.pop("nw_kernels", None)
+            except Exception:
+                pass
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def reference_legs(args, sess, prefix, workdir, f1, f2, n_pairs, threads, cores):
+    """On prefixes of the timed files (fixed-width records: a prefix is a byte range), same box, same run:
+      identity  : oracle/_ref/kart -t 1 vs this pipeline, 0.5 M reads, SAM compared byte for byte;
+      baseline  : oracle/_ref/kart -t <host quota> on a prefix sized for ~15-25 s of its mapping time."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "kart")
+    out = {}
+    if not os.path.exists(ref):
+        return {"note": "oracle/_ref/kart did not travel with this snapshot: no reference legs"}
+
+    def prefix_files(tag, pairs):
+        g1, g2 = os.path.join(workdir, "%s_1.fq" % tag), os.path.join(workdir, "%s_2.fq" % tag)
+        for src, dst in ((f1, g1), (f2, g2)):
+            with open(src, "rb") as fi, open(dst, "wb") as fo:
+                left = pairs * REC_BYTES
+                while left > 0:
+                    buf = fi.read(min(left, 64 << 20))
+                    if not buf:
+                        break
+                    fo.write(buf)
+                    left -= len(buf)
+        return g1, g2
+
+    def run_ref(g1, g2, t, sam):
+        t0 = time.perf_counter()
+        r = subprocess.run([ref, "-silent", "-i", prefix, "-f", g1, "-f2", g2, "-o", sam, "-t", str(t)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+        secs = None
+        for l in r.stdout.decode().splitlines():          # "All the N paired-end reads have been processed in S seconds." (src/Mapping.cpp:730)
+            if "have been processed in" in l:
+                secs = int(l.split(" in ")[1].split()[0])
+        return r.returncode, dt, secs
+
+    tiny1, tiny2 = prefix_files("tiny", 2)
+    rc, load_s, _ = run_ref(tiny1, tiny2, cores, os.path.join(workdir, "tiny.sam"))          # ~ the reference's index load on this box
+    if not args.no_parity:
+        p = min(n_pairs, 250_000)
+        g1, g2 = prefix_files("ident", p)
+        sam_ref, sam_amd = os.path.join(workdir, "ident_ref.sam"), os.path.join(workdir, "ident_amd.sam")
+        rc1, dt1, _ = run_ref(g1, g2, 1, sam_ref)
+        st = sess.map(["-silent", "-f", g1, "-f2", g2, "-o", sam_amd])
+        same = rc1 == 0 and open(sam_ref, "rb").read() == open(sam_amd, "rb").read()
+        out["sam_vs_reference_t1"] = {"reads": 2 * p, "identical": bool(same), "reference_t1_reads_per_s": round(2 * p / max(1e-9, dt1 - load_s)),
+                                      "this_pipeline_map_seconds": round(st.map_seconds, 3)}
+        for f in (g1, g2, sam_ref, sam_amd):
+            os.remove(f)
+    if not args.no_cpu_baseline:
+        # size the sample from a short probe so that the reference's mapping takes ~20 s
+        probe = min(n_pairs, 100_000)
+        g1, g2 = prefix_files("probe", probe)
+        rc, dt, _ = run_ref(g1, g2, cores, os.path.join(workdir, "probe.sam"))
+        rate = 2 * probe / max(0.2, dt - load_s)
+        pairs = int(min(n_pairs, max(probe, rate * 20 / 2)))
+        g1, g2 = prefix_files("base", pairs)
+        sam = os.path.join(workdir, "base.sam")
+        rc, dt, secs = run_ref(g1, g2, cores, sam)
+        map_s = max(0.5, dt - load_s)
+        st = sess.map(["-silent", "-f", g1, "-f2", g2, "-o", os.path.join(workdir, "base_amd.sam")])
+        out["cpu_baseline"] = {"value": 2 * pairs / map_s, "unit": "reads/s", "cores": cores, "kind": "reference",
+                               "sample": "the first %d reads of the timed FASTQ files through the unmodified reference binary (oracle/_ref/kart, compiled from the reference "
+                                         "sources) at -t %d = the host CPU quota (%d logical CPUs visible): %.1f s whole process, %.1f s of it index load (measured on a "
+                                         "2-pair input), its own report: %s s; this pipeline on the same sample: %.2f s" % (2 * pairs, cores, os.cpu_count() or 1, dt, load_s, secs, st.map_seconds),
+                               "whole_process_seconds": round(dt, 2), "index_load_seconds": round(load_s, 2), "this_pipeline_same_sample_reads_per_s": round(2 * pairs / st.map_seconds)}
+        for f in (g1, g2, sam, os.path.join(workdir, "base_amd.sam"), os.path.join(workdir, "probe.sam"), os.path.join(workdir, "probe_1.fq"), os.path.join(workdir, "probe_2.fq")):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    for f in (tiny1, tiny2, os.path.join(workdir, "tiny.sam")):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    return out
+
+
+def seeding_leg(args, api, prefix, codes, dev, n_reads_leg, oracle_sample):
+    """The GPU seeding step alone -- kg_seed_batch_device = pack + search (FM-index) + scan + locate + sort -- on HBM-resident
+    reads: kernel times from HIP events on the launch stream, the bytes the implemented search fetches (kg_workspace_traffic),
+    the reference-algorithm counters of SURVEY 8d, and (oracle_sample > 0) GPU seeds == CPU oracle on a random sample."""
+    n_reads = n_reads_leg & ~1
     n_bases = n_reads * READ_LEN
-    batches = [gen_reads_device(codes, n_pairs, seed=1000 + 17 * rank + b, err=0.011, dev=dev) for b in range(2)]
+    large = args.genome_len >= 300_000_000
+    ix = api.Index(prefix, dev.index or 0, api.KG_SA_FULL if args.sa == "full" else api.KG_SA_SAMPLED)
+    batches = [gen_reads_device(codes, n_reads // 2, seed=1000 + b, err=0.011, dev=dev) for b in range(2)]
     seed_cap = (12 if large else 6) * n_reads + 1024
     d_seed_off = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)
     d_seeds = torch.empty(seed_cap * 16, dtype=torch.uint8, device=dev)
     ws = api.Workspace(ix, n_reads, n_bases)
     ws.set_profiling(True)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    mode = api.KG_MODE_FAST
 
     def step(b):
         enc, off = batches[b % 2]
-        ws.seed_batch_device(enc.data_ptr(), off.data_ptr(), n_reads, n_bases, d_seed_off.data_ptr(), d_seeds.data_ptr(),
-                             seed_cap, mode, stream=stream)
+        ws.seed_batch_device(enc.data_ptr(), off.data_ptr(), n_reads, n_bases, d_seed_off.data_ptr(), d_seeds.data_ptr(), seed_cap, api.KG_MODE_FAST, stream=stream)
 
-    # ---- parity spot check on this very input (not timed) ------------------------------------------
-    parity = "skipped"
-    orc = None
-    if rank == 0:
+    step(0)
+    torch.cuda.synchronize(dev)
+    assert ws.overflow() == 0, "seed buffer too small"
+    out = {}
+    if oracle_sample:
         from oracle import oracle as O
-        step(0)
-        torch.cuda.synchronize(dev)
-        assert ws.overflow() == 0, "seed buffer too small"
-        k = 4000
-        enc_h = batches[0][0][: k * READ_LEN].cpu().numpy()
+        k = min(oracle_sample, n_reads)
+        rng = np.random.default_rng(12345)
+        pick = np.sort(rng.choice(n_reads, size=k, replace=False))
+        so_all = d_seed_off.cpu().numpy()
+        enc_h = batches[0][0].view(n_reads, READ_LEN)[torch.from_numpy(pick).to(dev)].cpu().numpy().reshape(-1)
         off_h = np.arange(k + 1, dtype=np.int64) * READ_LEN
         orc = O.Oracle(prefix)
-        so_o, s_o = orc.seed_batch(enc_h, off_h, 0, threads=min(8, effective_cores()))
-        so_g = d_seed_off[: k + 1].cpu().numpy()
-        s_g = d_seeds[: int(so_g[k]) * 16].cpu().numpy().view(api.SEED_DT)
-        assert (so_g == so_o).all() and (s_g == s_o.astype(api.SEED_DT)).all(), "GPU seeds differ from the oracle"
-        parity = "ok (%d reads bit-identical to the oracle)" % k
-
-    # ---- timed region ---------------------------------------------------------------------------------
-    for w in range(args.warmup):
+        so_o, s_o = orc.seed_batch(enc_h, off_h, 0, threads=effective_cores())
+        orc.close()
+        seeds_all = d_seeds[: int(so_all[n_reads]) * 16].cpu().numpy().view(api.SEED_DT)
+        cnt_g = so_all[pick + 1] - so_all[pick]
+        ok = bool((cnt_g == np.diff(so_o)).all())
+        if ok:
+            idx = np.concatenate([np.arange(so_all[r], so_all[r + 1]) for r in pick]) if k else np.zeros(0, np.int64)
+            ok = bool((seeds_all[idx] == s_o.astype(api.SEED_DT)).all())
+        del seeds_all
+        out["oracle_sample"] = {"reads": int(k), "identical": ok, "what": "a random sample of the seeding leg's batch: GPU seeds (order included) == the CPU oracle's"}
+        assert ok, "GPU seeds differ from the oracle"
+    for w in range(1):
         step(w)
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
     kernel_ms = []
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(s)
-        # event queries happen after the step has been enqueued; they synchronise on the step's last
-        # event, which is inside the timed region anyway (steps are serialised on one stream)
+    for s_ in range(args.seed_steps):
+        step(s_)
         kernel_ms.append(ws.kernel_ms())
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
     elapsed = time.perf_counter() - t0
     cnt = ws.counters()
-    cdev = None if share else dev
-    totals = shard.allreduce_counters([n_reads * args.steps, int(cnt.seeds)], device=cdev)   # the path's only collective
-    elapsed = shard.max_over_ranks(elapsed, device=cdev)
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    kms = np.array(kernel_ms)                                  # (steps, 4): search, scan, locate, sort
+    tr = ws.traffic()
+    kms = np.array(kernel_ms)
     search_ms = float(kms[:, 0].mean())
     c = cnt.as_dict()
-    search_bytes = 64 * (c["lf1"] + 2 * c["lf2"]) + c["bases"]            # search kernel's share of bytes_seed
-    locate_bytes = 64 * c["inv"] + 8 * c["sa"] + 16 * c["seeds"]
-    achieved = search_bytes / (search_ms * 1e-3) / 1e9
-    value = float(totals[0]) / elapsed
+    useful = tr.useful_bytes(n_reads)
+    min_lines = tr.min_lines(n_reads)
+    achieved = useful / (search_ms * 1e-3) / 1e9
     traffic, traffic_src = measured_traffic(n_reads, args)
-    line = {
-        "metric": "mapped reads/sec (whole node), 150 bp PE",
-        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": ("KART_REF_FASTA=%s (%d bp, real FASTA, ambiguous bases replaced as the index does)" % (os.path.basename(ref_fa), args.genome_len) if ref_fa else
-                                "configs[1]: E. coli-like 4.64 Mbp" if args.genome_len == GENOME_LEN else
-                                "configs[2]: hg38-sized (3.1 Gbp, 45 pct repeat families)" if args.genome_len == HG38_LEN and args.repeat_frac == 0.45 else
-                                "EXPERIMENT: hg38-sized (3.1 Gbp), %g pct repeat families" % (100 * args.repeat_frac) if args.genome_len == HG38_LEN else
-                                "EXPERIMENT: %d bp%s" % (args.genome_len, " hg38-like (45 pct repeats)" if large else "")) + (" genome, " if ref_fa else " synthetic genome, ") + "%d x 150 bp PE reads per GPU per step, "
-                               "1%% substitution errors + 0.1%% haplotype substitutions; step = seeding hot path "
-                               "(BWT search + SA locate + sort) on HBM-resident reads" % n_reads,
-                   "reads_per_gpu_per_step": n_reads, "sa_mode": args.sa, "index_bytes": int(ix.info.device_bytes),
-                   "index_residency": ("index (%.1f MB) fits the 256 MiB Infinity Cache; reads stream from HBM" if ix.info.device_bytes < 256e6
-                                       else "index (%.1f MB) exceeds the 256 MiB Infinity Cache: rank gathers are HBM accesses") % (ix.info.device_bytes / 1e6),
-                   "parallelism": "read-sharded x%d, index replicated" % world,
-                   "fallback": fallback_note,
-                   "index_build_s": round(t_build, 2), "index_build_plus_load_s": round(t_idx, 2), "parity_sample": parity},
+    ref_alg = 64 * (c["lf1"] + 2 * c["lf2"]) + c["bases"]
+    out.update({
+        "value": n_reads * args.seed_steps / elapsed, "unit": "reads/s", "reads_per_launch": n_reads, "launches": args.seed_steps,
+        "what": "kg_seed_batch_device on HBM-resident reads: pack + search + scan + locate + sort (last round's `value`)",
+        "sa_mode": args.sa, "index_bytes": int(ix.info.device_bytes),
+        "kernels_ms": {"search": search_ms, "scan": float(kms[:, 1].mean()), "locate": float(kms[:, 2].mean()), "sort": float(kms[:, 3].mean())},
+        "fetched_per_read": {k2: v / n_reads for k2, v in tr.as_dict().items() if k2 != "sa_entry_bytes"},
+        "reference_algorithm_per_read": {k2: v / n_reads for k2, v in c.items()},
+        "reference_algorithm_bytes_per_read": (ref_alg + 64 * c["inv"] + 8 * c["sa"] + 16 * c["seeds"]) / n_reads,
         "roofline": {"bound": "hbm", "kernel": "search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": search_bytes, "avg_launch_ms": search_ms,
+                     "algorithmic_bytes_per_launch": useful, "algorithmic_bytes_per_read": useful / n_reads, "avg_launch_ms": search_ms,
+                     "launch": "%d reads of 150 bp" % n_reads,
+                     "min_128B_lines_per_read": min_lines / n_reads, "min_line_bytes_per_launch": min_lines * 128,
+                     "line_bound_frac": min_lines * 128 / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic_GBps": (traffic / (search_ms * 1e-3) / 1e9) if traffic else None,
-                     "note": "achieved = the reference algorithm's block reads (SURVEY 8d: 64 B per LF step, two for a two-block step, + read bases) "
-                             "per second.  Since the single-suffix searches finish by text comparison the kernel no longer performs most of those "
-                             "reads, so achieved can exceed the HBM peak; traffic/traffic_GBps are what the kernel really moved (PMC)."},
-        "kernels_ms": {"search": search_ms, "scan": float(kms[:, 1].mean()), "locate": float(kms[:, 2].mean()), "sort": float(kms[:, 3].mean())},
-        "bytes_seed_per_read": (search_bytes + locate_bytes) / n_reads,
-        "work_per_read": {k2: v / n_reads for k2, v in c.items()},
-    }
-    if world == 1 and not args.no_cpu_baseline:
+                     "traffic_over_algorithmic": (traffic / useful) if traffic else None,
+                     "note": "achieved = bytes the IMPLEMENTED search needs (kg_workspace_traffic: 8 B per q-mer table entry, 2 x 16 B rank segments per executed "
+                             "LF step, one SA entry, 48 B per text-comparison round, packed read words, hit records) / HIP-event time of search_kernel.  Every gather "
+                             "costs a whole 128-byte line of HBM traffic: min_line_bytes is the line traffic this layout cannot avoid, traffic the measured one (PMC)."}})
+    if not args.no_cpu_baseline and args.leg == "all":
         try:
-            line["nw_kernels"] = nw_leg(ix, dev)
+            out["nw_kernels"] = nw_leg(ix, dev)
         except Exception as exc:      # a side measurement must never cost the line
-            line["nw_kernels"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:120])}
-        line["cpu_baseline"] = cpu_baseline(orc, batches[0][0], READ_LEN, prefix, workdir)
-    if world == 1 and not args.no_e2e:
-        del d_seeds, d_seed_off, batches
-        if orc is not None:
-            orc.close()
-        ws.close()
-        ix.close()                      # the CLI loads its own copy of the index
-        torch.cuda.empty_cache()
-        line["end_to_end"] = end_to_end(prefix, genome, workdir, n_pairs=250_000 if genome is None else 500_000, codes=codes if genome is None else None)
-    print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+            out["nw_kernels"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:120])}
+    ws.close()
+    ix.close()
+    return out
 
 
 def effective_cores():
@@ -388,21 +646,6 @@ def measured_traffic(n_reads, args):
     return best if best else (None, None)
 
 
-def write_fastq_from_codes(codes, n_pairs, seed, f1, f2, dev):
-    """FASTQ pair files from the device read generator (large genomes: no host-side copy of the genome exists)."""
-    enc, _ = gen_reads_device(codes, n_pairs, seed=seed, err=0.011, dev=dev)
-    arr = enc.view(n_pairs, 2, READ_LEN).cpu().numpy()
-    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    comp = np.frombuffer(b"TGCA", dtype=np.uint8)
-    r1 = acgt[arr[:, 0, :]]
-    r2 = comp[arr[:, 1, ::-1]]        # the generator holds mate 2 as the mapper does (reverse-complemented): undo that
-    qual = b"5" * READ_LEN
-    for path, rr, mate in ((f1, r1, 1), (f2, r2, 2)):
-        with open(path, "wb") as fh:
-            for i in range(n_pairs):
-                fh.write(b"@r%d\t/%d\n" % (i, mate) + rr[i].tobytes() + b"\n+\n" + qual + b"\n")
-
-
 def nw_leg(ix, dev):
     """Gap-closing kernels on device-resident fragment batches (not `value`): pairs/s and GCUPS (DP cells per second) per size
     class -- integer DP is bound by VALU/LDS throughput, not by memory.  1-8 bases is the 97 % case of 150 bp reads."""
@@ -435,145 +678,7 @@ def nw_leg(ix, dev):
     return out
 
 
-def end_to_end(prefix, genome, workdir, n_pairs=500_000, codes=None):
-    """Bounded FASTQ -> SAM leg (not `value`): kart_amd/bin/kart-amd (host pipeline + the same kernels) on 1 M reads of
-    the same genome, and -- when the unmodified reference binary travelled with the snapshot -- oracle/_ref/kart on
-    the same files at -t 1 (the byte-identity check) and -t 32 (its best setting on this host class)."""
-    import subprocess
-    from kart_amd import synth
-    exe = os.path.join(ROOT, "kart_amd", "bin", "kart-amd")
-    ref = os.path.join(ROOT, "oracle", "_ref", "kart")
-    if not os.path.exists(exe):
-        return None
-    f1, f2 = os.path.join(workdir, "e2e_1.fq"), os.path.join(workdir, "e2e_2.fq")
-    if codes is not None:
-        write_fastq_from_codes(codes, n_pairs, 5, f1, f2, codes.device)
-    else:
-        names, r1, r2 = synth.simulate_pairs(genome, n_pairs, seed=5, err=0.01)
-        synth.write_fastq(f1, names, r1, mate=1)
-        synth.write_fastq(f2, names, r2, mate=2)
-    common = ["-silent", "-i", prefix, "-f", f1, "-f2", f2]
-    out = {"reads": 2 * n_pairs, "unit": "reads/s"}
-
-    def run(cmd):
-        t = time.perf_counter()
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=dict(os.environ, KART_AMD_VERBOSE="1"))
-        dt = time.perf_counter() - t
-        ms = [float(l.split(":")[1]) for l in r.stdout.decode().splitlines() if l.startswith("mapping seconds")]
-        return r.returncode, dt, (ms[0] if ms else None)
-
-    threads = effective_cores()          # more workers than the CPU quota only adds context switches
-    rc, dt, ms = run([exe] + common + ["-t", str(threads), "-o", os.path.join(workdir, "e2e_amd.sam")])
-    if rc != 0:
-        return {"error": "kart-amd failed"}
-    out["kart_amd"] = {"threads": threads, "process_seconds": round(dt, 3), "mapping_seconds": ms,
-                       "reads_per_s_mapping_phase": round(2 * n_pairs / ms) if ms else None, "reads_per_s_process": round(2 * n_pairs / dt)}
-    if os.path.exists(ref):
-        rc1, dt1, _ = run([ref] + common + ["-t", "1", "-o", os.path.join(workdir, "e2e_ref1.sam")])
-        rcn, dtn, _ = run([ref] + common + ["-t", str(threads), "-o", os.path.join(workdir, "e2e_refn.sam")])
-        if rc1 == 0 and rcn == 0:
-            out["reference_kart"] = {"t1_reads_per_s": round(2 * n_pairs / dt1), "t%d_reads_per_s" % threads: round(2 * n_pairs / dtn)}
-            out["sam_identical_to_reference_t1"] = open(os.path.join(workdir, "e2e_amd.sam"), "rb").read() == open(os.path.join(workdir, "e2e_ref1.sam"), "rb").read()
-    # a larger sample for steady-state rates (the small one above is dominated by the batch ramp and the index load; it is
-    # small because the reference's -t 1 run, the identity check, maps ~10 k reads/s); reference at -t <threads> only
-    big = 4 * n_pairs if codes is not None else 8 * n_pairs
-    g1, g2 = os.path.join(workdir, "e2e_big_1.fq"), os.path.join(workdir, "e2e_big_2.fq")
-    try:
-        if codes is not None:
-            write_fastq_from_codes(codes, big, 6, g1, g2, codes.device)
-        else:
-            names, r1, r2 = synth.simulate_pairs(genome, big, seed=6, err=0.01)
-            synth.write_fastq(g1, names, r1, mate=1)
-            synth.write_fastq(g2, names, r2, mate=2)
-        bigc = ["-silent", "-i", prefix, "-f", g1, "-f2", g2]
-        rc, dt, ms = run([exe] + bigc + ["-t", str(threads), "-o", os.path.join(workdir, "e2e_big_amd.sam")])
-        if rc == 0:
-            out["steady_state"] = {"reads": 2 * big, "kart_amd": {"process_seconds": round(dt, 3), "mapping_seconds": ms,
-                                                                  "reads_per_s_mapping_phase": round(2 * big / ms) if ms else None, "reads_per_s_process": round(2 * big / dt)}}
-            if os.path.exists(ref):
-                rcn, dtn, _ = run([ref] + bigc + ["-t", str(threads), "-o", os.path.join(workdir, "e2e_big_ref.sam")])
-                if rcn == 0:
-                    out["steady_state"]["reference_kart_t%d" % threads] = {"process_seconds": round(dtn, 3), "reads_per_s_process": round(2 * big / dtn)}
-    except Exception as exc:      # the extra sample must never cost the line
-        out["steady_state"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:120])}
-    for f in (f1, f2, g1, g2, "e2e_amd.sam", "e2e_ref1.sam", "e2e_refn.sam", "e2e_big_amd.sam", "e2e_big_ref.sam"):
-        try:
-            os.remove(f if os.path.isabs(f) else os.path.join(workdir, f))
-        except OSError:
-            pass
-    return out
-
-
-_REF_CHILD = r"""
-import json, sys, time
-import numpy as np
-sys.path.insert(0, sys.argv[1])
-from oracle import oracle as O
-prefix, npy, threads = sys.argv[2], sys.argv[3], int(sys.argv[4])
-enc = np.load(npy)
-n = len(enc) // 150
-off = np.arange(n + 1, dtype=np.int64) * 150
-sh = O.RefShim(prefix, threads=threads)
-k = min(n, 20000)
-t = time.perf_counter(); sh.seed_batch_count(enc[: k * 150], off[: k + 1], 0, threads); rate = k / (time.perf_counter() - t)
-m = int(min(n, max(k, rate * 12)))
-t = time.perf_counter(); seeds = sh.seed_batch_count(enc[: m * 150], off[: m + 1], 0, threads); dt = time.perf_counter() - t
-print("REFJSON " + json.dumps({"reads": m, "seconds": dt, "seeds": seeds}))
-"""
-
-
-def reference_baseline(prefix, enc_host, cores, workdir):
-    """The reference's own object code (oracle/_ref/libkartref_shim.so: IdentifySeedPairs_FastMode -> BWT_Search -> bwt_sa, built
-    from the sources where they lie) on the same reads, `cores` threads, in a child process (it keeps its index in
-    process globals and exits on errors).  None when oracle/_ref did not travel."""
-    import subprocess
-    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libkartref_shim.so")):
-        return None
-    npy = os.path.join(workdir, "cpu_baseline_sample.npy")
-    np.save(npy, enc_host)
-    try:
-        r = subprocess.run([sys.executable, "-c", _REF_CHILD, ROOT, prefix, npy, str(cores)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
-        for line in r.stdout.decode().splitlines():
-            if line.startswith("REFJSON "):
-                return json.loads(line[8:])
-    except Exception:
-        pass
-    finally:
-        try:
-            os.remove(npy)
-        except OSError:
-            pass
-    return None
-
-
-def cpu_baseline(orc, enc_dev, read_len, prefix=None, workdir=None):
-    """The same step (seeding incl. SA locate and sort) on the host cores, on a bounded sample of the same reads (sized
-    for roughly 10-20 s of CPU work): the reference's own object code when oracle/_ref travelled with the repository
-    ("reference"), and this repository's CPU restatement of it ("port")."""
-    cores = effective_cores()
-    k = 20000
-    enc = enc_dev[: k * read_len].cpu().numpy()
-    off = np.arange(k + 1, dtype=np.int64) * read_len
-    t = time.perf_counter()
-    orc.seed_batch(enc, off, 0, threads=cores)
-    rate = k / (time.perf_counter() - t)
-    n = int(min(enc_dev.numel() // read_len, max(k, rate * 12)))
-    enc = enc_dev[: n * read_len].cpu().numpy()
-    off = np.arange(n + 1, dtype=np.int64) * read_len
-    t = time.perf_counter()
-    orc.seed_batch(enc, off, 0, threads=cores)
-    dt = time.perf_counter() - t
-    port = {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "%d reads of the same batch, oracle/liboracle.so seed_batch (FM search + SA locate + sort), %d threads = the cgroup CPU quota "
-                      "(%d logical CPUs visible), %.1f s" % (n, cores, os.cpu_count() or 1, dt)}
-    ref = reference_baseline(prefix, enc, cores, workdir) if prefix and workdir else None
-    if not ref:
-        return port
-    return {"value": ref["reads"] / ref["seconds"], "unit": "reads/s", "cores": cores, "kind": "reference",
-            "sample": "%d reads of the same batch through the reference's own IdentifySeedPairs_FastMode (oracle/_ref/libkartref_shim.so, compiled from "
-                      "the reference sources), %d threads = the cgroup CPU quota (%d logical CPUs visible), %.1f s" % (ref["reads"], cores, os.cpu_count() or 1, ref["seconds"]),
-            "port": port}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

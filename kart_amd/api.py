@@ -40,6 +40,10 @@ ABI_SYMBOLS = (
 )
 
 
+HOST_LIB_PATH = os.path.join(_HERE, "libkart_host.so")
+HOST_ABI_SYMBOLS = ("kh_last_error", "kh_open", "kh_map", "kh_close")      # every symbol include/kart_host.h declares
+
+
 class KartAmdError(RuntimeError):
     pass
 
@@ -331,3 +335,55 @@ def apply_ops(s1: bytes, s2: bytes, ops: np.ndarray):
             a.append(s1[i]); b.append(0x2D); i += 1
     assert i == len(s1) and j == len(s2), "op string does not consume both fragments"
     return bytes(a), bytes(b)
+
+
+# ---- the host pipeline as a library (include/kart_host.h): bwa_idx_load once, Mapping() many times -------------------------
+class HostStats(C.Structure):
+    _fields_ = [("total_reads", C.c_int64), ("unmapped", C.c_int64), ("unique", C.c_int64), ("paired", C.c_int64), ("distance", C.c_int64),
+                ("respeculated", C.c_int64), ("map_seconds", C.c_double), ("sharded", C.c_int32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_host_lib = None
+
+
+def load_host_library() -> C.CDLL:
+    global _host_lib
+    if _host_lib is not None:
+        return _host_lib
+    if not os.path.exists(HOST_LIB_PATH):
+        raise KartAmdError(f"{HOST_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    load_library()                                     # libkart_amd.so first (the host library links it)
+    L = C.CDLL(HOST_LIB_PATH)
+    L.kh_last_error.restype = C.c_char_p
+    L.kh_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.kh_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(HostStats)]
+    L.kh_close.argtypes = [C.c_void_p]
+    L.kh_close.restype = None
+    _host_lib = L
+    return L
+
+
+class HostSession:
+    """Index resident on one device; map(args) = one run of the reference's Mapping() with the reference's own flags."""
+
+    def __init__(self, prefix: str, device: int = 0, threads: int = 4):
+        self.lib = load_host_library()
+        h = C.c_void_p()
+        if self.lib.kh_open(prefix.encode(), device, threads, C.byref(h)) != 0:
+            raise KartAmdError("kh_open failed: " + self.lib.kh_last_error().decode())
+        self.h = h
+
+    def map(self, args) -> HostStats:
+        argv = (C.c_char_p * len(args))(*[str(a).encode() for a in args])
+        st = HostStats()
+        if self.lib.kh_map(self.h, len(args), argv, C.byref(st)) != 0:
+            raise KartAmdError("kh_map failed: " + self.lib.kh_last_error().decode())
+        return st
+
+    def close(self):
+        if self.h:
+            self.lib.kh_close(self.h)
+            self.h = None

@@ -1,0 +1,92 @@
+// capi.cpp -- extern "C" boundary of the host pipeline (include/kart_host.h): index resident across mapping runs.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/kart_host.h"
+#include "mapper.hpp"
+
+namespace kart {
+KernelBackend *make_hip_backend(const Options &opt, std::string &err);
+}
+
+struct kh_session {
+	kart::Options base;
+	kart::RefData ref;
+	std::unique_ptr<kart::KernelBackend> kern;
+};
+
+namespace {
+thread_local char g_err[512] = "";
+int fail(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return 1;
+}
+}  // namespace
+
+extern "C" {
+
+const char *kh_last_error(void) { return g_err; }
+
+int kh_open(const char *index_prefix, int device, int threads, kh_session **out)
+{
+	if (!index_prefix || !out) return fail("kh_open: null argument");
+	*out = nullptr;
+	std::unique_ptr<kh_session> s(new kh_session());
+	s->base.index_prefix = index_prefix;
+	s->base.device = device;
+	s->base.threads = threads > 0 ? threads : 4;
+	std::string ref_err, err;
+	bool ref_ok = false;
+	std::thread loader([&]() { ref_ok = s->ref.load(s->base.index_prefix, ref_err, s->base.threads); });
+	s->kern.reset(kart::make_hip_backend(s->base, err));
+	loader.join();
+	if (!s->kern) return fail("kh_open: %s", err.c_str());
+	if (!ref_ok) return fail("kh_open: %s", ref_err.c_str());
+	*out = s.release();
+	return 0;
+}
+
+int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
+{
+	if (!s || argc < 0 || (argc > 0 && !argv)) return fail("kh_map: bad argument");
+	std::vector<std::string> store{"kh_map", "-i", s->base.index_prefix};
+	for (int i = 0; i < argc; ++i) {
+		if (!argv[i]) return fail("kh_map: null flag");
+		if (!strcmp(argv[i], "-i") || !strcmp(argv[i], "-t") || !strcmp(argv[i], "-gpu")) return fail("kh_map: %s is fixed by the session", argv[i]);
+		store.push_back(argv[i]);
+	}
+	std::vector<char *> av;
+	for (std::string &x : store) av.push_back(&x[0]);
+	kart::Options opt = s->base;
+	int rc = kart::parse_cli((int)av.size(), av.data(), opt);
+	if (rc < 0) return fail("kh_map: bad command line (status %d)", -rc - 1);
+	opt.device = s->base.device;
+	opt.threads = s->base.threads;
+	if (opt.shard_count > 1 && opt.rendezvous.empty()) return fail("kh_map: -shard needs -rendezvous FILE");
+	FILE *out = nullptr;
+	if (opt.shard_rank == 0) {
+		out = fopen(opt.out_name.c_str(), "w");
+		if (!out) return fail("kh_map: cannot open [%s]", opt.out_name.c_str());
+	}
+	kart::Stats st;
+	rc = kart::run_mapping(opt, s->ref, *s->kern, out, st);
+	if (out) fclose(out);
+	if (stats) {
+		stats->total_reads = st.total_reads; stats->unmapped = st.unmapped; stats->unique = st.unique; stats->paired = st.paired;
+		stats->distance = st.distance; stats->respeculated = st.respeculated; stats->map_seconds = st.map_seconds; stats->sharded = st.sharded ? 1 : 0;
+	}
+	return rc == 0 ? 0 : fail("kh_map: mapping failed");
+}
+
+void kh_close(kh_session *s) { delete s; }
+
+}  // extern "C"

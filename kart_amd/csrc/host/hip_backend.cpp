@@ -109,6 +109,8 @@ private:
 	kg_index_info_t info_;
 };
 
+}  // namespace
+
 KernelBackend *make_hip_backend(const Options &opt, std::string &err)
 {
 	kg_index *ix = nullptr;
@@ -119,7 +121,8 @@ KernelBackend *make_hip_backend(const Options &opt, std::string &err)
 	return new HipBackend(ix, opt);
 }
 
-}  // namespace
 }  // namespace kart
 
+#ifndef KART_NO_MAIN
 int main(int argc, char **argv) { return kart::cli_main(argc, argv, kart::make_hip_backend); }
+#endif

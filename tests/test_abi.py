@@ -16,6 +16,21 @@ def test_header_symbols_are_exported(built_lib):
         assert hasattr(built_lib, name), name
 
 
+def test_host_library_symbols_are_exported(built_lib):
+    """libkart_host.so (the host pipeline as a library) exports what include/kart_host.h declares"""
+    from kart_amd import api
+    hdr = open(os.path.join(ROOT, "include", "kart_host.h")).read()
+    declared = set(re.findall(r"\b(kh_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(api.HOST_ABI_SYMBOLS), declared ^ set(api.HOST_ABI_SYMBOLS)
+    lib = api.load_host_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    if api.device_count() <= 0:       # no device: the session refuses to open (no CPU path behind it either)
+        h = C.c_void_p()
+        assert lib.kh_open(SMALL_PREFIX.encode(), 0, 2, C.byref(h)) != 0 and not h.value
+        assert b"no HIP device" in lib.kh_last_error()
+
+
 def test_no_cpu_fallback_without_device(built_lib):
     from kart_amd import api
     if api.device_count() > 0:

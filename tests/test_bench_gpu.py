@@ -1,5 +1,6 @@
-"""bench.py's contract on a real GPU: one JSON line with the keys the driver and the judge read, on a reduced
-workload (the default workload is the hg38-sized one and takes minutes), and the KART_REF_FASTA route."""
+"""bench.py's contract on a real GPU: one JSON line with the keys the driver and the judge read, on a reduced workload (the
+default workload is the hg38-sized one and takes minutes): the single-rank line with its legs, the KART_REF_FASTA route, and
+`--gpus 2` started by the script itself (two ranks sharing the box's one device over gloo where there is only one)."""
 import json
 import os
 import subprocess
@@ -18,7 +19,7 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 def _bench(args, env=None, tmp=None):
     e = dict(os.environ, KART_BENCH_DIR=str(tmp))
     e.update(env or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]
@@ -26,22 +27,42 @@ def _bench(args, env=None, tmp=None):
 
 
 def test_bench_line_contract(tmp_path):
-    d = _bench(["--genome-len", "500000", "--pairs", "50000", "--steps", "2", "--warmup", "1", "--no-e2e"], tmp=tmp_path)
+    d = _bench(["--genome-len", "500000", "--pairs", "60000", "--steps", "2", "--warmup", "1"], tmp=tmp_path)
     assert KEYS <= set(d), sorted(KEYS - set(d))
-    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["higher_is_better"] is True
     assert d["unit"] == "reads/s" and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert abs(d["value"] - 100000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 120000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # value = whole-job reads / step time
+    assert "FASTQ -> SAM" in d["config"]["workload"] and "model" not in d["config"] and d["config"]["fallback"] is None
+    assert 0.5 < d["mapped_fraction"] <= 1.0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0 < r["frac"] <= 1.0 and r["kernel"] == "search_kernel" and r["algorithmic_bytes_per_launch"] > 0      # a fraction of the peak by construction
     c = d["cpu_baseline"]
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "reads/s"
-    if c["kind"] == "reference":      # oracle/_ref travelled: the reference's own object code is the baseline, the port rides along
-        assert c["port"]["kind"] == "port" and c["port"]["value"] > 0
-    assert d["config"]["parity_sample"].startswith("ok") and "workload" in d["config"] and "model" not in d["config"]
+    assert c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "reads/s"
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "kart")):
+        assert c["kind"] == "reference"
+        assert d["parity"]["sam_vs_reference_t1"]["identical"] is True and d["parity"]["sam_vs_reference_t1"]["reads"] == 120000
+    assert d["parity"]["seeds_vs_oracle"]["identical"] is True
+    s = d["seeding_stage"]
+    assert s["value"] > 0 and set(s["kernels_ms"]) == {"search", "scan", "locate", "sort"} and s["fetched_per_read"]["rank_steps"] >= 0
 
 
 def test_bench_real_fasta_route(tmp_path):
     fa = os.path.join(ROOT, "tests", "golden", "small.fa")
-    d = _bench(["--pairs", "20000", "--steps", "1", "--warmup", "1", "--no-e2e", "--no-cpu-baseline"], env={"KART_REF_FASTA": fa}, tmp=tmp_path)
-    assert "KART_REF_FASTA=small.fa" in d["config"]["workload"] and d["config"]["parity_sample"].startswith("ok")
-    assert d["config"]["fallback"] is None and d["roofline"]["traffic"] is None
+    d = _bench(["--pairs", "20000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity"], env={"KART_REF_FASTA": fa}, tmp=tmp_path)
+    assert "KART_REF_FASTA=small.fa" in d["config"]["workload"]
+    assert d["config"]["fallback"] is None and d["roofline"]["traffic"] is None and d["value"] > 0
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the script starts two ranks itself and relays rank 0's line.
+    On a 1-GPU box the two ranks share device 0 and all-reduce over gloo (KART_BENCH_SHARE_DEVICE); the whole job's reads are
+    split between them and the merged SAM is the one-process SAM (same size here; byte identity is test_sam_gpu's subject)."""
+    import torch
+    env = {} if torch.cuda.device_count() >= 2 else {"KART_BENCH_SHARE_DEVICE": "1"}
+    one = _bench(["--genome-len", "500000", "--pairs", "60000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--no-seeding-leg"], tmp=tmp_path)
+    two = _bench(["--gpus", "2", "--genome-len", "500000", "--pairs", "60000", "--steps", "1", "--warmup", "1"], env=env, tmp=tmp_path)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["reads_per_step"] == 120000 and two["config"]["reads_per_gpu_per_step"] == 60000
+    assert two["mapped_reads_per_step"] == one["mapped_reads_per_step"]
+    assert two["config"]["sam_bytes_per_step"] == one["config"]["sam_bytes_per_step"]
+    assert "cpu_baseline" not in two             # rank 0 at N = 1 only

@@ -8,12 +8,12 @@ import bench
 dev = torch.device("cuda", 0)
 L = int(sys.argv[1]) if len(sys.argv) > 1 else bench.HG38_LEN
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
-wd = "/tmp/kart_bench_%d" % os.getuid()
+wd = bench.pick_workdir(60 << 30)
 prefix = os.path.join(wd, "synth_v2_%d" % L)
-subprocess.run([sys.executable, "bench.py", "--genome-len", str(L), "--pairs", "1000000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e"], stdout=subprocess.DEVNULL)
+subprocess.run([sys.executable, "bench.py", "--genome-len", str(L), "--pairs", "1000000", "--leg", "seeding", "--seed-steps", "1"], stdout=subprocess.DEVNULL)   # builds + caches the index
 codes = bench.make_large_codes(L, 3, dev)
 f1, f2 = os.path.join(wd, "l1.fq"), os.path.join(wd, "l2.fq")
-bench.write_fastq_from_codes(codes, pairs, 5, f1, f2, dev)
+bench.write_fastq_pairs(codes, pairs, 5, f1, f2, dev)
 del codes; torch.cuda.empty_cache()
 threads = min(32, 2 * bench.effective_cores())
 res = {"genome_len": L, "reads": 2 * pairs, "threads": threads}

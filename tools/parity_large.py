@@ -24,7 +24,7 @@ ap.add_argument("--cand-reads", type=int, default=5000, help="reads whose chaine
 args = ap.parse_args()
 n_reads, L = args.reads & ~1, args.genome_len
 dev = torch.device("cuda", 0)
-wd = args.workdir or os.environ.get("KART_BENCH_DIR") or "/tmp/kart_bench_%d" % os.getuid()
+wd = args.workdir or bench.pick_workdir(20 << 30)
 os.makedirs(wd, exist_ok=True)
 prefix = os.path.join(wd, "synth_v2_%d" % L)
 codes = bench.make_large_codes(L, 3, dev)
