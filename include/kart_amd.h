@@ -18,6 +18,8 @@
  *   nw_alignment (src/structure.h:229, src/nw_alignment.cpp:18)  kg_nw_batch (+ _device form)
  *   GenerateAlignmentCandidateForIlluminaSeq / ForPacBioSeq      kg_candidates_batch
  *       (src/structure.h:193-194; src/AlignmentCandidates.cpp:82,171)
+ *   CheckPairedAlignmentCandidates ... GenMappingReport ... EvaluateMAPQ (src/structure.h:192; src/Mapping.cpp:542-578)
+ *                                                                kg_align_batch
  *
  * Threading: an index handle is immutable after load and may be shared by any number of host
  * threads; a workspace (kg_workspace) owns the scratch of one in-flight batch and must not be
@@ -166,6 +168,55 @@ typedef struct {
 } kg_candidate;
 int  kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_reads, int64_t n_seeds, int32_t *n_cands,
                          const kg_candidate **cands, int64_t *n_cands_total, const kg_seed **cand_seeds, int64_t *n_cand_seeds_total);
+
+/* ---- the per-read report on the device --------------------------------------------------------------------------- */
+/* Everything ReadMapping() does between chaining and the SAM text, for the reads of the batch the last kg_seed_batch +
+ * kg_candidates_batch calls on this workspace left on the device, in the reference's short-read configuration (neither
+ * -pacbio nor -m):
+ *   CheckPairedAlignmentCandidates / RemoveUnMatedAlignmentCandidates / RemoveRedundantCandidates (src/Mapping.cpp:317-427),
+ *   GenMappingReport: IdentifyNormalPairs + filters (src/AlignmentCandidates.cpp:226-490), Process{Head,Normal,Tail}SequencePair
+ *   (src/tools.cpp:225-397) with nw_alignment on the device, GenCoordinateInfo / GenerateCIGAR / GapPenalty (:492-745),
+ *   CheckPairedFinalAlignments, Set{Paired,Single}AlignmentFlag, EvaluateMAPQ (src/Mapping.cpp:49-175, 429-480),
+ *   and what OutputPairedAlignments / OutputSingledAlignments would print for every read (:177-315).
+ * One record per read.  A read pair the device path does not take -- RescueUnpairedAlignment is due, a gap fragment needs the
+ * 8-mer partition (both sides > 30), a candidate has more seeds or a longer CIGAR than the kernels hold -- comes back with
+ * kind KG_ALN_HOST on both reads: the caller maps it with its own implementation of the same reference code (the candidates
+ * kg_candidates_batch returned are unmodified). */
+#define KG_ALN_NONE      0   /* nothing is printed for this read (the reference's loop finds no candidate to print) */
+#define KG_ALN_UNMAPPED  1   /* the unmapped record: FLAG as given */
+#define KG_ALN_MAPPED    2
+#define KG_ALN_HOST      3   /* not decided here */
+#define KG_ALN_CIGAR_MAX 48
+typedef struct {
+	int64_t pos;             /* 1-based position on the contig (AlignmentReport_t::coor.gPos) */
+	int64_t mate_pos;
+	int32_t kind;
+	int32_t flag, chr, mapq, tlen;
+	int32_t score, sub_score;    /* AS / XS; NM = rlen - score */
+	uint8_t has_mate;        /* RNEXT "=" + PNEXT + TLEN, else "*\t0\t0" */
+	uint8_t flip;            /* the record shows the reverse complement of the read as the caller holds it (mate 2 is held
+	                            reverse-complemented, src/GetData.cpp:125-135) */
+	uint8_t cigar_len, pad;
+	char    cigar[KG_ALN_CIGAR_MAX];
+} kg_aln_record;
+
+/* per 4000-read chunk: what the chunk adds to the run's pairing statistics (iPaired / iDistance, src/Mapping.cpp:209-213),
+ * and for which EstDistance values its pairing decisions hold: every "dist < EstiDistance" test of
+ * CheckPairedAlignmentCandidates (:372) made under est_distance comes out the same for any value in (lo, hi] */
+typedef struct {
+	int64_t paired, distance;
+	int64_t lo, hi;
+	int32_t unmapped, unique;    /* reads with score 0 / MAPQ 60 among the reads decided here */
+	int32_t host_pairs;          /* reads handed back (KG_ALN_HOST) */
+	int32_t rescue_wanted;       /* pairs for which RescueUnpairedAlignment was due (:559-560): its windows depend on EstDistance too */
+} kg_chunk_stats;
+
+/* chunk_off[n_chunks + 1]: read index ranges of the batch's chunks (GetNextChunk: 4000 reads each but possibly the last);
+ * chunk_paired[c] != 0: the reads of chunk c are pairs (2q, 2q+1), mate 2 reverse-complemented by the caller.
+ * *records points at a library-owned pinned array of n_reads entries, valid until the next call on the workspace;
+ * chunk_stats[n_chunks] is filled.  KG_ERR_ARG when no chained batch is resident or the chunks do not cover it. */
+int  kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks,
+                    int est_distance, int max_insert, int max_gaps, const kg_aln_record **records, kg_chunk_stats *chunk_stats);
 
 /* ---- Needleman-Wunsch gap closing ----------------------------------------------------------- */
 /* n fragment pairs: frag1 (read side, raw characters) concatenated with offsets off1[n+1], frag2

@@ -4,6 +4,8 @@
 // CPU implementation of the kernels lives here: without a usable HIP device every entry point
 // returns KG_ERR_NO_DEVICE.
 #include "seed_kernels.hpp"
+#include "align_kernels.hpp"
+#include <cmath>
 
 #include <algorithm>
 #include <cstdarg>
@@ -112,6 +114,9 @@ struct kg_index {
 	uint8_t *d_pac = nullptr;
 	int64_t *d_contig_end = nullptr;   // ChrLocMap keys, ascending
 	int n_ends = 0;
+	int32_t *d_end_chr = nullptr;      // contig of every key
+	int64_t *d_chr_tab = nullptr;      // [3 * n_contigs]: FowardLocation, ReverseLocation, len
+	uint8_t *d_mapq_tab = nullptr;     // EvaluateMAPQ's libm branch, tabulated (kg_align_batch)
 	uint64_t device_bytes = 0;
 };
 
@@ -144,6 +149,24 @@ struct kg_workspace {
 	int64_t cand_capacity = 0, ncand_capacity = 0;
 	kg_seed *h_seeds = nullptr;     // pinned
 	int64_t h_seed_capacity = 0;
+	// alignment stage (kg_align_batch)
+	int64_t last_cands = -1;            // candidates the last kg_candidates_batch left on the device
+	bool last_ascii = false;            // the resident reads are characters (KG_INPUT_ASCII)
+	void *d_aln_cand = nullptr;         // per-candidate state, one block
+	int64_t aln_cand_capacity = 0;
+	void *d_aln_read = nullptr;         // per-read state (host flags, records), one block
+	int64_t aln_read_capacity = 0;
+	kg_aln_record *h_records = nullptr; // pinned
+	AlnSpill *d_spill = nullptr;
+	NwJobDesc *d_jobs = nullptr;
+	uint8_t *d_job_ops = nullptr;
+	int32_t *d_job_len = nullptr;
+	int64_t spill_capacity = 0, job_capacity = 0, ops_capacity = 0;
+	int64_t *d_chunk_off = nullptr;
+	uint8_t *d_chunk_paired = nullptr;
+	kg_chunk_stats *d_chunk_stats = nullptr;
+	int chunk_capacity = 0;
+	unsigned long long *d_aln_ctl = nullptr;
 	hipStream_t stream = nullptr;
 	bool profiling = false;
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -262,12 +285,38 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	HIP_TRY(hipMalloc((void **)&ix->d_pac, pac_bytes));
 	HIP_TRY(hipMemcpy(ix->d_pac, ix->pac.data(), pac_bytes, hipMemcpyHostToDevice));
 	{
+		std::vector<std::pair<int64_t, int32_t>> ec;
+		for (size_t i = 0; i < ix->contigs.size(); ++i) {
+			const ContigRec &c = ix->contigs[i];
+			ec.emplace_back(c.fwd_start + c.len - 1, (int32_t)i);
+			ec.emplace_back(c.rev_start + c.len - 1, (int32_t)i);
+		}
+		std::sort(ec.begin(), ec.end());
 		std::vector<int64_t> ends;
-		for (const ContigRec &c : ix->contigs) { ends.push_back(c.fwd_start + c.len - 1); ends.push_back(c.rev_start + c.len - 1); }
-		std::sort(ends.begin(), ends.end());
+		std::vector<int32_t> echr;
+		for (const std::pair<int64_t, int32_t> &e : ec) { ends.push_back(e.first); echr.push_back(e.second); }
 		ix->n_ends = (int)ends.size();
 		HIP_TRY(hipMalloc((void **)&ix->d_contig_end, 8 * ends.size() + 8));
 		HIP_TRY(hipMemcpy(ix->d_contig_end, ends.data(), 8 * ends.size(), hipMemcpyHostToDevice));
+		HIP_TRY(hipMalloc((void **)&ix->d_end_chr, 4 * echr.size() + 8));
+		HIP_TRY(hipMemcpy(ix->d_end_chr, echr.data(), 4 * echr.size(), hipMemcpyHostToDevice));
+		std::vector<int64_t> tab;
+		for (const ContigRec &c : ix->contigs) tab.push_back(c.fwd_start);
+		for (const ContigRec &c : ix->contigs) tab.push_back(c.rev_start);
+		for (const ContigRec &c : ix->contigs) tab.push_back(c.len);
+		HIP_TRY(hipMalloc((void **)&ix->d_chr_tab, 8 * tab.size() + 8));
+		HIP_TRY(hipMemcpy(ix->d_chr_tab, tab.data(), 8 * tab.size(), hipMemcpyHostToDevice));
+		// EvaluateMAPQ (src/Mapping.cpp:172): (int)(30 * (1 - (float)(score - sub_score) / score) * log(score) + 0.4999) for the
+		// only arguments that reach it (score - sub_score in 1..5), evaluated here with the host's libm -- float / double mix as written
+		std::vector<uint8_t> mq((size_t)(kAlnMaxScore + 1) * 6, 0);
+		for (int sc = 1; sc <= kAlnMaxScore; ++sc)
+			for (int d = 1; d <= 5 && d < sc; ++d) {
+				int sub = sc - d;
+				int q = (int)(30 * (1 - (float)(sc - sub) / sc) * log(sc) + 0.4999);
+				mq[(size_t)sc * 6 + (size_t)d] = (uint8_t)(q > 60 ? 60 : q < 0 ? 0 : q);
+			}
+		HIP_TRY(hipMalloc((void **)&ix->d_mapq_tab, mq.size()));
+		HIP_TRY(hipMemcpy(ix->d_mapq_tab, mq.data(), mq.size(), hipMemcpyHostToDevice));
 	}
 	ix->device_bytes = occ_bytes + ix->n_sa * 8 + pac_bytes;
 	v.occ = ix->d_occ;
@@ -286,6 +335,15 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	v.fsa32 = nullptr;
 	v.fsa64 = nullptr;
 	v.text = nullptr;
+	{
+		// the indexed text itself, 2 bits per base, forward + reverse complement: the alignment stage compares reads with it;
+		// with the full suffix array resident the search kernel finishes single-suffix searches against it as well
+		size_t text_bytes = (size_t)(v.seq_len / 4 + 1) + 16;
+		HIP_TRY(hipMalloc((void **)&ix->d_text, text_bytes));
+		HIP_TRY(launch_build_text(ix->d_pac, (uint64_t)ix->l_pac, ix->d_text, text_bytes, nullptr));
+		HIP_TRY(hipDeviceSynchronize());
+		ix->device_bytes += text_bytes;
+	}
 	v.qtab32 = nullptr;
 	v.qtab64 = nullptr;
 	v.qmer = 0;
@@ -301,14 +359,7 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		v.fsa32 = f32;
 		v.fsa64 = f64;
 		ix->device_bytes += fsa_bytes;
-		if (!getenv("KG_NO_DIRECT")) {   // the text, for finishing single-suffix searches by comparison
-			size_t text_bytes = (size_t)(v.seq_len / 4 + 1) + 16;
-			HIP_TRY(hipMalloc((void **)&ix->d_text, text_bytes));
-			HIP_TRY(launch_build_text(ix->d_pac, (uint64_t)ix->l_pac, ix->d_text, text_bytes, nullptr));
-			HIP_TRY(hipDeviceSynchronize());
-			v.text = ix->d_text;
-			ix->device_bytes += text_bytes;
-		}
+		if (!getenv("KG_NO_DIRECT")) v.text = ix->d_text;   // finishing single-suffix searches by comparison against the text
 	} else if (sa_mode != KG_SA_SAMPLED) {
 		return fail(KG_ERR_ARG, "kg_index_load: unknown sa_mode %d", sa_mode);
 	}
@@ -358,6 +409,9 @@ void kg_index_destroy(kg_index *ix)
 	if (ix->d_text) (void)hipFree(ix->d_text);
 	if (ix->d_pac) (void)hipFree(ix->d_pac);
 	if (ix->d_contig_end) (void)hipFree(ix->d_contig_end);
+	if (ix->d_end_chr) (void)hipFree(ix->d_end_chr);
+	if (ix->d_chr_tab) (void)hipFree(ix->d_chr_tab);
+	if (ix->d_mapq_tab) (void)hipFree(ix->d_mapq_tab);
 	delete ix;
 }
 
@@ -440,7 +494,8 @@ void kg_workspace_destroy(kg_workspace *ws)
 	if (ws->stream) { (void)hipStreamSynchronize(ws->stream); (void)hipStreamDestroy(ws->stream); }
 	if (ws->h_cands) (void)hipHostFree(ws->h_cands);
 	if (ws->h_cand_seeds) (void)hipHostFree(ws->h_cand_seeds);
-	void *ptrs[] = {ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
+	if (ws->h_records) (void)hipHostFree(ws->h_records);
+	void *ptrs[] = {ws->d_aln_cand, ws->d_aln_read, ws->d_spill, ws->d_jobs, ws->d_job_ops, ws->d_job_len, ws->d_chunk_off, ws->d_chunk_paired, ws->d_chunk_stats, ws->d_aln_ctl, ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (ws->h_seeds) (void)hipHostFree(ws->h_seeds);
@@ -597,6 +652,8 @@ int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, con
 	int64_t total = seed_offsets[n_reads];
 	ws->last_reads = n_reads;
 	ws->last_seeds = total;
+	ws->last_cands = -1;
+	ws->last_ascii = (mode & KG_INPUT_ASCII) != 0;
 	if (!seeds) return KG_OK;             // the caller only wants the candidates: the seeds stay on the device
 	if (total > ws->h_seed_capacity) {
 		if (ws->h_seeds) HIP_TRY(hipHostFree(ws->h_seeds));
@@ -679,6 +736,7 @@ int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_re
 	HIP_TRY(hipStreamSynchronize(ws->stream));
 	*cands = ws->h_cands; *cand_seeds = ws->h_cand_seeds;
 	*n_cands_total = totals[0]; *n_cand_seeds_total = totals[1];
+	ws->last_cands = totals[0];
 	return KG_OK;
 }
 
@@ -755,6 +813,129 @@ static int nw_run(kg_index *ix, const char *d_frag1, const int64_t *d_off1, cons
 	hipError_t e = launch_nw_batch(a, ix->n_cu, st);
 	hipError_t e2 = hipEventRecord(sc->done, st);
 	if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_nw_batch: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+	return KG_OK;
+}
+
+// Replaces, for a batch, what ReadMapping() does per read between chaining and the SAM text (reference src/Mapping.cpp:542-578);
+// see align_kernels.hip for the kernel <-> reference correspondence.
+int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks, int est_distance, int max_insert,
+                   int max_gaps, const kg_aln_record **records, kg_chunk_stats *chunk_stats)
+{
+	if (!ws || !chunk_off || !chunk_paired || !records || !chunk_stats || n_chunks <= 0) return fail(KG_ERR_ARG, "kg_align_batch: bad argument");
+	*records = nullptr;
+	if (ws->last_reads <= 0 || ws->last_cands < 0) return fail(KG_ERR_ARG, "kg_align_batch: no chained batch on this workspace (kg_seed_batch + kg_candidates_batch first)");
+	kg_index *ix = ws->ix;
+	const int64_t n = ws->last_reads, nc = ws->last_cands;
+	if (chunk_off[0] != 0 || chunk_off[n_chunks] != n) return fail(KG_ERR_ARG, "kg_align_batch: the chunks do not cover the %lld reads of the batch", (long long)n);
+	for (int c = 0; c < n_chunks; ++c) {
+		if (chunk_off[c + 1] < chunk_off[c]) return fail(KG_ERR_ARG, "kg_align_batch: chunk offsets must not decrease");
+		if (chunk_paired[c] && ((chunk_off[c + 1] - chunk_off[c]) & 1)) return fail(KG_ERR_ARG, "kg_align_batch: a paired chunk holds an odd number of reads");
+	}
+	if (!ix->d_text) return fail(KG_ERR_ARG, "kg_align_batch: the index holds no text");
+	if (!ws->last_ascii) return fail(KG_ERR_ARG, "kg_align_batch: the batch must have been seeded from read characters (KG_INPUT_ASCII): mismatch counting and CIGAR scoring compare raw characters");
+	HIP_TRY(hipSetDevice(ix->device));
+	hipStream_t st = ws->stream;
+	// ---- buffers, grown on demand -------------------------------------------------------------------------------------------
+	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	if (nc + 1 > ws->aln_cand_capacity) {
+		if (ws->d_aln_cand) HIP_TRY(hipFree(ws->d_aln_cand));
+		ws->d_aln_cand = nullptr;
+		int64_t cap = nc + nc / 4 + 4096;
+		HIP_TRY(hipMalloc(&ws->d_aln_cand, up(4 * (size_t)cap) * 5 + up(8 * (size_t)cap) + up((size_t)cap) * 2 + up((size_t)cap * KG_ALN_CIGAR_MAX)));
+		ws->aln_cand_capacity = cap;
+	}
+	if (n + 2 > ws->aln_read_capacity) {
+		if (ws->d_aln_read) HIP_TRY(hipFree(ws->d_aln_read));
+		if (ws->h_records) HIP_TRY(hipHostFree(ws->h_records));
+		for (void *p : {(void *)ws->d_spill, (void *)ws->d_jobs, (void *)ws->d_job_ops, (void *)ws->d_job_len})
+			if (p) HIP_TRY(hipFree(p));
+		ws->d_aln_read = nullptr; ws->h_records = nullptr; ws->d_spill = nullptr; ws->d_jobs = nullptr; ws->d_job_ops = nullptr; ws->d_job_len = nullptr;
+		int64_t cap = n + n / 4 + 4096;
+		HIP_TRY(hipMalloc(&ws->d_aln_read, up((size_t)cap) + sizeof(kg_aln_record) * (size_t)cap));
+		HIP_TRY(hipHostMalloc((void **)&ws->h_records, sizeof(kg_aln_record) * (size_t)cap, hipHostMallocDefault));
+		// about one candidate in ten waits for an alignment; room for one in two
+		ws->spill_capacity = cap / 2 + 4096;
+		ws->job_capacity = cap / 2 + 4096;
+		ws->ops_capacity = 64 * ws->job_capacity;
+		HIP_TRY(hipMalloc((void **)&ws->d_spill, sizeof(AlnSpill) * (size_t)ws->spill_capacity));
+		HIP_TRY(hipMalloc((void **)&ws->d_jobs, sizeof(NwJobDesc) * (size_t)ws->job_capacity));
+		HIP_TRY(hipMalloc((void **)&ws->d_job_ops, (size_t)ws->ops_capacity + 1024));
+		HIP_TRY(hipMalloc((void **)&ws->d_job_len, 4 * (size_t)ws->job_capacity));
+		ws->aln_read_capacity = cap;
+	}
+	if (n_chunks > ws->chunk_capacity) {
+		for (void *p : {(void *)ws->d_chunk_off, (void *)ws->d_chunk_paired, (void *)ws->d_chunk_stats})
+			if (p) HIP_TRY(hipFree(p));
+		ws->d_chunk_off = nullptr; ws->d_chunk_paired = nullptr; ws->d_chunk_stats = nullptr;
+		int cap = n_chunks + n_chunks / 2 + 64;
+		HIP_TRY(hipMalloc((void **)&ws->d_chunk_off, 8 * (size_t)(cap + 1)));
+		HIP_TRY(hipMalloc((void **)&ws->d_chunk_paired, (size_t)cap));
+		HIP_TRY(hipMalloc((void **)&ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)cap));
+		ws->chunk_capacity = cap;
+	}
+	if (!ws->d_aln_ctl) HIP_TRY(hipMalloc((void **)&ws->d_aln_ctl, 8 * 4));
+	HIP_TRY(hipMemcpyAsync(ws->d_chunk_off, chunk_off, 8 * (size_t)(n_chunks + 1), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(ws->d_chunk_paired, chunk_paired, (size_t)n_chunks, hipMemcpyHostToDevice, st));
+	// ---- arguments ------------------------------------------------------------------------------------------------------------
+	AlnArgs a;
+	a.ix = ix->view;
+	a.ix.text = ix->d_text;
+	a.enc = ws->d_enc; a.read_off = ws->d_read_off; a.n_reads = n;
+	a.chunk_off = ws->d_chunk_off; a.chunk_paired = ws->d_chunk_paired; a.n_chunks = n_chunks;
+	a.cand_off = ws->d_cand_off; a.cands = ws->d_dense_cands; a.cand_seeds = ws->d_dense_seeds; a.n_cands = nc;
+	a.contig_end = ix->d_contig_end; a.end_chr = ix->d_end_chr; a.n_ends = ix->n_ends;
+	a.n_chr = (int)ix->contigs.size();
+	a.chr_fwd_start = ix->d_chr_tab; a.chr_rev_start = ix->d_chr_tab + a.n_chr; a.chr_len = ix->d_chr_tab + 2 * a.n_chr;
+	a.genome_size = ix->l_pac; a.two_genome_size = 2 * ix->l_pac;
+	a.est_distance = est_distance; a.max_insert = max_insert; a.max_gaps = max_gaps;
+	a.mapq_tab = ix->d_mapq_tab;
+	{
+		char *p = (char *)ws->d_aln_cand;
+		size_t cap = (size_t)ws->aln_cand_capacity;
+		a.c_score = (int32_t *)p; p += up(4 * cap);
+		a.c_mate = (int32_t *)p; p += up(4 * cap);
+		a.c_read = (int32_t *)p; p += up(4 * cap);
+		a.rep_score = (int32_t *)p; p += up(4 * cap);
+		a.rep_chr = (int32_t *)p; p += up(4 * cap);
+		a.rep_pos = (int64_t *)p; p += up(8 * cap);
+		a.rep_fwd = (uint8_t *)p; p += up(cap);
+		a.rep_cigar_len = (uint8_t *)p; p += up(cap);
+		a.rep_cigar = p;
+		char *q = (char *)ws->d_aln_read;
+		a.r_host = (uint8_t *)q; q += up((size_t)ws->aln_read_capacity);
+		a.records = (kg_aln_record *)q;
+	}
+	a.spill = ws->d_spill; a.spill_capacity = ws->spill_capacity;
+	a.jobs = ws->d_jobs; a.job_capacity = ws->job_capacity; a.ops_capacity = ws->ops_capacity;
+	a.ctl = ws->d_aln_ctl;
+	a.nw_ops = ws->d_job_ops; a.nw_len = ws->d_job_len;
+	a.chunk_stats = ws->d_chunk_stats;
+	HIP_TRY(launch_align_front(a, ix->n_cu, st));
+	// ---- gap closing: the NW kernels on the job descriptors, fragments read in place --------------------------------------------
+	{
+		NwArgs w;
+		w.desc = ws->d_jobs; w.text2 = ix->d_text; w.n_dev = ws->d_aln_ctl + 1;
+		w.f1 = (const char *)ws->d_enc; w.off1 = nullptr; w.f2 = nullptr; w.off2 = nullptr;
+		w.n = ws->job_capacity;
+		w.ops = ws->d_job_ops; w.aln_len = ws->d_job_len;
+		w.big_lds_bytes = nw_big_lds_bytes(kAlnMaxFrag);
+		w.gb_offset_words = 0;
+		w.dir_words_per_wave = nw_dir_words(kAlnMaxFrag);
+		int per_cu = std::max(1, std::min(16, (160 * 1024) / std::max(w.big_lds_bytes, 1024)));
+		w.big_waves = (int)std::min<int64_t>((int64_t)ix->n_cu * per_cu, ws->job_capacity);
+		NwScratch *sc = nullptr;
+		int rc = nw_acquire(ix, 3 * (size_t)ws->job_capacity, (size_t)w.big_waves * (size_t)w.dir_words_per_wave, &sc);
+		if (rc != KG_OK) return rc;
+		w.big_list = sc->lists; w.queue = sc->queue; w.dir_scratch = sc->dir;
+		hipError_t e = launch_nw_batch(w, ix->n_cu, st);
+		hipError_t e2 = hipEventRecord(sc->done, st);
+		if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_align_batch: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+	}
+	HIP_TRY(launch_align_back(a, ix->n_cu, st));
+	HIP_TRY(hipMemcpyAsync(ws->h_records, a.records, sizeof(kg_aln_record) * (size_t)n, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(chunk_stats, ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)n_chunks, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	*records = ws->h_records;
 	return KG_OK;
 }
 

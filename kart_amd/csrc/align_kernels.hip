@@ -1,0 +1,1024 @@
+// align_kernels.hip -- the per-read report on the device (gfx950): pairing, normal pairs, gap closing, CIGAR, flags, MAPQ.
+//
+// Replaces, for the short-read configuration (neither -pacbio nor -m) and per batch, what ReadMapping() does for every read
+// between chaining and the SAM text (reference src/Mapping.cpp:542-578):
+//   aln_pair_kernel   CheckPairedAlignmentCandidates, RemoveUnMatedAlignmentCandidates, RemoveRedundantCandidates
+//                     (src/Mapping.cpp:317-427); one read pair per lane.
+//   aln_plan_kernel   GenMappingReport pass 1 (src/AlignmentCandidates.cpp:624-745), one candidate per lane: IdentifyNormalPairs
+//                     with RemoveTandemRepeatSeeds / RemoveTranslocatedSeeds / CheckOverlappingSeeds (:226-490),
+//                     CheckCoordinateValidity (:582-610), and for every normal pair the decisions of
+//                     Process{Head,Normal,Tail}SequencePair that need no alignment (src/tools.cpp:225-253, 292-312, 344-363):
+//                     pure insertion / deletion, the <= 2-mismatch shortcut against the 2-bit text, the long-end soft clip, the
+//                     1 x 1 gap.  A pair that needs nw_alignment becomes a job descriptor for the NW kernels (nw_kernels.hip read
+//                     the read characters and the 2-bit text in place); the candidate is then parked in a spill slot.  A
+//                     candidate without jobs is finished right here.
+//   aln_finish_kernel pass 2 for the parked candidates: CheckLocalAlignmentQuality, the leading / trailing gap trimming of the head
+//                     and tail pairs, AddNewCigarElements (src/tools.cpp:49-104, 255-290, 314-339, 366-394) over the op strings.
+//   aln_final_kernel  best / second best (src/AlignmentCandidates.cpp:724-740), CheckPairedFinalAlignments,
+//                     Set{Paired,Single}AlignmentFlag, EvaluateMAPQ (src/Mapping.cpp:49-175, 429-480) and what
+//                     Output{Paired,Singled}Alignments print (:177-315) as one kg_aln_record per read, plus the chunk's
+//                     contribution to iPaired / iDistance and its EstDistance validity interval.
+// Integer work throughout; MAPQ's one libm expression comes from a table the host fills with its own log().  No MFMA: there is
+// no contraction here.  Anything outside the envelope (mate rescue, 8-mer partition of long fragments, > 12 seeds, > 47 CIGAR
+// characters) marks the read pair for the host path instead.
+#include "align_kernels.hpp"
+
+namespace kg {
+
+namespace {
+
+// ---- small helpers --------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int text_code(const AlnArgs &a, int64_t g)       // base of the indexed text (forward + reverse complement)
+{
+	return (a.ix.text[(uint64_t)g >> 2] >> (((uint32_t)g & 3) << 1)) & 3;
+}
+__device__ __forceinline__ char text_char(const AlnArgs &a, int64_t g)      // RefSequence[g]: always upper-case ACGT
+{
+	int c = text_code(a, g);
+	return c == 0 ? 'A' : c == 1 ? 'C' : c == 2 ? 'G' : 'T';
+}
+
+__device__ __forceinline__ int chunk_of(const AlnArgs &a, int64_t r)
+{
+	int lo = 0, hi = a.n_chunks - 1;
+	while (lo < hi) {
+		int mid = (lo + hi + 1) >> 1;
+		if (a.chunk_off[mid] <= r) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+
+// ChrLocMap.lower_bound(g): index of the first key >= g, n_ends when there is none
+__device__ __forceinline__ int end_lower_bound(const AlnArgs &a, int64_t g)
+{
+	int lo = 0, hi = a.n_ends;
+	while (lo < hi) {
+		int mid = (lo + hi) >> 1;
+		if (a.contig_end[mid] < g) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+__device__ __forceinline__ void flag_host(const AlnArgs &a, int64_t r)       // the pair of read r goes back to the host
+{
+	int c = chunk_of(a, r);
+	int64_t base = a.chunk_off[c];
+	if (a.chunk_paired[c]) {
+		int64_t first = base + (((r - base) >> 1) << 1);
+		a.r_host[first] = 1;
+		a.r_host[first + 1] = 1;
+	} else a.r_host[r] = 1;
+}
+
+// RemoveRedundantCandidates, src/Mapping.cpp:317-346 (non-PacBio) on candidates [c0, c0 + n)
+__device__ void remove_redundant(const AlnArgs &a, int64_t c0, int n)
+{
+	if (n <= 1) return;
+	int s1 = 0, s2 = 0;
+	for (int i = 0; i < n; ++i) {
+		int s = a.c_score[c0 + i];
+		if (s > s2) {
+			if (s >= s1) { s2 = s1; s1 = s; }
+			else s2 = s;
+		}
+	}
+	int thr = (s1 == s2 || s1 - s2 > 20) ? s1 : s2;
+	for (int i = 0; i < n; ++i)
+		if (a.c_score[c0 + i] < thr) a.c_score[c0 + i] = 0;
+}
+
+}  // namespace
+
+// ---- pairing ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
+{
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; r < a.n_reads; r += stride) {
+		const int ck = chunk_of(a, r);
+		const bool paired = a.chunk_paired[ck] != 0;
+		const int64_t in_chunk = r - a.chunk_off[ck];
+		if (paired && (in_chunk & 1)) continue;                      // the first mate's lane does the pair
+		const int64_t a0 = a.cand_off[r], a1 = a.cand_off[r + 1];
+		const int n1 = (int)(a1 - a0);
+		for (int i = 0; i < n1; ++i) { a.c_score[a0 + i] = a.cands[a0 + i].score; a.c_mate[a0 + i] = -1; a.c_read[a0 + i] = (int32_t)r; }
+		if (!paired) {
+			remove_redundant(a, a0, n1);                             // src/Mapping.cpp:589
+			continue;
+		}
+		const int64_t b1 = a.cand_off[r + 2];
+		const int n2 = (int)(b1 - a1);
+		for (int j = 0; j < n2; ++j) { a.c_score[a1 + j] = a.cands[a1 + j].score; a.c_mate[a1 + j] = -1; a.c_read[a1 + j] = (int32_t)(r + 1); }
+		if ((int64_t)n1 * n2 > kAlnPairProduct) { a.r_host[r] = 1; a.r_host[r + 1] = 1; continue; }
+		// CheckPairedAlignmentCandidates, src/Mapping.cpp:348-400
+		if (n1 * n2 > 1000) { remove_redundant(a, a0, n1); remove_redundant(a, a1, n2); }
+		bool pairing = false;
+		long long lo = -1, hi = 0x7fffffffffffffffll;
+		const long long est = a.est_distance;
+		for (int i = 0; i < n1; ++i) {
+			if (a.c_score[a0 + i] == 0) continue;
+			const int64_t pd1 = a.cands[a0 + i].posDiff;
+			int best = -1, s = 0;
+			for (int j = 0; j < n2; ++j) {
+				int sj = a.c_score[a1 + j];
+				int64_t pd2 = a.cands[a1 + j].posDiff;
+				if (sj == 0 || pd2 < pd1) continue;
+				long long dist = pd2 - pd1;
+				if (dist < est) {
+					if (dist > lo) lo = dist;
+					if (sj > s) { best = j; s = sj; }
+					else if (sj == s) best = -1;
+				} else if (dist < hi) hi = dist;
+			}
+			if (s > 0 && best != -1) {
+				int j = best;
+				int mj = a.c_mate[a1 + j];
+				if (mj == -1) {
+					pairing = true;
+					a.c_mate[a0 + i] = j;
+					a.c_mate[a1 + j] = i;
+				} else if (a.c_score[a0 + i] > a.c_score[a0 + mj]) {
+					a.c_mate[a0 + mj] = -1;
+					a.c_mate[a0 + i] = j;
+					a.c_mate[a1 + j] = i;
+				}
+			}
+		}
+		if (lo > -1) atomicMax((long long *)&a.chunk_stats[ck].lo, lo);
+		if (hi != 0x7fffffffffffffffll) atomicMin((long long *)&a.chunk_stats[ck].hi, hi);
+		if (!pairing) {
+			// RescueUnpairedAlignment is due (src/Mapping.cpp:559-560).  Its first two exits need no k-mers
+			// (src/AlignmentRescue.cpp:83-84): no scoring candidate at all, or both mates below 10 % of their length
+			a.chunk_stats[ck].rescue_wanted = 1;
+			int sc1 = 0, sc2 = 0;
+			for (int i = 0; i < n1; ++i) sc1 = max(sc1, a.c_score[a0 + i]);
+			for (int j = 0; j < n2; ++j) sc2 = max(sc2, a.c_score[a1 + j]);
+			const int rl1 = (int)(a.read_off[r + 1] - a.read_off[r]), rl2 = (int)(a.read_off[r + 2] - a.read_off[r + 1]);
+			bool no_op = (sc1 == 0 && sc2 == 0) || (sc1 < (int)(rl1 * 0.1) && sc2 < (int)(rl2 * 0.1));
+			if (!no_op) { a.r_host[r] = 1; a.r_host[r + 1] = 1; continue; }
+		} else {
+			// RemoveUnMatedAlignmentCandidates, src/Mapping.cpp:402-427
+			for (int i = 0; i < n1; ++i) {
+				int j = a.c_mate[a0 + i];
+				if (j == -1) a.c_score[a0 + i] = 0;
+				else { int s = a.c_score[a0 + i] + a.c_score[a1 + j]; a.c_score[a0 + i] = s; a.c_score[a1 + j] = s; }
+			}
+			for (int j = 0; j < n2; ++j)
+				if (a.c_mate[a1 + j] == -1) a.c_score[a1 + j] = 0;
+		}
+		remove_redundant(a, a0, n1);                                 // src/Mapping.cpp:563
+		remove_redundant(a, a1, n2);
+	}
+}
+
+// ---- normal pairs ------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Pairs {                      // vector<SeedPair_t> of one candidate, in the lane's private memory
+	int64_t gPos[kAlnMaxPairs];
+	int32_t rPos[kAlnMaxPairs];
+	int32_t rLen[kAlnMaxPairs], gLen[kAlnMaxPairs];
+	uint8_t simple[kAlnMaxPairs];
+	int num;
+};
+
+__device__ __forceinline__ void erase_empty(Pairs &v)
+{
+	int w = 0;
+	for (int i = 0; i < v.num; ++i)
+		if (v.rLen[i] != 0) {
+			if (w != i) { v.gPos[w] = v.gPos[i]; v.rPos[w] = v.rPos[i]; v.rLen[w] = v.rLen[i]; v.gLen[w] = v.gLen[i]; v.simple[w] = v.simple[i]; }
+			w++;
+		}
+	v.num = w;
+}
+
+// RemoveTandemRepeatSeeds, src/AlignmentCandidates.cpp:235-260: every read position hit by more than one seed goes
+__device__ void remove_tandem_repeats(Pairs &v)
+{
+	if (v.num < 2) return;
+	bool any = false;
+	uint32_t drop = 0;
+	for (int i = 0; i < v.num; ++i)
+		for (int j = i + 1; j < v.num; ++j)
+			if (v.rPos[i] == v.rPos[j]) { drop |= (1u << i) | (1u << j); any = true; }
+	if (!any) return;
+	for (int i = 0; i < v.num; ++i)
+		if ((drop >> i) & 1) v.rLen[i] = v.gLen[i] = 0;
+	erase_empty(v);
+}
+
+// RemoveTranslocatedSeeds, src/AlignmentCandidates.cpp:262-321.  ord[k] = index (in genome order) of the seed with the k-th
+// smallest read position (read positions are distinct once the tandem repeats are gone)
+__device__ void remove_translocated(Pairs &v)
+{
+	const int num = v.num;
+	if (num < 2) return;
+	int ord[kAlnMaxSeeds];
+	for (int i = 0; i < num; ++i) {
+		int x = i, p = i;
+		while (p > 0 && v.rPos[ord[p - 1]] > v.rPos[x]) { ord[p] = ord[p - 1]; --p; }
+		ord[p] = x;
+	}
+	bool any = false;
+	for (int i = 0; i < num; ++i) {
+		if (ord[i] == i) continue;
+		any = true;
+		int hi = ord[i];
+		for (int j = i + 1; j <= hi; ++j)
+			if (ord[j] > hi) hi = ord[j];
+		int s1 = 0, s2 = 0;
+		for (int k = i; k <= hi; ++k) {
+			if (k < ord[k]) s1 += v.rLen[ord[k]];
+			else s2 += v.rLen[ord[k]];
+		}
+		for (int k = i; k <= hi; ++k) {
+			bool drop = s1 > s2 ? k > ord[k] : k < ord[k];
+			if (drop) v.rLen[ord[k]] = v.gLen[ord[k]] = 0;
+		}
+		i = hi;
+	}
+	if (any) erase_empty(v);
+}
+
+// CheckSeedOverlapping, src/AlignmentCandidates.cpp:323-373
+__device__ bool resolve_overlap(Pairs &v, int i, int j)
+{
+	bool master = true;
+	int ov;
+	if ((ov = v.rPos[i] + v.rLen[i] - v.rPos[j]) > 0) {
+		if (v.rLen[i] < v.rLen[j]) {
+			master = false;
+			if (v.rLen[i] > ov) v.gLen[i] = (v.rLen[i] -= ov);
+			else v.rLen[i] = v.gLen[i] = 0;
+		} else if (v.rLen[j] > ov) {
+			v.rPos[j] += ov; v.gPos[j] += ov; v.gLen[j] = (v.rLen[j] -= ov);
+		} else v.rLen[j] = v.gLen[j] = 0;
+	}
+	if (v.rLen[i] > 0 && v.rLen[j] > 0 && (ov = (int)(v.gPos[i] + v.gLen[i] - v.gPos[j])) > 0) {
+		if (v.gLen[i] < v.gLen[j]) {
+			master = false;
+			if (v.rLen[i] > ov) v.gLen[i] = (v.rLen[i] -= ov);
+			else v.rLen[i] = v.gLen[i] = 0;
+		} else if (v.rLen[j] > ov) {
+			v.rPos[j] += ov; v.gPos[j] += ov; v.gLen[j] = (v.rLen[j] -= ov);
+		} else v.rLen[j] = v.gLen[j] = 0;
+	}
+	return master;
+}
+
+// CheckOverlappingSeeds, src/AlignmentCandidates.cpp:375-418
+__device__ void check_overlaps(Pairs &v)
+{
+	const int num = v.num;
+	if (num < 2) return;
+	bool any = false;
+	for (int i = 0; i < num;) {
+		if (v.rLen[i] > 0) {
+			int r_end = v.rPos[i] + v.rLen[i] - 1;
+			int64_t g_end = v.gPos[i] + v.gLen[i] - 1;
+			for (int j = i + 1; j < num; ++j) {
+				if (v.rLen[j] == 0) continue;
+				if (r_end < v.rPos[j] && g_end < v.gPos[j]) break;
+				if (!resolve_overlap(v, i, j)) break;
+			}
+			if (v.rLen[i] == 0) {
+				any = true;
+				int q = i - 1;
+				while (q > 0 && v.rLen[q] == 0) q--;
+				i = q < 0 ? 0 : q;
+			} else i++;
+		} else {
+			any = true;
+			i++;
+		}
+	}
+	if (any) erase_empty(v);
+}
+
+__device__ __forceinline__ bool by_gpos_less(int64_t g1, int r1, int64_t g2, int r2)   // CompByGenomePos, :17-21
+{
+	return g1 == g2 ? r1 < r2 : g1 < g2;
+}
+
+// IdentifyNormalPairs(rlen, -1, v), src/AlignmentCandidates.cpp:420-490.  false: more gap pairs than the envelope holds
+__device__ bool identify_normal_pairs(int rlen, Pairs &v)
+{
+	if (v.num > 1) {
+		remove_tandem_repeats(v);
+		remove_translocated(v);
+		check_overlaps(v);
+		const int num = v.num;
+		int added = 0;
+		for (int i = 0, j = 1; j < num; ++i, ++j) {
+			int r_gap = v.rPos[j] - (v.rPos[i] + v.rLen[i]);
+			if (r_gap < 0) r_gap = 0;
+			int g_gap = (int)(v.gPos[j] - (v.gPos[i] + v.gLen[i]));
+			if (g_gap < 0) g_gap = 0;
+			if (r_gap > 0 || g_gap > 0) {
+				if (added == kAlnMaxGaps) return false;
+				int t = num + added++;
+				v.simple[t] = 0;
+				v.rPos[t] = v.rPos[i] + v.rLen[i];
+				v.gPos[t] = v.gPos[i] + v.gLen[i];
+				v.rLen[t] = r_gap; v.gLen[t] = g_gap;
+			}
+		}
+		// the appended gap pairs go between the seeds in (gPos, rPos) order: insertion, as the host does for up to 8 of them
+		for (int t = num; t < num + added; ++t) {
+			int64_t xg = v.gPos[t];
+			int xr = v.rPos[t], xrl = v.rLen[t], xgl = v.gLen[t];
+			uint8_t xs = v.simple[t];
+			int p = t;
+			while (p > 0 && by_gpos_less(xg, xr, v.gPos[p - 1], v.rPos[p - 1])) {
+				v.gPos[p] = v.gPos[p - 1]; v.rPos[p] = v.rPos[p - 1]; v.rLen[p] = v.rLen[p - 1]; v.gLen[p] = v.gLen[p - 1]; v.simple[p] = v.simple[p - 1];
+				--p;
+			}
+			v.gPos[p] = xg; v.rPos[p] = xr; v.rLen[p] = xrl; v.gLen[p] = xgl; v.simple[p] = xs;
+		}
+		v.num = num + added;
+	}
+	if (v.num > 0) {
+		int r_gap = v.rPos[0] > 0 ? v.rPos[0] : 0;
+		int g_gap = r_gap;                                        // glen = -1: the genome gap is the read gap (:458)
+		if (r_gap > 0 || g_gap > 0) {
+			for (int p = v.num; p > 0; --p) {
+				v.gPos[p] = v.gPos[p - 1]; v.rPos[p] = v.rPos[p - 1]; v.rLen[p] = v.rLen[p - 1]; v.gLen[p] = v.gLen[p - 1]; v.simple[p] = v.simple[p - 1];
+			}
+			int64_t g = v.gPos[1] - g_gap;
+			v.gPos[0] = g < 0 ? 0 : g;                             // (the reference's follow-up "gGaps += gPos" adds zero, :464)
+			v.rPos[0] = 0; v.rLen[0] = r_gap; v.gLen[0] = g_gap; v.simple[0] = 0;
+			v.num++;
+		}
+		int last = v.num - 1;
+		r_gap = rlen - (v.rPos[last] + v.rLen[last]);
+		g_gap = r_gap;
+		if (r_gap > 0 || g_gap > 0) {
+			int t = v.num++;
+			v.simple[t] = 0;
+			v.rPos[t] = v.rPos[last] + v.rLen[last];
+			v.gPos[t] = v.gPos[last] + v.gLen[last];
+			v.rLen[t] = r_gap; v.gLen[t] = g_gap;
+		}
+	}
+	return true;
+}
+
+// CheckCoordinateValidity, src/AlignmentCandidates.cpp:582-610
+__device__ bool coordinates_valid(const AlnArgs &a, const Pairs &v)
+{
+	int64_t g1 = 0, g2 = a.two_genome_size;
+	for (int i = 0; i < v.num; ++i)
+		if (v.gLen[i] > 0) { g1 = v.gPos[i]; break; }
+	for (int i = v.num; i-- > 0;)
+		if (v.gLen[i] > 0) { g2 = v.gPos[i] + v.gLen[i] - 1; break; }
+	const int64_t L = a.genome_size;
+	if ((g1 < L && g2 >= L) || (g1 >= L && g2 < L)) return false;
+	int i1 = end_lower_bound(a, g1), i2 = end_lower_bound(a, g2);
+	if (i1 == a.n_ends || i2 == a.n_ends || a.end_chr[i1] != a.end_chr[i2]) return false;
+	return true;
+}
+
+// ---- CIGAR building --------------------------------------------------------------------------------------------------------
+struct Cigar {                      // vector<pair<int,char>> cigar_vec
+	int32_t len[kAlnMaxCigar];
+	char op[kAlnMaxCigar];
+	int n;
+	bool overflow;
+	__device__ __forceinline__ void push(int l, char o)
+	{
+		if (n < kAlnMaxCigar) { len[n] = l; op[n] = o; n++; }
+		else overflow = true;
+	}
+};
+
+// One column of the aligned strings nw_alignment leaves behind (src/nw_alignment.cpp:59-72), rebuilt from the op string.
+// AddNewCigarElements and CheckLocalAlignmentQuality look at the CHARACTERS (a literal '-' in a read counts as a gap there),
+// so the columns are characters here too.
+struct Columns {
+	const uint8_t *ops;
+	int len;
+	const uint8_t *rd;              // read characters of the fragment
+	int64_t g;                      // text coordinate of the fragment
+};
+
+// AddNewCigarElements over columns [from, to), src/tools.cpp:49-104; (ri, gi) = characters consumed before `from`
+__device__ int add_cigar_columns(const AlnArgs &a, const Columns &c, int from, int to, int ri, int gi, Cigar &cig)
+{
+	char state = '*';
+	int cnt = 0, score = 0;
+	for (int t = from; t < to; ++t) {
+		uint8_t op = c.ops[t];
+		char c1 = op == KG_OP_GAP1 ? '-' : (char)c.rd[ri];
+		char c2 = op == KG_OP_GAP2 ? '-' : text_char(a, c.g + gi);
+		if (op != KG_OP_GAP1) ri++;
+		if (op != KG_OP_GAP2) gi++;
+		char st;
+		if (c1 == '-') st = 'D';
+		else if (c2 == '-') st = 'I';
+		else { st = 'M'; if (c1 == c2) score++; }
+		if (st == state) cnt++;
+		else {
+			if (cnt > 0) cig.push(cnt, state);
+			cnt = 1;
+			state = st;
+		}
+	}
+	if (cnt > 0) cig.push(cnt, state);
+	return score;
+}
+
+// CheckLocalAlignmentQuality, src/tools.cpp:255-290
+__device__ bool local_quality_ok(const AlnArgs &a, const Columns &c)
+{
+	int type = -1, n = 0, mis = 0, runs = 0, ri = 0, gi = 0;
+	for (int t = 0; t < c.len; ++t) {
+		uint8_t op = c.ops[t];
+		char c1 = op == KG_OP_GAP1 ? '-' : (char)c.rd[ri];
+		char c2 = op == KG_OP_GAP2 ? '-' : text_char(a, c.g + gi);
+		if (op != KG_OP_GAP1) ri++;
+		if (op != KG_OP_GAP2) gi++;
+		int ty;
+		if (c1 == '-') ty = 0;
+		else if (c2 == '-') ty = 1;
+		else { ty = 2; n++; if (c1 != c2) mis++; }
+		if (ty != type) { type = ty; runs++; }
+	}
+	return !(runs >= 4 || (mis >= 3 && mis >= (int)(n * 0.3)));
+}
+
+// character of column t on either side ('-' for a gap); (ri, gi) advance
+__device__ __forceinline__ void column_chars(const AlnArgs &a, const Columns &c, int t, int &ri, int &gi, char &c1, char &c2)
+{
+	uint8_t op = c.ops[t];
+	c1 = op == KG_OP_GAP1 ? '-' : (char)c.rd[ri];
+	c2 = op == KG_OP_GAP2 ? '-' : text_char(a, c.g + gi);
+	if (op != KG_OP_GAP1) ri++;
+	if (op != KG_OP_GAP2) gi++;
+}
+
+// ProcessHeadSequencePair after the alignment, src/tools.cpp:314-339: leading gaps of either string are trimmed
+__device__ int finish_head(const AlnArgs &a, const Columns &c, int64_t &gPos, int &gLen, int &rPos, int &rLen, Cigar &cig)
+{
+	if (!local_quality_ok(a, c)) { cig.push(rLen, 'S'); return 0; }
+	int t = 0, ri = 0, gi = 0;
+	// leading '-' of the read side: genome characters without a partner
+	int p = 0;
+	for (;;) {
+		if (t >= c.len) break;
+		int r2 = ri, g2 = gi;
+		char c1, c2;
+		column_chars(a, c, t, r2, g2, c1, c2);
+		if (c1 != '-') break;
+		ri = r2; gi = g2; t++; p++;
+	}
+	if (p > 0) { gPos += p; gLen -= p; }
+	p = 0;
+	for (;;) {
+		if (t >= c.len) break;
+		int r2 = ri, g2 = gi;
+		char c1, c2;
+		column_chars(a, c, t, r2, g2, c1, c2);
+		if (c2 != '-') break;
+		ri = r2; gi = g2; t++; p++;
+	}
+	if (p > 0) { rPos += p; rLen -= p; cig.push(p, 'S'); }
+	return add_cigar_columns(a, c, t, c.len, ri, gi, cig);
+}
+
+// ProcessTailSequencePair after the alignment, src/tools.cpp:366-394
+__device__ int finish_tail(const AlnArgs &a, const Columns &c, int &gLen, int &rLen, Cigar &cig)
+{
+	if (!local_quality_ok(a, c)) { cig.push(rLen, 'S'); return 0; }
+	// characters of every column once (needed from the back)
+	int end = c.len;
+	// trailing '-' of the read side
+	int cnt = 0;
+	{
+		// walk forward to know (ri, gi) at every column; the tail is short, so recompute by scanning
+		for (;;) {
+			if (end <= 0) break;
+			int ri = 0, gi = 0;
+			char c1 = 0, c2 = 0;
+			for (int t = 0; t < end; ++t) column_chars(a, c, t, ri, gi, c1, c2);
+			if (c1 != '-') break;
+			end--; cnt++;
+		}
+	}
+	if (cnt > 0) gLen -= cnt;
+	int cnt2 = 0;
+	for (;;) {
+		if (end <= 0) break;
+		int ri = 0, gi = 0;
+		char c1 = 0, c2 = 0;
+		for (int t = 0; t < end; ++t) column_chars(a, c, t, ri, gi, c1, c2);
+		if (c2 != '-') break;
+		end--; cnt2++;
+	}
+	if (cnt2 > 0) rLen -= cnt2;
+	int score = add_cigar_columns(a, c, 0, end, 0, 0, cig);
+	if (cnt2 > 0) cig.push(cnt2, 'S');
+	return score;
+}
+
+// what pass 1 decided for a pair
+enum : uint8_t { W_NONE = 0, W_SIMPLE = 1, W_IMMEDIATE = 2, W_JOB = 3 };
+struct Work {
+	uint8_t kind[kAlnMaxPairs];
+	uint8_t op[kAlnMaxPairs];
+	int32_t op_len[kAlnMaxPairs];
+	int32_t val[kAlnMaxPairs];      // IMMEDIATE: score (-1 = the > 3000 soft clip); JOB: job index
+};
+
+// GenMappingReport's pair loop and tail for one candidate (src/AlignmentCandidates.cpp:657-722): CIGAR, AlnScore, coordinates.
+// `first`: the read is the first of its pair (or single).  Returns false when the result does not fit the record.
+__device__ bool finish_candidate(const AlnArgs &a, int64_t cand, bool first, const uint8_t *rd, Pairs &v, const Work &w)
+{
+	const int num = v.num;
+	Cigar cig;
+	cig.n = 0; cig.overflow = false;
+	int score = 0;
+	for (int j = 0; j < num; ++j) {
+		if (w.kind[j] == W_NONE) continue;
+		if (w.kind[j] == W_SIMPLE) {
+			cig.push(v.rLen[j], 'M');
+			score += v.rLen[j];
+			continue;
+		}
+		const bool head = j == 0, tail = j == num - 1 && !head;
+		int s;
+		if (w.kind[j] == W_IMMEDIATE) {
+			if (w.op[j] != 0) cig.push(w.op_len[j], (char)w.op[j]);
+			s = w.val[j];
+		} else {
+			const NwJobDesc jd = a.jobs[w.val[j]];
+			Columns c;
+			c.ops = a.nw_ops + jd.ops;
+			c.len = a.nw_len[w.val[j]];
+			c.rd = rd + v.rPos[j];
+			c.g = v.gPos[j];
+			if (head) s = finish_head(a, c, v.gPos[j], v.gLen[j], v.rPos[j], v.rLen[j], cig);
+			else if (tail) s = finish_tail(a, c, v.gLen[j], v.rLen[j], cig);
+			else s = add_cigar_columns(a, c, 0, c.len, 0, 0, cig);
+		}
+		if (head) {
+			if (s > 0) score += s;
+			if (s <= 0) { v.gPos[0] = v.gPos[1]; v.gLen[0] = 0; }         // :674-686
+		} else if (tail) {
+			if (s > 0) score += s;
+			if (s <= 0) { v.gPos[j] = v.gPos[j - 1] + v.gLen[j - 1]; v.gLen[j] = 0; }
+		} else score += s;
+	}
+	if (cig.overflow) return false;
+	a.rep_chr[cand] = 0;
+	a.rep_pos[cand] = 0;
+	a.rep_fwd[cand] = 1;
+	a.rep_cigar_len[cand] = 0;
+	if (cig.n > 1) {                                                     // GapPenalty, :612-622, :701-706
+		int gp = 0;
+		for (int i = 0; i < cig.n; ++i)
+			if (cig.op[i] == 'I' || cig.op[i] == 'D') gp += cig.len[i];
+		score -= gp;
+		if (score <= 0) { a.rep_score[cand] = 0; a.c_score[cand] = -1; return true; }     // (c_score -1: "continue" before the best/second-best step)
+	}
+	if (cig.n == 0) score = 0;
+	else {
+		// GenCoordinateInfo, :515-562
+		const int64_t gPos = v.gPos[0], end_gPos = v.gPos[num - 1] + v.gLen[num - 1] - 1;
+		bool fwd;
+		int chr;
+		int64_t pos;
+		bool rev = false;
+		if (gPos < a.genome_size) {
+			fwd = first;
+			if (a.n_chr == 1) { chr = 0; pos = gPos + 1; }
+			else {
+				int it = end_lower_bound(a, gPos);
+				chr = a.end_chr[it];
+				pos = gPos + 1 - a.chr_fwd_start[chr];
+			}
+		} else {
+			fwd = !first;
+			rev = true;
+			if (a.n_chr == 1) { chr = 0; pos = a.two_genome_size - end_gPos; }
+			else {
+				int it = end_lower_bound(a, gPos);
+				if (it == a.n_ends) it = a.n_ends - 1;
+				pos = a.contig_end[it] - end_gPos + 1;
+				chr = a.end_chr[it];
+			}
+		}
+		// GenerateCIGAR, :492-513 (the reverse strand shows the elements in reverse order)
+		char *out = a.rep_cigar + cand * KG_ALN_CIGAR_MAX;
+		int at = 0;
+		char state = 0;
+		int cnt = 0;
+		bool fits = true;
+		auto emit = [&](int nn, char st) {
+			char buf[12];
+			int k = 0;
+			do { buf[k++] = (char)('0' + nn % 10); nn /= 10; } while (nn);
+			if (at + k + 1 > KG_ALN_CIGAR_MAX - 1) { fits = false; return; }
+			while (k) out[at++] = buf[--k];
+			out[at++] = st;
+		};
+		for (int q = 0; q < cig.n; ++q) {
+			int i = rev ? cig.n - 1 - q : q;
+			if (cig.op[i] != state) {
+				if (cnt > 0) emit(cnt, state);
+				cnt = cig.len[i];
+				state = cig.op[i];
+			} else cnt += cig.len[i];
+		}
+		if (cnt > 0) emit(cnt, state);
+		if (!fits) return false;
+		a.rep_cigar_len[cand] = (uint8_t)at;
+		a.rep_chr[cand] = chr;
+		a.rep_pos[cand] = pos;
+		a.rep_fwd[cand] = fwd ? 1 : 0;
+		if (pos <= 0) score = 0;
+	}
+	a.rep_score[cand] = score;
+	return true;
+}
+
+// raw-character mismatches of a read fragment against the text (CalFragPairMismatchBases, src/tools.cpp:40-47)
+__device__ __forceinline__ int mismatches(const AlnArgs &a, const uint8_t *rd, int64_t g, int len)
+{
+	int c = 0;
+	for (int i = 0; i < len; ++i)
+		if ((char)rd[i] != text_char(a, g + i)) c++;
+	return c;
+}
+
+}  // namespace
+
+// ---- pass 1: one candidate per lane -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
+{
+	int64_t cand = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; cand < a.n_cands; cand += stride) {
+		a.rep_score[cand] = 0; a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
+		const int64_t r = a.c_read[cand];
+		if (a.r_host[r]) continue;
+		if (a.c_score[cand] == 0) continue;                                  // GenMappingReport skips it, :643
+		const kg_candidate cd = a.cands[cand];
+		if (cd.count > kAlnMaxSeeds) { flag_host(a, r); continue; }
+		const int64_t rbase = a.read_off[r];
+		const int rlen = (int)(a.read_off[r + 1] - rbase);
+		const uint8_t *rd = a.enc + rbase;
+		const int ck = chunk_of(a, r);
+		const bool first = a.chunk_paired[ck] ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
+		Pairs v;
+		v.num = cd.count;
+		for (int i = 0; i < cd.count; ++i) {
+			kg_seed s = a.cand_seeds[cd.first + i];
+			v.gPos[i] = s.gPos; v.rPos[i] = s.rPos; v.rLen[i] = v.gLen[i] = s.len; v.simple[i] = 1;
+		}
+		if (!identify_normal_pairs(rlen, v)) { flag_host(a, r); continue; }
+		if (!coordinates_valid(a, v)) { a.c_score[cand] = -1; continue; }      // no report, and no best/second-best step (:647)
+		Work w;
+		const int num = v.num;
+		bool host = false, jobs = false;
+		for (int j = 0; j < num && !host; ++j) {
+			w.kind[j] = W_NONE; w.op[j] = 0; w.op_len[j] = 0; w.val[j] = 0;
+			const int rL = v.rLen[j], gL = v.gLen[j];
+			if (rL == 0 && gL == 0) continue;
+			if (v.simple[j]) { w.kind[j] = W_SIMPLE; continue; }
+			const int role = j == 0 ? 0 : j == num - 1 ? 2 : 1;
+			if (role != 1 && rL > 3000) {                                      // :671-676, :690-695
+				w.kind[j] = W_IMMEDIATE; w.op[j] = 'S'; w.op_len[j] = rL; w.val[j] = -1;
+				continue;
+			}
+			if (role == 1 && (rL == 0 || gL == 0)) {                           // ProcessNormalSequencePair, src/tools.cpp:229-233
+				w.kind[j] = W_IMMEDIATE;
+				if (rL > 0) { w.op[j] = 'I'; w.op_len[j] = rL; }
+				else if (gL > 0) { w.op[j] = 'D'; w.op_len[j] = gL; }
+				continue;
+			}
+			const uint8_t *f1 = rd + v.rPos[j];
+			if (rL == gL) {                                                     // the <= 2-mismatch shortcut, :240, :301, :352
+				int n = mismatches(a, f1, v.gPos[j], rL);
+				if (n <= 2 && n <= (int)(rL * 0.2)) {
+					w.kind[j] = W_IMMEDIATE; w.op[j] = 'M'; w.op_len[j] = rL; w.val[j] = rL - n;
+					continue;
+				}
+			}
+			if ((role == 0 && rL > 50) || (role == 2 && rL > 100)) {           // :307-311, :358-362
+				w.kind[j] = W_IMMEDIATE; w.op[j] = 'S'; w.op_len[j] = rL; w.val[j] = 0;
+				continue;
+			}
+			if (rL == 1 && gL == 1 && f1[0] != '-') {
+				// one base against one base: nw_alignment can only answer with the diagonal, the quality check passes a single
+				// column, nothing is trimmed, AddNewCigarElements books 1M with one identical base iff the characters are equal
+				w.kind[j] = W_IMMEDIATE; w.op[j] = 'M'; w.op_len[j] = 1; w.val[j] = (char)f1[0] == text_char(a, v.gPos[j]) ? 1 : 0;
+				continue;
+			}
+			if ((rL > 30 && gL > 30) || rL > kAlnMaxFrag || gL > kAlnMaxFrag || rL <= 0 || gL <= 0) { host = true; break; }   // 8-mer partition route, src/tools.cpp:146
+			// nw_alignment(rL, frag1, gL, frag2): a job for the NW kernels
+			unsigned long long slot = atomicAdd(&a.ctl[1], 1ull);
+			unsigned long long ops_at = atomicAdd(&a.ctl[2], (unsigned long long)(rL + gL));
+			if (slot >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(rL + gL) > (unsigned long long)a.ops_capacity) { host = true; break; }
+			NwJobDesc jd;
+			jd.o1 = rbase + v.rPos[j]; jd.o2 = v.gPos[j]; jd.ops = (int64_t)ops_at; jd.m = rL; jd.n = gL;
+			a.jobs[slot] = jd;
+			w.kind[j] = W_JOB; w.val[j] = (int32_t)slot;
+			jobs = true;
+		}
+		if (host) { flag_host(a, r); continue; }
+		if (!jobs) {
+			if (!finish_candidate(a, cand, first, rd, v, w)) flag_host(a, r);
+			continue;
+		}
+		// park the candidate until its alignments exist
+		unsigned long long sp = atomicAdd(&a.ctl[0], 1ull);
+		if (sp >= (unsigned long long)a.spill_capacity) { flag_host(a, r); continue; }
+		AlnSpill &o = a.spill[sp];
+		o.cand = (int32_t)cand;
+		o.num = num;
+		for (int j = 0; j < num; ++j) {
+			AlnSpillPair q;
+			q.gPos = v.gPos[j]; q.rPos = v.rPos[j]; q.rLen = (int16_t)v.rLen[j]; q.gLen = (int16_t)v.gLen[j];
+			q.val = w.val[j]; q.kind = w.kind[j]; q.op = w.op[j]; q.op_len = (int16_t)w.op_len[j];
+			o.p[j] = q;
+		}
+	}
+}
+
+// ---- pass 2: the parked candidates ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aln_finish_kernel(AlnArgs a)
+{
+	unsigned long long n = a.ctl[0];
+	if (n > (unsigned long long)a.spill_capacity) n = (unsigned long long)a.spill_capacity;
+	unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+	for (; t < n; t += stride) {
+		const AlnSpill &sp = a.spill[t];
+		const int64_t cand = sp.cand;
+		const int64_t r = a.c_read[cand];
+		if (a.r_host[r]) continue;
+		const int ck = chunk_of(a, r);
+		const bool first = a.chunk_paired[ck] ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
+		Pairs v;
+		Work w;
+		v.num = sp.num;
+		for (int j = 0; j < sp.num; ++j) {
+			AlnSpillPair q = sp.p[j];
+			v.gPos[j] = q.gPos; v.rPos[j] = q.rPos; v.rLen[j] = q.rLen; v.gLen[j] = q.gLen; v.simple[j] = q.kind == W_SIMPLE;
+			w.kind[j] = q.kind; w.op[j] = q.op; w.op_len[j] = q.op_len; w.val[j] = q.val;
+		}
+		if (!finish_candidate(a, cand, first, a.enc + a.read_off[r], v, w)) flag_host(a, r);
+	}
+}
+
+// ---- per read: best / second best, final pair check, flags, MAPQ, records ----------------------------------------------------
+namespace {
+
+struct ReadSum {                    // the ReadItem_t fields the output depends on
+	int score, sub_score, best, can_num, mapq, rlen;
+	int64_t c0;                     // first candidate
+};
+
+// the tail of GenMappingReport's loop, src/AlignmentCandidates.cpp:724-740 (bMultiHit false)
+__device__ void summarise(const AlnArgs &a, int64_t r, ReadSum &s)
+{
+	s.c0 = a.cand_off[r];
+	s.can_num = (int)(a.cand_off[r + 1] - s.c0);
+	s.rlen = (int)(a.read_off[r + 1] - a.read_off[r]);
+	s.score = s.sub_score = s.best = 0;
+	s.mapq = 0;
+	for (int i = 0; i < s.can_num; ++i) {
+		int cs = a.c_score[s.c0 + i];
+		if (cs == 0 || cs == -1) continue;                          // skipped before the comparison (Score == 0, invalid coordinates, gap penalty)
+		int sc = a.rep_score[s.c0 + i];
+		if (sc > s.score) { s.best = i; s.sub_score = s.score; s.score = sc; }
+		else if (sc == s.score) {
+			s.sub_score = s.score;
+			if (a.chr_len[a.rep_chr[s.c0 + i]] > a.chr_len[a.rep_chr[s.c0 + s.best]]) s.best = i;
+		}
+	}
+}
+
+__device__ __forceinline__ int eval_mapq(const AlnArgs &a, const ReadSum &s)   // EvaluateMAPQ, src/Mapping.cpp:160-175
+{
+	if (s.score == 0 || s.score == s.sub_score) return 0;
+	int q;
+	if (s.sub_score == 0 || s.score - s.sub_score > 5) q = 60;
+	else q = a.mapq_tab[s.score * 6 + (s.score - s.sub_score)];
+	return q > 60 ? 60 : q;
+}
+
+__device__ __forceinline__ int rep_score_at(const AlnArgs &a, const ReadSum &s, int i) { return (s.can_num == 0) ? 0 : a.rep_score[s.c0 + i]; }
+__device__ __forceinline__ int rep_mate_at(const AlnArgs &a, const ReadSum &s, int i) { return (s.can_num == 0) ? -1 : a.c_mate[s.c0 + i]; }
+__device__ __forceinline__ bool rep_fwd_at(const AlnArgs &a, const ReadSum &s, int i) { return (s.can_num == 0) ? true : a.rep_fwd[s.c0 + i] != 0; }
+
+// the per-mate halves of SetPairedAlignmentFlag, src/Mapping.cpp:96-156: the flag of the record that can be printed for `me`
+// (its best candidate), or of the unmapped record
+__device__ int one_mate_flag(const AlnArgs &a, const ReadSum &me, const ReadSum &other, int base)
+{
+	if (me.score > 0) {                                            // (score > sub_score and score == sub_score > 0 set the best candidate's flag alike)
+		if (me.score <= me.sub_score && rep_score_at(a, me, me.best) <= 0) return 0;   // not assigned; such a record is never printed
+		int f = base | (rep_fwd_at(a, me, me.best) ? 0x20 : 0x10);
+		int j = rep_mate_at(a, me, me.best);
+		if (j != -1 && rep_score_at(a, other, j) > 0) f |= 0x2;
+		else f |= 0x8;
+		return f;
+	}
+	int f = base | 0x4;
+	if (other.score == 0) f |= 0x8;
+	else f |= (rep_fwd_at(a, other, other.best) ? 0x10 : 0x20);
+	return f;
+}
+
+__device__ void write_record(const AlnArgs &a, int64_t r, const ReadSum &s, int kind, int flag, bool has_mate, int64_t mate_pos, int tlen, bool flip)
+{
+	kg_aln_record &o = a.records[r];
+	o.kind = kind; o.flag = flag; o.mapq = s.mapq; o.score = s.score; o.sub_score = s.sub_score;
+	o.has_mate = has_mate ? 1 : 0; o.mate_pos = mate_pos; o.tlen = tlen; o.flip = flip ? 1 : 0; o.pad = 0;
+	o.chr = -1; o.pos = 0; o.cigar_len = 0;
+	if (kind == KG_ALN_MAPPED) {
+		int64_t c = s.c0 + s.best;
+		o.chr = a.rep_chr[c]; o.pos = a.rep_pos[c];
+		int n = a.rep_cigar_len[c];
+		o.cigar_len = (uint8_t)n;
+		const char *src = a.rep_cigar + c * KG_ALN_CIGAR_MAX;
+		for (int i = 0; i < n; ++i) o.cigar[i] = src[i];
+	}
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
+{
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; r < a.n_reads; r += stride) {
+		const int ck = chunk_of(a, r);
+		const bool paired = a.chunk_paired[ck] != 0;
+		if (paired && ((r - a.chunk_off[ck]) & 1)) continue;
+		kg_chunk_stats &cs = a.chunk_stats[ck];
+		if (a.r_host[r]) {
+			a.records[r].kind = KG_ALN_HOST;
+			if (paired) a.records[r + 1].kind = KG_ALN_HOST;
+			atomicAdd(&cs.host_pairs, paired ? 2 : 1);
+			continue;
+		}
+		ReadSum s1;
+		summarise(a, r, s1);
+		if (!paired) {
+			// SetSingleAlignmentFlag + EvaluateMAPQ + OutputSingledAlignments, src/Mapping.cpp:49-71, 160-175, 272-315
+			s1.mapq = eval_mapq(a, s1);
+			if (s1.score == 0) {
+				atomicAdd(&cs.unmapped, 1);
+				write_record(a, r, s1, KG_ALN_UNMAPPED, 0x4, false, 0, 0, false);
+			} else {
+				if (s1.mapq == 60) atomicAdd(&cs.unique, 1);
+				// the first candidate from `best` on whose score is the read's (the best one itself)
+				int pick = -1;
+				for (int i = s1.best; i < s1.can_num; ++i)
+					if (a.rep_score[s1.c0 + i] == s1.score) { pick = i; break; }
+				if (pick < 0) a.records[r].kind = KG_ALN_NONE;
+				else {
+					s1.best = pick;
+					bool fwd = a.rep_fwd[s1.c0 + pick] != 0;
+					write_record(a, r, s1, KG_ALN_MAPPED, fwd ? 0 : 0x10, false, 0, 0, !fwd);
+				}
+			}
+			continue;
+		}
+		ReadSum s2;
+		summarise(a, r + 1, s2);
+		// CheckPairedFinalAlignments, src/Mapping.cpp:429-480 (bMultiHit false)
+		{
+			bool mated = false;
+			if (s1.can_num > 0 && s2.can_num > 0) mated = a.c_mate[s1.c0 + s1.best] == s2.best;
+			else if (s1.can_num == 0 && s2.can_num > 0) mated = -1 == s2.best;       // (a report of an empty read: mate -1)
+			else if (s1.can_num > 0 && s2.can_num == 0) mated = a.c_mate[s1.c0 + s1.best] == 0;
+			else mated = false;                                                      // -1 == 0
+			if (!mated) {
+				if (s1.score > 0 && s2.score > 0) {
+					int s = 0;
+					for (int i = 0; i < s1.can_num; ++i) {
+						int j;
+						if (a.rep_score[s1.c0 + i] > 0 && (j = a.c_mate[s1.c0 + i]) != -1 && a.rep_score[s2.c0 + j] > 0) {
+							mated = true;
+							int t = a.rep_score[s1.c0 + i] + a.rep_score[s2.c0 + j];
+							if (s < t) {
+								s = t;
+								s1.best = i; s1.score = a.rep_score[s1.c0 + i];
+								s2.best = j; s2.score = a.rep_score[s2.c0 + j];
+							}
+						}
+					}
+				}
+				if (mated) {
+					for (int i = 0; i < s1.can_num; ++i) {
+						int j;
+						if (a.rep_score[s1.c0 + i] != s1.score || ((j = a.c_mate[s1.c0 + i]) != -1 && a.rep_score[s2.c0 + j] != s2.score)) {
+							a.rep_score[s1.c0 + i] = 0;
+							a.c_mate[s1.c0 + i] = -1;
+						}
+					}
+				} else {
+					for (int i = 0; i < s1.can_num; ++i) {
+						a.c_mate[s1.c0 + i] = -1;
+						if (a.rep_score[s1.c0 + i] > 0 && a.rep_score[s1.c0 + i] != s1.score) a.rep_score[s1.c0 + i] = 0;
+					}
+					for (int j = 0; j < s2.can_num; ++j) {
+						a.c_mate[s2.c0 + j] = -1;
+						if (a.rep_score[s2.c0 + j] > 0 && a.rep_score[s2.c0 + j] != s2.score) a.rep_score[s2.c0 + j] = 0;
+					}
+				}
+			}
+		}
+		// SetPairedAlignmentFlag, src/Mapping.cpp:73-158
+		int f1, f2;
+		if (s1.score > s1.sub_score && s2.score > s2.sub_score) {
+			f1 = 0x41; f2 = 0x81;
+			if (s2.best == rep_mate_at(a, s1, s1.best)) { f1 |= 0x2; f2 |= 0x2; }
+			f1 |= rep_fwd_at(a, s1, s1.best) ? 0x20 : 0x10;
+			f2 |= rep_fwd_at(a, s2, s2.best) ? 0x20 : 0x10;
+		} else {
+			f1 = one_mate_flag(a, s1, s2, 0x41);
+			f2 = one_mate_flag(a, s2, s1, 0x81);
+		}
+		s1.mapq = eval_mapq(a, s1);
+		s2.mapq = eval_mapq(a, s2);
+		// OutputPairedAlignments, src/Mapping.cpp:177-270 (bMultiHit false: only the best candidate is looked at)
+		long long add_paired = 0, add_dist = 0;
+		if (s1.score == 0) {
+			atomicAdd(&cs.unmapped, 1);
+			write_record(a, r, s1, KG_ALN_UNMAPPED, f1, false, 0, 0, false);
+		} else {
+			if (s1.mapq == 60) atomicAdd(&cs.unique, 1);
+			if (rep_score_at(a, s1, s1.best) > 0) {
+				int j = rep_mate_at(a, s1, s1.best);
+				bool fwd = rep_fwd_at(a, s1, s1.best);
+				if (j != -1 && rep_score_at(a, s2, j) > 0) {
+					int dist = (int)(a.rep_pos[s2.c0 + j] - a.rep_pos[s1.c0 + s1.best] + (fwd ? s2.rlen : 0 - s1.rlen));
+					add_paired = 2;
+					int ad = dist < 0 ? -dist : dist;
+					if (ad < 10000) add_dist = ad;
+					write_record(a, r, s1, KG_ALN_MAPPED, f1, true, a.rep_pos[s2.c0 + j], dist, !fwd);
+				} else write_record(a, r, s1, KG_ALN_MAPPED, f1, false, 0, 0, !fwd);
+			} else a.records[r].kind = KG_ALN_NONE;
+		}
+		if (s2.score == 0) {
+			atomicAdd(&cs.unmapped, 1);
+			write_record(a, r + 1, s2, KG_ALN_UNMAPPED, f2, false, 0, 0, false);
+		} else {
+			if (s2.mapq == 60) atomicAdd(&cs.unique, 1);
+			if (rep_score_at(a, s2, s2.best) > 0) {
+				int i = rep_mate_at(a, s2, s2.best);
+				bool fwd = rep_fwd_at(a, s2, s2.best);
+				if (i != -1 && rep_score_at(a, s1, i) > 0) {
+					bool fwd1 = rep_fwd_at(a, s1, i);
+					int dist = 0 - (int)(a.rep_pos[s2.c0 + s2.best] - a.rep_pos[s1.c0 + i] + (fwd1 ? s2.rlen : 0 - s1.rlen));
+					write_record(a, r + 1, s2, KG_ALN_MAPPED, f2, true, a.rep_pos[s1.c0 + i], dist, fwd);
+				} else write_record(a, r + 1, s2, KG_ALN_MAPPED, f2, false, 0, 0, fwd);
+			} else a.records[r + 1].kind = KG_ALN_NONE;
+		}
+		if (add_paired) {
+			atomicAdd((unsigned long long *)&cs.paired, (unsigned long long)add_paired);
+			if (add_dist) atomicAdd((unsigned long long *)&cs.distance, (unsigned long long)add_dist);
+		}
+	}
+}
+
+__global__ void aln_reset_kernel(AlnArgs a)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < 4) a.ctl[i] = 0;
+	for (int c = i; c < a.n_chunks; c += gridDim.x * blockDim.x) {
+		kg_chunk_stats z;
+		z.paired = 0; z.distance = 0; z.lo = -1; z.hi = 0x7fffffffffffffffll; z.unmapped = 0; z.unique = 0; z.host_pairs = 0; z.rescue_wanted = 0;
+		a.chunk_stats[c] = z;
+	}
+	for (int64_t r = i; r < a.n_reads; r += (int64_t)gridDim.x * blockDim.x) a.r_host[r] = 0;
+}
+
+static inline int grid_for_aln(int64_t items, int block, int max_blocks)
+{
+	int64_t g = (items + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > max_blocks) g = max_blocks;
+	return (int)g;
+}
+
+hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
+{
+	hipLaunchKernelGGL(aln_reset_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(aln_pair_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	if (a.n_cands > 0) hipLaunchKernelGGL(aln_plan_kernel, dim3(grid_for_aln(a.n_cands, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_align_back(const AlnArgs &a, int n_cu, hipStream_t stream)
+{
+	hipLaunchKernelGGL(aln_finish_kernel, dim3(grid_for_aln(a.spill_capacity, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(aln_final_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+}  // namespace kg

@@ -1,0 +1,89 @@
+// align_kernels.hpp -- argument block of the device-side alignment stage (align_kernels.hip) shared with the C-ABI layer.
+//
+// What runs on the device after chaining, for the common case of short-read candidates (reference file:line in
+// align_kernels.hip): candidate pairing + filters, IdentifyNormalPairs, the per-pair decisions of
+// Process{Head,Normal,Tail}SequencePair, gap closing through the NW kernels, CIGAR / AlnScore / coordinates
+// (GenMappingReport), best / second-best, CheckPairedFinalAlignments, SAM flags, MAPQ -- one kg_aln_record per read.
+// Whatever the device path does not take (mate rescue, the 8-mer partition of long gap fragments, candidates with many
+// seeds, very long CIGARs) is handed back per read pair (record kind KG_ALN_HOST) to the host's implementation of the same
+// reference code.
+#pragma once
+#include "seed_kernels.hpp"
+
+namespace kg {
+
+constexpr int kAlnMaxSeeds = 12;                       // seeds of one candidate the device path takes
+constexpr int kAlnMaxGaps = 8;                         // gap pairs inserted between them (the host merges more than 8 differently)
+constexpr int kAlnMaxPairs = kAlnMaxSeeds + kAlnMaxGaps + 2;   // + head + tail
+constexpr int kAlnMaxCigar = 2 * kAlnMaxPairs + 8;     // (length, op) elements before merging
+constexpr int kAlnMaxFrag = 255;                       // longest side of a gap fragment sent to the NW kernels from here
+constexpr int kAlnMaxScore = 2047;                     // rows of the MAPQ table
+constexpr int kAlnPairProduct = 4096;                  // n1 * n2 above which a pair's candidate pairing is left to the host
+
+// one normal pair as the finish pass needs it
+struct AlnSpillPair {
+	int64_t gPos;
+	int32_t rPos;
+	int16_t rLen, gLen;
+	int32_t val;          // SIMPLE: unused; IMMEDIATE: score; JOB: job index
+	uint8_t kind;         // 0 none, 1 simple, 2 immediate, 3 NW job
+	uint8_t op;           // IMMEDIATE: CIGAR op character (0 = no element)
+	int16_t op_len;
+};
+
+struct AlnSpill {
+	int32_t cand;         // dense candidate index
+	int32_t num;
+	AlnSpillPair p[kAlnMaxPairs];
+};
+
+struct AlnArgs {
+	FmView ix;                      // text
+	// reads
+	const uint8_t *enc;             // read characters
+	const int64_t *read_off;
+	int64_t n_reads;
+	// chunks of the batch (reference: 4000-read chunks; a chunk is paired when the run is and its count is even)
+	const int64_t *chunk_off;       // [n_chunks + 1]
+	const uint8_t *chunk_paired;    // [n_chunks]
+	int n_chunks;
+	// candidates (dense, read order)
+	const int64_t *cand_off;        // [n_reads + 1]
+	const kg_candidate *cands;
+	const kg_seed *cand_seeds;
+	int64_t n_cands;
+	// contigs
+	const int64_t *contig_end;      // ChrLocMap keys, ascending
+	const int32_t *end_chr;         // contig index of every key
+	int n_ends;
+	const int64_t *chr_fwd_start, *chr_rev_start, *chr_len;
+	int n_chr;
+	int64_t genome_size, two_genome_size;
+	// parameters
+	int est_distance, max_insert, max_gaps;
+	const uint8_t *mapq_tab;        // [(kAlnMaxScore + 1) * 6]: EvaluateMAPQ's libm branch, tabulated by the host
+	// per-candidate state
+	int32_t *c_score, *c_mate, *c_read;
+	int32_t *rep_score, *rep_chr;
+	int64_t *rep_pos;
+	uint8_t *rep_fwd, *rep_cigar_len;
+	char *rep_cigar;                // [n_cands * KG_ALN_CIGAR_MAX]
+	// per-read state
+	uint8_t *r_host;                // the pair of this read goes back to the host
+	// spill + jobs
+	AlnSpill *spill;
+	int64_t spill_capacity;
+	NwJobDesc *jobs;
+	int64_t job_capacity, ops_capacity;
+	unsigned long long *ctl;        // [0] spill count, [1] job count, [2] ops bytes, [3] pairs handed to the host
+	uint8_t *nw_ops;
+	int32_t *nw_len;
+	// outputs
+	kg_aln_record *records;         // [n_reads]
+	kg_chunk_stats *chunk_stats;    // [n_chunks]
+};
+
+hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream);     // pairing + plan (+ finish of job-free candidates)
+hipError_t launch_align_back(const AlnArgs &a, int n_cu, hipStream_t stream);      // finish of the spilled candidates + per-read records
+
+}  // namespace kg

@@ -58,6 +58,18 @@ public:
 		for (int64_t r = 0; r < n; ++r) { cand_off[(size_t)r] = at; at += n_cands[(size_t)r]; }
 		cand_off[(size_t)n] = at;
 	}
+	bool align(const std::vector<int64_t> &chunk_off, const std::vector<uint8_t> &chunk_paired, int est, int max_insert, int max_gaps,
+	           std::vector<kg_aln_record> &records, std::vector<kg_chunk_stats> &chunk_stats) override
+	{
+		static const bool off = getenv("KART_AMD_HOST_ALIGN") != nullptr;      // A/B aid: the whole report on the host, as before
+		if (off) return false;
+		int n_chunks = (int)chunk_paired.size();
+		chunk_stats.resize((size_t)n_chunks);
+		const kg_aln_record *rec = nullptr;
+		if (kg_align_batch(ws_, chunk_off.data(), chunk_paired.data(), n_chunks, est, max_insert, max_gaps, &rec, chunk_stats.data()) != KG_OK) die("kg_align_batch");
+		records.assign(rec, rec + chunk_off[(size_t)n_chunks]);              // the library's pinned array is overwritten by the next batch
+		return true;
+	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
 	{
 		std::lock_guard<std::mutex> lk(nw_mu_);   // the staging vectors below are shared; calls from the commit path are rare

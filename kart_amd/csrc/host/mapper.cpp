@@ -136,6 +136,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	double t_begin = now_s();
 	g_sections = getenv("KART_AMD_VERBOSE") != nullptr;
 	if (const char *uf = getenv("KART_AMD_UNSET_FLAG")) g_unset_flag = atoi(uf);
+	g_check_align = getenv("KART_AMD_CHECK_ALIGN") != nullptr;
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	Options &o = const_cast<Options &>(opt);
 	RunTotals tot;
@@ -223,6 +224,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	if (getenv("KART_AMD_VERBOSE"))
 		fprintf(stdout, "stage seconds: unhidden read+encode+seed %.2f (seed calls %.2f) | finish+format(k-1) with chain+pair+plan(k) %.2f | nw %.2f | commit %.2f | writer drain %.2f | libraries %.2f of %.2f\n",
 		        tot.t_read, tot.t_seed, tot.t_a, tot.t_nw, tot.t_commit, tot.t_drain, tot.t_lib, stats.map_seconds);
+	if (g_check_align) fprintf(stdout, "CHECK_ALIGN: %lld device records compared with the host's text, %lld differ\n", (long long)g_check_n.load(), (long long)g_check_bad.load());
 	if (g_sections) {
 		fprintf(stdout, "worker thread-seconds:");
 		for (int i = 0; i < 6; ++i) fprintf(stdout, " %s %.2f%s", g_sec_name[i], 1e-9 * (double)g_sec_ns[i].load(), i < 5 ? " |" : "\n");

@@ -78,6 +78,15 @@ struct KernelBackend {
 	                            std::vector<kg_seed> &cand_seeds) = 0;
 	// nw_alignment for the jobs of several chunks in one call (fills ops/len of every part)
 	virtual void nw_batch(std::vector<NwJobs *> &parts) = 0;
+	// The per-read report of the batch the last seed_and_chain() call left on the device (kg_align_batch): one record per read
+	// (kind KG_ALN_HOST = this pair is the host's) and the chunks' pairing statistics under `est`.  false: this backend has no
+	// such stage -- the host maps every read itself.
+	virtual bool align(const std::vector<int64_t> &chunk_off, const std::vector<uint8_t> &chunk_paired, int est, int max_insert, int max_gaps,
+	                   std::vector<kg_aln_record> &records, std::vector<kg_chunk_stats> &chunk_stats)
+	{
+		(void)chunk_off; (void)chunk_paired; (void)est; (void)max_insert; (void)max_gaps; (void)records; (void)chunk_stats;
+		return false;
+	}
 };
 
 struct Contig {

@@ -30,6 +30,33 @@ __device__ __forceinline__ int nt4_code(unsigned char ch)  // nst_nt4_table, src
 	return u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
 }
 
+// A pair of the batch: offsets/lengths either from the two prefix-sum arrays of the C ABI (kg_nw_batch*) or from a job
+// descriptor the alignment stage wrote on the device (align_kernels.hip).  In descriptor mode sequence 2 is read straight
+// from the 2-bit text of the index (its codes ARE nst_nt4_table's), sequence 1 from the read characters.
+struct NwPair {
+	int64_t o1, o2, oo;
+	int m, n;
+};
+__device__ __forceinline__ NwPair nw_pair(const NwArgs &a, int64_t p)
+{
+	NwPair q;
+	if (a.desc) {
+		const NwJobDesc d = a.desc[p];
+		q.o1 = d.o1; q.o2 = d.o2; q.oo = d.ops; q.m = d.m; q.n = d.n;
+	} else {
+		q.o1 = a.off1[p]; q.o2 = a.off2[p];
+		q.m = (int)(a.off1[p + 1] - q.o1); q.n = (int)(a.off2[p + 1] - q.o2);
+		q.oo = q.o1 + q.o2;
+	}
+	return q;
+}
+__device__ __forceinline__ int nw_code2(const NwArgs &a, int64_t at)      // code of sequence-2 character `at`
+{
+	if (a.text2) return (a.text2[(uint64_t)at >> 2] >> (((uint32_t)at & 3) << 1)) & 3;
+	return nt4_code((unsigned char)a.f2[at]);
+}
+__device__ __forceinline__ int64_t nw_count(const NwArgs &a) { return a.n_dev ? (int64_t)min(*a.n_dev, (unsigned long long)a.n) : a.n; }
+
 __device__ __forceinline__ int lane_rank_nw(uint64_t mask)
 {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
@@ -58,11 +85,13 @@ __global__ __launch_bounds__(256) void nw_classify_kernel(NwArgs a)
 {
 	int64_t base_idx = (int64_t)blockIdx.x * blockDim.x;
 	int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	for (; base_idx < a.n; base_idx += stride) {
+	const int64_t count = nw_count(a);
+	for (; base_idx < count; base_idx += stride) {
 		int64_t p = base_idx + threadIdx.x;
 		int cls = -1;
-		if (p < a.n) {
-			int m = (int)(a.off1[p + 1] - a.off1[p]), n = (int)(a.off2[p + 1] - a.off2[p]);
+		if (p < count) {
+			NwPair q = nw_pair(a, p);
+			int m = q.m, n = q.n;
 			int mx = m > n ? m : n;
 			cls = mx <= 8 ? 0 : mx <= 32 ? 1 : 2;
 		}
@@ -87,11 +116,12 @@ __global__ __launch_bounds__(256) void nw_small8_kernel(NwArgs a)
 	unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
 	for (; t < count; t += stride) {
 		int64_t p = list[t];
-		int64_t o1 = a.off1[p], o2 = a.off2[p];
-		int m = (int)(a.off1[p + 1] - o1), n = (int)(a.off2[p + 1] - o2);
+		const NwPair q = nw_pair(a, p);
+		const int64_t o1 = q.o1, o2 = q.o2;
+		const int m = q.m, n = q.n;
 		int c2[8];
 #pragma unroll
-		for (int j = 0; j < 8; ++j) c2[j] = j < n ? nt4_code((unsigned char)a.f2[o2 + j]) : 8 + j;
+		for (int j = 0; j < 8; ++j) c2[j] = j < n ? nw_code2(a, o2 + j) : 8 + j;
 		int S[9], T[9];
 		S[0] = 0; T[0] = 0;
 #pragma unroll
@@ -117,7 +147,7 @@ __global__ __launch_bounds__(256) void nw_small8_kernel(NwArgs a)
 				}
 			}
 		}
-		uint8_t *ops = a.ops + o1 + o2;
+		uint8_t *ops = a.ops + q.oo;
 		int i = m, j = n, len = 0;
 		while (i > 0 || j > 0) {
 			int bit = 8 * (i - 1) + (j - 1);
@@ -141,11 +171,12 @@ __global__ __launch_bounds__(256) void nw_small32_kernel(NwArgs a)
 	unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
 	for (; t < count; t += stride) {
 		int64_t p = list[t];
-		int64_t o1 = a.off1[p], o2 = a.off2[p];
-		int m = (int)(a.off1[p + 1] - o1), n = (int)(a.off2[p + 1] - o2);
+		const NwPair q = nw_pair(a, p);
+		const int64_t o1 = q.o1, o2 = q.o2;
+		const int m = q.m, n = q.n;
 		int c2[32];
 #pragma unroll
-		for (int j = 0; j < 32; ++j) c2[j] = j < n ? nt4_code((unsigned char)a.f2[o2 + j]) : 8 + j;
+		for (int j = 0; j < 32; ++j) c2[j] = j < n ? nw_code2(a, o2 + j) : 8 + j;
 		int S[33], T[33];
 		S[0] = 0; T[0] = 0;
 #pragma unroll
@@ -169,7 +200,7 @@ __global__ __launch_bounds__(256) void nw_small32_kernel(NwArgs a)
 			}
 			dirs[i - 1][threadIdx.x] = make_uint2(fr, ft);
 		}
-		uint8_t *ops = a.ops + o1 + o2;
+		uint8_t *ops = a.ops + q.oo;
 		int i = m, j = n, len = 0;
 		while (i > 0 || j > 0) {
 			uint2 w = i > 0 ? dirs[i - 1][threadIdx.x] : make_uint2(0, 0);
@@ -204,8 +235,9 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 		t = __shfl(t, 0);
 		if (t >= count) break;
 		int64_t p = list[t];
-		int64_t o1 = a.off1[p], o2 = a.off2[p];
-		int m = (int)(a.off1[p + 1] - o1), n = (int)(a.off2[p + 1] - o2);
+		const NwPair q = nw_pair(a, p);
+		const int64_t o1 = q.o1, o2 = q.o2;
+		const int m = q.m, n = q.n;
 		int *lds = kGlobal ? reinterpret_cast<int *>(dir + a.gb_offset_words) : lds_dyn;
 		int *bS = lds, *bR = lds + (m + 1);
 		unsigned char *s1c = reinterpret_cast<unsigned char *>(lds + 2 * (m + 1));  // fits: see nw_big_lds_bytes()
@@ -217,7 +249,7 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 		const int64_t ncols_pad = (int64_t)n_stripes * 64;
 		for (int st = 0; st < n_stripes; ++st) {
 			int j = st * 64 + lane + 1;          // 1-based column of this lane
-			int c2 = j <= n ? nt4_code((unsigned char)a.f2[o2 + j - 1]) : 9;
+			int c2 = j <= n ? nw_code2(a, o2 + j - 1) : 9;
 			int up_s = -2 - j, up_t = NEG;       // row 0
 			int res_s = 0, res_r = 0;            // this lane's last result (what lane+1 sees as "left")
 			int diag_s = 0;
@@ -259,7 +291,7 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 		}
 		(void)words_per_col;
 		// traceback by lane 0
-		uint8_t *ops = a.ops + o1 + o2;
+		uint8_t *ops = a.ops + q.oo;
 		int len = 0;
 		if (lane == 0) {
 			int i = m, jj = n;

@@ -75,7 +75,20 @@ struct ChainArgs {
 };
 hipError_t launch_chain_batch(const ChainArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream);
 
+// a gap-closing job written on the device by the alignment stage (align_kernels.hip)
+struct NwJobDesc {
+	int64_t o1;           // offset of the read-side fragment in the read characters
+	int64_t o2;           // text coordinate of the genome-side fragment
+	int64_t ops;          // offset of the job's op string
+	int32_t m, n;
+};
+
 struct NwArgs {
+	// descriptor mode (jobs written on the device by the alignment stage): desc[p] instead of the offset arrays, sequence 2
+	// from the 2-bit text, the job count from device memory (n = capacity of the lists)
+	const NwJobDesc *desc = nullptr;
+	const uint8_t *text2 = nullptr;
+	const unsigned long long *n_dev = nullptr;
 	const char *f1;
 	const int64_t *off1;
 	const char *f2;
