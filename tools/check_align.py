@@ -28,7 +28,11 @@ def run(tag, args, want=None, env=None):
     if r.returncode != 0 or (summ and not summ[0].endswith(" 0 differ")) or same is False:
         bad += 1
     # the same run with the device records actually used
-    r2 = subprocess.run([EXE, "-silent", "-i", PREFIX] + args + ["-o", out + ".dev", "-t", "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    r2 = subprocess.run([EXE, "-silent", "-i", PREFIX] + args + ["-o", out + ".dev", "-t", "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KART_AMD_VERBOSE="1"))
+    if r2.returncode != 0:
+        print("   device-records run FAILED rc", r2.returncode, r2.stderr.decode()[-500:])
+        bad += 1
+    print("   ", [l for l in r2.stdout.decode().splitlines() if l.startswith("worker thread-seconds") or "re-mapped" in l or l.startswith("device report")])
     if want is not None:
         ok = open(out + ".dev", "rb").read() == want
         print("   device records used: golden identical:", ok)
