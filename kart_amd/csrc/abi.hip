@@ -162,6 +162,8 @@ struct kg_workspace {
 	uint8_t *d_job_ops = nullptr;
 	int32_t *d_job_len = nullptr;
 	int64_t spill_capacity = 0, job_capacity = 0, ops_capacity = 0;
+	void *d_tasks = nullptr;            // rescue windows and the candidates they yield, one block
+	int64_t task_capacity = 0;
 	int64_t *d_chunk_off = nullptr;
 	uint8_t *d_chunk_paired = nullptr;
 	kg_chunk_stats *d_chunk_stats = nullptr;
@@ -495,7 +497,7 @@ void kg_workspace_destroy(kg_workspace *ws)
 	if (ws->h_cands) (void)hipHostFree(ws->h_cands);
 	if (ws->h_cand_seeds) (void)hipHostFree(ws->h_cand_seeds);
 	if (ws->h_records) (void)hipHostFree(ws->h_records);
-	void *ptrs[] = {ws->d_aln_cand, ws->d_aln_read, ws->d_spill, ws->d_jobs, ws->d_job_ops, ws->d_job_len, ws->d_chunk_off, ws->d_chunk_paired, ws->d_chunk_stats, ws->d_aln_ctl, ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
+	void *ptrs[] = {ws->d_tasks, ws->d_aln_cand, ws->d_aln_read, ws->d_spill, ws->d_jobs, ws->d_job_ops, ws->d_job_len, ws->d_chunk_off, ws->d_chunk_paired, ws->d_chunk_stats, ws->d_aln_ctl, ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (ws->h_seeds) (void)hipHostFree(ws->h_seeds);
@@ -837,21 +839,25 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 	hipStream_t st = ws->stream;
 	// ---- buffers, grown on demand -------------------------------------------------------------------------------------------
 	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-	if (nc + 1 > ws->aln_cand_capacity) {
+	const int64_t task_cap = n / 4 + 4096;                 // rescue windows: room for one per two pairs (more: those pairs go to the host)
+	if (nc + task_cap + 1 > ws->aln_cand_capacity) {
 		if (ws->d_aln_cand) HIP_TRY(hipFree(ws->d_aln_cand));
 		ws->d_aln_cand = nullptr;
-		int64_t cap = nc + nc / 4 + 4096;
+		int64_t cap = nc + nc / 4 + task_cap + task_cap / 4 + 4096;
 		HIP_TRY(hipMalloc(&ws->d_aln_cand, up(4 * (size_t)cap) * 5 + up(8 * (size_t)cap) + up((size_t)cap) * 2 + up((size_t)cap * KG_ALN_CIGAR_MAX)));
 		ws->aln_cand_capacity = cap;
 	}
 	if (n + 2 > ws->aln_read_capacity) {
 		if (ws->d_aln_read) HIP_TRY(hipFree(ws->d_aln_read));
 		if (ws->h_records) HIP_TRY(hipHostFree(ws->h_records));
-		for (void *p : {(void *)ws->d_spill, (void *)ws->d_jobs, (void *)ws->d_job_ops, (void *)ws->d_job_len})
+		for (void *p : {(void *)ws->d_spill, (void *)ws->d_jobs, (void *)ws->d_job_ops, (void *)ws->d_job_len, (void *)ws->d_tasks})
 			if (p) HIP_TRY(hipFree(p));
-		ws->d_aln_read = nullptr; ws->h_records = nullptr; ws->d_spill = nullptr; ws->d_jobs = nullptr; ws->d_job_ops = nullptr; ws->d_job_len = nullptr;
+		ws->d_aln_read = nullptr; ws->h_records = nullptr; ws->d_spill = nullptr; ws->d_jobs = nullptr; ws->d_job_ops = nullptr; ws->d_job_len = nullptr; ws->d_tasks = nullptr;
 		int64_t cap = n + n / 4 + 4096;
-		HIP_TRY(hipMalloc(&ws->d_aln_read, up((size_t)cap) + sizeof(kg_aln_record) * (size_t)cap));
+		HIP_TRY(hipMalloc(&ws->d_aln_read, 3 * up((size_t)cap) + up(4 * (size_t)cap) + sizeof(kg_aln_record) * (size_t)cap));
+		ws->task_capacity = cap / 4 + 4096;
+		HIP_TRY(hipMalloc(&ws->d_tasks, up(sizeof(RescueTask) * (size_t)ws->task_capacity) + up(8 * (size_t)ws->task_capacity) + up(4 * (size_t)ws->task_capacity) +
+		                                    sizeof(kg_seed) * (size_t)ws->task_capacity * kAlnMaxSeeds));
 		HIP_TRY(hipHostMalloc((void **)&ws->h_records, sizeof(kg_aln_record) * (size_t)cap, hipHostMallocDefault));
 		// about one candidate in ten waits for an alignment; room for one in two
 		ws->spill_capacity = cap / 2 + 4096;
@@ -873,7 +879,7 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		HIP_TRY(hipMalloc((void **)&ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)cap));
 		ws->chunk_capacity = cap;
 	}
-	if (!ws->d_aln_ctl) HIP_TRY(hipMalloc((void **)&ws->d_aln_ctl, 8 * 4));
+	if (!ws->d_aln_ctl) HIP_TRY(hipMalloc((void **)&ws->d_aln_ctl, 8 * 8));
 	HIP_TRY(hipMemcpyAsync(ws->d_chunk_off, chunk_off, 8 * (size_t)(n_chunks + 1), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(ws->d_chunk_paired, chunk_paired, (size_t)n_chunks, hipMemcpyHostToDevice, st));
 	// ---- arguments ------------------------------------------------------------------------------------------------------------
@@ -902,8 +908,19 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		a.rep_cigar_len = (uint8_t *)p; p += up(cap);
 		a.rep_cigar = p;
 		char *q = (char *)ws->d_aln_read;
-		a.r_host = (uint8_t *)q; q += up((size_t)ws->aln_read_capacity);
+		size_t rcap = (size_t)ws->aln_read_capacity;
+		a.r_host = (uint8_t *)q; q += up(rcap);
+		a.r_pending = (uint8_t *)q; q += up(rcap);
+		a.resc_n = (uint8_t *)q; q += up(rcap);
+		a.resc_off = (int32_t *)q; q += up(4 * rcap);
 		a.records = (kg_aln_record *)q;
+		char *t = (char *)ws->d_tasks;
+		size_t tcap = (size_t)ws->task_capacity;
+		a.tasks = (RescueTask *)t; t += up(sizeof(RescueTask) * tcap);
+		a.resc_posdiff = (int64_t *)t; t += up(8 * tcap);
+		a.resc_count = (int32_t *)t; t += up(4 * tcap);
+		a.resc_seeds = (kg_seed *)t;
+		a.task_capacity = std::min<int64_t>(ws->task_capacity, task_cap);
 	}
 	a.spill = ws->d_spill; a.spill_capacity = ws->spill_capacity;
 	a.jobs = ws->d_jobs; a.job_capacity = ws->job_capacity; a.ops_capacity = ws->ops_capacity;

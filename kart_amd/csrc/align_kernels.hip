@@ -70,13 +70,33 @@ __device__ __forceinline__ void flag_host(const AlnArgs &a, int64_t r)       // 
 	} else a.r_host[r] = 1;
 }
 
-// RemoveRedundantCandidates, src/Mapping.cpp:317-346 (non-PacBio) on candidates [c0, c0 + n)
-__device__ void remove_redundant(const AlnArgs &a, int64_t c0, int n)
+// vector<AlignmentCandidate_t> of one read: the chained candidates (dense, [c0, c0 + nd)) followed by the slots of the pair's
+// rescue windows ([r0, r0 + nr), mate 1 of a rescued pair only; a window that found nothing leaves a slot of score 0, which
+// every consumer skips exactly like a candidate of score 0)
+struct CandList {
+	int64_t c0, r0;
+	int nd, nr;
+	__device__ __forceinline__ int n() const { return nd + nr; }
+	__device__ __forceinline__ int64_t at(int i) const { return i < nd ? c0 + i : r0 + (i - nd); }
+};
+__device__ __forceinline__ CandList cand_list(const AlnArgs &a, int64_t r)
 {
+	CandList l;
+	l.c0 = a.cand_off[r];
+	l.nd = (int)(a.cand_off[r + 1] - l.c0);
+	l.nr = a.resc_n[r];
+	l.r0 = a.n_cands + (l.nr ? a.resc_off[r] : 0);
+	return l;
+}
+
+// RemoveRedundantCandidates, src/Mapping.cpp:317-346 (non-PacBio)
+__device__ void remove_redundant(const AlnArgs &a, const CandList &l)
+{
+	const int n = l.n();
 	if (n <= 1) return;
 	int s1 = 0, s2 = 0;
 	for (int i = 0; i < n; ++i) {
-		int s = a.c_score[c0 + i];
+		int s = a.c_score[l.at(i)];
 		if (s > s2) {
 			if (s >= s1) { s2 = s1; s1 = s; }
 			else s2 = s;
@@ -84,7 +104,19 @@ __device__ void remove_redundant(const AlnArgs &a, int64_t c0, int n)
 	}
 	int thr = (s1 == s2 || s1 - s2 > 20) ? s1 : s2;
 	for (int i = 0; i < n; ++i)
-		if (a.c_score[c0 + i] < thr) a.c_score[c0 + i] = 0;
+		if (a.c_score[l.at(i)] < thr) a.c_score[l.at(i)] = 0;
+}
+
+// RemoveUnMatedAlignmentCandidates, src/Mapping.cpp:402-427
+__device__ void remove_unmated(const AlnArgs &a, const CandList &l1, const CandList &l2)
+{
+	for (int i = 0; i < l1.n(); ++i) {
+		int j = a.c_mate[l1.at(i)];
+		if (j == -1) a.c_score[l1.at(i)] = 0;
+		else { int s = a.c_score[l1.at(i)] + a.c_score[l2.at(j)]; a.c_score[l1.at(i)] = s; a.c_score[l2.at(j)] = s; }
+	}
+	for (int j = 0; j < l2.n(); ++j)
+		if (a.c_mate[l2.at(j)] == -1) a.c_score[l2.at(j)] = 0;
 }
 
 }  // namespace
@@ -99,19 +131,21 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 		const bool paired = a.chunk_paired[ck] != 0;
 		const int64_t in_chunk = r - a.chunk_off[ck];
 		if (paired && (in_chunk & 1)) continue;                      // the first mate's lane does the pair
-		const int64_t a0 = a.cand_off[r], a1 = a.cand_off[r + 1];
-		const int n1 = (int)(a1 - a0);
+		const CandList l1 = cand_list(a, r);                         // (no rescue slots yet: resc_n is zero)
+		const int64_t a0 = l1.c0;
+		const int n1 = l1.nd;
 		for (int i = 0; i < n1; ++i) { a.c_score[a0 + i] = a.cands[a0 + i].score; a.c_mate[a0 + i] = -1; a.c_read[a0 + i] = (int32_t)r; }
 		if (!paired) {
-			remove_redundant(a, a0, n1);                             // src/Mapping.cpp:589
+			remove_redundant(a, l1);                                 // src/Mapping.cpp:589
 			continue;
 		}
-		const int64_t b1 = a.cand_off[r + 2];
-		const int n2 = (int)(b1 - a1);
+		const CandList l2 = cand_list(a, r + 1);
+		const int64_t a1 = l2.c0;
+		const int n2 = l2.nd;
 		for (int j = 0; j < n2; ++j) { a.c_score[a1 + j] = a.cands[a1 + j].score; a.c_mate[a1 + j] = -1; a.c_read[a1 + j] = (int32_t)(r + 1); }
 		if ((int64_t)n1 * n2 > kAlnPairProduct) { a.r_host[r] = 1; a.r_host[r + 1] = 1; continue; }
 		// CheckPairedAlignmentCandidates, src/Mapping.cpp:348-400
-		if (n1 * n2 > 1000) { remove_redundant(a, a0, n1); remove_redundant(a, a1, n2); }
+		if (n1 * n2 > 1000) { remove_redundant(a, l1); remove_redundant(a, l2); }
 		bool pairing = false;
 		long long lo = -1, hi = 0x7fffffffffffffffll;
 		const long long est = a.est_distance;
@@ -146,28 +180,271 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 		}
 		if (lo > -1) atomicMax((long long *)&a.chunk_stats[ck].lo, lo);
 		if (hi != 0x7fffffffffffffffll) atomicMin((long long *)&a.chunk_stats[ck].hi, hi);
-		if (!pairing) {
-			// RescueUnpairedAlignment is due (src/Mapping.cpp:559-560).  Its first two exits need no k-mers
-			// (src/AlignmentRescue.cpp:83-84): no scoring candidate at all, or both mates below 10 % of their length
+		if (pairing) remove_unmated(a, l1, l2);
+		else {
+			// RescueUnpairedAlignment is due (src/Mapping.cpp:559-560; src/AlignmentRescue.cpp:73-170)
 			a.chunk_stats[ck].rescue_wanted = 1;
 			int sc1 = 0, sc2 = 0;
 			for (int i = 0; i < n1; ++i) sc1 = max(sc1, a.c_score[a0 + i]);
 			for (int j = 0; j < n2; ++j) sc2 = max(sc2, a.c_score[a1 + j]);
 			const int rl1 = (int)(a.read_off[r + 1] - a.read_off[r]), rl2 = (int)(a.read_off[r + 2] - a.read_off[r + 1]);
-			bool no_op = (sc1 == 0 && sc2 == 0) || (sc1 < (int)(rl1 * 0.1) && sc2 < (int)(rl2 * 0.1));
-			if (!no_op) { a.r_host[r] = 1; a.r_host[r + 1] = 1; continue; }
-		} else {
-			// RemoveUnMatedAlignmentCandidates, src/Mapping.cpp:402-427
-			for (int i = 0; i < n1; ++i) {
-				int j = a.c_mate[a0 + i];
-				if (j == -1) a.c_score[a0 + i] = 0;
-				else { int s = a.c_score[a0 + i] + a.c_score[a1 + j]; a.c_score[a0 + i] = s; a.c_score[a1 + j] = s; }
+			int strategy;
+			if (sc1 == 0 && sc2 == 0) strategy = 0;                                            // :83 returns at once
+			else if (sc1 < (int)(rl1 * 0.1) && sc2 < (int)(rl2 * 0.1)) strategy = 4;          // :84: neither direction is tried
+			else if (sc1 > sc2 && sc1 - sc2 > 50) strategy = 1;
+			else if (sc2 > sc1 && sc2 - sc1 > 50) strategy = 2;
+			else strategy = 3;
+			const int est_r = a.est_distance > a.max_insert ? a.max_insert : a.est_distance;   // :95
+			bool host = false;
+			if (strategy == 1 || strategy == 3) {
+				// mate 2 next to the candidates of mate 1 (:97-125).  The right end of that window is clamped against the START
+				// of the contig (:111-112), which collapses it: the "slen < rlen" test skips it.  Verified per window here; a
+				// window that would be scanned after all goes to the host.
+				int thr = sc1 - 30;
+				if (thr < 50) thr = 50;
+				for (int i = 0; i < n1 && !host; ++i) {
+					if (a.c_score[a0 + i] < thr) continue;
+					int64_t left = a.cands[a0 + i].posDiff, right = left + est_r + rl2;
+					int it = end_lower_bound(a, left);
+					if (it == a.n_ends) continue;
+					int chr = a.end_chr[it];
+					if (right < a.genome_size && right > a.chr_fwd_start[chr]) right = a.chr_fwd_start[chr] - 1;
+					else if (right >= a.genome_size && right > a.chr_rev_start[chr]) right = a.chr_rev_start[chr] - 1;
+					int slen = (int)(right - left);
+					if (slen < rl2) continue;
+					if (left < 0 || right > a.two_genome_size) continue;
+					host = true;
+				}
 			}
-			for (int j = 0; j < n2; ++j)
-				if (a.c_mate[a1 + j] == -1) a.c_score[a1 + j] = 0;
+			int nt = 0;
+			if (!host && (strategy == 2 || strategy == 3)) {
+				// mate 1 next to the candidates of mate 2 (:127-165): one task per window
+				int thr = sc2 - 30;                       // (nothing was appended to mate 2's list above)
+				if (thr < 50) thr = 50;
+				// pass 1 counts the windows, pass 2 writes them
+				for (int pass = 0; pass < 2 && !host; ++pass) {
+					unsigned long long base = 0;
+					if (pass == 1) {
+						if (nt == 0) break;
+						base = atomicAdd(&a.ctl[4], (unsigned long long)nt);
+						if (base + (unsigned long long)nt > (unsigned long long)a.task_capacity || nt > 200) { host = true; break; }
+					}
+					int k = 0;
+					for (int j = 0; j < n2; ++j) {
+						if (a.c_score[a1 + j] < thr) continue;
+						int64_t pd = a.cands[a1 + j].posDiff;
+						int64_t left = pd - est_r, right = pd + rl2;
+						int it = end_lower_bound(a, right);
+						if (it == a.n_ends) continue;
+						int chr = a.end_chr[it];
+						int64_t fs = a.chr_fwd_start[chr], rs = a.chr_rev_start[chr], cl = a.chr_len[chr];
+						if (left < a.genome_size && left < (fs - cl)) left = fs - cl + 1;
+						else if (right >= a.genome_size && left < (rs - cl)) left = rs - cl + 1;
+						int slen = (int)(right - left);
+						if (slen < rl1) continue;
+						if (left < 0) { left = 0; slen = (int)(right - left); if (slen < rl1) continue; }
+						if (right > a.two_genome_size) continue;
+						if (slen > kRescueMaxWindow) { host = true; break; }
+						if (pass == 1) {
+							RescueTask t;
+							t.left = left; t.read = (int32_t)r; t.j = j; t.slen = slen; t.score1 = sc1; t.ordinal = k;
+							a.tasks[base + k] = t;
+							int64_t slot = a.n_cands + (int64_t)(base + k);
+							a.c_score[slot] = 0; a.c_mate[slot] = -1; a.c_read[slot] = (int32_t)r;
+						}
+						k++;
+					}
+					if (pass == 0) nt = k;
+					else { a.resc_off[r] = (int32_t)base; a.resc_n[r] = (uint8_t)nt; }
+				}
+				if (!host && nt > 0) {
+					// the 8-mer code skips 'N' and maps everything else through nst_nt4_table (src/KmerAnalysis.cpp:25-32, 56-102);
+					// the kernel compares 2-bit codes, which is the same thing for reads made of A/C/G/T in either case
+					if (rl1 > kRescueMaxRead || rl1 < 8) host = true;
+					const uint8_t *rd = a.enc + a.read_off[r];
+					for (int i = 0; i < rl1 && !host; ++i) {
+						unsigned u = rd[i] & 0xDFu;
+						if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) host = true;
+					}
+				}
+			}
+			if (host) { a.resc_n[r] = 0; a.r_host[r] = 1; a.r_host[r + 1] = 1; continue; }
+			if (nt > 0) { a.r_pending[r] = 1; continue; }           // filters follow once the windows are scanned (aln_post_rescue_kernel)
 		}
-		remove_redundant(a, a0, n1);                                 // src/Mapping.cpp:563
-		remove_redundant(a, a1, n2);
+		remove_redundant(a, l1);                                     // src/Mapping.cpp:563
+		remove_redundant(a, l2);
+	}
+}
+
+// ---- mate rescue: one wave per window ----------------------------------------------------------------------------------------
+// IdentifyCommonKmers + GenerateSimplePairsFromCommonKmers(10) over a window (src/KmerAnalysis.cpp:104-162) produce, per diagonal,
+// the maximal runs of consecutive common 8-mers = the maximal exact matches of at least 10 bases between the read and the window
+// along that diagonal, sorted by (diagonal, read position).  The kernel finds those runs directly: every lane takes a block of
+// consecutive diagonals and XORs 2-bit packed read words against the window shifted to that diagonal.
+// IdnetifyRescueCandidate (src/AlignmentRescue.cpp:24-69) then groups consecutive runs whose diagonals lie within MaxGaps of
+// the group's first one and keeps the first group of the largest total length.
+__global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
+{
+	__shared__ uint64_t rd2[kRescueMaxRead / 32 + 2];          // read, 2 bits per base, base t in bits 2*(t&31) of word t>>5
+	__shared__ uint64_t win2[kRescueMaxWindow / 32 + 4];       // window likewise
+	__shared__ int run_d[kRescueMaxRuns], run_t[kRescueMaxRuns], run_l[kRescueMaxRuns];
+	const int lane = threadIdx.x;
+	unsigned long long n_tasks = a.ctl[4];
+	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
+	for (unsigned long long ti = blockIdx.x; ti < n_tasks; ti += gridDim.x) {
+		const RescueTask t = a.tasks[ti];
+		const int64_t slot = a.n_cands + (int64_t)ti;
+		if (a.r_host[t.read]) continue;                            // (uniform per block)
+		const int rlen = (int)(a.read_off[t.read + 1] - a.read_off[t.read]);
+		const uint8_t *rd = a.enc + a.read_off[t.read];
+		const int slen = t.slen;
+		const int rwords = (rlen + 31) >> 5, wwords = (slen + 31) >> 5;
+		__syncthreads();
+		for (int w = lane; w < rwords + 1; w += 64) {
+			uint64_t x = 0;
+			for (int b = 0; b < 32; ++b) {
+				int p = (w << 5) + b;
+				if (p < rlen) {
+					unsigned ch = rd[p];
+					unsigned g = (ch >> 1) & 3;                            // A 00, C 01, G 11, T 10 in either case ...
+					x |= (uint64_t)(g ^ (g >> 1)) << (b << 1);           // ... one Gray step from the codes 0..3
+				}
+			}
+			rd2[w] = x;
+		}
+		for (int w = lane; w < wwords + 2; w += 64) {
+			uint64_t x = 0;
+			for (int b = 0; b < 32; ++b) {
+				int p = (w << 5) + b;
+				if (p < slen) x |= (uint64_t)text_code(a, t.left + p) << (b << 1);
+			}
+			win2[w] = x;
+		}
+		__syncthreads();
+		// diagonals d = gpos - rpos of k-mer pairs: -(rlen - 8) .. slen - 8
+		const int d_lo = -(rlen - 8), nd = slen + rlen - 15;
+		const int per = (nd + 63) >> 6;
+		int my_n = 0;
+		int md[4], mt[4], ml[4];
+		bool overflow = false;
+		// a run of equal bases ended: it is a simple pair when it holds at least 10 bases (three consecutive common 8-mers)
+#define KG_RESCUE_EMIT()                                                                                        \
+	do {                                                                                                        \
+		if (run >= 10) {                                                                                        \
+			if (my_n < 4) { md[my_n] = d; mt[my_n] = run_start; ml[my_n] = run; my_n++; }                       \
+			else overflow = true;                                                                               \
+		}                                                                                                       \
+		run = 0;                                                                                                \
+	} while (0)
+		for (int q = 0; q < per; ++q) {
+			int di = lane * per + q;
+			if (di >= nd) break;
+			int d = d_lo + di;
+			int t_lo = d < 0 ? -d : 0;
+			int t_hi = rlen < slen - d ? rlen : slen - d;               // read positions [t_lo, t_hi) face window positions t + d
+			int run = 0, run_start = 0;
+			for (int w = t_lo >> 5; (w << 5) < t_hi; ++w) {
+				int base = w << 5;
+				// window bases base + d .. base + d + 31 as one word
+				int wp = base + d;                                      // may be negative for the first word: bases before 0 are masked below
+				uint64_t ww;
+				{
+					int idx = wp >> 5;                                   // floor division (arithmetic shift)
+					int sh = (wp & 31) << 1;
+					uint64_t lo_w = idx >= 0 ? win2[idx] : 0, hi_w = idx + 1 >= 0 ? win2[idx + 1] : 0;
+					ww = sh ? (lo_w >> sh) | (hi_w << (64 - sh)) : lo_w;
+				}
+				uint64_t diff = rd2[w] ^ ww;
+				uint64_t eq = ~(diff | (diff >> 1)) & 0x5555555555555555ull;   // bit 2b set: base b equal
+				int b0 = t_lo > base ? t_lo - base : 0, b1 = t_hi - base < 32 ? t_hi - base : 32;
+				uint64_t valid = (b1 >= 32 ? ~0ull : ((1ull << (b1 << 1)) - 1)) & ~((1ull << (b0 << 1)) - 1);
+				const uint64_t e = eq & valid;
+				int b = b0;
+				while (b < b1) {
+					uint64_t rest = e >> (b << 1);                                  // bit 0: base b of this word
+					if (rest & 1) {
+						uint64_t z = ~rest & 0x5555555555555555ull;                  // (bits shifted in from above are zero = "differs")
+						int ones = z ? (__ffsll((unsigned long long)z) - 1) >> 1 : 32;
+						if (ones > b1 - b) ones = b1 - b;
+						if (run == 0) run_start = base + b;
+						run += ones;
+						b += ones;
+					} else {
+						KG_RESCUE_EMIT();
+						uint64_t o = rest & 0x5555555555555555ull;
+						int zeros = o ? (__ffsll((unsigned long long)o) - 1) >> 1 : b1 - b;
+						if (zeros > b1 - b) zeros = b1 - b;
+						b += zeros;
+					}
+				}
+			}
+			KG_RESCUE_EMIT();
+		}
+		// the runs of all lanes, in (diagonal, read position) order: lanes hold consecutive diagonal blocks
+		int incl = my_n;
+		for (int o = 1; o < 64; o <<= 1) {
+			int v = __shfl_up(incl, o);
+			if (lane >= o) incl += v;
+		}
+		const int total = __shfl(incl, 63);
+		const bool any_overflow = __ballot(overflow) != 0 || total > kRescueMaxRuns;
+		if (any_overflow) {
+			if (lane == 0) flag_host(a, t.read);
+			continue;
+		}
+		for (int k = 0; k < my_n; ++k) { int at = incl - my_n + k; run_d[at] = md[k]; run_t[at] = mt[k]; run_l[at] = ml[k]; }
+		__syncthreads();
+		if (lane == 0) {
+			// IdnetifyRescueCandidate
+			int best_s = 0, best_i = 0, best_j = 0;
+			for (int i = 0; i < total;) {
+				int s = run_l[i], j;
+				for (j = i + 1; j < total; ++j) {
+					if (run_d[j] - run_d[i] < a.max_gaps) s += run_l[j];
+					else break;
+				}
+				if (s > best_s) { best_s = s; best_i = i; best_j = j; }
+				i = j;
+			}
+			int cnt = best_j - best_i;
+			if (best_s > t.score1) {
+				if (cnt > kAlnMaxSeeds) flag_host(a, t.read);
+				else {
+					// the group's pairs by (gPos, rPos) (:61); text coordinates
+					kg_seed *out = a.resc_seeds + (int64_t)ti * kAlnMaxSeeds;
+					for (int k = 0; k < cnt; ++k) {
+						kg_seed sd;
+						sd.rPos = run_t[best_i + k]; sd.len = run_l[best_i + k]; sd.gPos = t.left + run_t[best_i + k] + run_d[best_i + k];
+						int p = k;
+						while (p > 0 && (out[p - 1].gPos > sd.gPos || (out[p - 1].gPos == sd.gPos && out[p - 1].rPos > sd.rPos))) { out[p] = out[p - 1]; --p; }
+						out[p] = sd;
+					}
+					a.resc_count[ti] = cnt;
+					a.resc_posdiff[ti] = (int64_t)run_d[best_i] + t.left;
+					// the new candidate of mate 1 is mated with candidate j of mate 2 (:158-164)
+					const CandList l1 = cand_list(a, t.read);
+					a.c_score[slot] = best_s;
+					a.c_mate[slot] = t.j;
+					a.c_mate[a.cand_off[t.read + 1] + t.j] = l1.nd + t.ordinal;
+				}
+			}
+		}
+	}
+}
+
+// what follows RescueUnpairedAlignment for the pairs that had windows (src/Mapping.cpp:561-563)
+__global__ __launch_bounds__(256) void aln_post_rescue_kernel(AlnArgs a)
+{
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; r < a.n_reads; r += stride) {
+		if (!a.r_pending[r] || a.r_host[r]) continue;
+		const CandList l1 = cand_list(a, r), l2 = cand_list(a, r + 1);
+		bool mated = false;
+		for (int i = l1.nd; i < l1.n(); ++i) mated = mated || a.c_score[l1.at(i)] > 0;
+		if (mated) remove_unmated(a, l1, l2);
+		remove_redundant(a, l1);
+		remove_redundant(a, l2);
 	}
 }
 
@@ -658,12 +935,23 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 {
 	int64_t cand = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	for (; cand < a.n_cands; cand += stride) {
+	unsigned long long n_tasks = a.ctl[4];
+	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
+	const int64_t n_all = a.n_cands + (int64_t)n_tasks;                          // chained candidates, then the slots of the rescue windows
+	for (; cand < n_all; cand += stride) {
 		a.rep_score[cand] = 0; a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
 		const int64_t r = a.c_read[cand];
 		if (a.r_host[r]) continue;
 		if (a.c_score[cand] == 0) continue;                                  // GenMappingReport skips it, :643
-		const kg_candidate cd = a.cands[cand];
+		const bool rescued = cand >= a.n_cands;
+		kg_candidate cd;
+		const kg_seed *seeds;
+		if (!rescued) { cd = a.cands[cand]; seeds = a.cand_seeds + cd.first; }
+		else {
+			int64_t t = cand - a.n_cands;
+			cd.count = a.resc_count[t]; cd.first = 0; cd.posDiff = a.resc_posdiff[t]; cd.score = 0;
+			seeds = a.resc_seeds + t * kAlnMaxSeeds;
+		}
 		if (cd.count > kAlnMaxSeeds) { flag_host(a, r); continue; }
 		const int64_t rbase = a.read_off[r];
 		const int rlen = (int)(a.read_off[r + 1] - rbase);
@@ -673,7 +961,7 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 		Pairs v;
 		v.num = cd.count;
 		for (int i = 0; i < cd.count; ++i) {
-			kg_seed s = a.cand_seeds[cd.first + i];
+			kg_seed s = seeds[i];
 			v.gPos[i] = s.gPos; v.rPos[i] = s.rPos; v.rLen[i] = v.gLen[i] = s.len; v.simple[i] = 1;
 		}
 		if (!identify_normal_pairs(rlen, v)) { flag_host(a, r); continue; }
@@ -777,25 +1065,25 @@ namespace {
 
 struct ReadSum {                    // the ReadItem_t fields the output depends on
 	int score, sub_score, best, can_num, mapq, rlen;
-	int64_t c0;                     // first candidate
+	CandList l;
 };
 
 // the tail of GenMappingReport's loop, src/AlignmentCandidates.cpp:724-740 (bMultiHit false)
 __device__ void summarise(const AlnArgs &a, int64_t r, ReadSum &s)
 {
-	s.c0 = a.cand_off[r];
-	s.can_num = (int)(a.cand_off[r + 1] - s.c0);
+	s.l = cand_list(a, r);
+	s.can_num = s.l.n();
 	s.rlen = (int)(a.read_off[r + 1] - a.read_off[r]);
 	s.score = s.sub_score = s.best = 0;
 	s.mapq = 0;
 	for (int i = 0; i < s.can_num; ++i) {
-		int cs = a.c_score[s.c0 + i];
+		int cs = a.c_score[s.l.at(i)];
 		if (cs == 0 || cs == -1) continue;                          // skipped before the comparison (Score == 0, invalid coordinates, gap penalty)
-		int sc = a.rep_score[s.c0 + i];
+		int sc = a.rep_score[s.l.at(i)];
 		if (sc > s.score) { s.best = i; s.sub_score = s.score; s.score = sc; }
 		else if (sc == s.score) {
 			s.sub_score = s.score;
-			if (a.chr_len[a.rep_chr[s.c0 + i]] > a.chr_len[a.rep_chr[s.c0 + s.best]]) s.best = i;
+			if (a.chr_len[a.rep_chr[s.l.at(i)]] > a.chr_len[a.rep_chr[s.l.at(s.best)]]) s.best = i;
 		}
 	}
 }
@@ -809,9 +1097,10 @@ __device__ __forceinline__ int eval_mapq(const AlnArgs &a, const ReadSum &s)   /
 	return q > 60 ? 60 : q;
 }
 
-__device__ __forceinline__ int rep_score_at(const AlnArgs &a, const ReadSum &s, int i) { return (s.can_num == 0) ? 0 : a.rep_score[s.c0 + i]; }
-__device__ __forceinline__ int rep_mate_at(const AlnArgs &a, const ReadSum &s, int i) { return (s.can_num == 0) ? -1 : a.c_mate[s.c0 + i]; }
-__device__ __forceinline__ bool rep_fwd_at(const AlnArgs &a, const ReadSum &s, int i) { return (s.can_num == 0) ? true : a.rep_fwd[s.c0 + i] != 0; }
+// rep[i] of a read; a read without candidates holds one empty report (score 0, mate -1, forward; :627-634)
+__device__ __forceinline__ int rep_score_at(const AlnArgs &a, const ReadSum &s, int i) { return (s.can_num == 0) ? 0 : a.rep_score[s.l.at(i)]; }
+__device__ __forceinline__ int rep_mate_at(const AlnArgs &a, const ReadSum &s, int i) { return (s.can_num == 0) ? -1 : a.c_mate[s.l.at(i)]; }
+__device__ __forceinline__ bool rep_fwd_at(const AlnArgs &a, const ReadSum &s, int i) { return (s.can_num == 0) ? true : a.rep_fwd[s.l.at(i)] != 0; }
 
 // the per-mate halves of SetPairedAlignmentFlag, src/Mapping.cpp:96-156: the flag of the record that can be printed for `me`
 // (its best candidate), or of the unmapped record
@@ -838,7 +1127,7 @@ __device__ void write_record(const AlnArgs &a, int64_t r, const ReadSum &s, int 
 	o.has_mate = has_mate ? 1 : 0; o.mate_pos = mate_pos; o.tlen = tlen; o.flip = flip ? 1 : 0; o.pad = 0;
 	o.chr = -1; o.pos = 0; o.cigar_len = 0;
 	if (kind == KG_ALN_MAPPED) {
-		int64_t c = s.c0 + s.best;
+		int64_t c = s.l.at(s.best);
 		o.chr = a.rep_chr[c]; o.pos = a.rep_pos[c];
 		int n = a.rep_cigar_len[c];
 		o.cigar_len = (uint8_t)n;
@@ -877,11 +1166,11 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 				// the first candidate from `best` on whose score is the read's (the best one itself)
 				int pick = -1;
 				for (int i = s1.best; i < s1.can_num; ++i)
-					if (a.rep_score[s1.c0 + i] == s1.score) { pick = i; break; }
+					if (a.rep_score[s1.l.at(i)] == s1.score) { pick = i; break; }
 				if (pick < 0) a.records[r].kind = KG_ALN_NONE;
 				else {
 					s1.best = pick;
-					bool fwd = a.rep_fwd[s1.c0 + pick] != 0;
+					bool fwd = a.rep_fwd[s1.l.at(pick)] != 0;
 					write_record(a, r, s1, KG_ALN_MAPPED, fwd ? 0 : 0x10, false, 0, 0, !fwd);
 				}
 			}
@@ -892,22 +1181,22 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 		// CheckPairedFinalAlignments, src/Mapping.cpp:429-480 (bMultiHit false)
 		{
 			bool mated = false;
-			if (s1.can_num > 0 && s2.can_num > 0) mated = a.c_mate[s1.c0 + s1.best] == s2.best;
+			if (s1.can_num > 0 && s2.can_num > 0) mated = a.c_mate[s1.l.at(s1.best)] == s2.best;
 			else if (s1.can_num == 0 && s2.can_num > 0) mated = -1 == s2.best;       // (a report of an empty read: mate -1)
-			else if (s1.can_num > 0 && s2.can_num == 0) mated = a.c_mate[s1.c0 + s1.best] == 0;
+			else if (s1.can_num > 0 && s2.can_num == 0) mated = a.c_mate[s1.l.at(s1.best)] == 0;
 			else mated = false;                                                      // -1 == 0
 			if (!mated) {
 				if (s1.score > 0 && s2.score > 0) {
 					int s = 0;
 					for (int i = 0; i < s1.can_num; ++i) {
 						int j;
-						if (a.rep_score[s1.c0 + i] > 0 && (j = a.c_mate[s1.c0 + i]) != -1 && a.rep_score[s2.c0 + j] > 0) {
+						if (a.rep_score[s1.l.at(i)] > 0 && (j = a.c_mate[s1.l.at(i)]) != -1 && a.rep_score[s2.l.at(j)] > 0) {
 							mated = true;
-							int t = a.rep_score[s1.c0 + i] + a.rep_score[s2.c0 + j];
+							int t = a.rep_score[s1.l.at(i)] + a.rep_score[s2.l.at(j)];
 							if (s < t) {
 								s = t;
-								s1.best = i; s1.score = a.rep_score[s1.c0 + i];
-								s2.best = j; s2.score = a.rep_score[s2.c0 + j];
+								s1.best = i; s1.score = a.rep_score[s1.l.at(i)];
+								s2.best = j; s2.score = a.rep_score[s2.l.at(j)];
 							}
 						}
 					}
@@ -915,19 +1204,19 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 				if (mated) {
 					for (int i = 0; i < s1.can_num; ++i) {
 						int j;
-						if (a.rep_score[s1.c0 + i] != s1.score || ((j = a.c_mate[s1.c0 + i]) != -1 && a.rep_score[s2.c0 + j] != s2.score)) {
-							a.rep_score[s1.c0 + i] = 0;
-							a.c_mate[s1.c0 + i] = -1;
+						if (a.rep_score[s1.l.at(i)] != s1.score || ((j = a.c_mate[s1.l.at(i)]) != -1 && a.rep_score[s2.l.at(j)] != s2.score)) {
+							a.rep_score[s1.l.at(i)] = 0;
+							a.c_mate[s1.l.at(i)] = -1;
 						}
 					}
 				} else {
 					for (int i = 0; i < s1.can_num; ++i) {
-						a.c_mate[s1.c0 + i] = -1;
-						if (a.rep_score[s1.c0 + i] > 0 && a.rep_score[s1.c0 + i] != s1.score) a.rep_score[s1.c0 + i] = 0;
+						a.c_mate[s1.l.at(i)] = -1;
+						if (a.rep_score[s1.l.at(i)] > 0 && a.rep_score[s1.l.at(i)] != s1.score) a.rep_score[s1.l.at(i)] = 0;
 					}
 					for (int j = 0; j < s2.can_num; ++j) {
-						a.c_mate[s2.c0 + j] = -1;
-						if (a.rep_score[s2.c0 + j] > 0 && a.rep_score[s2.c0 + j] != s2.score) a.rep_score[s2.c0 + j] = 0;
+						a.c_mate[s2.l.at(j)] = -1;
+						if (a.rep_score[s2.l.at(j)] > 0 && a.rep_score[s2.l.at(j)] != s2.score) a.rep_score[s2.l.at(j)] = 0;
 					}
 				}
 			}
@@ -956,11 +1245,11 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 				int j = rep_mate_at(a, s1, s1.best);
 				bool fwd = rep_fwd_at(a, s1, s1.best);
 				if (j != -1 && rep_score_at(a, s2, j) > 0) {
-					int dist = (int)(a.rep_pos[s2.c0 + j] - a.rep_pos[s1.c0 + s1.best] + (fwd ? s2.rlen : 0 - s1.rlen));
+					int dist = (int)(a.rep_pos[s2.l.at(j)] - a.rep_pos[s1.l.at(s1.best)] + (fwd ? s2.rlen : 0 - s1.rlen));
 					add_paired = 2;
 					int ad = dist < 0 ? -dist : dist;
 					if (ad < 10000) add_dist = ad;
-					write_record(a, r, s1, KG_ALN_MAPPED, f1, true, a.rep_pos[s2.c0 + j], dist, !fwd);
+					write_record(a, r, s1, KG_ALN_MAPPED, f1, true, a.rep_pos[s2.l.at(j)], dist, !fwd);
 				} else write_record(a, r, s1, KG_ALN_MAPPED, f1, false, 0, 0, !fwd);
 			} else a.records[r].kind = KG_ALN_NONE;
 		}
@@ -974,8 +1263,8 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 				bool fwd = rep_fwd_at(a, s2, s2.best);
 				if (i != -1 && rep_score_at(a, s1, i) > 0) {
 					bool fwd1 = rep_fwd_at(a, s1, i);
-					int dist = 0 - (int)(a.rep_pos[s2.c0 + s2.best] - a.rep_pos[s1.c0 + i] + (fwd1 ? s2.rlen : 0 - s1.rlen));
-					write_record(a, r + 1, s2, KG_ALN_MAPPED, f2, true, a.rep_pos[s1.c0 + i], dist, fwd);
+					int dist = 0 - (int)(a.rep_pos[s2.l.at(s2.best)] - a.rep_pos[s1.l.at(i)] + (fwd1 ? s2.rlen : 0 - s1.rlen));
+					write_record(a, r + 1, s2, KG_ALN_MAPPED, f2, true, a.rep_pos[s1.l.at(i)], dist, fwd);
 				} else write_record(a, r + 1, s2, KG_ALN_MAPPED, f2, false, 0, 0, fwd);
 			} else a.records[r + 1].kind = KG_ALN_NONE;
 		}
@@ -989,13 +1278,13 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 __global__ void aln_reset_kernel(AlnArgs a)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < 4) a.ctl[i] = 0;
+	if (i < 5) a.ctl[i] = 0;
 	for (int c = i; c < a.n_chunks; c += gridDim.x * blockDim.x) {
 		kg_chunk_stats z;
 		z.paired = 0; z.distance = 0; z.lo = -1; z.hi = 0x7fffffffffffffffll; z.unmapped = 0; z.unique = 0; z.host_pairs = 0; z.rescue_wanted = 0;
 		a.chunk_stats[c] = z;
 	}
-	for (int64_t r = i; r < a.n_reads; r += (int64_t)gridDim.x * blockDim.x) a.r_host[r] = 0;
+	for (int64_t r = i; r < a.n_reads; r += (int64_t)gridDim.x * blockDim.x) { a.r_host[r] = 0; a.r_pending[r] = 0; a.resc_n[r] = 0; a.resc_off[r] = 0; }
 }
 
 static inline int grid_for_aln(int64_t items, int block, int max_blocks)
@@ -1010,7 +1299,9 @@ hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 {
 	hipLaunchKernelGGL(aln_reset_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 8)), dim3(256), 0, stream, a);
 	hipLaunchKernelGGL(aln_pair_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
-	if (a.n_cands > 0) hipLaunchKernelGGL(aln_plan_kernel, dim3(grid_for_aln(a.n_cands, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(aln_rescue_kernel, dim3(grid_for_aln(a.task_capacity, 1, n_cu * 32)), dim3(64), 0, stream, a);
+	hipLaunchKernelGGL(aln_post_rescue_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	if (a.n_cands > 0) hipLaunchKernelGGL(aln_plan_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
 	return hipGetLastError();
 }
 

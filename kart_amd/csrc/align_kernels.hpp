@@ -37,6 +37,22 @@ struct AlnSpill {
 	AlnSpillPair p[kAlnMaxPairs];
 };
 
+// One window of RescueUnpairedAlignment (src/AlignmentRescue.cpp:127-165): mate 1 of pair `read` is searched in the reference
+// window [left, left + slen) next to candidate `j` of mate 2.  The rescued candidate, if any, takes candidate slot
+// n_cands + (index of the task).
+struct RescueTask {
+	int64_t left;
+	int32_t read;         // mate 1 (the read whose 8-mers are looked up)
+	int32_t j;            // candidate of mate 2 the window belongs to
+	int32_t slen;
+	int32_t score1;       // the rescued candidate must beat this (best score of mate 1 before the rescue)
+	int32_t ordinal;      // index of the task among the tasks of its pair
+};
+
+constexpr int kRescueMaxRead = 256;                    // longest mate the rescue kernel takes
+constexpr int kRescueMaxWindow = 2048;                 // longest window (EstDistance <= MaxInsertSize 1500 + read length)
+constexpr int kRescueMaxRuns = 96;                     // exact-match runs of one window the kernel keeps
+
 struct AlnArgs {
 	FmView ix;                      // text
 	// reads
@@ -68,6 +84,15 @@ struct AlnArgs {
 	int64_t *rep_pos;
 	uint8_t *rep_fwd, *rep_cigar_len;
 	char *rep_cigar;                // [n_cands * KG_ALN_CIGAR_MAX]
+	// mate rescue
+	RescueTask *tasks;
+	int64_t task_capacity;
+	int64_t *resc_posdiff;          // [task_capacity] PosDiff of the rescued candidate
+	int32_t *resc_count;            // [task_capacity] its simple pairs ...
+	kg_seed *resc_seeds;            // [task_capacity * kAlnMaxSeeds] ... sorted by (gPos, rPos)
+	int32_t *resc_off;              // [n_reads] first task of the pair whose mate 1 this read is
+	uint8_t *resc_n;                // [n_reads] number of tasks (= rescue candidate slots appended to this read's list)
+	uint8_t *r_pending;             // [n_reads] the pair waits for its rescue windows
 	// per-read state
 	uint8_t *r_host;                // the pair of this read goes back to the host
 	// spill + jobs
@@ -75,7 +100,7 @@ struct AlnArgs {
 	int64_t spill_capacity;
 	NwJobDesc *jobs;
 	int64_t job_capacity, ops_capacity;
-	unsigned long long *ctl;        // [0] spill count, [1] job count, [2] ops bytes, [3] pairs handed to the host
+	unsigned long long *ctl;        // [0] spill count, [1] job count, [2] ops bytes, [3] unused, [4] rescue tasks
 	uint8_t *nw_ops;
 	int32_t *nw_len;
 	// outputs
@@ -83,7 +108,7 @@ struct AlnArgs {
 	kg_chunk_stats *chunk_stats;    // [n_chunks]
 };
 
-hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream);     // pairing + plan (+ finish of job-free candidates)
+hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream);     // pairing, mate rescue, plan (+ finish of job-free candidates)
 hipError_t launch_align_back(const AlnArgs &a, int n_cu, hipStream_t stream);      // finish of the spilled candidates + per-read records
 
 }  // namespace kg

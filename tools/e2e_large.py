@@ -26,9 +26,13 @@ def run(tag, exe, t):
     for line in r.stdout.decode().splitlines():
         if line.startswith("mapping seconds"):
             ms = float(line.split(":")[1]); res[tag]["mapping_seconds"] = ms; res[tag]["reads_per_s_mapping_phase"] = round(2 * pairs / ms)
-        if line.startswith("stage seconds") or line.startswith("worker thread-seconds") or line.startswith("All the"):
+        if line.startswith(("stage seconds", "worker thread-seconds", "All the", "device report", "CHECK_ALIGN", "chunks re-mapped")):
             res[tag].setdefault("log", []).append(line.strip())
 run("kart_amd", "kart_amd/bin/kart-amd", threads)
+if os.environ.get("E2E_CHECK_ALIGN"):      # every device record against the host's text for the same read (slow: the host maps everything too)
+    os.environ["KART_AMD_CHECK_ALIGN"] = "1"
+    run("kart_amd_check_align", "kart_amd/bin/kart-amd", threads)
+    del os.environ["KART_AMD_CHECK_ALIGN"]
 if os.path.exists("oracle/_ref/kart"):
     run("reference_kart", "oracle/_ref/kart", threads)
     # the reference prints its own mapping time ("... processed in N seconds"), which excludes its index load
