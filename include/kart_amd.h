@@ -193,10 +193,12 @@ typedef struct {
 	int32_t kind;
 	int32_t flag, chr, mapq, tlen;
 	int32_t score, sub_score;    /* AS / XS; NM = rlen - score */
+	int32_t est_lo, est_hi;  /* pairs: the pair's own EstDistance validity interval (est_lo, est_hi] (on both mates' records) */
 	uint8_t has_mate;        /* RNEXT "=" + PNEXT + TLEN, else "*\t0\t0" */
 	uint8_t flip;            /* the record shows the reverse complement of the read as the caller holds it (mate 2 is held
 	                            reverse-complemented, src/GetData.cpp:125-135) */
-	uint8_t cigar_len, pad;
+	uint8_t cigar_len;
+	uint8_t rescue;          /* pairs: RescueUnpairedAlignment was due for this pair (its windows depend on min(EstDistance, MaxInsertSize)) */
 	char    cigar[KG_ALN_CIGAR_MAX];
 } kg_aln_record;
 

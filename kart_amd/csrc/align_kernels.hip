@@ -135,10 +135,12 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 		const int64_t a0 = l1.c0;
 		const int n1 = l1.nd;
 		for (int i = 0; i < n1; ++i) { a.c_score[a0 + i] = a.cands[a0 + i].score; a.c_mate[a0 + i] = -1; a.c_read[a0 + i] = (int32_t)r; }
+		a.records[r].est_lo = -1; a.records[r].est_hi = 0x7fffffff; a.records[r].rescue = 0;
 		if (!paired) {
 			remove_redundant(a, l1);                                 // src/Mapping.cpp:589
 			continue;
 		}
+		a.records[r + 1].est_lo = -1; a.records[r + 1].est_hi = 0x7fffffff; a.records[r + 1].rescue = 0;
 		const CandList l2 = cand_list(a, r + 1);
 		const int64_t a1 = l2.c0;
 		const int n2 = l2.nd;
@@ -180,10 +182,17 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 		}
 		if (lo > -1) atomicMax((long long *)&a.chunk_stats[ck].lo, lo);
 		if (hi != 0x7fffffffffffffffll) atomicMin((long long *)&a.chunk_stats[ck].hi, hi);
+		{
+			// the pair's own interval (every distance that matters is far below 2^31: EstDistance never exceeds 1.5 x 10000)
+			int32_t plo = (int32_t)lo, phi = hi > 0x7fffffffll ? 0x7fffffff : (int32_t)hi;
+			a.records[r].est_lo = plo; a.records[r].est_hi = phi;
+			a.records[r + 1].est_lo = plo; a.records[r + 1].est_hi = phi;
+		}
 		if (pairing) remove_unmated(a, l1, l2);
 		else {
 			// RescueUnpairedAlignment is due (src/Mapping.cpp:559-560; src/AlignmentRescue.cpp:73-170)
 			a.chunk_stats[ck].rescue_wanted = 1;
+			a.records[r].rescue = 1; a.records[r + 1].rescue = 1;
 			int sc1 = 0, sc2 = 0;
 			for (int i = 0; i < n1; ++i) sc1 = max(sc1, a.c_score[a0 + i]);
 			for (int j = 0; j < n2; ++j) sc2 = max(sc2, a.c_score[a1 + j]);
@@ -1124,7 +1133,7 @@ __device__ void write_record(const AlnArgs &a, int64_t r, const ReadSum &s, int 
 {
 	kg_aln_record &o = a.records[r];
 	o.kind = kind; o.flag = flag; o.mapq = s.mapq; o.score = s.score; o.sub_score = s.sub_score;
-	o.has_mate = has_mate ? 1 : 0; o.mate_pos = mate_pos; o.tlen = tlen; o.flip = flip ? 1 : 0; o.pad = 0;
+	o.has_mate = has_mate ? 1 : 0; o.mate_pos = mate_pos; o.tlen = tlen; o.flip = flip ? 1 : 0;      // (est_lo / est_hi / rescue: aln_pair_kernel)
 	o.chr = -1; o.pos = 0; o.cigar_len = 0;
 	if (kind == KG_ALN_MAPPED) {
 		int64_t c = s.l.at(s.best);
@@ -1167,7 +1176,7 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 				int pick = -1;
 				for (int i = s1.best; i < s1.can_num; ++i)
 					if (a.rep_score[s1.l.at(i)] == s1.score) { pick = i; break; }
-				if (pick < 0) a.records[r].kind = KG_ALN_NONE;
+				if (pick < 0) write_record(a, r, s1, KG_ALN_NONE, 0, false, 0, 0, false);
 				else {
 					s1.best = pick;
 					bool fwd = a.rep_fwd[s1.l.at(pick)] != 0;
@@ -1251,7 +1260,7 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 					if (ad < 10000) add_dist = ad;
 					write_record(a, r, s1, KG_ALN_MAPPED, f1, true, a.rep_pos[s2.l.at(j)], dist, !fwd);
 				} else write_record(a, r, s1, KG_ALN_MAPPED, f1, false, 0, 0, !fwd);
-			} else a.records[r].kind = KG_ALN_NONE;
+			} else write_record(a, r, s1, KG_ALN_NONE, 0, false, 0, 0, false);
 		}
 		if (s2.score == 0) {
 			atomicAdd(&cs.unmapped, 1);
@@ -1266,7 +1275,7 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 					int dist = 0 - (int)(a.rep_pos[s2.l.at(s2.best)] - a.rep_pos[s1.l.at(i)] + (fwd1 ? s2.rlen : 0 - s1.rlen));
 					write_record(a, r + 1, s2, KG_ALN_MAPPED, f2, true, a.rep_pos[s1.l.at(i)], dist, fwd);
 				} else write_record(a, r + 1, s2, KG_ALN_MAPPED, f2, false, 0, 0, fwd);
-			} else a.records[r + 1].kind = KG_ALN_NONE;
+			} else write_record(a, r + 1, s2, KG_ALN_NONE, 0, false, 0, 0, false);
 		}
 		if (add_paired) {
 			atomicAdd((unsigned long long *)&cs.paired, (unsigned long long)add_paired);
