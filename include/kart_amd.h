@@ -220,6 +220,13 @@ typedef struct {
 int  kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks,
                     int est_distance, int max_insert, int max_gaps, const kg_aln_record **records, kg_chunk_stats *chunk_stats);
 
+/* Running tallies (since the workspace was created) of why read pairs came back as KG_ALN_HOST: [0] candidate product too large,
+ * [1] a mate-2 rescue window would be scanned, [2] rescue window too long, [3] mate not plain A/C/G/T or too long for the rescue
+ * kernel, [4] too many exact-match runs in a window, [5] rescued candidate with too many pairs, [6] candidate with too many
+ * seeds, [7] too many gap pairs, [8] a gap fragment needs the 8-mer partition (both sides > 30), [9] a device list was full,
+ * [10] CIGAR too long, [11] score beyond the MAPQ table, [12] read too long.  Diagnostics only. */
+int  kg_align_reasons(kg_workspace *ws, uint64_t out[16]);
+
 /* ---- Needleman-Wunsch gap closing ----------------------------------------------------------- */
 /* n fragment pairs: frag1 (read side, raw characters) concatenated with offsets off1[n+1], frag2
  * (genome side) with off2[n+1].  For pair i the alignment is returned as ops[ops_off[i] ..

@@ -879,7 +879,7 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		HIP_TRY(hipMalloc((void **)&ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)cap));
 		ws->chunk_capacity = cap;
 	}
-	if (!ws->d_aln_ctl) HIP_TRY(hipMalloc((void **)&ws->d_aln_ctl, 8 * 8));
+	if (!ws->d_aln_ctl) { HIP_TRY(hipMalloc((void **)&ws->d_aln_ctl, 8 * 24)); HIP_TRY(hipMemset(ws->d_aln_ctl, 0, 8 * 24)); }
 	HIP_TRY(hipMemcpyAsync(ws->d_chunk_off, chunk_off, 8 * (size_t)(n_chunks + 1), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(ws->d_chunk_paired, chunk_paired, (size_t)n_chunks, hipMemcpyHostToDevice, st));
 	// ---- arguments ------------------------------------------------------------------------------------------------------------
@@ -953,6 +953,16 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 	HIP_TRY(hipMemcpyAsync(chunk_stats, ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)n_chunks, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	*records = ws->h_records;
+	return KG_OK;
+}
+
+int kg_align_reasons(kg_workspace *ws, uint64_t out[16])
+{
+	if (!ws || !out) return fail(KG_ERR_ARG, "kg_align_reasons: null argument");
+	for (int i = 0; i < 16; ++i) out[i] = 0;
+	if (!ws->d_aln_ctl) return KG_OK;
+	HIP_TRY(hipSetDevice(ws->ix->device));
+	HIP_TRY(hipMemcpy(out, ws->d_aln_ctl + 8, 8 * 16, hipMemcpyDeviceToHost));
 	return KG_OK;
 }
 

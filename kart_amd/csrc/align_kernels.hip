@@ -59,8 +59,13 @@ __device__ __forceinline__ int end_lower_bound(const AlnArgs &a, int64_t g)
 	return lo;
 }
 
-__device__ __forceinline__ void flag_host(const AlnArgs &a, int64_t r)       // the pair of read r goes back to the host
+// why a pair went back to the host (kg_align_reasons)
+enum { WHY_PAIR_PRODUCT = 0, WHY_RESCUE_DIR1 = 1, WHY_RESCUE_WINDOW = 2, WHY_RESCUE_READ = 3, WHY_RESCUE_RUNS = 4, WHY_RESCUE_SEEDS = 5, WHY_SEEDS = 6,
+       WHY_GAPS = 7, WHY_PARTITION = 8, WHY_CAPACITY = 9, WHY_CIGAR = 10, WHY_SCORE = 11, WHY_READ_LEN = 12 };
+
+__device__ __forceinline__ void flag_host(const AlnArgs &a, int64_t r, int why)       // the pair of read r goes back to the host
 {
+	atomicAdd(&a.ctl[8 + why], 1ull);
 	int c = chunk_of(a, r);
 	int64_t base = a.chunk_off[c];
 	if (a.chunk_paired[c]) {
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 		const int64_t a1 = l2.c0;
 		const int n2 = l2.nd;
 		for (int j = 0; j < n2; ++j) { a.c_score[a1 + j] = a.cands[a1 + j].score; a.c_mate[a1 + j] = -1; a.c_read[a1 + j] = (int32_t)(r + 1); }
-		if ((int64_t)n1 * n2 > kAlnPairProduct) { a.r_host[r] = 1; a.r_host[r + 1] = 1; continue; }
+		if ((int64_t)n1 * n2 > kAlnPairProduct) { flag_host(a, r, WHY_PAIR_PRODUCT); continue; }
 		// CheckPairedAlignmentCandidates, src/Mapping.cpp:348-400
 		if (n1 * n2 > 1000) { remove_redundant(a, l1); remove_redundant(a, l2); }
 		bool pairing = false;
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 			else strategy = 3;
 			const int est_r = a.est_distance > a.max_insert ? a.max_insert : a.est_distance;   // :95
 			bool host = false;
+			int why = 0;
 			if (strategy == 1 || strategy == 3) {
 				// mate 2 next to the candidates of mate 1 (:97-125).  The right end of that window is clamped against the START
 				// of the contig (:111-112), which collapses it: the "slen < rlen" test skips it.  Verified per window here; a
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 					int slen = (int)(right - left);
 					if (slen < rl2) continue;
 					if (left < 0 || right > a.two_genome_size) continue;
-					host = true;
+					host = true; why = WHY_RESCUE_DIR1;
 				}
 			}
 			int nt = 0;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 					if (pass == 1) {
 						if (nt == 0) break;
 						base = atomicAdd(&a.ctl[4], (unsigned long long)nt);
-						if (base + (unsigned long long)nt > (unsigned long long)a.task_capacity || nt > 200) { host = true; break; }
+						if (base + (unsigned long long)nt > (unsigned long long)a.task_capacity || nt > 200) { host = true; why = WHY_CAPACITY; break; }
 					}
 					int k = 0;
 					for (int j = 0; j < n2; ++j) {
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 						if (slen < rl1) continue;
 						if (left < 0) { left = 0; slen = (int)(right - left); if (slen < rl1) continue; }
 						if (right > a.two_genome_size) continue;
-						if (slen > kRescueMaxWindow) { host = true; break; }
+						if (slen > kRescueMaxWindow) { host = true; why = WHY_RESCUE_WINDOW; break; }
 						if (pass == 1) {
 							RescueTask t;
 							t.left = left; t.read = (int32_t)r; t.j = j; t.slen = slen; t.score1 = sc1; t.ordinal = k;
@@ -269,15 +275,15 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 				if (!host && nt > 0) {
 					// the 8-mer code skips 'N' and maps everything else through nst_nt4_table (src/KmerAnalysis.cpp:25-32, 56-102);
 					// the kernel compares 2-bit codes, which is the same thing for reads made of A/C/G/T in either case
-					if (rl1 > kRescueMaxRead || rl1 < 8) host = true;
+					if (rl1 > kRescueMaxRead || rl1 < 8) { host = true; why = WHY_RESCUE_READ; }
 					const uint8_t *rd = a.enc + a.read_off[r];
 					for (int i = 0; i < rl1 && !host; ++i) {
 						unsigned u = rd[i] & 0xDFu;
-						if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) host = true;
+						if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) { host = true; why = WHY_RESCUE_READ; }
 					}
 				}
 			}
-			if (host) { a.resc_n[r] = 0; a.r_host[r] = 1; a.r_host[r + 1] = 1; continue; }
+			if (host) { a.resc_n[r] = 0; flag_host(a, r, why); continue; }
 			if (nt > 0) { a.r_pending[r] = 1; continue; }           // filters follow once the windows are scanned (aln_post_rescue_kernel)
 		}
 		remove_redundant(a, l1);                                     // src/Mapping.cpp:563
@@ -296,7 +302,9 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 {
 	__shared__ uint64_t rd2[kRescueMaxRead / 32 + 2];          // read, 2 bits per base, base t in bits 2*(t&31) of word t>>5
 	__shared__ uint64_t win2[kRescueMaxWindow / 32 + 4];       // window likewise
-	__shared__ int run_d[kRescueMaxRuns], run_t[kRescueMaxRuns], run_l[kRescueMaxRuns];
+	__shared__ int raw_key[kRescueMaxRuns], raw_len[kRescueMaxRuns];      // runs as the lanes find them: (diagonal index << 8 | read position), length
+	__shared__ int run_d[kRescueMaxRuns], run_t[kRescueMaxRuns], run_l[kRescueMaxRuns];   // ... sorted by (diagonal, read position)
+	__shared__ int n_raw;
 	const int lane = threadIdx.x;
 	unsigned long long n_tasks = a.ctl[4];
 	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
@@ -329,19 +337,18 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 			}
 			win2[w] = x;
 		}
+		if (lane == 0) n_raw = 0;
 		__syncthreads();
 		// diagonals d = gpos - rpos of k-mer pairs: -(rlen - 8) .. slen - 8
 		const int d_lo = -(rlen - 8), nd = slen + rlen - 15;
 		const int per = (nd + 63) >> 6;
-		int my_n = 0;
-		int md[4], mt[4], ml[4];
-		bool overflow = false;
+		int di_cur = 0;
 		// a run of equal bases ended: it is a simple pair when it holds at least 10 bases (three consecutive common 8-mers)
 #define KG_RESCUE_EMIT()                                                                                        \
 	do {                                                                                                        \
 		if (run >= 10) {                                                                                        \
-			if (my_n < 4) { md[my_n] = d; mt[my_n] = run_start; ml[my_n] = run; my_n++; }                       \
-			else overflow = true;                                                                               \
+			int at_ = atomicAdd(&n_raw, 1);                                                                     \
+			if (at_ < kRescueMaxRuns) { raw_key[at_] = (di_cur << 8) | run_start; raw_len[at_] = run; }         \
 		}                                                                                                       \
 		run = 0;                                                                                                \
 	} while (0)
@@ -349,6 +356,7 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 			int di = lane * per + q;
 			if (di >= nd) break;
 			int d = d_lo + di;
+			di_cur = di;
 			int t_lo = d < 0 ? -d : 0;
 			int t_hi = rlen < slen - d ? rlen : slen - d;               // read positions [t_lo, t_hi) face window positions t + d
 			int run = 0, run_start = 0;
@@ -389,19 +397,18 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 			}
 			KG_RESCUE_EMIT();
 		}
-		// the runs of all lanes, in (diagonal, read position) order: lanes hold consecutive diagonal blocks
-		int incl = my_n;
-		for (int o = 1; o < 64; o <<= 1) {
-			int v = __shfl_up(incl, o);
-			if (lane >= o) incl += v;
-		}
-		const int total = __shfl(incl, 63);
-		const bool any_overflow = __ballot(overflow) != 0 || total > kRescueMaxRuns;
-		if (any_overflow) {
-			if (lane == 0) flag_host(a, t.read);
+		// the runs in (diagonal, read position) order -- the order IdentifyCommonKmers' sort leaves the k-mer hits in: rank sort
+		__syncthreads();
+		const int total = n_raw;
+		if (total > kRescueMaxRuns) {
+			if (lane == 0) flag_host(a, t.read, WHY_RESCUE_RUNS);
 			continue;
 		}
-		for (int k = 0; k < my_n; ++k) { int at = incl - my_n + k; run_d[at] = md[k]; run_t[at] = mt[k]; run_l[at] = ml[k]; }
+		for (int i = lane; i < total; i += 64) {
+			int key = raw_key[i], rank = 0;
+			for (int j = 0; j < total; ++j) rank += raw_key[j] < key ? 1 : 0;
+			run_d[rank] = d_lo + (key >> 8); run_t[rank] = key & 255; run_l[rank] = raw_len[i];
+		}
 		__syncthreads();
 		if (lane == 0) {
 			// IdnetifyRescueCandidate
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 			}
 			int cnt = best_j - best_i;
 			if (best_s > t.score1) {
-				if (cnt > kAlnMaxSeeds) flag_host(a, t.read);
+				if (cnt > kAlnMaxSeeds) flag_host(a, t.read, WHY_RESCUE_SEEDS);
 				else {
 					// the group's pairs by (gPos, rPos) (:61); text coordinates
 					kg_seed *out = a.resc_seeds + (int64_t)ti * kAlnMaxSeeds;
@@ -961,7 +968,7 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			cd.count = a.resc_count[t]; cd.first = 0; cd.posDiff = a.resc_posdiff[t]; cd.score = 0;
 			seeds = a.resc_seeds + t * kAlnMaxSeeds;
 		}
-		if (cd.count > kAlnMaxSeeds) { flag_host(a, r); continue; }
+		if (cd.count > kAlnMaxSeeds) { flag_host(a, r, WHY_SEEDS); continue; }
 		const int64_t rbase = a.read_off[r];
 		const int rlen = (int)(a.read_off[r + 1] - rbase);
 		const uint8_t *rd = a.enc + rbase;
@@ -973,11 +980,13 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			kg_seed s = seeds[i];
 			v.gPos[i] = s.gPos; v.rPos[i] = s.rPos; v.rLen[i] = v.gLen[i] = s.len; v.simple[i] = 1;
 		}
-		if (!identify_normal_pairs(rlen, v)) { flag_host(a, r); continue; }
+		if (rlen > 4000) { flag_host(a, r, WHY_READ_LEN); continue; }
+		if (!identify_normal_pairs(rlen, v)) { flag_host(a, r, WHY_GAPS); continue; }
 		if (!coordinates_valid(a, v)) { a.c_score[cand] = -1; continue; }      // no report, and no best/second-best step (:647)
 		Work w;
 		const int num = v.num;
 		bool host = false, jobs = false;
+		int why = WHY_PARTITION;
 		for (int j = 0; j < num && !host; ++j) {
 			w.kind[j] = W_NONE; w.op[j] = 0; w.op_len[j] = 0; w.val[j] = 0;
 			const int rL = v.rLen[j], gL = v.gLen[j];
@@ -1016,21 +1025,21 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			// nw_alignment(rL, frag1, gL, frag2): a job for the NW kernels
 			unsigned long long slot = atomicAdd(&a.ctl[1], 1ull);
 			unsigned long long ops_at = atomicAdd(&a.ctl[2], (unsigned long long)(rL + gL));
-			if (slot >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(rL + gL) > (unsigned long long)a.ops_capacity) { host = true; break; }
+			if (slot >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(rL + gL) > (unsigned long long)a.ops_capacity) { host = true; why = WHY_CAPACITY; break; }
 			NwJobDesc jd;
 			jd.o1 = rbase + v.rPos[j]; jd.o2 = v.gPos[j]; jd.ops = (int64_t)ops_at; jd.m = rL; jd.n = gL;
 			a.jobs[slot] = jd;
 			w.kind[j] = W_JOB; w.val[j] = (int32_t)slot;
 			jobs = true;
 		}
-		if (host) { flag_host(a, r); continue; }
+		if (host) { flag_host(a, r, why); continue; }
 		if (!jobs) {
-			if (!finish_candidate(a, cand, first, rd, v, w)) flag_host(a, r);
+			if (!finish_candidate(a, cand, first, rd, v, w)) flag_host(a, r, WHY_CIGAR);
 			continue;
 		}
 		// park the candidate until its alignments exist
 		unsigned long long sp = atomicAdd(&a.ctl[0], 1ull);
-		if (sp >= (unsigned long long)a.spill_capacity) { flag_host(a, r); continue; }
+		if (sp >= (unsigned long long)a.spill_capacity) { flag_host(a, r, WHY_CAPACITY); continue; }
 		AlnSpill &o = a.spill[sp];
 		o.cand = (int32_t)cand;
 		o.num = num;
@@ -1065,7 +1074,7 @@ __global__ __launch_bounds__(256) void aln_finish_kernel(AlnArgs a)
 			v.gPos[j] = q.gPos; v.rPos[j] = q.rPos; v.rLen[j] = q.rLen; v.gLen[j] = q.gLen; v.simple[j] = q.kind == W_SIMPLE;
 			w.kind[j] = q.kind; w.op[j] = q.op; w.op_len[j] = q.op_len; w.val[j] = q.val;
 		}
-		if (!finish_candidate(a, cand, first, a.enc + a.read_off[r], v, w)) flag_host(a, r);
+		if (!finish_candidate(a, cand, first, a.enc + a.read_off[r], v, w)) flag_host(a, r, WHY_CIGAR);
 	}
 }
 
@@ -1287,7 +1296,7 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 __global__ void aln_reset_kernel(AlnArgs a)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < 5) a.ctl[i] = 0;
+	if (i < 5) a.ctl[i] = 0;       // (ctl[8..23]: running tallies of why pairs went back to the host, never reset)
 	for (int c = i; c < a.n_chunks; c += gridDim.x * blockDim.x) {
 		kg_chunk_stats z;
 		z.paired = 0; z.distance = 0; z.lo = -1; z.hi = 0x7fffffffffffffffll; z.unmapped = 0; z.unique = 0; z.host_pairs = 0; z.rescue_wanted = 0;

@@ -51,7 +51,7 @@ struct RescueTask {
 
 constexpr int kRescueMaxRead = 256;                    // longest mate the rescue kernel takes
 constexpr int kRescueMaxWindow = 2048;                 // longest window (EstDistance <= MaxInsertSize 1500 + read length)
-constexpr int kRescueMaxRuns = 96;                     // exact-match runs of one window the kernel keeps
+constexpr int kRescueMaxRuns = 256;                    // exact-match runs of one window the kernel keeps
 
 struct AlnArgs {
 	FmView ix;                      // text

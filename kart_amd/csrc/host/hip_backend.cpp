@@ -70,6 +70,17 @@ public:
 		records.assign(rec, rec + chunk_off[(size_t)n_chunks]);              // the library's pinned array is overwritten by the next batch
 		return true;
 	}
+	std::string align_diagnostics() override
+	{
+		uint64_t w[16];
+		if (kg_align_reasons(ws_, w) != KG_OK) return std::string();
+		static const char *const name[13] = {"candidate product", "mate-2 window", "window length", "mate characters/length", "runs per window", "rescued pairs", "seeds",
+		                                     "gap pairs", "8-mer partition", "list capacity", "CIGAR length", "score", "read length"};
+		std::string s;
+		for (int i = 0; i < 13; ++i)
+			if (w[i]) s += std::string(s.empty() ? "" : ", ") + name[i] + " " + std::to_string((unsigned long long)w[i]);
+		return s;
+	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
 	{
 		std::lock_guard<std::mutex> lk(nw_mu_);   // the staging vectors below are shared; calls from the commit path are rare

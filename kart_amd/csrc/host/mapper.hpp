@@ -87,6 +87,8 @@ struct KernelBackend {
 		(void)chunk_off; (void)chunk_paired; (void)est; (void)max_insert; (void)max_gaps; (void)records; (void)chunk_stats;
 		return false;
 	}
+	// diagnostics of the stage above (why pairs came back for the host), empty when there is none
+	virtual std::string align_diagnostics() { return std::string(); }
 };
 
 struct Contig {
