@@ -87,6 +87,7 @@ struct NwScratch {
 	size_t dir_words = 0;
 	hipEvent_t done = nullptr;
 	bool busy = false;
+	bool pending = false;     // acquired, but the event behind its kernels is not recorded yet: `done` still reports the PREVIOUS use
 	// staging of the host-buffer entry (kg_nw_batch): inputs, offsets and outputs, grown on demand
 	char *io = nullptr;
 	size_t io_bytes = 0;
@@ -749,7 +750,7 @@ static int nw_acquire(kg_index *ix, size_t list_words, size_t dir_words, NwScrat
 	std::lock_guard<std::mutex> lock(ix->nw_mu);
 	NwScratch *pick = nullptr;
 	for (NwScratch *s : ix->nw_pool) {
-		if (s->busy && hipEventQuery(s->done) == hipSuccess) s->busy = false;
+		if (s->busy && !s->pending && hipEventQuery(s->done) == hipSuccess) s->busy = false;
 		if (!s->busy && (!pick || (s->list_words >= list_words && s->dir_words >= dir_words))) pick = s;
 	}
 	if (!pick) {
@@ -772,8 +773,18 @@ static int nw_acquire(kg_index *ix, size_t list_words, size_t dir_words, NwScrat
 		pick->dir_words = dir_words;
 	}
 	pick->busy = true;
+	pick->pending = true;
 	*out = pick;
 	return KG_OK;
+}
+
+// the kernels that use the scratch are enqueued: from here on `done` speaks for this use
+static hipError_t nw_submitted(kg_index *ix, NwScratch *sc, hipStream_t st)
+{
+	hipError_t e = hipEventRecord(sc->done, st);
+	std::lock_guard<std::mutex> lock(ix->nw_mu);
+	sc->pending = false;
+	return e;
 }
 
 // shared launcher: scratch = 3n list words + 4 queue words (+ direction slabs when a pair is longer than 32)
@@ -813,7 +824,7 @@ static int nw_run(kg_index *ix, const char *d_frag1, const int64_t *d_off1, cons
 	a.queue = sc->queue;
 	if (dir_words) a.dir_scratch = sc->dir;
 	hipError_t e = launch_nw_batch(a, ix->n_cu, st);
-	hipError_t e2 = hipEventRecord(sc->done, st);
+	hipError_t e2 = nw_submitted(ix, sc, st);
 	if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_nw_batch: %s", hipGetErrorString(e != hipSuccess ? e : e2));
 	return KG_OK;
 }
@@ -945,7 +956,7 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		if (rc != KG_OK) return rc;
 		w.big_list = sc->lists; w.queue = sc->queue; w.dir_scratch = sc->dir;
 		hipError_t e = launch_nw_batch(w, ix->n_cu, st);
-		hipError_t e2 = hipEventRecord(sc->done, st);
+		hipError_t e2 = nw_submitted(ix, sc, st);
 		if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_align_batch: %s", hipGetErrorString(e != hipSuccess ? e : e2));
 	}
 	HIP_TRY(launch_align_back(a, ix->n_cu, st));

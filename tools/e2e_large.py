@@ -19,7 +19,8 @@ threads = min(32, 2 * bench.effective_cores())
 res = {"genome_len": L, "reads": 2 * pairs, "threads": threads}
 def run(tag, exe, t):
     t0 = time.time()
-    r = subprocess.run([exe, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-o", os.path.join(wd, tag + ".sam"), "-t", str(t)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+    r = subprocess.run([exe, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-o", os.path.join(wd, tag + ".sam"), "-t", str(t)], stdout=subprocess.PIPE,
+                       stderr=open(os.path.join("gpurun_out", tag + ".stderr"), "wb") if os.path.isdir("gpurun_out") else subprocess.DEVNULL,
                        env=dict(os.environ, KART_AMD_VERBOSE="1"))
     dt = time.time() - t0
     res[tag] = {"rc": r.returncode, "process_seconds": round(dt, 2), "reads_per_s_process": round(2 * pairs / dt)}
