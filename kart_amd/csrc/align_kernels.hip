@@ -317,23 +317,42 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 		const int slen = t.slen;
 		const int rwords = (rlen + 31) >> 5, wwords = (slen + 31) >> 5;
 		__syncthreads();
-		for (int w = lane; w < rwords + 1; w += 64) {
-			uint64_t x = 0;
-			for (int b = 0; b < 32; ++b) {
-				int p = (w << 5) + b;
-				if (p < rlen) {
-					unsigned ch = rd[p];
-					unsigned g = (ch >> 1) & 3;                            // A 00, C 01, G 11, T 10 in either case ...
-					x |= (uint64_t)(g ^ (g >> 1)) << (b << 1);           // ... one Gray step from the codes 0..3
-				}
+		// the read as 2-bit codes, 64 bases per step: every lane converts one character (A 00, C 01, G 11, T 10 in either case
+		// is one Gray step from the codes 0..3), two ballots collect the bit planes, which are then interleaved
+		for (int w2 = 0; (w2 << 6) < rlen + 32; ++w2) {
+			int p = (w2 << 6) + lane;
+			unsigned g = 0;
+			if (p < rlen) { unsigned ch = rd[p]; g = (ch >> 1) & 3; g ^= g >> 1; }
+			uint64_t m0 = __ballot(g & 1), m1 = __ballot(g & 2);
+			if (lane < 2) {
+				uint32_t lo0 = (uint32_t)(m0 >> (lane << 5)), lo1 = (uint32_t)(m1 >> (lane << 5));
+				auto spread = [](uint32_t v) {
+					uint64_t x = v;
+					x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+					x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+					x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+					x = (x | (x << 2)) & 0x3333333333333333ull;
+					x = (x | (x << 1)) & 0x5555555555555555ull;
+					return x;
+				};
+				int w = (w2 << 1) + lane;
+				if (w < rwords + 1) rd2[w] = spread(lo0) | (spread(lo1) << 1);
 			}
-			rd2[w] = x;
 		}
+		// the window straight from the 2-bit text (same packing: base i in bits 2 (i & 3) of byte i >> 2): one unaligned 64-bit
+		// load + the next byte per word
 		for (int w = lane; w < wwords + 2; w += 64) {
+			int64_t g0 = t.left + ((int64_t)w << 5);
 			uint64_t x = 0;
-			for (int b = 0; b < 32; ++b) {
-				int p = (w << 5) + b;
-				if (p < slen) x |= (uint64_t)text_code(a, t.left + p) << (b << 1);
+			if ((w << 5) < slen) {
+				const uint8_t *tp = a.ix.text + ((uint64_t)g0 >> 2);
+				uint64_t lo_w = 0;
+				for (int k = 0; k < 8; ++k) lo_w |= (uint64_t)tp[k] << (k << 3);
+				uint64_t hi_b = tp[8];
+				int sh = ((int)g0 & 3) << 1;
+				x = sh ? (lo_w >> sh) | (hi_b << (64 - sh)) : lo_w;
+				int valid = slen - (w << 5);
+				if (valid < 32) x &= (1ull << (valid << 1)) - 1;
 			}
 			win2[w] = x;
 		}

@@ -7,6 +7,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <thread>
+#include <ctime>
 
 #include "mapper.hpp"
 
@@ -23,8 +24,16 @@ namespace {
 	exit(1);
 }
 
+static double now_sec()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
 class HipBackend : public KernelBackend {
 public:
+	double t_seed = 0, t_cands = 0, t_copy = 0, t_align = 0, t_reccopy = 0;   // KART_AMD_VERBOSE: where the per-batch device stage spends its time
 	HipBackend(kg_index *ix, const Options &opt) : ix_(ix), threads_(std::max(1, std::min(opt.threads, 16)))
 	{
 		kg_index_info(ix_, &info_);
@@ -44,19 +53,24 @@ public:
 		int64_t n = (int64_t)off.size() - 1;
 		reserve(n, off[(size_t)n]);
 		seed_off_.assign(off.size(), 0);
+		double t0 = now_sec();
 		// the seeds stay on the device (seeds = NULL); only the chained candidates come back, packed
 		if (kg_seed_batch(ws_, mode | KG_INPUT_ASCII, info_.min_seed_len, KG_OCC_THR_DEFAULT, enc.data(), off.data(), n, seed_off_.data(), nullptr) != KG_OK) die("kg_seed_batch");
+		double t1 = now_sec();
 		n_cands.assign((size_t)n + 1, 0);
 		const kg_candidate *c = nullptr;
 		const kg_seed *cs = nullptr;
 		int64_t nc = 0, ns = 0;
 		if (kg_candidates_batch(ws_, pacbio ? 1 : 0, max_gaps, n, seed_off_[(size_t)n], n_cands.data(), &c, &nc, &cs, &ns) != KG_OK) die("kg_candidates_batch");
+		double t2 = now_sec();
 		cands.assign(c, c + nc);          // the library's pinned arrays are overwritten by the next batch
 		cand_seeds.assign(cs, cs + ns);
 		cand_off.resize((size_t)n + 1);
 		int64_t at = 0;
 		for (int64_t r = 0; r < n; ++r) { cand_off[(size_t)r] = at; at += n_cands[(size_t)r]; }
 		cand_off[(size_t)n] = at;
+		double t3 = now_sec();
+		t_seed += t1 - t0; t_cands += t2 - t1; t_copy += t3 - t2;
 	}
 	bool align(const std::vector<int64_t> &chunk_off, const std::vector<uint8_t> &chunk_paired, int est, int max_insert, int max_gaps,
 	           std::vector<kg_aln_record> &records, std::vector<kg_chunk_stats> &chunk_stats) override
@@ -66,8 +80,11 @@ public:
 		int n_chunks = (int)chunk_paired.size();
 		chunk_stats.resize((size_t)n_chunks);
 		const kg_aln_record *rec = nullptr;
+		double t0 = now_sec();
 		if (kg_align_batch(ws_, chunk_off.data(), chunk_paired.data(), n_chunks, est, max_insert, max_gaps, &rec, chunk_stats.data()) != KG_OK) die("kg_align_batch");
+		double t1 = now_sec();
 		records.assign(rec, rec + chunk_off[(size_t)n_chunks]);              // the library's pinned array is overwritten by the next batch
+		t_align += t1 - t0; t_reccopy += now_sec() - t1;
 		return true;
 	}
 	std::string align_diagnostics() override
@@ -76,9 +93,11 @@ public:
 		if (kg_align_reasons(ws_, w) != KG_OK) return std::string();
 		static const char *const name[13] = {"candidate product", "mate-2 window", "window length", "mate characters/length", "runs per window", "rescued pairs", "seeds",
 		                                     "gap pairs", "8-mer partition", "list capacity", "CIGAR length", "score", "read length"};
-		std::string s;
+		char tb[256];
+		snprintf(tb, sizeof(tb), "device stage seconds: seed (H2D + kernels) %.3f | chain + D2H %.3f | candidate copies %.3f | align (kernels + D2H) %.3f | record copy %.3f || ", t_seed, t_cands, t_copy, t_align, t_reccopy);
+		std::string s(tb);
 		for (int i = 0; i < 13; ++i)
-			if (w[i]) s += std::string(s.empty() ? "" : ", ") + name[i] + " " + std::to_string((unsigned long long)w[i]);
+			if (w[i]) s += std::string(name[i]) + " " + std::to_string((unsigned long long)w[i]) + ", ";
 		return s;
 	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
