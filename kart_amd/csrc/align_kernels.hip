@@ -361,60 +361,63 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 		// diagonals d = gpos - rpos of k-mer pairs: -(rlen - 8) .. slen - 8
 		const int d_lo = -(rlen - 8), nd = slen + rlen - 15;
 		const int per = (nd + 63) >> 6;
-		int di_cur = 0;
-		// a run of equal bases ended: it is a simple pair when it holds at least 10 bases (three consecutive common 8-mers)
-#define KG_RESCUE_EMIT()                                                                                        \
-	do {                                                                                                        \
-		if (run >= 10) {                                                                                        \
-			int at_ = atomicAdd(&n_raw, 1);                                                                     \
-			if (at_ < kRescueMaxRuns) { raw_key[at_] = (di_cur << 8) | run_start; raw_len[at_] = run; }         \
-		}                                                                                                       \
-		run = 0;                                                                                                \
-	} while (0)
+		// per diagonal: the equality bit of every read position (one bit per base, up to 256), then the positions where ten
+		// consecutive bits are set by shift-and doubling; almost every diagonal ends there with nothing set
 		for (int q = 0; q < per; ++q) {
 			int di = lane * per + q;
 			if (di >= nd) break;
 			int d = d_lo + di;
-			di_cur = di;
 			int t_lo = d < 0 ? -d : 0;
 			int t_hi = rlen < slen - d ? rlen : slen - d;               // read positions [t_lo, t_hi) face window positions t + d
-			int run = 0, run_start = 0;
-			for (int w = t_lo >> 5; (w << 5) < t_hi; ++w) {
+			uint64_t E[4] = {0, 0, 0, 0};
+#pragma unroll
+			for (int w = 0; w < kRescueMaxRead / 32; ++w) {                // (fixed trip count: E[] stays in registers)
 				int base = w << 5;
-				// window bases base + d .. base + d + 31 as one word
-				int wp = base + d;                                      // may be negative for the first word: bases before 0 are masked below
-				uint64_t ww;
-				{
-					int idx = wp >> 5;                                   // floor division (arithmetic shift)
-					int sh = (wp & 31) << 1;
-					uint64_t lo_w = idx >= 0 ? win2[idx] : 0, hi_w = idx + 1 >= 0 ? win2[idx + 1] : 0;
-					ww = sh ? (lo_w >> sh) | (hi_w << (64 - sh)) : lo_w;
-				}
+				if (base >= t_hi || base + 32 <= t_lo) continue;
+				int wp = base + d;                                      // window position facing read position `base` (negative: masked below)
+				int idx = wp >> 5;                                      // floor division (arithmetic shift)
+				int sh = (wp & 31) << 1;
+				uint64_t lo_w = idx >= 0 ? win2[idx] : 0, hi_w = idx + 1 >= 0 ? win2[idx + 1] : 0;
+				uint64_t ww = sh ? (lo_w >> sh) | (hi_w << (64 - sh)) : lo_w;
 				uint64_t diff = rd2[w] ^ ww;
 				uint64_t eq = ~(diff | (diff >> 1)) & 0x5555555555555555ull;   // bit 2b set: base b equal
 				int b0 = t_lo > base ? t_lo - base : 0, b1 = t_hi - base < 32 ? t_hi - base : 32;
-				uint64_t valid = (b1 >= 32 ? ~0ull : ((1ull << (b1 << 1)) - 1)) & ~((1ull << (b0 << 1)) - 1);
-				const uint64_t e = eq & valid;
-				int b = b0;
-				while (b < b1) {
-					uint64_t rest = e >> (b << 1);                                  // bit 0: base b of this word
-					if (rest & 1) {
-						uint64_t z = ~rest & 0x5555555555555555ull;                  // (bits shifted in from above are zero = "differs")
-						int ones = z ? (__ffsll((unsigned long long)z) - 1) >> 1 : 32;
-						if (ones > b1 - b) ones = b1 - b;
-						if (run == 0) run_start = base + b;
-						run += ones;
-						b += ones;
-					} else {
-						KG_RESCUE_EMIT();
-						uint64_t o = rest & 0x5555555555555555ull;
-						int zeros = o ? (__ffsll((unsigned long long)o) - 1) >> 1 : b1 - b;
-						if (zeros > b1 - b) zeros = b1 - b;
-						b += zeros;
-					}
-				}
+				eq &= (b1 >= 32 ? ~0ull : ((1ull << (b1 << 1)) - 1)) & ~((1ull << (b0 << 1)) - 1);
+				// 2 bits per base -> 1 bit per base
+				uint64_t x = eq;
+				x = (x | (x >> 1)) & 0x3333333333333333ull;
+				x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+				x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+				x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+				x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+				E[w >> 1] |= x << ((w & 1) << 5);
 			}
-			KG_RESCUE_EMIT();
+			// R[p]: positions p .. p+9 all equal
+			auto shr = [](const uint64_t *v, int k, uint64_t *o) {     // o = v >> k over 256 bits, 0 < k < 64
+				o[0] = (v[0] >> k) | (v[1] << (64 - k)); o[1] = (v[1] >> k) | (v[2] << (64 - k)); o[2] = (v[2] >> k) | (v[3] << (64 - k)); o[3] = v[3] >> k;
+			};
+			uint64_t T[4], R2[4], R[4];
+			shr(E, 1, T);
+			for (int i = 0; i < 4; ++i) R2[i] = E[i] & T[i];            // >= 2
+			shr(R2, 2, T);
+			for (int i = 0; i < 4; ++i) R[i] = R2[i] & T[i];            // >= 4
+			shr(R, 4, T);
+			for (int i = 0; i < 4; ++i) R[i] &= T[i];                   // >= 8
+			shr(R2, 8, T);
+			for (int i = 0; i < 4; ++i) R[i] &= T[i];                   // >= 10
+			if ((R[0] | R[1] | R[2] | R[3]) == 0) continue;
+			// the maximal runs of at least 10: each starts at the lowest remaining bit of R
+			for (;;) {
+				int p = -1;
+				for (int i = 0; i < 4; ++i)
+					if (R[i]) { p = (i << 6) + __ffsll((unsigned long long)R[i]) - 1; break; }
+				if (p < 0) break;
+				int e = p + 10;                                         // extend while the bases stay equal
+				while (e < 256 && ((E[e >> 6] >> (e & 63)) & 1)) e++;
+				int at_ = atomicAdd(&n_raw, 1);
+				if (at_ < kRescueMaxRuns) { raw_key[at_] = (di << 8) | p; raw_len[at_] = e - p; }
+				for (int c = p; c < e; ++c) R[c >> 6] &= ~(1ull << (c & 63));   // (positions of this run cannot start another)
+			}
 		}
 		// the runs in (diagonal, read position) order -- the order IdentifyCommonKmers' sort leaves the k-mer hits in: rank sort
 		__syncthreads();

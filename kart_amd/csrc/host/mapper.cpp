@@ -225,7 +225,8 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		fprintf(stdout, "stage seconds: unhidden read+encode+seed %.2f (seed calls %.2f) | finish+format(k-1) with chain+pair+plan(k) %.2f | nw %.2f | commit %.2f | writer drain %.2f | libraries %.2f of %.2f\n",
 		        tot.t_read, tot.t_seed, tot.t_a, tot.t_nw, tot.t_commit, tot.t_drain, tot.t_lib, stats.map_seconds);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: %lld reads decided on the device, %lld mapped by the host stages\n", (long long)tot.dev_reads, (long long)tot.host_reads);
-	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: read_batch total %.3f s | %s\n", 1e-9 * (double)g_read_ns.load(), kern.align_diagnostics().c_str());
+	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: read_batch total %.3f s (line index %.3f, views %.3f, views + chunk assembly %.3f, materialise + characters %.3f) | %s\n", 1e-9 * (double)g_read_ns.load(),
+		        1e-9 * (double)g_read_part_ns[0].load(), 1e-9 * (double)g_read_part_ns[1].load(), 1e-9 * (double)g_read_part_ns[2].load(), 1e-9 * (double)g_read_part_ns[3].load(), kern.align_diagnostics().c_str());
 	if (g_check_align) fprintf(stdout, "CHECK_ALIGN: %lld device records compared with the host's text, %lld differ\n", (long long)g_check_n.load(), (long long)g_check_bad.load());
 	if (g_sections) {
 		fprintf(stdout, "worker thread-seconds:");
