@@ -30,6 +30,7 @@
 #ifndef KART_AMD_H
 #define KART_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -118,6 +119,11 @@ int  kg_index_contig(const kg_index *ix, int i, kg_contig_t *out);
  * where the reference's sa[0] = -1 yields 2^64-1), else (uint64_t)-1. */
 int  kg_rank_sa_batch(kg_index *ix, const uint64_t *k, int64_t n, uint64_t *occ4, uint64_t *sa_walk, uint64_t *sa_full);
 
+/* Page-locked host memory for the buffers a caller hands to kg_seed_batch (the copy to the device then runs at the link's
+ * rate instead of through a staging buffer).  NULL when none can be had. */
+void *kg_host_alloc(size_t bytes);
+void  kg_host_free(void *p);
+
 /* ---- workspace ---------------------------------------------------------------------------- */
 /* Scratch for batches of up to max_reads reads / max_bases bases on the index's device. */
 int  kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_workspace **out);
@@ -158,7 +164,8 @@ int64_t kg_workspace_overflow(kg_workspace *ws);   /* 0 = fitted, else seeds nee
  * those of read r are (*cands)[o .. o + n_cands[r]) with o = n_cands[0] + ... + n_cands[r-1] -- and their seeds
  * (re-sorted by (gPos,rPos) for Illumina, in pick order for PacBio, exactly as the reference leaves
  * AlignmentCandidate_t::SeedVec) at (*cand_seeds)[first .. first+count).  *cands and *cand_seeds point at library-owned
- * pinned arrays of *n_cands_total / *n_cand_seeds_total entries, valid until the next call on the same workspace.
+ * pinned arrays of *n_cands_total / *n_cand_seeds_total entries; the library rotates through four sets of them, so they stay
+ * valid while the next three batches go through the workspace.
  * n_reads and n_seeds (= seed_offsets[n_reads]) must be those of the seeding call; a mismatch is KG_ERR_ARG. */
 typedef struct {
 	int64_t posDiff;    /* AlignmentCandidate_t::PosDiff (clamped at 0) */
@@ -215,7 +222,8 @@ typedef struct {
 
 /* chunk_off[n_chunks + 1]: read index ranges of the batch's chunks (GetNextChunk: 4000 reads each but possibly the last);
  * chunk_paired[c] != 0: the reads of chunk c are pairs (2q, 2q+1), mate 2 reverse-complemented by the caller.
- * *records points at a library-owned pinned array of n_reads entries, valid until the next call on the workspace;
+ * *records points at a library-owned pinned array of n_reads entries (four rotate: valid while the next three batches go
+ * through the workspace);
  * chunk_stats[n_chunks] is filled.  KG_ERR_ARG when no chained batch is resident or the chunks do not cover it. */
 int  kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks,
                     int est_distance, int max_insert, int max_gaps, const kg_aln_record **records, kg_chunk_stats *chunk_stats);

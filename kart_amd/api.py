@@ -35,7 +35,7 @@ CAND_DT = np.dtype([("posDiff", "<i8"), ("score", "<i4"), ("count", "<i4"), ("fi
 # every symbol include/kart_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "kg_last_error", "kg_device_count", "kg_index_load", "kg_index_destroy", "kg_index_info",
-    "kg_index_contig", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters", "kg_workspace_traffic",
+    "kg_index_contig", "kg_host_alloc", "kg_host_free", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters", "kg_workspace_traffic",
     "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_align_batch", "kg_align_reasons", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
 )
 

@@ -147,6 +147,16 @@ struct kg_workspace {
 	kg_candidate *d_dense_cands = nullptr, *h_cands = nullptr;
 	kg_seed *d_dense_seeds = nullptr, *h_cand_seeds = nullptr;
 	int64_t h_cand_capacity = 0;
+	// The pinned arrays kg_candidates_batch / kg_align_batch hand out rotate through kRing sets, so that a result stays valid
+	// while the next kRing - 1 batches go through the workspace (a pipelined caller keeps several batches in flight and need
+	// not copy anything out)
+	static constexpr int kRing = 4;
+	kg_candidate *ring_cands[kRing] = {nullptr, nullptr, nullptr, nullptr};
+	kg_seed *ring_seeds[kRing] = {nullptr, nullptr, nullptr, nullptr};
+	int64_t ring_cand_capacity[kRing] = {0, 0, 0, 0};
+	kg_aln_record *ring_records[kRing] = {nullptr, nullptr, nullptr, nullptr};
+	int64_t ring_record_capacity[kRing] = {0, 0, 0, 0};
+	int ring_at = 0, ring_rec_at = 0;
 	int64_t cand_capacity = 0, ncand_capacity = 0;
 	kg_seed *h_seeds = nullptr;     // pinned
 	int64_t h_seed_capacity = 0;
@@ -466,6 +476,18 @@ int kg_rank_sa_batch(kg_index *ix, const uint64_t *k, int64_t n, uint64_t *occ4,
 	return KG_OK;
 }
 
+void *kg_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return p;
+}
+
+void kg_host_free(void *p)
+{
+	if (p) (void)hipHostFree(p);
+}
+
 int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_workspace **out)
 {
 	if (!ix || !out || max_reads <= 0 || max_bases <= 0) return fail(KG_ERR_ARG, "kg_workspace_create: bad argument");
@@ -495,9 +517,11 @@ void kg_workspace_destroy(kg_workspace *ws)
 	if (!ws) return;
 	(void)hipSetDevice(ws->ix->device);
 	if (ws->stream) { (void)hipStreamSynchronize(ws->stream); (void)hipStreamDestroy(ws->stream); }
-	if (ws->h_cands) (void)hipHostFree(ws->h_cands);
-	if (ws->h_cand_seeds) (void)hipHostFree(ws->h_cand_seeds);
-	if (ws->h_records) (void)hipHostFree(ws->h_records);
+	for (int i = 0; i < kg_workspace::kRing; ++i) {
+		if (ws->ring_cands[i]) (void)hipHostFree(ws->ring_cands[i]);
+		if (ws->ring_seeds[i]) (void)hipHostFree(ws->ring_seeds[i]);
+		if (ws->ring_records[i]) (void)hipHostFree(ws->ring_records[i]);
+	}
 	void *ptrs[] = {ws->d_tasks, ws->d_aln_cand, ws->d_aln_read, ws->d_spill, ws->d_jobs, ws->d_job_ops, ws->d_job_len, ws->d_chunk_off, ws->d_chunk_paired, ws->d_chunk_stats, ws->d_aln_ctl, ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -725,15 +749,18 @@ int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_re
 	HIP_TRY(hipMemcpyAsync(&totals[1], ws->d_cseed_off + n, 8, hipMemcpyDeviceToHost, ws->stream));
 	HIP_TRY(hipStreamSynchronize(ws->stream));
 	int64_t need = std::max(totals[0], totals[1]);
-	if (need > ws->h_cand_capacity) {
-		if (ws->h_cands) HIP_TRY(hipHostFree(ws->h_cands));
-		if (ws->h_cand_seeds) HIP_TRY(hipHostFree(ws->h_cand_seeds));
-		ws->h_cands = nullptr; ws->h_cand_seeds = nullptr;
+	const int slot = ws->ring_at;
+	ws->ring_at = (ws->ring_at + 1) % kg_workspace::kRing;
+	if (need > ws->ring_cand_capacity[slot]) {
+		if (ws->ring_cands[slot]) HIP_TRY(hipHostFree(ws->ring_cands[slot]));
+		if (ws->ring_seeds[slot]) HIP_TRY(hipHostFree(ws->ring_seeds[slot]));
+		ws->ring_cands[slot] = nullptr; ws->ring_seeds[slot] = nullptr;
 		int64_t cap = need + need / 4 + 1024;
-		HIP_TRY(hipHostMalloc((void **)&ws->h_cands, sizeof(kg_candidate) * (size_t)cap, hipHostMallocDefault));
-		HIP_TRY(hipHostMalloc((void **)&ws->h_cand_seeds, sizeof(kg_seed) * (size_t)cap, hipHostMallocDefault));
-		ws->h_cand_capacity = cap;
+		HIP_TRY(hipHostMalloc((void **)&ws->ring_cands[slot], sizeof(kg_candidate) * (size_t)cap, hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void **)&ws->ring_seeds[slot], sizeof(kg_seed) * (size_t)cap, hipHostMallocDefault));
+		ws->ring_cand_capacity[slot] = cap;
 	}
+	ws->h_cands = ws->ring_cands[slot]; ws->h_cand_seeds = ws->ring_seeds[slot];
 	if (totals[0] > 0) HIP_TRY(hipMemcpyAsync(ws->h_cands, ws->d_dense_cands, sizeof(kg_candidate) * (size_t)totals[0], hipMemcpyDeviceToHost, ws->stream));
 	if (totals[1] > 0) HIP_TRY(hipMemcpyAsync(ws->h_cand_seeds, ws->d_dense_seeds, sizeof(kg_seed) * (size_t)totals[1], hipMemcpyDeviceToHost, ws->stream));
 	HIP_TRY(hipStreamSynchronize(ws->stream));
@@ -860,16 +887,14 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 	}
 	if (n + 2 > ws->aln_read_capacity) {
 		if (ws->d_aln_read) HIP_TRY(hipFree(ws->d_aln_read));
-		if (ws->h_records) HIP_TRY(hipHostFree(ws->h_records));
 		for (void *p : {(void *)ws->d_spill, (void *)ws->d_jobs, (void *)ws->d_job_ops, (void *)ws->d_job_len, (void *)ws->d_tasks})
 			if (p) HIP_TRY(hipFree(p));
-		ws->d_aln_read = nullptr; ws->h_records = nullptr; ws->d_spill = nullptr; ws->d_jobs = nullptr; ws->d_job_ops = nullptr; ws->d_job_len = nullptr; ws->d_tasks = nullptr;
+		ws->d_aln_read = nullptr; ws->d_spill = nullptr; ws->d_jobs = nullptr; ws->d_job_ops = nullptr; ws->d_job_len = nullptr; ws->d_tasks = nullptr;
 		int64_t cap = n + n / 4 + 4096;
 		HIP_TRY(hipMalloc(&ws->d_aln_read, 3 * up((size_t)cap) + up(4 * (size_t)cap) + sizeof(kg_aln_record) * (size_t)cap));
 		ws->task_capacity = cap / 4 + 4096;
 		HIP_TRY(hipMalloc(&ws->d_tasks, up(sizeof(RescueTask) * (size_t)ws->task_capacity) + up(8 * (size_t)ws->task_capacity) + up(4 * (size_t)ws->task_capacity) +
 		                                    sizeof(kg_seed) * (size_t)ws->task_capacity * kAlnMaxSeeds));
-		HIP_TRY(hipHostMalloc((void **)&ws->h_records, sizeof(kg_aln_record) * (size_t)cap, hipHostMallocDefault));
 		// about one candidate in ten waits for an alignment; room for one in two
 		ws->spill_capacity = cap / 2 + 4096;
 		ws->job_capacity = cap / 2 + 4096;
@@ -960,6 +985,18 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_align_batch: %s", hipGetErrorString(e != hipSuccess ? e : e2));
 	}
 	HIP_TRY(launch_align_back(a, ix->n_cu, st));
+	{
+		const int slot = ws->ring_rec_at;
+		ws->ring_rec_at = (ws->ring_rec_at + 1) % kg_workspace::kRing;
+		if (n > ws->ring_record_capacity[slot]) {
+			if (ws->ring_records[slot]) HIP_TRY(hipHostFree(ws->ring_records[slot]));
+			ws->ring_records[slot] = nullptr;
+			int64_t cap = n + n / 4 + 4096;
+			HIP_TRY(hipHostMalloc((void **)&ws->ring_records[slot], sizeof(kg_aln_record) * (size_t)cap, hipHostMallocDefault));
+			ws->ring_record_capacity[slot] = cap;
+		}
+		ws->h_records = ws->ring_records[slot];
+	}
 	HIP_TRY(hipMemcpyAsync(ws->h_records, a.records, sizeof(kg_aln_record) * (size_t)n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(chunk_stats, ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)n_chunks, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));

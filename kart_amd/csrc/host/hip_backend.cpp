@@ -46,16 +46,18 @@ public:
 		kg_index_destroy(ix_);
 	}
 	int min_seed_len() const override { return info_.min_seed_len; }
-	void seed_and_chain(int mode, bool pacbio, int max_gaps, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off,
-	                    std::vector<int32_t> &n_cands, std::vector<int64_t> &cand_off, std::vector<kg_candidate> &cands,
-	                    std::vector<kg_seed> &cand_seeds) override
+	void *host_alloc(size_t bytes) override { return kg_host_alloc(bytes); }
+	void host_free(void *p) override { kg_host_free(p); }
+	void seed_and_chain(int mode, bool pacbio, int max_gaps, const uint8_t *enc, const std::vector<int64_t> &off,
+	                    std::vector<int32_t> &n_cands, std::vector<int64_t> &cand_off, std::vector<kg_candidate> &, std::vector<kg_seed> &,
+	                    const kg_candidate *&cands, const kg_seed *&cand_seeds) override
 	{
 		int64_t n = (int64_t)off.size() - 1;
 		reserve(n, off[(size_t)n]);
 		seed_off_.assign(off.size(), 0);
 		double t0 = now_sec();
 		// the seeds stay on the device (seeds = NULL); only the chained candidates come back, packed
-		if (kg_seed_batch(ws_, mode | KG_INPUT_ASCII, info_.min_seed_len, KG_OCC_THR_DEFAULT, enc.data(), off.data(), n, seed_off_.data(), nullptr) != KG_OK) die("kg_seed_batch");
+		if (kg_seed_batch(ws_, mode | KG_INPUT_ASCII, info_.min_seed_len, KG_OCC_THR_DEFAULT, enc, off.data(), n, seed_off_.data(), nullptr) != KG_OK) die("kg_seed_batch");
 		double t1 = now_sec();
 		n_cands.assign((size_t)n + 1, 0);
 		const kg_candidate *c = nullptr;
@@ -63,8 +65,8 @@ public:
 		int64_t nc = 0, ns = 0;
 		if (kg_candidates_batch(ws_, pacbio ? 1 : 0, max_gaps, n, seed_off_[(size_t)n], n_cands.data(), &c, &nc, &cs, &ns) != KG_OK) die("kg_candidates_batch");
 		double t2 = now_sec();
-		cands.assign(c, c + nc);          // the library's pinned arrays are overwritten by the next batch
-		cand_seeds.assign(cs, cs + ns);
+		cands = c;                        // the library rotates its pinned arrays: valid while the next three batches pass
+		cand_seeds = cs;
 		cand_off.resize((size_t)n + 1);
 		int64_t at = 0;
 		for (int64_t r = 0; r < n; ++r) { cand_off[(size_t)r] = at; at += n_cands[(size_t)r]; }
@@ -73,7 +75,7 @@ public:
 		t_seed += t1 - t0; t_cands += t2 - t1; t_copy += t3 - t2;
 	}
 	bool align(const std::vector<int64_t> &chunk_off, const std::vector<uint8_t> &chunk_paired, int est, int max_insert, int max_gaps,
-	           std::vector<kg_aln_record> &records, std::vector<kg_chunk_stats> &chunk_stats) override
+	           const kg_aln_record *&records, std::vector<kg_chunk_stats> &chunk_stats) override
 	{
 		static const bool off = getenv("KART_AMD_HOST_ALIGN") != nullptr;      // A/B aid: the whole report on the host, as before
 		if (off) return false;
@@ -83,7 +85,7 @@ public:
 		double t0 = now_sec();
 		if (kg_align_batch(ws_, chunk_off.data(), chunk_paired.data(), n_chunks, est, max_insert, max_gaps, &rec, chunk_stats.data()) != KG_OK) die("kg_align_batch");
 		double t1 = now_sec();
-		records.assign(rec, rec + chunk_off[(size_t)n_chunks]);              // the library's pinned array is overwritten by the next batch
+		records = rec;                    // (rotating pinned arrays, as above)
 		t_align += t1 - t0; t_reccopy += now_sec() - t1;
 		return true;
 	}

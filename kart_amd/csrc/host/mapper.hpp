@@ -73,16 +73,22 @@ struct KernelBackend {
 	// IdentifySeedPairs_{Fast,Sensitive}Mode + GenerateAlignmentCandidateFor{Illumina,PacBio}Seq for a batch: enc = the concatenated
 	// read CHARACTERS (the backend applies EnCodeReadSeq), off[n+1].  Out: n_cands[r] candidates per read, stored densely in read order (those of read r start at
 	// cand_off[r]), their seeds at cand_seeds[cands[].first ...].  The seeds themselves never leave the device.
-	virtual void seed_and_chain(int mode, bool pacbio, int max_gaps, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off,
-	                            std::vector<int32_t> &n_cands, std::vector<int64_t> &cand_off, std::vector<kg_candidate> &cands,
-	                            std::vector<kg_seed> &cand_seeds) = 0;
+	// `cands` / `cand_seeds` may point at the vectors (which the backend then fills) or at storage of the backend's own that
+	// stays valid while the next three batches go through it.
+	virtual void seed_and_chain(int mode, bool pacbio, int max_gaps, const uint8_t *enc, const std::vector<int64_t> &off,
+	                            std::vector<int32_t> &n_cands, std::vector<int64_t> &cand_off, std::vector<kg_candidate> &own_cands,
+	                            std::vector<kg_seed> &own_seeds, const kg_candidate *&cands, const kg_seed *&cand_seeds) = 0;
+	// memory for the read characters of a batch (page-locked where the backend copies it to a device)
+	virtual void *host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+	virtual void host_free(void *p) { free(p); }
 	// nw_alignment for the jobs of several chunks in one call (fills ops/len of every part)
 	virtual void nw_batch(std::vector<NwJobs *> &parts) = 0;
 	// The per-read report of the batch the last seed_and_chain() call left on the device (kg_align_batch): one record per read
 	// (kind KG_ALN_HOST = this pair is the host's) and the chunks' pairing statistics under `est`.  false: this backend has no
 	// such stage -- the host maps every read itself.
+	// (`records`: storage of the backend, valid while the next three batches go through it)
 	virtual bool align(const std::vector<int64_t> &chunk_off, const std::vector<uint8_t> &chunk_paired, int est, int max_insert, int max_gaps,
-	                   std::vector<kg_aln_record> &records, std::vector<kg_chunk_stats> &chunk_stats)
+	                   const kg_aln_record *&records, std::vector<kg_chunk_stats> &chunk_stats)
 	{
 		(void)chunk_off; (void)chunk_paired; (void)est; (void)max_insert; (void)max_gaps; (void)records; (void)chunk_stats;
 		return false;

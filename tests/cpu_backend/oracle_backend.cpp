@@ -19,15 +19,16 @@ public:
 	explicit OracleBackend(ko_index *ix) : ix_(ix) {}
 	~OracleBackend() override { ko_index_free(ix_); }
 	int min_seed_len() const override { return ko_min_seed_len(ix_); }
-	void seed_and_chain(int mode, bool pacbio, int max_gaps, const std::vector<uint8_t> &enc, const std::vector<int64_t> &off,
+	void seed_and_chain(int mode, bool pacbio, int max_gaps, const uint8_t *enc, const std::vector<int64_t> &off,
 	                    std::vector<int32_t> &n_cands, std::vector<int64_t> &cand_off, std::vector<kg_candidate> &cands,
-	                    std::vector<kg_seed> &cand_seeds) override
+	                    std::vector<kg_seed> &cand_seeds, const kg_candidate *&cands_out, const kg_seed *&seeds_out) override
 	{
 		int64_t n = (int64_t)off.size() - 1;
+		const size_t n_enc = (size_t)off[(size_t)n];
 		std::vector<int64_t> seed_off(off.size(), 0);
 		std::vector<ko_seed> buf((size_t)(64 * n + 65536));
-		std::vector<uint8_t> codes(enc.size());          // EnCodeReadSeq (src/Mapping.cpp:482-485): nst_nt4_table
-		for (size_t i = 0; i < enc.size(); ++i) {
+		std::vector<uint8_t> codes(n_enc);               // EnCodeReadSeq (src/Mapping.cpp:482-485): nst_nt4_table
+		for (size_t i = 0; i < n_enc; ++i) {
 			switch (enc[i]) {
 			case 'A': case 'a': codes[i] = 0; break;
 			case 'C': case 'c': codes[i] = 1; break;
@@ -69,6 +70,8 @@ public:
 			}
 		}
 		cand_off[(size_t)n] = (int64_t)cands.size();
+		cands_out = cands.data();
+		seeds_out = cand_seeds.data();
 	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
 	{
