@@ -173,6 +173,7 @@ struct kg_workspace {
 	uint8_t *d_job_ops = nullptr;
 	int32_t *d_job_len = nullptr;
 	int64_t spill_capacity = 0, job_capacity = 0, ops_capacity = 0;
+	void *d_plans = nullptr;            // partition plans + pieces, one block
 	void *d_tasks = nullptr;            // rescue windows and the candidates they yield, one block
 	int64_t task_capacity = 0;
 	int64_t *d_chunk_off = nullptr;
@@ -522,7 +523,7 @@ void kg_workspace_destroy(kg_workspace *ws)
 		if (ws->ring_seeds[i]) (void)hipHostFree(ws->ring_seeds[i]);
 		if (ws->ring_records[i]) (void)hipHostFree(ws->ring_records[i]);
 	}
-	void *ptrs[] = {ws->d_tasks, ws->d_aln_cand, ws->d_aln_read, ws->d_spill, ws->d_jobs, ws->d_job_ops, ws->d_job_len, ws->d_chunk_off, ws->d_chunk_paired, ws->d_chunk_stats, ws->d_aln_ctl, ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
+	void *ptrs[] = {ws->d_plans, ws->d_tasks, ws->d_aln_cand, ws->d_aln_read, ws->d_spill, ws->d_jobs, ws->d_job_ops, ws->d_job_len, ws->d_chunk_off, ws->d_chunk_paired, ws->d_chunk_stats, ws->d_aln_ctl, ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (ws->h_seeds) (void)hipHostFree(ws->h_seeds);
@@ -887,9 +888,9 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 	}
 	if (n + 2 > ws->aln_read_capacity) {
 		if (ws->d_aln_read) HIP_TRY(hipFree(ws->d_aln_read));
-		for (void *p : {(void *)ws->d_spill, (void *)ws->d_jobs, (void *)ws->d_job_ops, (void *)ws->d_job_len, (void *)ws->d_tasks})
+		for (void *p : {(void *)ws->d_spill, (void *)ws->d_jobs, (void *)ws->d_job_ops, (void *)ws->d_job_len, (void *)ws->d_tasks, (void *)ws->d_plans})
 			if (p) HIP_TRY(hipFree(p));
-		ws->d_aln_read = nullptr; ws->d_spill = nullptr; ws->d_jobs = nullptr; ws->d_job_ops = nullptr; ws->d_job_len = nullptr; ws->d_tasks = nullptr;
+		ws->d_aln_read = nullptr; ws->d_spill = nullptr; ws->d_jobs = nullptr; ws->d_job_ops = nullptr; ws->d_job_len = nullptr; ws->d_tasks = nullptr; ws->d_plans = nullptr;
 		int64_t cap = n + n / 4 + 4096;
 		HIP_TRY(hipMalloc(&ws->d_aln_read, 3 * up((size_t)cap) + up(4 * (size_t)cap) + sizeof(kg_aln_record) * (size_t)cap));
 		ws->task_capacity = cap / 4 + 4096;
@@ -898,11 +899,12 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		// about one candidate in ten waits for an alignment; room for one in two
 		ws->spill_capacity = cap / 2 + 4096;
 		ws->job_capacity = cap / 2 + 4096;
-		ws->ops_capacity = 64 * ws->job_capacity;
+		ws->ops_capacity = 96 * ws->job_capacity;
 		HIP_TRY(hipMalloc((void **)&ws->d_spill, sizeof(AlnSpill) * (size_t)ws->spill_capacity));
 		HIP_TRY(hipMalloc((void **)&ws->d_jobs, sizeof(NwJobDesc) * (size_t)ws->job_capacity));
 		HIP_TRY(hipMalloc((void **)&ws->d_job_ops, (size_t)ws->ops_capacity + 1024));
 		HIP_TRY(hipMalloc((void **)&ws->d_job_len, 4 * (size_t)ws->job_capacity));
+		HIP_TRY(hipMalloc((void **)&ws->d_plans, sizeof(AlnPlan) * (size_t)ws->job_capacity + sizeof(AlnPiece) * 4 * (size_t)ws->job_capacity));
 		ws->aln_read_capacity = cap;
 	}
 	if (n_chunks > ws->chunk_capacity) {
@@ -962,6 +964,7 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 	a.jobs = ws->d_jobs; a.job_capacity = ws->job_capacity; a.ops_capacity = ws->ops_capacity;
 	a.ctl = ws->d_aln_ctl;
 	a.nw_ops = ws->d_job_ops; a.nw_len = ws->d_job_len;
+	a.plans = (AlnPlan *)ws->d_plans; a.pieces = (AlnPiece *)((char *)ws->d_plans + sizeof(AlnPlan) * (size_t)ws->job_capacity);
 	a.chunk_stats = ws->d_chunk_stats;
 	HIP_TRY(launch_align_front(a, ix->n_cu, st));
 	// ---- gap closing: the NW kernels on the job descriptors, fragments read in place --------------------------------------------

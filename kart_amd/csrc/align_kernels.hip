@@ -616,8 +616,9 @@ __device__ __forceinline__ bool by_gpos_less(int64_t g1, int r1, int64_t g2, int
 	return g1 == g2 ? r1 < r2 : g1 < g2;
 }
 
-// IdentifyNormalPairs(rlen, -1, v), src/AlignmentCandidates.cpp:420-490.  false: more gap pairs than the envelope holds
-__device__ bool identify_normal_pairs(int rlen, Pairs &v)
+// IdentifyNormalPairs(rlen, glen, v), src/AlignmentCandidates.cpp:420-490 (glen = -1 for a read against the genome, the
+// fragment's genome length inside GenerateNormalPairAlignment).  false: more gap pairs than the envelope holds
+__device__ bool identify_normal_pairs(int rlen, int glen, Pairs &v)
 {
 	if (v.num > 1) {
 		remove_tandem_repeats(v);
@@ -655,7 +656,7 @@ __device__ bool identify_normal_pairs(int rlen, Pairs &v)
 	}
 	if (v.num > 0) {
 		int r_gap = v.rPos[0] > 0 ? v.rPos[0] : 0;
-		int g_gap = r_gap;                                        // glen = -1: the genome gap is the read gap (:458)
+		int g_gap = glen > 0 ? (int)v.gPos[0] : r_gap;            // glen = -1: the genome gap is the read gap (:458)
 		if (r_gap > 0 || g_gap > 0) {
 			for (int p = v.num; p > 0; --p) {
 				v.gPos[p] = v.gPos[p - 1]; v.rPos[p] = v.rPos[p - 1]; v.rLen[p] = v.rLen[p - 1]; v.gLen[p] = v.gLen[p - 1]; v.simple[p] = v.simple[p - 1];
@@ -667,7 +668,7 @@ __device__ bool identify_normal_pairs(int rlen, Pairs &v)
 		}
 		int last = v.num - 1;
 		r_gap = rlen - (v.rPos[last] + v.rLen[last]);
-		g_gap = r_gap;
+		g_gap = glen > 0 ? (int)(glen - (v.gPos[last] + v.gLen[last])) : r_gap;
 		if (r_gap > 0 || g_gap > 0) {
 			int t = v.num++;
 			v.simple[t] = 0;
@@ -837,7 +838,7 @@ __device__ int finish_tail(const AlnArgs &a, const Columns &c, int &gLen, int &r
 }
 
 // what pass 1 decided for a pair
-enum : uint8_t { W_NONE = 0, W_SIMPLE = 1, W_IMMEDIATE = 2, W_JOB = 3 };
+enum : uint8_t { W_NONE = 0, W_SIMPLE = 1, W_IMMEDIATE = 2, W_JOB = 3, W_PLAN = 4 };
 struct Work {
 	uint8_t kind[kAlnMaxPairs];
 	uint8_t op[kAlnMaxPairs];
@@ -866,10 +867,28 @@ __device__ bool finish_candidate(const AlnArgs &a, int64_t cand, bool first, con
 			if (w.op[j] != 0) cig.push(w.op_len[j], (char)w.op[j]);
 			s = w.val[j];
 		} else {
-			const NwJobDesc jd = a.jobs[w.val[j]];
 			Columns c;
-			c.ops = a.nw_ops + jd.ops;
-			c.len = a.nw_len[w.val[j]];
+			if (w.kind[j] == W_JOB) {
+				const NwJobDesc jd = a.jobs[w.val[j]];
+				c.ops = a.nw_ops + jd.ops;
+				c.len = a.nw_len[w.val[j]];
+			} else {
+				// the partitioned fragment: literal runs and the sub-fragments' op strings, one after the other (src/tools.cpp:165-208)
+				const AlnPlan pl = a.plans[w.val[j]];
+				uint8_t *out = a.nw_ops + pl.ops;
+				int at = 0;
+				for (int k = 0; k < pl.count; ++k) {
+					const AlnPiece pc = a.pieces[pl.first + k];
+					if (pc.kind <= KG_OP_GAP2) { for (int t = 0; t < pc.v; ++t) out[at++] = pc.kind; }
+					else {
+						const uint8_t *src = a.nw_ops + a.jobs[pc.v].ops;
+						int L = a.nw_len[pc.v];
+						for (int t = 0; t < L; ++t) out[at++] = src[t];
+					}
+				}
+				c.ops = out;
+				c.len = at;
+			}
 			c.rd = rd + v.rPos[j];
 			c.g = v.gPos[j];
 			if (head) s = finish_head(a, c, v.gPos[j], v.gLen[j], v.rPos[j], v.rLen[j], cig);
@@ -968,6 +987,104 @@ __device__ __forceinline__ int mismatches(const AlnArgs &a, const uint8_t *rd, i
 
 }  // namespace
 
+// GenerateNormalPairAlignment for a fragment pair with both sides > 30 (src/tools.cpp:146-212; non-PacBio: MaxShift = MaxGaps):
+// GenerateSimplePairsFromFragmentPair -- the common 8-mers of the two fragments whose positions differ by less than MaxShift,
+// merged into exact matches of at least 8 bases (src/KmerAnalysis.cpp:104-179) -- then IdentifyNormalPairs(rLen, gLen, ...) on
+// them, and per resulting piece either a literal stretch or a sub-fragment alignment.
+// Returns 1: the pair is planned (w.kind[j] = W_PLAN); 0: the partition is empty (the caller aligns the whole fragment);
+// -1: outside the envelope (host); -2: a device list is full (host).
+__device__ int plan_partition(const AlnArgs &a, int64_t enc_off, const uint8_t *f1, int64_t g, int rL, int gL, Work &w, int j)
+{
+	// the 8-mer code maps characters through nst_nt4_table and skips 'N': plain A/C/G/T (either case) is what the comparison
+	// of 2-bit codes below reproduces
+	for (int i = 0; i < rL; ++i) {
+		unsigned u = f1[i] & 0xDFu;
+		if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) return -1;
+	}
+	Pairs v;
+	v.num = 0;
+	const int mg = a.max_gaps;
+	// runs of at least 8 equal bases along the diagonals |gpos - rpos| < MaxShift, in (diagonal, read position) order
+	for (int d = -(mg - 1); d <= mg - 1; ++d) {
+		int t_lo = d < 0 ? -d : 0;
+		int t_hi = rL < gL - d ? rL : gL - d;
+		int run = 0;
+		for (int t = t_lo; t <= t_hi; ++t) {
+			bool eq = false;
+			if (t < t_hi) {
+				unsigned ch = f1[t];
+				unsigned c1 = (ch >> 1) & 3;
+				c1 ^= c1 >> 1;
+				eq = (int)c1 == text_code(a, g + t + d);
+			}
+			if (eq) run++;
+			else {
+				if (run >= 8) {
+					if (v.num == kAlnMaxSeeds) return -1;
+					int k = v.num++;
+					v.rPos[k] = t - run; v.gPos[k] = t - run + d; v.rLen[k] = v.gLen[k] = run; v.simple[k] = 1;
+				}
+				run = 0;
+			}
+		}
+	}
+	if (v.num == 0) return 0;
+	// sort(SimplePairVec, CompByGenomePos), src/KmerAnalysis.cpp:177
+	for (int i = 1; i < v.num; ++i) {
+		int64_t xg = v.gPos[i];
+		int xr = v.rPos[i], xl = v.rLen[i];
+		int p = i;
+		while (p > 0 && by_gpos_less(xg, xr, v.gPos[p - 1], v.rPos[p - 1])) { v.gPos[p] = v.gPos[p - 1]; v.rPos[p] = v.rPos[p - 1]; v.rLen[p] = v.gLen[p] = v.rLen[p - 1]; --p; }
+		v.gPos[p] = xg; v.rPos[p] = xr; v.rLen[p] = v.gLen[p] = xl;
+	}
+	if (!identify_normal_pairs(rL, gL, v)) return -1;
+	if (v.num == 0) return 0;
+	// the pieces
+	int n_jobs = 0, n_pieces = 0;
+	for (int i = 0; i < v.num; ++i) {
+		if (v.rLen[i] <= 0 && v.gLen[i] <= 0) continue;
+		n_pieces++;
+		bool lit = v.gLen[i] == 0 || v.rLen[i] == 0 || (v.rLen[i] == 1 && v.gLen[i] == 1) || v.simple[i];
+		if (!lit) n_jobs++;
+	}
+	unsigned long long plan_at = atomicAdd(&a.ctl[5], 1ull);
+	unsigned long long piece_at = atomicAdd(&a.ctl[6], (unsigned long long)n_pieces);
+	unsigned long long job_at = n_jobs ? atomicAdd(&a.ctl[1], (unsigned long long)n_jobs) : 0;
+	// op strings: the assembled one (at most rL + gL columns) and one per sub-fragment
+	int ops_need = rL + gL;
+	for (int i = 0; i < v.num; ++i) {
+		bool lit = v.gLen[i] == 0 || v.rLen[i] == 0 || (v.rLen[i] == 1 && v.gLen[i] == 1) || v.simple[i];
+		if ((v.rLen[i] > 0 || v.gLen[i] > 0) && !lit) ops_need += v.rLen[i] + v.gLen[i];
+	}
+	unsigned long long ops_at = atomicAdd(&a.ctl[2], (unsigned long long)ops_need);
+	if (plan_at >= (unsigned long long)a.job_capacity || piece_at + n_pieces > 4ull * (unsigned long long)a.job_capacity ||
+	    job_at + n_jobs > (unsigned long long)a.job_capacity || ops_at + ops_need > (unsigned long long)a.ops_capacity) return -2;
+	AlnPlan pl;
+	pl.ops = (int64_t)ops_at; pl.first = (int32_t)piece_at; pl.count = n_pieces;
+	a.plans[plan_at] = pl;
+	unsigned long long ops_next = ops_at + (unsigned long long)(rL + gL);
+	int pk = 0, jk = 0;
+	for (int i = 0; i < v.num; ++i) {
+		const int prl = v.rLen[i], pgl = v.gLen[i];
+		if (prl <= 0 && pgl <= 0) continue;
+		AlnPiece pc;
+		if (pgl == 0) { pc.kind = KG_OP_GAP2; pc.v = prl; }                     // read bases against '-' (:170-174)
+		else if (prl == 0) { pc.kind = KG_OP_GAP1; pc.v = pgl; }                // '-' against genome bases (:176-180)
+		else if ((prl == 1 && pgl == 1) || v.simple[i]) { pc.kind = KG_OP_DIAG; pc.v = prl; }   // copied as they are (:182-186, :192)
+		else {
+			NwJobDesc jd;
+			jd.o1 = enc_off + v.rPos[i]; jd.o2 = g + v.gPos[i]; jd.ops = (int64_t)ops_next; jd.m = prl; jd.n = pgl;
+			ops_next += (unsigned long long)(prl + pgl);
+			a.jobs[job_at + jk] = jd;
+			pc.kind = 3; pc.v = (int32_t)(job_at + jk);
+			jk++;
+		}
+		a.pieces[piece_at + pk++] = pc;
+	}
+	w.kind[j] = W_PLAN; w.val[j] = (int32_t)plan_at;
+	return 1;
+}
+
 // ---- pass 1: one candidate per lane -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 {
@@ -1003,7 +1120,7 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			v.gPos[i] = s.gPos; v.rPos[i] = s.rPos; v.rLen[i] = v.gLen[i] = s.len; v.simple[i] = 1;
 		}
 		if (rlen > 4000) { flag_host(a, r, WHY_READ_LEN); continue; }
-		if (!identify_normal_pairs(rlen, v)) { flag_host(a, r, WHY_GAPS); continue; }
+		if (!identify_normal_pairs(rlen, -1, v)) { flag_host(a, r, WHY_GAPS); continue; }
 		if (!coordinates_valid(a, v)) { a.c_score[cand] = -1; continue; }      // no report, and no best/second-best step (:647)
 		Work w;
 		const int num = v.num;
@@ -1043,7 +1160,14 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 				w.kind[j] = W_IMMEDIATE; w.op[j] = 'M'; w.op_len[j] = 1; w.val[j] = (char)f1[0] == text_char(a, v.gPos[j]) ? 1 : 0;
 				continue;
 			}
-			if ((rL > 30 && gL > 30) || rL > kAlnMaxFrag || gL > kAlnMaxFrag || rL <= 0 || gL <= 0) { host = true; break; }   // 8-mer partition route, src/tools.cpp:146
+			if (rL > kAlnMaxFrag || gL > kAlnMaxFrag || rL <= 0 || gL <= 0) { host = true; break; }
+			if (rL > 30 && gL > 30) {
+				// GenerateNormalPairAlignment's 8-mer partition, src/tools.cpp:146-212
+				int pr = plan_partition(a, rbase + v.rPos[j], f1, v.gPos[j], rL, gL, w, j);
+				if (pr < 0) { host = true; why = pr == -2 ? WHY_CAPACITY : WHY_PARTITION; break; }
+				if (pr == 1) { jobs = true; continue; }
+				// (0: no common 8-mer survived: the whole fragment is one alignment, below)
+			}
 			// nw_alignment(rL, frag1, gL, frag2): a job for the NW kernels
 			unsigned long long slot = atomicAdd(&a.ctl[1], 1ull);
 			unsigned long long ops_at = atomicAdd(&a.ctl[2], (unsigned long long)(rL + gL));
@@ -1318,7 +1442,7 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 __global__ void aln_reset_kernel(AlnArgs a)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < 5) a.ctl[i] = 0;       // (ctl[8..23]: running tallies of why pairs went back to the host, never reset)
+	if (i < 7) a.ctl[i] = 0;       // (ctl[8..23]: running tallies of why pairs went back to the host, never reset)
 	for (int c = i; c < a.n_chunks; c += gridDim.x * blockDim.x) {
 		kg_chunk_stats z;
 		z.paired = 0; z.distance = 0; z.lo = -1; z.hi = 0x7fffffffffffffffll; z.unmapped = 0; z.unique = 0; z.host_pairs = 0; z.rescue_wanted = 0;

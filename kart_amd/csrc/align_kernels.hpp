@@ -31,6 +31,18 @@ struct AlnSpillPair {
 	int16_t op_len;
 };
 
+// A normal pair that took the 8-mer partition route of GenerateNormalPairAlignment (src/tools.cpp:146-212): its alignment is the
+// concatenation of pieces -- literal stretches and the op strings of sub-fragment jobs -- assembled into one op string by the
+// finish pass.
+struct AlnPiece {
+	int32_t v;            // literal: number of columns; job: job index
+	uint8_t kind;         // KG_OP_DIAG / KG_OP_GAP1 / KG_OP_GAP2: a literal run of that op; 3: an NW job
+};
+struct AlnPlan {
+	int64_t ops;          // where the assembled op string goes (room for rLen + gLen columns)
+	int32_t first, count; // pieces
+};
+
 struct AlnSpill {
 	int32_t cand;         // dense candidate index
 	int32_t num;
@@ -100,7 +112,9 @@ struct AlnArgs {
 	int64_t spill_capacity;
 	NwJobDesc *jobs;
 	int64_t job_capacity, ops_capacity;
-	unsigned long long *ctl;        // [0] spill count, [1] job count, [2] ops bytes, [3] unused, [4] rescue tasks
+	AlnPlan *plans;                 // [job_capacity]
+	AlnPiece *pieces;               // [4 * job_capacity]
+	unsigned long long *ctl;        // [0] spill count, [1] job count, [2] ops bytes, [3] unused, [4] rescue tasks, [5] plans, [6] pieces
 	uint8_t *nw_ops;
 	int32_t *nw_len;
 	// outputs
