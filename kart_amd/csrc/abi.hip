@@ -322,12 +322,19 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		HIP_TRY(hipMemcpy(ix->d_chr_tab, tab.data(), 8 * tab.size(), hipMemcpyHostToDevice));
 		// EvaluateMAPQ (src/Mapping.cpp:172): (int)(30 * (1 - (float)(score - sub_score) / score) * log(score) + 0.4999) for the
 		// only arguments that reach it (score - sub_score in 1..5), evaluated here with the host's libm -- float / double mix as written
-		std::vector<uint8_t> mq((size_t)(kAlnMaxScore + 1) * 6, 0);
+		// ... and for score < sub_score with score < 8 (larger scores always give more than 60 there)
+		std::vector<uint8_t> mq((size_t)(kAlnMaxScore + 1) * 6 + (size_t)(kAlnMaxScore + 1) * 8, 0);
 		for (int sc = 1; sc <= kAlnMaxScore; ++sc)
 			for (int d = 1; d <= 5 && d < sc; ++d) {
 				int sub = sc - d;
 				int q = (int)(30 * (1 - (float)(sc - sub) / sc) * log(sc) + 0.4999);
 				mq[(size_t)sc * 6 + (size_t)d] = (uint8_t)(q > 60 ? 60 : q < 0 ? 0 : q);
+			}
+		for (int sc = 1; sc < 8; ++sc)
+			for (int nd = 1; nd <= kAlnMaxScore; ++nd) {
+				int sub = sc + nd;
+				int q = (int)(30 * (1 - (float)(sc - sub) / sc) * log(sc) + 0.4999);
+				mq[(size_t)(kAlnMaxScore + 1) * 6 + (size_t)sc * (kAlnMaxScore + 1) + (size_t)nd] = (uint8_t)(q > 60 ? 60 : q < 0 ? 0 : q);
 			}
 		HIP_TRY(hipMalloc((void **)&ix->d_mapq_tab, mq.size()));
 		HIP_TRY(hipMemcpy(ix->d_mapq_tab, mq.data(), mq.size(), hipMemcpyHostToDevice));

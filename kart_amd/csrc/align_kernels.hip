@@ -1256,8 +1256,13 @@ __device__ __forceinline__ int eval_mapq(const AlnArgs &a, const ReadSum &s)   /
 {
 	if (s.score == 0 || s.score == s.sub_score) return 0;
 	int q;
-	if (s.sub_score == 0 || s.score - s.sub_score > 5) q = 60;
-	else q = a.mapq_tab[s.score * 6 + (s.score - s.sub_score)];
+	const int d = s.score - s.sub_score;
+	if (s.sub_score == 0 || d > 5) q = 60;
+	else if (d > 0) q = a.mapq_tab[s.score * 6 + d];
+	// score < sub_score happens (CheckPairedFinalAlignments can settle on a mated candidate below the read's second best): the
+	// expression then exceeds 60 for every score >= 8 (30 ln 8 = 62.4); the few smaller scores are tabulated as well
+	else if (s.score >= 8) q = 60;
+	else q = a.mapq_tab[(kAlnMaxScore + 1) * 6 + s.score * (kAlnMaxScore + 1) + (-d)];
 	return q > 60 ? 60 : q;
 }
 
@@ -1319,6 +1324,12 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 		}
 		ReadSum s1;
 		summarise(a, r, s1);
+		if (s1.score > kAlnMaxScore || s1.sub_score > kAlnMaxScore) {             // beyond the MAPQ table (reads longer than 2047 bases)
+			atomicAdd(&a.ctl[8 + WHY_SCORE], 1ull);
+			a.records[r].kind = KG_ALN_HOST;
+			if (paired) a.records[r + 1].kind = KG_ALN_HOST;
+			continue;
+		}
 		if (!paired) {
 			// SetSingleAlignmentFlag + EvaluateMAPQ + OutputSingledAlignments, src/Mapping.cpp:49-71, 160-175, 272-315
 			s1.mapq = eval_mapq(a, s1);
@@ -1342,6 +1353,11 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 		}
 		ReadSum s2;
 		summarise(a, r + 1, s2);
+		if (s2.score > kAlnMaxScore || s2.sub_score > kAlnMaxScore) {
+			atomicAdd(&a.ctl[8 + WHY_SCORE], 1ull);
+			a.records[r].kind = KG_ALN_HOST; a.records[r + 1].kind = KG_ALN_HOST;
+			continue;
+		}
 		// CheckPairedFinalAlignments, src/Mapping.cpp:429-480 (bMultiHit false)
 		{
 			bool mated = false;
