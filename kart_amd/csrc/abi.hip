@@ -763,7 +763,8 @@ int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_re
 		if (ws->ring_cands[slot]) HIP_TRY(hipHostFree(ws->ring_cands[slot]));
 		if (ws->ring_seeds[slot]) HIP_TRY(hipHostFree(ws->ring_seeds[slot]));
 		ws->ring_cands[slot] = nullptr; ws->ring_seeds[slot] = nullptr;
-		int64_t cap = need + need / 4 + 1024;
+		// (sized for the workspace's largest batch at once: page-locked allocations are slow, and batches grow while a run ramps up)
+		int64_t cap = std::max<int64_t>(need + need / 4 + 1024, std::min<int64_t>(3 * ws->max_reads, 2500000));
 		HIP_TRY(hipHostMalloc((void **)&ws->ring_cands[slot], sizeof(kg_candidate) * (size_t)cap, hipHostMallocDefault));
 		HIP_TRY(hipHostMalloc((void **)&ws->ring_seeds[slot], sizeof(kg_seed) * (size_t)cap, hipHostMallocDefault));
 		ws->ring_cand_capacity[slot] = cap;
@@ -1001,7 +1002,7 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		if (n > ws->ring_record_capacity[slot]) {
 			if (ws->ring_records[slot]) HIP_TRY(hipHostFree(ws->ring_records[slot]));
 			ws->ring_records[slot] = nullptr;
-			int64_t cap = n + n / 4 + 4096;
+			int64_t cap = std::max<int64_t>(n + n / 4 + 4096, std::min<int64_t>(ws->max_reads, 1000000));
 			HIP_TRY(hipHostMalloc((void **)&ws->ring_records[slot], sizeof(kg_aln_record) * (size_t)cap, hipHostMallocDefault));
 			ws->ring_record_capacity[slot] = cap;
 		}

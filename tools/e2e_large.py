@@ -15,7 +15,7 @@ codes = bench.make_large_codes(L, 3, dev)
 f1, f2 = os.path.join(wd, "l1.fq"), os.path.join(wd, "l2.fq")
 bench.write_fastq_pairs(codes, pairs, 5, f1, f2, dev)
 del codes; torch.cuda.empty_cache()
-threads = min(32, 2 * bench.effective_cores())
+threads = int(os.environ.get("E2E_THREADS", min(32, 2 * bench.effective_cores())))
 res = {"genome_len": L, "reads": 2 * pairs, "threads": threads}
 def run(tag, exe, t):
     t0 = time.time()
@@ -34,7 +34,7 @@ if os.environ.get("E2E_CHECK_ALIGN"):      # every device record against the hos
     os.environ["KART_AMD_CHECK_ALIGN"] = "1"
     run("kart_amd_check_align", "kart_amd/bin/kart-amd", threads)
     del os.environ["KART_AMD_CHECK_ALIGN"]
-if os.path.exists("oracle/_ref/kart"):
+if os.path.exists("oracle/_ref/kart") and not os.environ.get("E2E_NO_REF"):
     run("reference_kart", "oracle/_ref/kart", threads)
     # the reference prints its own mapping time ("... processed in N seconds"), which excludes its index load
 print(json.dumps(res))
