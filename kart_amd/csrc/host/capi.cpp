@@ -74,7 +74,7 @@ int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
 	if (opt.shard_count > 1 && opt.rendezvous.empty()) return fail("kh_map: -shard needs -rendezvous FILE");
 	FILE *out = nullptr;
 	if (opt.shard_rank == 0) {
-		out = fopen(opt.out_name.c_str(), "w");
+		out = kart::open_output(opt.out_name);
 		if (!out) return fail("kh_map: cannot open [%s]", opt.out_name.c_str());
 	}
 	kart::Stats st;

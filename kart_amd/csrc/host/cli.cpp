@@ -140,7 +140,7 @@ static int run_one(const Options &opt, KernelBackend *(*make_backend)(const Opti
 	if (!kern) { fprintf(stderr, "Error! %s\n", err.c_str()); return 1; }
 	FILE *out = nullptr;
 	if (opt.shard_rank == 0) {                               // later shards open the file once shard 0 has created it
-		out = fopen(opt.out_name.c_str(), "w");
+		out = kart::open_output(opt.out_name);
 		if (!out) { fprintf(stderr, "Error! Cannot open file [%s]\n", opt.out_name.c_str()); delete kern; return 1; }
 	}
 	if (opt.silent && !quiet) fprintf(stdout, "Start read mapping...\n");

@@ -235,6 +235,13 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	return 0;
 }
 
+FILE *open_output(const std::string &path)
+{
+	struct stat sb;
+	bool regular = stat(path.c_str(), &sb) != 0 || S_ISREG(sb.st_mode);
+	return fopen(path.c_str(), regular ? "w+" : "w");
+}
+
 bool shard_totals(const std::string &rendezvous, int shard_count, Stats &sum)
 {
 	Rendezvous *rv = rendezvous_open(rendezvous);

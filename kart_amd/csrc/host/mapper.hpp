@@ -126,6 +126,9 @@ void shard_mark_failed(const std::string &rendezvous);
 // Returns 0 on success; `summary` receives the reference's end-of-run statistics.
 int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FILE *out, Stats &stats);
 
+// the output file: read-write on a regular file (the writer places chunks through shared mappings), write-only otherwise (pipes)
+FILE *open_output(const std::string &path);
+
 int parse_cli(int argc, char **argv, Options &opt);   // reference src/main.cpp:106-190; <0 = exit(code)
 
 }  // namespace kart
