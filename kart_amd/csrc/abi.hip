@@ -904,10 +904,10 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		ws->task_capacity = cap / 4 + 4096;
 		HIP_TRY(hipMalloc(&ws->d_tasks, up(sizeof(RescueTask) * (size_t)ws->task_capacity) + up(8 * (size_t)ws->task_capacity) + up(4 * (size_t)ws->task_capacity) +
 		                                    sizeof(kg_seed) * (size_t)ws->task_capacity * kAlnMaxSeeds));
-		// about one candidate in ten waits for an alignment; room for one in two
-		ws->spill_capacity = cap / 2 + 4096;
-		ws->job_capacity = cap / 2 + 4096;
-		ws->ops_capacity = 96 * ws->job_capacity;
+		// about one candidate in ten waits for an alignment at 1 % error (one in three at 2 %): room for one per read
+		ws->spill_capacity = cap + 4096;
+		ws->job_capacity = cap + 4096;
+		ws->ops_capacity = 64 * ws->job_capacity;
 		HIP_TRY(hipMalloc((void **)&ws->d_spill, sizeof(AlnSpill) * (size_t)ws->spill_capacity));
 		HIP_TRY(hipMalloc((void **)&ws->d_jobs, sizeof(NwJobDesc) * (size_t)ws->job_capacity));
 		HIP_TRY(hipMalloc((void **)&ws->d_job_ops, (size_t)ws->ops_capacity + 1024));

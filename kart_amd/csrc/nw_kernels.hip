@@ -290,30 +290,43 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 			__syncthreads();
 		}
 		(void)words_per_col;
-		// traceback by lane 0
+		// Traceback, wave-cooperative: the path is one dependent chain, but what made it slow was a global-memory load every few
+		// steps from one lane.  All lanes walk the same (uniform) path; the direction words of the current 16-row block for the 64
+		// columns left of the current one are loaded by the 64 lanes at once and read by lane shuffle.
 		uint8_t *ops = a.ops + q.oo;
 		int len = 0;
-		if (lane == 0) {
+		{
 			int i = m, jj = n;
-			int64_t cached = -1;
-			uint32_t cr = 0, ct = 0;
 			while (i > 0 || jj > 0) {
-				bool g1, g2;
-				if (i == 0) { g1 = true; g2 = false; }
-				else if (jj == 0) { g1 = false; g2 = true; }
-				else {
-					int64_t w = (int64_t)((i - 1) >> 4) * ncols_pad + (jj - 1);
-					if (w != cached) { cr = dir[2 * w]; ct = dir[2 * w + 1]; cached = w; }
-					int sh = ((i - 1) & 15) << 1;
-					g1 = (cr >> sh) & 1;
-					g2 = !g1 && ((ct >> sh) & 1);
+				if (i == 0) {                                         // the rest of the top row: gaps in sequence 1
+					for (int x = lane; x < jj; x += 64) ops[len + x] = KG_OP_GAP1;
+					len += jj; jj = 0;
+					break;
 				}
-				ops[len++] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
-				if (g1) jj--; else if (g2) i--; else { i--; jj--; }
+				if (jj == 0) {
+					for (int x = lane; x < i; x += 64) ops[len + x] = KG_OP_GAP2;
+					len += i; i = 0;
+					break;
+				}
+				const int rb = (i - 1) >> 4, cb = jj > 64 ? jj - 64 : 0;
+				uint32_t cr = 0, ct = 0;
+				if (cb + lane < jj) {
+					int64_t w = (int64_t)rb * ncols_pad + (cb + lane);
+					cr = dir[2 * w]; ct = dir[2 * w + 1];
+				}
+				while (i > 0 && jj > cb && ((i - 1) >> 4) == rb) {
+					const int src = jj - 1 - cb;
+					const uint32_t wr_ = (uint32_t)__shfl((int)cr, src), wt_ = (uint32_t)__shfl((int)ct, src);
+					const int sh = ((i - 1) & 15) << 1;
+					const bool g1 = (wr_ >> sh) & 1;
+					const bool g2 = !g1 && ((wt_ >> sh) & 1);
+					if (lane == 0) ops[len] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
+					len++;
+					if (g1) jj--; else if (g2) i--; else { i--; jj--; }
+				}
 			}
-			a.aln_len[p] = len;
+			if (lane == 0) a.aln_len[p] = len;
 		}
-		len = __shfl(len, 0);
 		__threadfence_block();
 		__syncthreads();
 		for (int x = lane; x < len / 2; x += 64) {

@@ -181,3 +181,54 @@ def test_sharded_live_reference_160k_reads(product_binary, tmp_path):
         r = subprocess.run([product_binary, "-silent", "-i", SMALL_PREFIX, "-f", f1, "-f2", f2, "-o", out, "-gpu", devices, "-t", "8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         assert r.returncode == 0, (devices, r.stdout.decode()[-600:])
         assert open(out, "rb").read() == want, devices
+
+
+def _run_verbose(binary, args, out, env=None):
+    r = subprocess.run([binary, "-silent", "-i", SMALL_PREFIX] + args + ["-o", out, "-t", "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, KART_AMD_VERBOSE="1", **(env or {})))
+    assert r.returncode == 0, r.stderr.decode()[-600:]
+    return r.stdout.decode(), r.stderr.decode()
+
+
+@pytest.mark.parametrize("case", ["pe", "pe_g2", "se", "edge_pe", "edge_se"])
+def test_device_report_equals_the_host_report_record_by_record(case, product_binary, tmp_path):
+    """kg_align_batch (pairing, mate rescue, normal pairs, 8-mer partition, NW, CIGAR, flags, MAPQ on the device) against the host
+    implementation of the same reference code: KART_AMD_CHECK_ALIGN maps every read on the host as well and compares the SAM text
+    made from each device record with the host's; and with the report forced onto the host (KART_AMD_HOST_ALIGN) the golden SAM
+    still comes out"""
+    from test_host_pipeline import materialise
+    args = [materialise(str(tmp_path), a) if a.endswith((".fq", ".fa", ".gz")) else a for a in CASES[case]]
+    out = str(tmp_path / "o.sam")
+    log, err = _run_verbose(product_binary, args, out, {"KART_AMD_CHECK_ALIGN": "1"})
+    line = [l for l in log.splitlines() if l.startswith("CHECK_ALIGN")]
+    assert line and line[0].endswith(" 0 differ") and not line[0].startswith("CHECK_ALIGN: 0 device"), (line, err[:800])
+    want = gzip.open(os.path.join(GOLDEN, "sam", case + ".sam.gz")).read()
+    assert open(out, "rb").read() == want
+    log, _ = _run_verbose(product_binary, args, out, {"KART_AMD_HOST_ALIGN": "1"})
+    assert open(out, "rb").read() == want
+    assert "device report: 0 reads decided on the device" in log
+
+
+def test_device_report_on_30k_live_pairs_with_rescue_and_indels(product_binary, tmp_path):
+    """30 k pairs at 2 % error with indels and short inserts (rescue windows, gap fragments of every size, estimate below
+    MaxInsertSize): most reads are decided on the device, every device record equals the host's text, and the SAM equals the
+    live reference's"""
+    from kart_amd import synth
+    from kart_amd.index_build import read_fasta
+    genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
+    names, r1, r2 = synth.simulate_pairs(genome, 30000, seed=177, err=0.02, mut=0.003, indel_frac=0.3, n_frac=0.0005, ins_mean=400.0, ins_sd=50.0)
+    f1, f2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+    synth.write_fastq(f1, names, r1, mate=1)
+    synth.write_fastq(f2, names, r2, mate=2)
+    out = str(tmp_path / "o.sam")
+    log, err = _run_verbose(product_binary, ["-f", f1, "-f2", f2], out, {"KART_AMD_CHECK_ALIGN": "1"})
+    line = [l for l in log.splitlines() if l.startswith("CHECK_ALIGN")]
+    assert line and line[0].endswith(" 0 differ"), (line, err[:800])
+    log, _ = _run_verbose(product_binary, ["-f", f1, "-f2", f2], out)
+    dev = [l for l in log.splitlines() if l.startswith("device report:") and "decided on the device" in l][0]
+    n_dev = int(dev.split()[2])
+    assert n_dev > 30000, dev                      # more than half of the 60 k reads
+    if os.path.exists(KART_REF):
+        ref = str(tmp_path / "ref.sam")
+        subprocess.run([KART_REF, "-silent", "-i", SMALL_PREFIX, "-f", f1, "-f2", f2, "-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert open(out, "rb").read() == open(ref, "rb").read()
