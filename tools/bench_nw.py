@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """NW kernel throughput (GCUPS = DP cells per second) on device-resident batches, per size class."""
-import sys, time, json
+import os, sys, time, json
 import numpy as np, torch
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from kart_amd import api
-ix = api.Index("tests/golden/idx/small", 0, api.KG_SA_SAMPLED)
+ix = api.Index(os.path.join(ROOT, "tests", "golden", "idx", "small"), 0, api.KG_SA_SAMPLED)
 L = ix.lib
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
