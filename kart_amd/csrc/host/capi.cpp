@@ -2,6 +2,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <thread>
@@ -78,8 +80,12 @@ int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
 		if (!out) return fail("kh_map: cannot open [%s]", opt.out_name.c_str());
 	}
 	kart::Stats st;
+	auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+	double t0 = now();
 	rc = kart::run_mapping(opt, s->ref, *s->kern, out, st);
+	double t1 = now();
 	if (out) fclose(out);
+	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "kh_map: run_mapping %.3f s (its own mapping seconds %.3f), closing the output %.3f s\n", t1 - t0, st.map_seconds, now() - t1);
 	if (stats) {
 		stats->total_reads = st.total_reads; stats->unmapped = st.unmapped; stats->unique = st.unique; stats->paired = st.paired;
 		stats->distance = st.distance; stats->respeculated = st.respeculated; stats->map_seconds = st.map_seconds; stats->sharded = st.sharded ? 1 : 0;

@@ -8,6 +8,7 @@
 
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -134,6 +135,8 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	mallopt(M_TRIM_THRESHOLD, -1);
 	mallopt(M_TOP_PAD, 64 << 20);
 	double t_begin = now_s();
+	struct rusage ru0;
+	getrusage(RUSAGE_SELF, &ru0);
 	g_sections = getenv("KART_AMD_VERBOSE") != nullptr;
 	if (const char *uf = getenv("KART_AMD_UNSET_FLAG")) g_unset_flag = atoi(uf);
 	g_check_align = getenv("KART_AMD_CHECK_ALIGN") != nullptr;
@@ -224,6 +227,12 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	if (getenv("KART_AMD_VERBOSE"))
 		fprintf(stdout, "stage seconds: unhidden read+encode+seed %.2f (seed calls %.2f) | finish+format(k-1) with chain+pair+plan(k) %.2f | nw %.2f | commit %.2f | writer drain %.2f | libraries %.2f of %.2f\n",
 		        tot.t_read, tot.t_seed, tot.t_a, tot.t_nw, tot.t_commit, tot.t_drain, tot.t_lib, stats.map_seconds);
+	if (getenv("KART_AMD_VERBOSE")) {
+		struct rusage ru1;
+		getrusage(RUSAGE_SELF, &ru1);
+		auto secs = [](const timeval &a, const timeval &b) { return (double)(a.tv_sec - b.tv_sec) + 1e-6 * (double)(a.tv_usec - b.tv_usec); };
+		fprintf(stdout, "cpu seconds of the mapping phase: user %.2f, system %.2f (wall %.2f)\n", secs(ru1.ru_utime, ru0.ru_utime), secs(ru1.ru_stime, ru0.ru_stime), stats.map_seconds);
+	}
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: %lld reads decided on the device, %lld mapped by the host stages\n", (long long)tot.dev_reads, (long long)tot.host_reads);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: read_batch total %.3f s (line index %.3f, views %.3f, views + chunk assembly %.3f, materialise + characters %.3f) | %s\n", 1e-9 * (double)g_read_ns.load(),
 		        1e-9 * (double)g_read_part_ns[0].load(), 1e-9 * (double)g_read_part_ns[1].load(), 1e-9 * (double)g_read_part_ns[2].load(), 1e-9 * (double)g_read_part_ns[3].load(), kern.align_diagnostics().c_str());

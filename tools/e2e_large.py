@@ -27,7 +27,7 @@ def run(tag, exe, t):
     for line in r.stdout.decode().splitlines():
         if line.startswith("mapping seconds"):
             ms = float(line.split(":")[1]); res[tag]["mapping_seconds"] = ms; res[tag]["reads_per_s_mapping_phase"] = round(2 * pairs / ms)
-        if line.startswith(("stage seconds", "worker thread-seconds", "All the", "device report", "CHECK_ALIGN", "chunks re-mapped")):
+        if line.startswith(("stage seconds", "worker thread-seconds", "All the", "device report", "CHECK_ALIGN", "chunks re-mapped", "cpu seconds")):
             res[tag].setdefault("log", []).append(line.strip())
 run("kart_amd", "kart_amd/bin/kart-amd", threads)
 if os.environ.get("E2E_CHECK_ALIGN"):      # every device record against the host's text for the same read (slow: the host maps everything too)
