@@ -99,6 +99,7 @@ typedef struct {
 typedef struct {
 	uint64_t table_lookups, rank_steps, rank_steps_two_lines, sa_gathers, text_rounds, window_words, hits, searches;
 	uint64_t sa_entry_bytes;
+	uint64_t rank_steps_two_lines_narrow;   /* two-line rank steps on an interval of fewer than 960 suffixes (what a 960-symbols-per-line plane layout would serve from one line) */
 } kg_traffic_t;
 
 const char *kg_last_error(void);            /* thread-local message of the last failure */

@@ -72,7 +72,7 @@ class Counters(C.Structure):
 class Traffic(C.Structure):
     """kg_traffic_t: what the search kernel itself fetched in the last batch (the implemented algorithm)."""
     _fields_ = [(n, C.c_uint64) for n in ("table_lookups", "rank_steps", "rank_steps_two_lines", "sa_gathers", "text_rounds", "window_words",
-                                          "hits", "searches", "sa_entry_bytes")]
+                                          "hits", "searches", "sa_entry_bytes", "rank_steps_two_lines_narrow")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -131,6 +131,9 @@ struct kg_workspace {
 	unsigned long long *d_ctl = nullptr;
 	void *d_scan_temp = nullptr;
 	size_t scan_bytes = 0;
+	uint32_t *d_sort_keys = nullptr;    // EXPERIMENT (KG_SORT_READS)
+	void *d_sort_temp = nullptr;
+	size_t sort_bytes = 0;
 	// staging for the host-buffer entry point
 	uint8_t *d_enc = nullptr;
 	int64_t *d_read_off = nullptr;
@@ -515,6 +518,11 @@ int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_w
 	HIP_TRY(hipMemset(ws->d_ctl, 0, 8 * kCtlWords));
 	ws->scan_bytes = scan_temp_bytes(max_reads + 1);
 	HIP_TRY(hipMalloc(&ws->d_scan_temp, ws->scan_bytes ? ws->scan_bytes : 256));
+	if (getenv("KG_SORT_READS")) {
+		ws->sort_bytes = sort_temp_bytes(max_reads);
+		HIP_TRY(hipMalloc((void **)&ws->d_sort_keys, 16 * (size_t)max_reads + 64));
+		HIP_TRY(hipMalloc(&ws->d_sort_temp, ws->sort_bytes ? ws->sort_bytes : 256));
+	}
 	HIP_TRY(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
 	*out = ws.release();
 	return KG_OK;
@@ -530,7 +538,7 @@ void kg_workspace_destroy(kg_workspace *ws)
 		if (ws->ring_seeds[i]) (void)hipHostFree(ws->ring_seeds[i]);
 		if (ws->ring_records[i]) (void)hipHostFree(ws->ring_records[i]);
 	}
-	void *ptrs[] = {ws->d_plans, ws->d_tasks, ws->d_aln_cand, ws->d_aln_read, ws->d_spill, ws->d_jobs, ws->d_job_ops, ws->d_job_len, ws->d_chunk_off, ws->d_chunk_paired, ws->d_chunk_stats, ws->d_aln_ctl, ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
+	void *ptrs[] = {ws->d_sort_keys, ws->d_sort_temp, ws->d_plans, ws->d_tasks, ws->d_aln_cand, ws->d_aln_read, ws->d_spill, ws->d_jobs, ws->d_job_ops, ws->d_job_len, ws->d_chunk_off, ws->d_chunk_paired, ws->d_chunk_stats, ws->d_aln_ctl, ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (ws->h_seeds) (void)hipHostFree(ws->h_seeds);
@@ -559,7 +567,7 @@ int kg_workspace_traffic(kg_workspace *ws, kg_traffic_t *out)
 	unsigned long long ctl[kCtlWords];
 	HIP_TRY(hipMemcpy(ctl, ws->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost));
 	out->table_lookups = ctl[17]; out->rank_steps = ctl[18]; out->rank_steps_two_lines = ctl[19];
-	out->text_rounds = ctl[20]; out->window_words = ctl[21];
+	out->text_rounds = ctl[20]; out->window_words = ctl[21]; out->rank_steps_two_lines_narrow = ctl[22];
 	out->sa_gathers = ctl[8]; out->hits = ctl[1]; out->searches = ctl[4];
 	out->sa_entry_bytes = (ws->ix->view.fsa32 ? 4 : 8);
 	return KG_OK;
@@ -630,6 +638,7 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.min_seed_len = min_seed_len;
 	a.occ_thr = occ_thr;
 	a.packed = ws->d_packed;
+	a.read_order = nullptr; a.sort_keys = ws->d_sort_keys; a.sort_temp = ws->d_sort_temp; a.sort_temp_bytes = ws->sort_bytes;
 	a.hits = ws->d_hits;
 	a.max_hits = ws->max_hits;
 	a.seeds_per_read = ws->d_seeds_per_read;

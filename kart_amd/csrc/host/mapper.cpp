@@ -7,6 +7,7 @@
 #include "mapper.hpp"
 
 #include <fcntl.h>
+#include <immintrin.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>

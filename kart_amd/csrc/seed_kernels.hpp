@@ -23,8 +23,8 @@ struct Hit {
 //   [12..16] reads on the sort work lists: 9..16, 17..32, 33..64 seeds (4 / 2 / 1 lists per wave), 65..256 (small LDS),
 //            > 256 (large LDS)
 //   [17..21] what the search kernel itself fetched: q-mer table lookups, rank steps executed, those touching two 128-byte
-//            lines, text-comparison rounds, packed window words (kg_workspace_traffic)
-constexpr int kCtlWords = 22;
+//            lines, text-comparison rounds, packed window words, two-line rank steps on intervals below 960 (kg_workspace_traffic)
+constexpr int kCtlWords = 23;
 
 struct SeedArgs {
 	FmView ix;
@@ -36,6 +36,12 @@ struct SeedArgs {
 	int ascii;           // the read bytes are characters, not codes (KG_INPUT_ASCII)
 	// scratch
 	uint64_t *packed;    // 4-bit read codes, 16 per word, read r at word (read_off[r] >> 4) + 3 r
+	// EXPERIMENT (KG_SORT_READS): the order in which the search kernel's lanes draw the reads -- sorted by the first 16 bases, so
+	// that lanes of a wave start in neighbouring q-mer table entries / rank lines; null = input order
+	int32_t *read_order;
+	uint32_t *sort_keys;      // [4 * max_reads]: keys in, keys out, ids in, ids out
+	void *sort_temp;
+	size_t sort_temp_bytes;
 	Hit *hits;
 	int64_t max_hits;
 	int32_t *seeds_per_read;
@@ -47,6 +53,7 @@ struct SeedArgs {
 };
 
 size_t scan_temp_bytes(int64_t max_reads);
+size_t sort_temp_bytes(int64_t max_reads);
 // ev: optional array of 5 events recorded before/after the four phases (search | scan | locate | sort)
 hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream, hipEvent_t *ev);
 hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *planes, hipStream_t stream);
