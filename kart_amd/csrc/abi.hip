@@ -853,7 +853,7 @@ static int nw_run(kg_index *ix, const char *d_frag1, const int64_t *d_off1, cons
 		if (max_len > kNwMaxLen) {
 			// beyond what the LDS holds: boundary column + codes behind the direction words of the wave's slab
 			a.gb_offset_words = a.dir_words_per_wave;
-			a.dir_words_per_wave += (nw_big_lds_bytes((int)max_len) + 3) / 4 + 16;
+			a.dir_words_per_wave += (((nw_big_lds_bytes((int)max_len) + 3) / 4 + 16) + 3) & ~3ll;      // (slabs stay 16-byte aligned)
 			a.big_lds_bytes = 0;
 			waves = std::min<int64_t>(waves, 64);        // such fragments are rare and each slab is large
 			if (a.dir_words_per_wave * 4 > (64ll << 30)) return fail(KG_ERR_CAPACITY, "kg_nw_batch: a fragment of %lld bases needs more than 64 GiB of traceback words", (long long)max_len);

@@ -239,60 +239,54 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 		const int64_t o1 = q.o1, o2 = q.o2;
 		const int m = q.m, n = q.n;
 		int *lds = kGlobal ? reinterpret_cast<int *>(dir + a.gb_offset_words) : lds_dyn;
-		int *bS = lds, *bR = lds + (m + 1);
+		int2 *bSR = reinterpret_cast<int2 *>(lds);                                   // boundary column: {S, R} of rows 0..m
 		unsigned char *s1c = reinterpret_cast<unsigned char *>(lds + 2 * (m + 1));  // fits: see nw_big_lds_bytes()
-		for (int i = lane; i <= m; i += 64) { bS[i] = i == 0 ? 0 : -2 - i; bR[i] = i == 0 ? 0 : NEG; }
+		for (int i = lane; i <= m; i += 64) bSR[i] = i == 0 ? make_int2(0, 0) : make_int2(-2 - i, NEG);
 		for (int i = lane; i < m; i += 64) s1c[i] = (unsigned char)nt4_code((unsigned char)a.f1[o1 + i]);
 		__syncthreads();
 		const int n_stripes = (n + 63) >> 6;
-		const int words_per_col = (m + 15) >> 4;
-		const int64_t ncols_pad = (int64_t)n_stripes * 64;
+		const int steps = m + 63;                          // anti-diagonal steps of one stripe
+		// direction bits: per stripe and step one pair of 64-bit lane masks (s == r, s == t) -- the compare results themselves
+		uint64_t *dir64 = reinterpret_cast<uint64_t *>(dir);
 		for (int st = 0; st < n_stripes; ++st) {
-			int j = st * 64 + lane + 1;          // 1-based column of this lane
-			int c2 = j <= n ? nw_code2(a, o2 + j - 1) : 9;
+			const int j = st * 64 + lane + 1;    // 1-based column of this lane
+			const int c2 = j <= n ? nw_code2(a, o2 + j - 1) : 9;
 			int up_s = -2 - j, up_t = NEG;       // row 0
 			int res_s = 0, res_r = 0;            // this lane's last result (what lane+1 sees as "left")
-			int diag_s = 0;
-			uint32_t wr = 0, wt = 0;
-			for (int d = 1; d <= m + 63; ++d) {
-				int i = d - lane;
-				// left neighbour = lane-1's result of the previous step; lane 0 reads the boundary
+			int prev_left_s = 0;                 // S(i-1, j-1): the left neighbour's value of the previous step
+			int c1 = 15;                         // sequence-1 code of this lane's row, handed on from lane to lane
+			uint64_t *dw = dir64 + (int64_t)st * steps * 2;
+			for (int d = 1; d <= steps; ++d) {
+				const int i = d - lane;
+				// what comes in from the left: lane-1's result of the previous step; lane 0 reads the boundary column and the
+				// code of the row that enters the stripe
 				int left_s = __shfl_up(res_s, 1), left_r = __shfl_up(res_r, 1);
-				int bi = d <= m ? d : m;
-				int b_s = bS[bi], b_r = bR[bi], b_d = bS[bi - 1];
-				if (lane == 0) { left_s = b_s; left_r = b_r; }
-				bool valid = i >= 1 && i <= m;
-				if (valid) {
-					if (i == 1) diag_s = j == 1 ? 0 : -2 - (j - 1);
-					if (lane == 0) diag_s = b_d;
-					int c1 = s1c[i - 1];
-					int r = max(left_r - 1, left_s - 3);
-					int tt = max(up_t - 1, up_s - 3);
-					int dd = diag_s + (c1 == c2 ? 3 : -3);
-					int s = max(dd, max(r, tt));
-					int sh = ((i - 1) & 15) << 1;
-					wr |= (uint32_t)(s == r) << sh;
-					wt |= (uint32_t)(s == tt) << sh;
-					if (((i & 15) == 0 || i == m) && j <= n) {
-						int64_t w = (int64_t)((i - 1) >> 4) * ncols_pad + (j - 1);
-						dir[2 * w] = wr; dir[2 * w + 1] = wt;
-						wr = wt = 0;
-					} else if ((i & 15) == 0 || i == m) { wr = wt = 0; }
-					diag_s = left_s;   // cell (i, j-1) is the diagonal of the next row
-					up_s = s; up_t = tt;
-					res_s = s; res_r = r;
-				}
+				c1 = __shfl_up(c1, 1);
+				const int bi = d <= m ? d : m;
+				const int2 b = bSR[bi];
+				const int code_in = s1c[bi - 1];
+				if (lane == 0) { left_s = b.x; left_r = b.y; c1 = code_in; }
+				const bool valid = (unsigned)(i - 1) < (unsigned)m;
+				const int diag_s = i == 1 ? (j == 1 ? 0 : -2 - (j - 1)) : prev_left_s;
+				const int r = max(left_r - 1, left_s - 3);
+				const int tt = max(up_t - 1, up_s - 3);
+				const int dd = diag_s + (c1 == c2 ? 3 : -3);
+				const int s = max(dd, max(r, tt));
+				const uint64_t mr = __ballot(valid && s == r), mt = __ballot(valid && s == tt);
+				if (lane == 0) { dw[2 * (d - 1)] = mr; dw[2 * (d - 1) + 1] = mt; }
+				prev_left_s = left_s;            // cell (i, j-1) is the diagonal of the next row
+				if (valid) { up_s = s; up_t = tt; }      // (a lane that has not started keeps row 0)
+				res_s = s; res_r = r;
 				// lane 63 publishes its column as the next stripe's boundary (row i of column 64*(st+1))
-				if (lane == 63 && valid) { bS[i] = res_s; bR[i] = res_r; }
+				if (lane == 63 && valid) bSR[i] = make_int2(s, r);
 			}
 			// row 0 of the next boundary column
-			if (lane == 63) { bS[0] = -2 - (st * 64 + 64); bR[0] = -2 - (st * 64 + 64); }
+			if (lane == 63) bSR[0] = make_int2(-2 - (st * 64 + 64), -2 - (st * 64 + 64));
 			__syncthreads();
 		}
-		(void)words_per_col;
-		// Traceback, wave-cooperative: the path is one dependent chain, but what made it slow was a global-memory load every few
-		// steps from one lane.  All lanes walk the same (uniform) path; the direction words of the current 16-row block for the 64
-		// columns left of the current one are loaded by the 64 lanes at once and read by lane shuffle.
+		// Traceback, wave-cooperative: the path is one dependent chain; all lanes walk the same (uniform) path.  Cell (i, j) of
+		// stripe st was computed by lane (j-1) & 63 at step i + lane: the mask pairs of the 64 steps below the current one are
+		// loaded by the 64 lanes at once and read by lane shuffle; every move lowers the step by one or two.
 		uint8_t *ops = a.ops + q.oo;
 		int len = 0;
 		{
@@ -308,18 +302,20 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 					len += i; i = 0;
 					break;
 				}
-				const int rb = (i - 1) >> 4, cb = jj > 64 ? jj - 64 : 0;
-				uint32_t cr = 0, ct = 0;
-				if (cb + lane < jj) {
-					int64_t w = (int64_t)rb * ncols_pad + (cb + lane);
-					cr = dir[2 * w]; ct = dir[2 * w + 1];
-				}
-				while (i > 0 && jj > cb && ((i - 1) >> 4) == rb) {
-					const int src = jj - 1 - cb;
-					const uint32_t wr_ = (uint32_t)__shfl((int)cr, src), wt_ = (uint32_t)__shfl((int)ct, src);
-					const int sh = ((i - 1) & 15) << 1;
-					const bool g1 = (wr_ >> sh) & 1;
-					const bool g2 = !g1 && ((wt_ >> sh) & 1);
+				const int st = (jj - 1) >> 6;
+				const int d_hi = i + ((jj - 1) & 63);
+				const uint64_t *dw = dir64 + (int64_t)st * steps * 2;
+				uint64_t cr = 0, ct = 0;
+				if (d_hi - lane >= 1) { cr = dw[2 * (d_hi - lane - 1)]; ct = dw[2 * (d_hi - lane - 1) + 1]; }
+				while (i > 0 && jj > 0 && ((jj - 1) >> 6) == st) {
+					const int cl = (jj - 1) & 63, d = i + cl;
+					const int src = d_hi - d;
+					if (src > 63) break;
+					const uint32_t lo_r = (uint32_t)__shfl((int)(uint32_t)cr, src), hi_r = (uint32_t)__shfl((int)(uint32_t)(cr >> 32), src);
+					const uint32_t lo_t = (uint32_t)__shfl((int)(uint32_t)ct, src), hi_t = (uint32_t)__shfl((int)(uint32_t)(ct >> 32), src);
+					const uint64_t wr_ = ((uint64_t)hi_r << 32) | lo_r, wt_ = ((uint64_t)hi_t << 32) | lo_t;
+					const bool g1 = (wr_ >> cl) & 1;
+					const bool g2 = !g1 && ((wt_ >> cl) & 1);
 					if (lane == 0) ops[len] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
 					len++;
 					if (g1) jj--; else if (g2) i--; else { i--; jj--; }

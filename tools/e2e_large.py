@@ -19,7 +19,7 @@ threads = int(os.environ.get("E2E_THREADS", min(32, 2 * bench.effective_cores())
 res = {"genome_len": L, "reads": 2 * pairs, "threads": threads}
 def run(tag, exe, t):
     t0 = time.time()
-    r = subprocess.run([exe, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-o", os.path.join(wd, tag + os.environ.get("E2E_OUT_SUFFIX", "") + ".sam"), "-t", str(t)], stdout=subprocess.PIPE,
+    r = subprocess.run([exe, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-o", os.environ.get("E2E_OUT") or os.path.join(wd, tag + os.environ.get("E2E_OUT_SUFFIX", "") + ".sam"), "-t", str(t)], stdout=subprocess.PIPE,
                        stderr=open(os.path.join("gpurun_out", tag + ".stderr"), "wb") if os.path.isdir("gpurun_out") else subprocess.DEVNULL,
                        env=dict(os.environ, KART_AMD_VERBOSE="1"))
     dt = time.time() - t0
