@@ -232,3 +232,35 @@ def test_device_report_on_30k_live_pairs_with_rescue_and_indels(product_binary, 
         ref = str(tmp_path / "ref.sam")
         subprocess.run([KART_REF, "-silent", "-i", SMALL_PREFIX, "-f", f1, "-f2", f2, "-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         assert open(out, "rb").read() == open(ref, "rb").read()
+
+
+def test_single_contig_genome_live_reference(product_binary, tmp_path):
+    """a genome of ONE contig takes the n_chr == 1 branches of GenCoordinateInfo (src/AlignmentCandidates.cpp:523,541) -- on the
+    device and on the host; reads keep 3 kb away from both ends (the reference's rescue windows index outside the text there, App. B-3)"""
+    if not os.path.exists(KART_REF):
+        pytest.skip("oracle/_ref/kart not present on this machine")
+    from kart_amd import index_build, synth
+    from kart_amd.index_build import read_fasta
+    genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
+    chrom = max(genome.values(), key=len)
+    fa = str(tmp_path / "one.fa")
+    synth.write_fasta(fa, {"solo": chrom})
+    prefix = str(tmp_path / "one")
+    index_build.build_index(fa, prefix, device="cpu")
+    inner = {"solo": chrom[3000:-3000]}
+    names, r1, r2 = synth.simulate_pairs(inner, 9000, seed=5, err=0.02, mut=0.003, indel_frac=0.3, skip=())
+    # the simulated fragment lies inside the trimmed copy: it is a substring of the full contig, so the reads map 3 kb further in
+    f1, f2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+    synth.write_fastq(f1, names, r1, mate=1)
+    synth.write_fastq(f2, names, r2, mate=2)
+    outs = []
+    for binary, extra in ((KART_REF, ["-t", "1"]), (product_binary, ["-t", "8"])):
+        out = str(tmp_path / (os.path.basename(binary) + ".sam"))
+        r = subprocess.run([binary, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-o", out] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           env=dict(os.environ, KART_AMD_VERBOSE="1"))
+        assert r.returncode == 0, r.stdout.decode()[-400:]
+        outs.append(open(out, "rb").read())
+        log = r.stdout.decode()
+    assert outs[0] == outs[1]
+    dev = [l for l in log.splitlines() if l.startswith("device report:") and "decided on the device" in l][0]
+    assert int(dev.split()[2]) > 9000, dev
