@@ -57,6 +57,12 @@ __device__ __forceinline__ int nw_code2(const NwArgs &a, int64_t at)      // cod
 }
 __device__ __forceinline__ int64_t nw_count(const NwArgs &a) { return a.n_dev ? (int64_t)min(*a.n_dev, (unsigned long long)a.n) : a.n; }
 
+// value of the lane below (lane 0 keeps its own): DPP wave shift right by one, no LDS traffic
+__device__ __forceinline__ int wave_shr1(int v)
+{
+	return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
 __device__ __forceinline__ int lane_rank_nw(uint64_t mask)
 {
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
@@ -256,23 +262,30 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 			int prev_left_s = 0;                 // S(i-1, j-1): the left neighbour's value of the previous step
 			int c1 = 15;                         // sequence-1 code of this lane's row, handed on from lane to lane
 			uint64_t *dw = dir64 + (int64_t)st * steps * 2;
+			// lane 0's inputs of a step (boundary values and the code of the row entering the stripe) are fetched one step ahead,
+			// so that the LDS latency is off the dependent chain
+			int2 b = bSR[m >= 1 ? 1 : 0];
+			int code_in = s1c[0];
 			for (int d = 1; d <= steps; ++d) {
 				const int i = d - lane;
-				// what comes in from the left: lane-1's result of the previous step; lane 0 reads the boundary column and the
-				// code of the row that enters the stripe
-				int left_s = __shfl_up(res_s, 1), left_r = __shfl_up(res_r, 1);
-				c1 = __shfl_up(c1, 1);
-				const int bi = d <= m ? d : m;
-				const int2 b = bSR[bi];
-				const int code_in = s1c[bi - 1];
+				// what comes in from the left: lane-1's result of the previous step (a wave shift by one lane); lane 0 takes the
+				// boundary column instead
+				int left_s = wave_shr1(res_s), left_r = wave_shr1(res_r);
+				c1 = wave_shr1(c1);
 				if (lane == 0) { left_s = b.x; left_r = b.y; c1 = code_in; }
+				{
+					const int bn = d + 1 <= m ? d + 1 : m;             // next step's boundary row
+					b = bSR[bn];
+					code_in = s1c[bn - 1];
+				}
 				const bool valid = (unsigned)(i - 1) < (unsigned)m;
 				const int diag_s = i == 1 ? (j == 1 ? 0 : -2 - (j - 1)) : prev_left_s;
 				const int r = max(left_r - 1, left_s - 3);
 				const int tt = max(up_t - 1, up_s - 3);
 				const int dd = diag_s + (c1 == c2 ? 3 : -3);
 				const int s = max(dd, max(r, tt));
-				const uint64_t mr = __ballot(valid && s == r), mt = __ballot(valid && s == tt);
+				const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);                  // (compare results are the lane masks: scalar ANDs, no VALU)
+				const uint64_t mr = __builtin_amdgcn_ballot_w64(s == r) & vm, mt = __builtin_amdgcn_ballot_w64(s == tt) & vm;
 				if (lane == 0) { dw[2 * (d - 1)] = mr; dw[2 * (d - 1) + 1] = mt; }
 				prev_left_s = left_s;            // cell (i, j-1) is the diagonal of the next row
 				if (valid) { up_s = s; up_t = tt; }      // (a lane that has not started keeps row 0)
