@@ -57,10 +57,10 @@ __device__ __forceinline__ int nw_code2(const NwArgs &a, int64_t at)      // cod
 }
 __device__ __forceinline__ int64_t nw_count(const NwArgs &a) { return a.n_dev ? (int64_t)min(*a.n_dev, (unsigned long long)a.n) : a.n; }
 
-// value of the lane below (lane 0 keeps its own): DPP wave shift right by one, no LDS traffic
-__device__ __forceinline__ int wave_shr1(int v)
+// value of the lane below; lane 0, which has none, gets `first`: DPP wave shift right by one, no LDS traffic
+__device__ __forceinline__ int wave_shr1(int v, int first)
 {
-	return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+	return __builtin_amdgcn_update_dpp(first, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
 __device__ __forceinline__ int lane_rank_nw(uint64_t mask)
@@ -270,9 +270,8 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 				const int i = d - lane;
 				// what comes in from the left: lane-1's result of the previous step (a wave shift by one lane); lane 0 takes the
 				// boundary column instead
-				int left_s = wave_shr1(res_s), left_r = wave_shr1(res_r);
-				c1 = wave_shr1(c1);
-				if (lane == 0) { left_s = b.x; left_r = b.y; c1 = code_in; }
+				const int left_s = wave_shr1(res_s, b.x), left_r = wave_shr1(res_r, b.y);
+				c1 = wave_shr1(c1, code_in);
 				{
 					const int bn = d + 1 <= m ? d + 1 : m;             // next step's boundary row
 					b = bSR[bn];
