@@ -179,14 +179,14 @@ int  kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_r
 
 /* ---- the per-read report on the device --------------------------------------------------------------------------- */
 /* Everything ReadMapping() does between chaining and the SAM text, for the reads of the batch the last kg_seed_batch +
- * kg_candidates_batch calls on this workspace left on the device, in the reference's short-read configuration (neither
- * -pacbio nor -m):
+ * kg_candidates_batch calls on this workspace left on the device, in the reference's short-read configuration (not -pacbio):
  *   CheckPairedAlignmentCandidates / RemoveUnMatedAlignmentCandidates / RemoveRedundantCandidates (src/Mapping.cpp:317-427),
  *   GenMappingReport: IdentifyNormalPairs + filters (src/AlignmentCandidates.cpp:226-490), Process{Head,Normal,Tail}SequencePair
  *   (src/tools.cpp:225-397) with nw_alignment on the device, GenCoordinateInfo / GenerateCIGAR / GapPenalty (:492-745),
  *   CheckPairedFinalAlignments, Set{Paired,Single}AlignmentFlag, EvaluateMAPQ (src/Mapping.cpp:49-175, 429-480),
- *   and what OutputPairedAlignments / OutputSingledAlignments would print for every read (:177-315).
- * One record per read.  A read pair the device path does not take -- RescueUnpairedAlignment is due, a gap fragment needs the
+ *   and what OutputPairedAlignments / OutputSingledAlignments would print for every read (:177-315), with or without -m.
+ * One record per read (with multi_hit further records of a read are chained through `next`; a record whose FLAG the reference
+ * never assigns -- SURVEY App. B-12 -- carries unset_flag).  A read pair the device path does not take -- RescueUnpairedAlignment is due, a gap fragment needs the
  * 8-mer partition (both sides > 30), a candidate has more seeds or a longer CIGAR than the kernels hold -- comes back with
  * kind KG_ALN_HOST on both reads: the caller maps it with its own implementation of the same reference code (the candidates
  * kg_candidates_batch returned are unmodified). */
@@ -208,6 +208,9 @@ typedef struct {
 	uint8_t cigar_len;
 	uint8_t rescue;          /* pairs: RescueUnpairedAlignment was due for this pair (its windows depend on min(EstDistance, MaxInsertSize)) */
 	char    cigar[KG_ALN_CIGAR_MAX];
+	int32_t next;            /* -m: index (into the same array, >= n_reads) of the next record printed for this read, or -1 */
+	uint8_t primary;         /* the record of the read's best candidate (iBestAlnCanIdx): the one iPaired / iDistance count (:209-213) */
+	uint8_t pad[3];
 } kg_aln_record;
 
 /* per 4000-read chunk: what the chunk adds to the run's pairing statistics (iPaired / iDistance, src/Mapping.cpp:209-213),
@@ -227,7 +230,8 @@ typedef struct {
  * through the workspace);
  * chunk_stats[n_chunks] is filled.  KG_ERR_ARG when no chained batch is resident or the chunks do not cover it. */
 int  kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks,
-                    int est_distance, int max_insert, int max_gaps, const kg_aln_record **records, kg_chunk_stats *chunk_stats);
+                    int est_distance, int max_insert, int max_gaps, int multi_hit, int unset_flag,
+                    const kg_aln_record **records, kg_chunk_stats *chunk_stats);
 
 /* Running tallies (since the workspace was created) of why read pairs came back as KG_ALN_HOST: [0] candidate product too large,
  * [1] a mate-2 rescue window would be scanned, [2] rescue window too long, [3] mate not plain A/C/G/T or too long for the rescue

@@ -877,7 +877,7 @@ static int nw_run(kg_index *ix, const char *d_frag1, const int64_t *d_off1, cons
 // Replaces, for a batch, what ReadMapping() does per read between chaining and the SAM text (reference src/Mapping.cpp:542-578);
 // see align_kernels.hip for the kernel <-> reference correspondence.
 int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks, int est_distance, int max_insert,
-                   int max_gaps, const kg_aln_record **records, kg_chunk_stats *chunk_stats)
+                   int max_gaps, int multi_hit, int unset_flag, const kg_aln_record **records, kg_chunk_stats *chunk_stats)
 {
 	if (!ws || !chunk_off || !chunk_paired || !records || !chunk_stats || n_chunks <= 0) return fail(KG_ERR_ARG, "kg_align_batch: bad argument");
 	*records = nullptr;
@@ -949,6 +949,8 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 	a.chr_fwd_start = ix->d_chr_tab; a.chr_rev_start = ix->d_chr_tab + a.n_chr; a.chr_len = ix->d_chr_tab + 2 * a.n_chr;
 	a.genome_size = ix->l_pac; a.two_genome_size = 2 * ix->l_pac;
 	a.est_distance = est_distance; a.max_insert = max_insert; a.max_gaps = max_gaps;
+	a.multi_hit = multi_hit ? 1 : 0; a.unset_flag = unset_flag;
+	a.extra_capacity = 0;                                  // (set below, once the pinned array of this call is known)
 	a.mapq_tab = ix->d_mapq_tab;
 	{
 		char *p = (char *)ws->d_aln_cand;
@@ -1004,7 +1006,6 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		hipError_t e2 = nw_submitted(ix, sc, st);
 		if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_align_batch: %s", hipGetErrorString(e != hipSuccess ? e : e2));
 	}
-	HIP_TRY(launch_align_back(a, ix->n_cu, st));
 	{
 		const int slot = ws->ring_rec_at;
 		ws->ring_rec_at = (ws->ring_rec_at + 1) % kg_workspace::kRing;
@@ -1016,9 +1017,19 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 			ws->ring_record_capacity[slot] = cap;
 		}
 		ws->h_records = ws->ring_records[slot];
+		// -m: the further records of a read take slots behind the n per-read ones, as many as both arrays hold
+		if (multi_hit) a.extra_capacity = std::min<int64_t>(ws->aln_read_capacity, ws->ring_record_capacity[slot]) - n;
 	}
+	HIP_TRY(launch_align_back(a, ix->n_cu, st));
 	HIP_TRY(hipMemcpyAsync(ws->h_records, a.records, sizeof(kg_aln_record) * (size_t)n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(chunk_stats, ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)n_chunks, hipMemcpyDeviceToHost, st));
+	if (multi_hit) {
+		unsigned long long extra = 0;
+		HIP_TRY(hipMemcpyAsync(&extra, ws->d_aln_ctl + 7, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		int64_t k = (int64_t)std::min<unsigned long long>(extra, (unsigned long long)a.extra_capacity);
+		if (k > 0) HIP_TRY(hipMemcpyAsync(ws->h_records + n, a.records + n, sizeof(kg_aln_record) * (size_t)k, hipMemcpyDeviceToHost, st));
+	}
 	HIP_TRY(hipStreamSynchronize(st));
 	*records = ws->h_records;
 	return KG_OK;

@@ -1247,7 +1247,7 @@ __device__ void summarise(const AlnArgs &a, int64_t r, ReadSum &s)
 		if (sc > s.score) { s.best = i; s.sub_score = s.score; s.score = sc; }
 		else if (sc == s.score) {
 			s.sub_score = s.score;
-			if (a.chr_len[a.rep_chr[s.l.at(i)]] > a.chr_len[a.rep_chr[s.l.at(s.best)]]) s.best = i;
+			if (!a.multi_hit && a.chr_len[a.rep_chr[s.l.at(i)]] > a.chr_len[a.rep_chr[s.l.at(s.best)]]) s.best = i;
 		}
 	}
 }
@@ -1289,20 +1289,52 @@ __device__ int one_mate_flag(const AlnArgs &a, const ReadSum &me, const ReadSum 
 	return f;
 }
 
-__device__ void write_record(const AlnArgs &a, int64_t r, const ReadSum &s, int kind, int flag, bool has_mate, int64_t mate_pos, int tlen, bool flip)
+// record slot `at` (the read's own slot, or one of the extra slots of -m) for candidate `cand_i` of the read
+__device__ void write_record_at(const AlnArgs &a, int64_t at, const ReadSum &s, int cand_i, int kind, int flag, bool has_mate, int64_t mate_pos, int tlen, bool flip)
 {
-	kg_aln_record &o = a.records[r];
+	kg_aln_record &o = a.records[at];
 	o.kind = kind; o.flag = flag; o.mapq = s.mapq; o.score = s.score; o.sub_score = s.sub_score;
 	o.has_mate = has_mate ? 1 : 0; o.mate_pos = mate_pos; o.tlen = tlen; o.flip = flip ? 1 : 0;      // (est_lo / est_hi / rescue: aln_pair_kernel)
 	o.chr = -1; o.pos = 0; o.cigar_len = 0;
+	o.next = -1; o.primary = cand_i == s.best ? 1 : 0; o.pad[0] = o.pad[1] = o.pad[2] = 0;
 	if (kind == KG_ALN_MAPPED) {
-		int64_t c = s.l.at(s.best);
+		int64_t c = s.l.at(cand_i);
 		o.chr = a.rep_chr[c]; o.pos = a.rep_pos[c];
 		int n = a.rep_cigar_len[c];
 		o.cigar_len = (uint8_t)n;
 		const char *src = a.rep_cigar + c * KG_ALN_CIGAR_MAX;
 		for (int i = 0; i < n; ++i) o.cigar[i] = src[i];
 	}
+}
+
+__device__ __forceinline__ void write_record(const AlnArgs &a, int64_t r, const ReadSum &s, int kind, int flag, bool has_mate, int64_t mate_pos, int tlen, bool flip)
+{
+	write_record_at(a, r, s, s.best, kind, flag, has_mate, mate_pos, tlen, flip);
+}
+
+// -m: the next record of read r goes into its own slot when that is still free, else into an extra slot chained behind `last`
+// (the slot written before).  false: the extra slots are used up.
+__device__ bool next_slot(const AlnArgs &a, int64_t r, int64_t &last, int64_t &at)
+{
+	if (last < 0) { at = r; last = r; return true; }
+	unsigned long long k = atomicAdd(&a.ctl[7], 1ull);
+	if (k >= (unsigned long long)a.extra_capacity) return false;
+	at = a.n_reads + (int64_t)k;
+	a.records[last].next = (int32_t)at;
+	last = at;
+	return true;
+}
+
+// SetPairedAlignmentFlag for candidate i of `me` when the run prints more than the best candidate (-m): assigned exactly where the
+// reference assigns it (src/Mapping.cpp:78-93, 96-156), the unset value elsewhere
+__device__ int multi_flag(const AlnArgs &a, const ReadSum &me, const ReadSum &other, int i, int base, bool both_unique, int best_flag)
+{
+	if (both_unique || me.score > me.sub_score) return i == me.best ? best_flag : a.unset_flag;
+	// me.score == me.sub_score > 0: every candidate with a positive score is assigned
+	int f = base | (rep_fwd_at(a, me, i) ? 0x20 : 0x10);
+	int j = rep_mate_at(a, me, i);
+	if (j != -1 && rep_score_at(a, other, j) > 0) f |= 0x2; else f |= 0x8;
+	return f;
 }
 
 }  // namespace
@@ -1337,17 +1369,20 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 				atomicAdd(&cs.unmapped, 1);
 				write_record(a, r, s1, KG_ALN_UNMAPPED, 0x4, false, 0, 0, false);
 			} else {
-				if (s1.mapq == 60) atomicAdd(&cs.unique, 1);
-				// the first candidate from `best` on whose score is the read's (the best one itself)
-				int pick = -1;
-				for (int i = s1.best; i < s1.can_num; ++i)
-					if (a.rep_score[s1.l.at(i)] == s1.score) { pick = i; break; }
-				if (pick < 0) write_record(a, r, s1, KG_ALN_NONE, 0, false, 0, 0, false);
-				else {
-					s1.best = pick;
-					bool fwd = a.rep_fwd[s1.l.at(pick)] != 0;
-					write_record(a, r, s1, KG_ALN_MAPPED, fwd ? 0 : 0x10, false, 0, 0, !fwd);
+				// the candidates from `best` on whose score is the read's: the first one, or with -m all of them (:291-304); every
+				// one of them carries an assigned flag (a second candidate of the read's score makes score == sub_score, :58-66)
+				int64_t last = -1, at = r;
+				bool full = false;
+				for (int i = s1.best; i < s1.can_num && !full; ++i) {
+					if (a.rep_score[s1.l.at(i)] != s1.score) continue;
+					if (!next_slot(a, r, last, at)) { full = true; break; }
+					bool fwd = a.rep_fwd[s1.l.at(i)] != 0;
+					write_record_at(a, at, s1, i, KG_ALN_MAPPED, fwd ? 0 : 0x10, false, 0, 0, !fwd);
+					if (!a.multi_hit) break;
 				}
+				if (full) { atomicAdd(&a.ctl[8 + WHY_CAPACITY], 1ull); a.records[r].kind = KG_ALN_HOST; continue; }
+				if (last < 0) write_record(a, r, s1, KG_ALN_NONE, 0, false, 0, 0, false);
+				if (s1.mapq == 60) atomicAdd(&cs.unique, 1);
 			}
 			continue;
 		}
@@ -1365,8 +1400,8 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 			else if (s1.can_num == 0 && s2.can_num > 0) mated = -1 == s2.best;       // (a report of an empty read: mate -1)
 			else if (s1.can_num > 0 && s2.can_num == 0) mated = a.c_mate[s1.l.at(s1.best)] == 0;
 			else mated = false;                                                      // -1 == 0
-			if (!mated) {
-				if (s1.score > 0 && s2.score > 0) {
+			if (!mated || a.multi_hit) {                                             // (!bMultiHit && bMated returns, :438)
+				if (!mated && s1.score > 0 && s2.score > 0) {
 					int s = 0;
 					for (int i = 0; i < s1.can_num; ++i) {
 						int j;
@@ -1414,40 +1449,67 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 		}
 		s1.mapq = eval_mapq(a, s1);
 		s2.mapq = eval_mapq(a, s2);
-		// OutputPairedAlignments, src/Mapping.cpp:177-270 (bMultiHit false: only the best candidate is looked at)
+		// OutputPairedAlignments, src/Mapping.cpp:177-270: the best candidate, or with -m every candidate from the best one on that
+		// still has a positive score
+		const bool both_unique = s1.score > s1.sub_score && s2.score > s2.sub_score;
 		long long add_paired = 0, add_dist = 0;
+		int add_unmapped = 0, add_unique = 0;
+		bool full = false;
 		if (s1.score == 0) {
-			atomicAdd(&cs.unmapped, 1);
+			add_unmapped++;
 			write_record(a, r, s1, KG_ALN_UNMAPPED, f1, false, 0, 0, false);
 		} else {
-			if (s1.mapq == 60) atomicAdd(&cs.unique, 1);
-			if (rep_score_at(a, s1, s1.best) > 0) {
-				int j = rep_mate_at(a, s1, s1.best);
-				bool fwd = rep_fwd_at(a, s1, s1.best);
-				if (j != -1 && rep_score_at(a, s2, j) > 0) {
-					int dist = (int)(a.rep_pos[s2.l.at(j)] - a.rep_pos[s1.l.at(s1.best)] + (fwd ? s2.rlen : 0 - s1.rlen));
-					add_paired = 2;
-					int ad = dist < 0 ? -dist : dist;
-					if (ad < 10000) add_dist = ad;
-					write_record(a, r, s1, KG_ALN_MAPPED, f1, true, a.rep_pos[s2.l.at(j)], dist, !fwd);
-				} else write_record(a, r, s1, KG_ALN_MAPPED, f1, false, 0, 0, !fwd);
-			} else write_record(a, r, s1, KG_ALN_NONE, 0, false, 0, 0, false);
+			if (s1.mapq == 60) add_unique++;
+			int64_t last = -1, at = r;
+			for (int i = s1.best; i < s1.can_num && !full; ++i) {
+				if (rep_score_at(a, s1, i) > 0) {
+					if (!next_slot(a, r, last, at)) { full = true; break; }
+					int fl = a.multi_hit ? multi_flag(a, s1, s2, i, 0x41, both_unique, f1) : f1;
+					int j = rep_mate_at(a, s1, i);
+					bool fwd = rep_fwd_at(a, s1, i);
+					if (j != -1 && rep_score_at(a, s2, j) > 0) {
+						int dist = (int)(a.rep_pos[s2.l.at(j)] - a.rep_pos[s1.l.at(i)] + (fwd ? s2.rlen : 0 - s1.rlen));
+						if (i == s1.best) {
+							add_paired = 2;
+							int ad = dist < 0 ? -dist : dist;
+							if (ad < 10000) add_dist = ad;
+						}
+						write_record_at(a, at, s1, i, KG_ALN_MAPPED, fl, true, a.rep_pos[s2.l.at(j)], dist, !fwd);
+					} else write_record_at(a, at, s1, i, KG_ALN_MAPPED, fl, false, 0, 0, !fwd);
+				}
+				if (!a.multi_hit) break;
+			}
+			if (last < 0) write_record(a, r, s1, KG_ALN_NONE, 0, false, 0, 0, false);
 		}
 		if (s2.score == 0) {
-			atomicAdd(&cs.unmapped, 1);
+			add_unmapped++;
 			write_record(a, r + 1, s2, KG_ALN_UNMAPPED, f2, false, 0, 0, false);
 		} else {
-			if (s2.mapq == 60) atomicAdd(&cs.unique, 1);
-			if (rep_score_at(a, s2, s2.best) > 0) {
-				int i = rep_mate_at(a, s2, s2.best);
-				bool fwd = rep_fwd_at(a, s2, s2.best);
-				if (i != -1 && rep_score_at(a, s1, i) > 0) {
-					bool fwd1 = rep_fwd_at(a, s1, i);
-					int dist = 0 - (int)(a.rep_pos[s2.l.at(s2.best)] - a.rep_pos[s1.l.at(i)] + (fwd1 ? s2.rlen : 0 - s1.rlen));
-					write_record(a, r + 1, s2, KG_ALN_MAPPED, f2, true, a.rep_pos[s1.l.at(i)], dist, fwd);
-				} else write_record(a, r + 1, s2, KG_ALN_MAPPED, f2, false, 0, 0, fwd);
-			} else write_record(a, r + 1, s2, KG_ALN_NONE, 0, false, 0, 0, false);
+			if (s2.mapq == 60) add_unique++;
+			int64_t last = -1, at = r + 1;
+			for (int j = s2.best; j < s2.can_num && !full; ++j) {
+				if (rep_score_at(a, s2, j) > 0) {
+					if (!next_slot(a, r + 1, last, at)) { full = true; break; }
+					int fl = a.multi_hit ? multi_flag(a, s2, s1, j, 0x81, both_unique, f2) : f2;
+					int i = rep_mate_at(a, s2, j);
+					bool fwd = rep_fwd_at(a, s2, j);
+					if (i != -1 && rep_score_at(a, s1, i) > 0) {
+						bool fwd1 = rep_fwd_at(a, s1, i);
+						int dist = 0 - (int)(a.rep_pos[s2.l.at(j)] - a.rep_pos[s1.l.at(i)] + (fwd1 ? s2.rlen : 0 - s1.rlen));
+						write_record_at(a, at, s2, j, KG_ALN_MAPPED, fl, true, a.rep_pos[s1.l.at(i)], dist, fwd);
+					} else write_record_at(a, at, s2, j, KG_ALN_MAPPED, fl, false, 0, 0, fwd);
+				}
+				if (!a.multi_hit) break;
+			}
+			if (last < 0) write_record(a, r + 1, s2, KG_ALN_NONE, 0, false, 0, 0, false);
 		}
+		if (full) {                                    // no extra record slot left: the pair goes to the host
+			atomicAdd(&a.ctl[8 + WHY_CAPACITY], 1ull);
+			a.records[r].kind = KG_ALN_HOST; a.records[r + 1].kind = KG_ALN_HOST;
+			continue;
+		}
+		if (add_unmapped) atomicAdd(&cs.unmapped, add_unmapped);
+		if (add_unique) atomicAdd(&cs.unique, add_unique);
 		if (add_paired) {
 			atomicAdd((unsigned long long *)&cs.paired, (unsigned long long)add_paired);
 			if (add_dist) atomicAdd((unsigned long long *)&cs.distance, (unsigned long long)add_dist);
@@ -1458,7 +1520,7 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 __global__ void aln_reset_kernel(AlnArgs a)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < 7) a.ctl[i] = 0;       // (ctl[8..23]: running tallies of why pairs went back to the host, never reset)
+	if (i < 8) a.ctl[i] = 0;       // (ctl[8..23]: running tallies of why pairs went back to the host, never reset)
 	for (int c = i; c < a.n_chunks; c += gridDim.x * blockDim.x) {
 		kg_chunk_stats z;
 		z.paired = 0; z.distance = 0; z.lo = -1; z.hi = 0x7fffffffffffffffll; z.unmapped = 0; z.unique = 0; z.host_pairs = 0; z.rescue_wanted = 0;

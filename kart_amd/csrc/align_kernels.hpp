@@ -89,6 +89,9 @@ struct AlnArgs {
 	int64_t genome_size, two_genome_size;
 	// parameters
 	int est_distance, max_insert, max_gaps;
+	int multi_hit;                  // -m: every candidate the reference's output loops print (src/Mapping.cpp:194-223, 242-263, 293)
+	int unset_flag;                 // what a never-assigned SamFlag prints as
+	int64_t extra_capacity;         // records beyond one per read: records[n_reads .. n_reads + extra_capacity), handed out through ctl[7]
 	const uint8_t *mapq_tab;        // [(kAlnMaxScore + 1) * 6]: EvaluateMAPQ's libm branch, tabulated by the host
 	// per-candidate state
 	int32_t *c_score, *c_mate, *c_read;
@@ -114,7 +117,7 @@ struct AlnArgs {
 	int64_t job_capacity, ops_capacity;
 	AlnPlan *plans;                 // [job_capacity]
 	AlnPiece *pieces;               // [4 * job_capacity]
-	unsigned long long *ctl;        // [0] spill count, [1] job count, [2] ops bytes, [3] unused, [4] rescue tasks, [5] plans, [6] pieces
+	unsigned long long *ctl;        // [0] spill count, [1] job count, [2] ops bytes, [3] unused, [4] rescue tasks, [5] plans, [6] pieces, [7] extra records (-m)
 	uint8_t *nw_ops;
 	int32_t *nw_len;
 	// outputs

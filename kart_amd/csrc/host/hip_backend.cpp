@@ -75,7 +75,7 @@ public:
 		t_seed += t1 - t0; t_cands += t2 - t1; t_copy += t3 - t2;
 	}
 	bool align(const std::vector<int64_t> &chunk_off, const std::vector<uint8_t> &chunk_paired, int est, int max_insert, int max_gaps,
-	           const kg_aln_record *&records, std::vector<kg_chunk_stats> &chunk_stats) override
+	           bool multi_hit, int unset_flag, const kg_aln_record *&records, std::vector<kg_chunk_stats> &chunk_stats) override
 	{
 		static const bool off = getenv("KART_AMD_HOST_ALIGN") != nullptr;      // A/B aid: the whole report on the host, as before
 		if (off) return false;
@@ -83,7 +83,7 @@ public:
 		chunk_stats.resize((size_t)n_chunks);
 		const kg_aln_record *rec = nullptr;
 		double t0 = now_sec();
-		if (kg_align_batch(ws_, chunk_off.data(), chunk_paired.data(), n_chunks, est, max_insert, max_gaps, &rec, chunk_stats.data()) != KG_OK) die("kg_align_batch");
+		if (kg_align_batch(ws_, chunk_off.data(), chunk_paired.data(), n_chunks, est, max_insert, max_gaps, multi_hit ? 1 : 0, unset_flag, &rec, chunk_stats.data()) != KG_OK) die("kg_align_batch");
 		double t1 = now_sec();
 		records = rec;                    // (rotating pinned arrays, as above)
 		t_align += t1 - t0; t_reccopy += now_sec() - t1;

@@ -83,14 +83,14 @@ struct KernelBackend {
 	virtual void host_free(void *p) { free(p); }
 	// nw_alignment for the jobs of several chunks in one call (fills ops/len of every part)
 	virtual void nw_batch(std::vector<NwJobs *> &parts) = 0;
-	// The per-read report of the batch the last seed_and_chain() call left on the device (kg_align_batch): one record per read
+	// The per-read report of the batch the last seed_and_chain() call left on the device (kg_align_batch): one record per read (+ the chained ones of -m)
 	// (kind KG_ALN_HOST = this pair is the host's) and the chunks' pairing statistics under `est`.  false: this backend has no
 	// such stage -- the host maps every read itself.
 	// (`records`: storage of the backend, valid while the next three batches go through it)
 	virtual bool align(const std::vector<int64_t> &chunk_off, const std::vector<uint8_t> &chunk_paired, int est, int max_insert, int max_gaps,
-	                   const kg_aln_record *&records, std::vector<kg_chunk_stats> &chunk_stats)
+	                   bool multi_hit, int unset_flag, const kg_aln_record *&records, std::vector<kg_chunk_stats> &chunk_stats)
 	{
-		(void)chunk_off; (void)chunk_paired; (void)est; (void)max_insert; (void)max_gaps; (void)records; (void)chunk_stats;
+		(void)chunk_off; (void)chunk_paired; (void)est; (void)max_insert; (void)max_gaps; (void)multi_hit; (void)unset_flag; (void)records; (void)chunk_stats;
 		return false;
 	}
 	// diagnostics of the stage above (why pairs came back for the host), empty when there is none

@@ -190,7 +190,7 @@ def _run_verbose(binary, args, out, env=None):
     return r.stdout.decode(), r.stderr.decode()
 
 
-@pytest.mark.parametrize("case", ["pe", "pe_g2", "se", "edge_pe", "edge_se"])
+@pytest.mark.parametrize("case", ["pe", "pe_g2", "se", "edge_pe", "edge_se", "pe_m", "se_m", "edge_se_m"])
 def test_device_report_equals_the_host_report_record_by_record(case, product_binary, tmp_path):
     """kg_align_batch (pairing, mate rescue, normal pairs, 8-mer partition, NW, CIGAR, flags, MAPQ on the device) against the host
     implementation of the same reference code: KART_AMD_CHECK_ALIGN maps every read on the host as well and compares the SAM text

@@ -41,9 +41,10 @@ def run(tag, args, want=None, env=None):
     return out + ".dev"
 
 
-for case in ("pe", "pe_plain", "pe_g2", "pe_interleaved", "se", "se_fasta", "edge_pe", "edge_se", "edge_multi_lib"):
+for case in ("pe", "pe_plain", "pe_g2", "pe_interleaved", "se", "se_fasta", "edge_pe", "edge_se", "edge_multi_lib", "pe_m", "se_m", "edge_se_m"):
     args = [materialise(tmp, a) if a.endswith((".fq", ".fa", ".gz")) else a for a in CASES[case]]
     want = gzip.open(os.path.join(SAM, GOLD_OF.get(case, case) + ".sam.gz")).read()
+    # (-m prints records whose FLAG the reference never assigns: the goldens hold the product's default for those, 0)
     run(case, args, want)
 
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
@@ -70,5 +71,8 @@ for seed, err, ins in ((77, 0.02, 500.0), (78, 0.01, 300.0), (79, 0.04, 200.0)):
                 if x != y and shown < 5:
                     print("     ref:", x[:200].decode()); print("     dev:", y[:200].decode()); shown += 1
     run("live_se_%d" % seed, ["-f", f1])
+    # -m: every record the output loops print; never-assigned FLAGs print as 3000 on both sides of the comparison
+    run("live_m_%d" % seed, ["-f", f1, "-f2", f2, "-m"], env={"KART_AMD_UNSET_FLAG": "3000"})
+    run("live_se_m_%d" % seed, ["-f", f1, "-m"], env={"KART_AMD_UNSET_FLAG": "3000"})
 print("FAILED" if bad else "ALL OK", bad)
 sys.exit(1 if bad else 0)

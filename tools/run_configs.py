@@ -82,51 +82,63 @@ def same_up_to_unset_flags(a, b):
 
 
 # ---- configs[3]: -pacbio ----------------------------------------------------------------------------------------------------------
-fq = os.path.join(wd, "cfg3_long.fq")
-write_long_reads(fq, n_long, 7000, 0.15, seed=31)
-c3 = {"reads": n_long, "read_len": 7000, "error": 0.15}
-a = run([exe, "-silent", "-i", prefix, "-f", fq, "-pacbio", "-t", str(cores), "-o", os.path.join(wd, "cfg3_amd.sam")])
-c3["kart_amd"] = dict(a, reads_per_s_mapping_phase=round(n_long / a["mapping_seconds"]) if a.get("mapping_seconds") else None, reads_per_s_process=round(n_long / a["process_seconds"]))
-if os.path.exists(ref):
-    b = run([ref, "-silent", "-i", prefix, "-f", fq, "-pacbio", "-t", str(cores), "-o", os.path.join(wd, "cfg3_ref.sam")])
-    c3["reference_t%d" % cores] = dict(b, reads_per_s_process=round(n_long / b["process_seconds"]))
-    c3["same_records_as_reference"] = sorted(open(os.path.join(wd, "cfg3_amd.sam"), "rb").read().split(b"\n")) == sorted(open(os.path.join(wd, "cfg3_ref.sam"), "rb").read().split(b"\n"))
-    k = min(n_long, 3000)
-    pq = os.path.join(wd, "cfg3_prefix.fq")
-    head(fq, pq, 4 * k)
-    run([exe, "-silent", "-i", prefix, "-f", pq, "-pacbio", "-t", str(cores), "-o", os.path.join(wd, "cfg3_p_amd.sam")])
-    r1 = run([ref, "-silent", "-i", prefix, "-f", pq, "-pacbio", "-t", "1", "-o", os.path.join(wd, "cfg3_p_ref.sam")])
-    c3["prefix_identity_vs_reference_t1"] = {"reads": k, "identical": open(os.path.join(wd, "cfg3_p_amd.sam"), "rb").read() == open(os.path.join(wd, "cfg3_p_ref.sam"), "rb").read(),
-                                             "reference_t1_process_seconds": r1["process_seconds"]}
-res["configs[3] -pacbio"] = c3
-for f in ("cfg3_long.fq", "cfg3_amd.sam", "cfg3_ref.sam", "cfg3_prefix.fq", "cfg3_p_amd.sam", "cfg3_p_ref.sam"):
-    try: os.remove(os.path.join(wd, f))
-    except OSError: pass
+def config3():
+    fq = os.path.join(wd, "cfg3_long.fq")
+    write_long_reads(fq, n_long, 7000, 0.15, seed=31)
+    c3 = {"reads": n_long, "read_len": 7000, "error": 0.15}
+    a = run([exe, "-silent", "-i", prefix, "-f", fq, "-pacbio", "-t", str(cores), "-o", os.path.join(wd, "cfg3_amd.sam")])
+    c3["kart_amd"] = dict(a, reads_per_s_mapping_phase=round(n_long / a["mapping_seconds"]) if a.get("mapping_seconds") else None, reads_per_s_process=round(n_long / a["process_seconds"]))
+    if os.path.exists(ref):
+        b = run([ref, "-silent", "-i", prefix, "-f", fq, "-pacbio", "-t", str(cores), "-o", os.path.join(wd, "cfg3_ref.sam")])
+        c3["reference_t%d" % cores] = dict(b, reads_per_s_process=round(n_long / b["process_seconds"]))
+        c3["same_records_as_reference"] = sorted(open(os.path.join(wd, "cfg3_amd.sam"), "rb").read().split(b"\n")) == sorted(open(os.path.join(wd, "cfg3_ref.sam"), "rb").read().split(b"\n"))
+        k = min(n_long, 3000)
+        pq = os.path.join(wd, "cfg3_prefix.fq")
+        head(fq, pq, 4 * k)
+        run([exe, "-silent", "-i", prefix, "-f", pq, "-pacbio", "-t", str(cores), "-o", os.path.join(wd, "cfg3_p_amd.sam")])
+        r1 = run([ref, "-silent", "-i", prefix, "-f", pq, "-pacbio", "-t", "1", "-o", os.path.join(wd, "cfg3_p_ref.sam")])
+        c3["prefix_identity_vs_reference_t1"] = {"reads": k, "identical": open(os.path.join(wd, "cfg3_p_amd.sam"), "rb").read() == open(os.path.join(wd, "cfg3_p_ref.sam"), "rb").read(),
+                                                 "reference_t1_process_seconds": r1["process_seconds"]}
+    res["configs[3] -pacbio"] = c3
+    for f in ("cfg3_long.fq", "cfg3_amd.sam", "cfg3_ref.sam", "cfg3_prefix.fq", "cfg3_p_amd.sam", "cfg3_p_ref.sam"):
+        try: os.remove(os.path.join(wd, f))
+        except OSError: pass
+
 
 # ---- configs[4]: -m, 2 % error ---------------------------------------------------------------------------------------------------
-f1, f2 = os.path.join(wd, "cfg4_1.fq"), os.path.join(wd, "cfg4_2.fq")
-bench.write_fastq_pairs(codes, n_mh, 41, f1, f2, dev, err=0.021)
-c4 = {"reads": 2 * n_mh, "error": 0.021}
-a = run([exe, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-m", "-t", str(cores), "-o", os.path.join(wd, "cfg4_amd.sam")])
-c4["kart_amd"] = dict(a, reads_per_s_mapping_phase=round(2 * n_mh / a["mapping_seconds"]) if a.get("mapping_seconds") else None, reads_per_s_process=round(2 * n_mh / a["process_seconds"]))
-# the same reads without -m (the device report handles the single-hit configuration)
-a2 = run([exe, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-t", str(cores), "-o", os.path.join(wd, "cfg4_amd_nom.sam")])
-c4["kart_amd_without_m"] = dict(a2, reads_per_s_mapping_phase=round(2 * n_mh / a2["mapping_seconds"]) if a2.get("mapping_seconds") else None)
-if os.path.exists(ref):
-    b = run([ref, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-m", "-t", str(cores), "-o", os.path.join(wd, "cfg4_ref.sam")])
-    c4["reference_t%d" % cores] = dict(b, reads_per_s_process=round(2 * n_mh / b["process_seconds"]))
-    k = min(n_mh, 100_000)
-    p1, p2 = os.path.join(wd, "cfg4_p1.fq"), os.path.join(wd, "cfg4_p2.fq")
-    head(f1, p1, 4 * k); head(f2, p2, 4 * k)
-    ident = {}
-    for tag, flags in (("with_m", ["-m"]), ("without_m", [])):
-        run([exe, "-silent", "-i", prefix, "-f", p1, "-f2", p2, "-t", str(cores), "-o", os.path.join(wd, "cfg4_p_amd.sam")] + flags, env={"KART_AMD_UNSET_FLAG": str(UNSET)})
-        run([ref, "-silent", "-i", prefix, "-f", p1, "-f2", p2, "-t", "1", "-o", os.path.join(wd, "cfg4_p_ref.sam")] + flags)
-        ok, masked = same_up_to_unset_flags(open(os.path.join(wd, "cfg4_p_ref.sam"), "rb").read(), open(os.path.join(wd, "cfg4_p_amd.sam"), "rb").read())
-        ident[tag] = {"reads": 2 * k, "identical_up_to_never_assigned_flags": ok, "records_with_never_assigned_flag": masked}
-    c4["prefix_identity_vs_reference_t1"] = ident
-res["configs[4] -m"] = c4
-for f in ("cfg4_1.fq", "cfg4_2.fq", "cfg4_amd.sam", "cfg4_amd_nom.sam", "cfg4_ref.sam", "cfg4_p1.fq", "cfg4_p2.fq", "cfg4_p_amd.sam", "cfg4_p_ref.sam"):
-    try: os.remove(os.path.join(wd, f))
-    except OSError: pass
+def config4():
+    f1, f2 = os.path.join(wd, "cfg4_1.fq"), os.path.join(wd, "cfg4_2.fq")
+    bench.write_fastq_pairs(codes, n_mh, 41, f1, f2, dev, err=0.021)
+    c4 = {"reads": 2 * n_mh, "error": 0.021}
+    a = run([exe, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-m", "-t", str(cores), "-o", os.path.join(wd, "cfg4_amd.sam")])
+    c4["kart_amd"] = dict(a, reads_per_s_mapping_phase=round(2 * n_mh / a["mapping_seconds"]) if a.get("mapping_seconds") else None, reads_per_s_process=round(2 * n_mh / a["process_seconds"]))
+    # the same reads without -m (same device report, one record per read)
+    a2 = run([exe, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-t", str(cores), "-o", os.path.join(wd, "cfg4_amd_nom.sam")])
+    c4["kart_amd_without_m"] = dict(a2, reads_per_s_mapping_phase=round(2 * n_mh / a2["mapping_seconds"]) if a2.get("mapping_seconds") else None)
+    if os.path.exists(ref):
+        b = run([ref, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-m", "-t", str(cores), "-o", os.path.join(wd, "cfg4_ref.sam")])
+        c4["reference_t%d" % cores] = dict(b, reads_per_s_process=round(2 * n_mh / b["process_seconds"]))
+        k = min(n_mh, 100_000)
+        p1, p2 = os.path.join(wd, "cfg4_p1.fq"), os.path.join(wd, "cfg4_p2.fq")
+        head(f1, p1, 4 * k); head(f2, p2, 4 * k)
+        ident = {}
+        for tag, flags in (("with_m", ["-m"]), ("without_m", [])):
+            run([exe, "-silent", "-i", prefix, "-f", p1, "-f2", p2, "-t", str(cores), "-o", os.path.join(wd, "cfg4_p_amd.sam")] + flags, env={"KART_AMD_UNSET_FLAG": str(UNSET)})
+            run([ref, "-silent", "-i", prefix, "-f", p1, "-f2", p2, "-t", "1", "-o", os.path.join(wd, "cfg4_p_ref.sam")] + flags)
+            ok, masked = same_up_to_unset_flags(open(os.path.join(wd, "cfg4_p_ref.sam"), "rb").read(), open(os.path.join(wd, "cfg4_p_amd.sam"), "rb").read())
+            ident[tag] = {"reads": 2 * k, "identical_up_to_never_assigned_flags": ok, "records_with_never_assigned_flag": masked}
+            # the device report against the host's implementation of the same reference code, record by record
+            chk = subprocess.run([exe, "-silent", "-i", prefix, "-f", p1, "-f2", p2, "-t", str(cores), "-o", os.path.join(wd, "cfg4_p_amd.sam")] + flags, stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, env=dict(os.environ, KART_AMD_VERBOSE="1", KART_AMD_CHECK_ALIGN="1", KART_AMD_UNSET_FLAG=str(UNSET)))
+            ident[tag]["check_align"] = [l for l in chk.stdout.decode().splitlines() if l.startswith("CHECK_ALIGN")]
+        c4["prefix_identity_vs_reference_t1"] = ident
+    res["configs[4] -m"] = c4
+    for f in ("cfg4_1.fq", "cfg4_2.fq", "cfg4_amd.sam", "cfg4_amd_nom.sam", "cfg4_ref.sam", "cfg4_p1.fq", "cfg4_p2.fq", "cfg4_p_amd.sam", "cfg4_p_ref.sam"):
+        try: os.remove(os.path.join(wd, f))
+        except OSError: pass
+
+if n_long > 0:
+    config3()
+if n_mh > 0:
+    config4()
 print(json.dumps(res))
