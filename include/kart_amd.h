@@ -100,6 +100,9 @@ typedef struct {
 	uint64_t table_lookups, rank_steps, rank_steps_two_lines, sa_gathers, text_rounds, window_words, hits, searches;
 	uint64_t sa_entry_bytes;
 	uint64_t rank_steps_two_lines_narrow;   /* two-line rank steps on an interval of fewer than 960 suffixes (what a 960-symbols-per-line plane layout would serve from one line) */
+	uint64_t double_steps;                  /* two extension steps taken at once on the pair planes (one or two 128-byte lines, 896 rows of one pair of bases each) */
+	uint64_t double_steps_two_lines;        /* ... whose interval ends lie in different lines */
+	uint64_t double_step_bytes;             /* bytes those ranks read: per line its 16-byte header and the 16-byte segment(s) holding the rows asked for */
 } kg_traffic_t;
 
 const char *kg_last_error(void);            /* thread-local message of the last failure */
@@ -119,6 +122,10 @@ int  kg_index_contig(const kg_index *ix, int i, kg_contig_t *out);
  * sa_full[n] (may be NULL): the expanded suffix array's entry when the index was loaded with KG_SA_FULL (there SA[0] = 2L,
  * where the reference's sa[0] = -1 yields 2^64-1), else (uint64_t)-1. */
 int  kg_rank_sa_batch(kg_index *ix, const uint64_t *k, int64_t n, uint64_t *occ4, uint64_t *sa_walk, uint64_t *sa_full);
+/* Known-answer check of the device-private two-step rank structure: `samples` pseudo-random intervals of every width and
+ * every pair of bases, one double step against two single BWT_Search steps (src/bwt_search.cpp:157-168) on the plain rank
+ * structure.  *disagreements must come back 0. */
+int  kg_index_selfcheck(kg_index *ix, int64_t samples, uint64_t seed, uint64_t *disagreements);
 
 /* Page-locked host memory for the buffers a caller hands to kg_seed_batch (the copy to the device then runs at the link's
  * rate instead of through a staging buffer).  NULL when none can be had. */
@@ -131,6 +138,10 @@ int  kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_
 void kg_workspace_destroy(kg_workspace *ws);
 int  kg_workspace_counters(kg_workspace *ws, kg_counters_t *out);   /* synchronises the device */
 int  kg_workspace_traffic(kg_workspace *ws, kg_traffic_t *out);     /* synchronises the device */
+/* The search takes two extension steps at once where it can (pair planes); the reference's per-step block accounting
+ * (kg_counters_t lf1 / lf2, bwt_2occ4's one-or-two-blocks split, src/bwt_search.cpp:92) is then exact for lf1 + lf2 only.
+ * enabled != 0: single steps only -- same seeds, the lf1 / lf2 split exact as well. */
+int  kg_workspace_set_single_steps(kg_workspace *ws, int enabled);
 /* Per-kernel timing: when enabled, every kg_seed_batch* call brackets its kernels with HIP events
  * on the launch stream; kg_workspace_kernel_ms() synchronises and returns the durations of the
  * last call in milliseconds: ms[0] search, ms[1] scan+offsets, ms[2] locate, ms[3] sort. */

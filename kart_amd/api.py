@@ -36,7 +36,7 @@ CAND_DT = np.dtype([("posDiff", "<i8"), ("score", "<i4"), ("count", "<i4"), ("fi
 ABI_SYMBOLS = (
     "kg_last_error", "kg_device_count", "kg_index_load", "kg_index_destroy", "kg_index_info",
     "kg_index_contig", "kg_host_alloc", "kg_host_free", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters", "kg_workspace_traffic",
-    "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_align_batch", "kg_align_reasons", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
+    "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_set_single_steps", "kg_index_selfcheck", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_align_batch", "kg_align_reasons", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
 )
 
 
@@ -72,21 +72,22 @@ class Counters(C.Structure):
 class Traffic(C.Structure):
     """kg_traffic_t: what the search kernel itself fetched in the last batch (the implemented algorithm)."""
     _fields_ = [(n, C.c_uint64) for n in ("table_lookups", "rank_steps", "rank_steps_two_lines", "sa_gathers", "text_rounds", "window_words",
-                                          "hits", "searches", "sa_entry_bytes", "rank_steps_two_lines_narrow")]
+                                          "hits", "searches", "sa_entry_bytes", "rank_steps_two_lines_narrow", "double_steps", "double_steps_two_lines",
+                                          "double_step_bytes")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
     def useful_bytes(self, n_reads: int) -> int:
         """bytes the implemented search needs per launch (see include/kart_amd.h, kg_traffic_t)"""
-        return (8 * self.table_lookups + 32 * self.rank_steps + self.sa_entry_bytes * self.sa_gathers + 48 * self.text_rounds
+        return (8 * self.table_lookups + 32 * self.rank_steps + self.double_step_bytes + self.sa_entry_bytes * self.sa_gathers + 48 * self.text_rounds
                 + 8 * self.window_words + 20 * n_reads + 32 * self.hits)
 
     def min_lines(self, n_reads: int) -> int:
         """128-byte lines a launch cannot avoid touching with this layout: one per table lookup / SA gather, one or two per rank
-        step, the text and read lines of a comparison round (a 16-byte text window straddles a line boundary 1 time in 8, a
+        single step, one or two per double step, the text and read lines of a comparison round (a 16-byte text window straddles a line boundary 1 time in 8, a
         32-byte read window 1 in 4), the hit records and per-read words (dense)"""
-        return int(self.table_lookups + self.rank_steps + self.rank_steps_two_lines + self.sa_gathers + self.text_rounds * (1.125 + 1.25)
+        return int(self.table_lookups + self.rank_steps + self.rank_steps_two_lines + self.double_steps + self.double_steps_two_lines + self.sa_gathers + self.text_rounds * (1.125 + 1.25)
                    + (8 * self.window_words + 20 * n_reads + 32 * self.hits) / 128)
 
 
@@ -116,6 +117,8 @@ def load_library() -> C.CDLL:
     L.kg_workspace_traffic.argtypes = [C.c_void_p, C.POINTER(Traffic)]
     L.kg_workspace_overflow.argtypes = [C.c_void_p]
     L.kg_workspace_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.kg_workspace_set_single_steps.argtypes = [C.c_void_p, C.c_int]
+    L.kg_index_selfcheck.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.kg_workspace_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float * 4)]
     L.kg_workspace_overflow.restype = C.c_int64
     L.kg_seed_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
@@ -179,6 +182,10 @@ class Workspace:
 
     def overflow(self) -> int:
         return int(self.lib.kg_workspace_overflow(self.h))
+
+    def set_single_steps(self, enabled: bool = True):
+        """single extension steps only: the reference's lf1 / lf2 block accounting is then exact (kg_workspace_set_single_steps)"""
+        _check(self.lib.kg_workspace_set_single_steps(self.h, int(enabled)), "kg_workspace_set_single_steps")
 
     def set_profiling(self, enabled: bool = True):
         _check(self.lib.kg_workspace_set_profiling(self.h, int(enabled)), "kg_workspace_set_profiling")
@@ -271,6 +278,12 @@ class Index:
         return ws
 
     # -- rank / suffix array (bwt_occ4, bwt_sa) ------------------------------------------------------
+    def selfcheck(self, samples: int = 1 << 20, seed: int = 1) -> int:
+        """disagreements between one double step on the pair planes and two single BWT_Search steps (kg_index_selfcheck)"""
+        bad = C.c_uint64(0)
+        _check(self.lib.kg_index_selfcheck(self.h, samples, seed, C.byref(bad)), "kg_index_selfcheck")
+        return int(bad.value)
+
     def rank_sa(self, ks):
         """(occ4[n,4], sa_walk[n], sa_full[n]) for ranks ks: bwt_occ4 / bwt_sa of the reference on the device layouts."""
         ks = np.ascontiguousarray(ks, dtype=np.uint64)

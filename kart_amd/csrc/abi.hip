@@ -108,6 +108,7 @@ struct kg_index {
 	// device allocations
 	uint32_t *d_occ = nullptr;
 	uint4 *d_planes = nullptr;
+	uint4 *d_planes2 = nullptr;        // two-step rank structure (fm_device.hpp)
 	void *d_qtab = nullptr;
 	uint64_t *d_sa = nullptr;
 	void *d_fsa = nullptr;
@@ -132,6 +133,7 @@ struct kg_workspace {
 	void *d_scan_temp = nullptr;
 	size_t scan_bytes = 0;
 	uint32_t *d_sort_keys = nullptr;    // EXPERIMENT (KG_SORT_READS)
+	bool single_steps = false;          // kg_workspace_set_single_steps
 	void *d_sort_temp = nullptr;
 	size_t sort_bytes = 0;
 	// staging for the host-buffer entry point
@@ -356,6 +358,23 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		v.planes = ix->d_planes;
 		ix->device_bytes += plane_bytes;
 	}
+	v.planes2 = nullptr;
+	for (int i = 0; i < 16; ++i) v.t2[i] = 0;
+	if (!getenv("KG_NO_PLANES2")) {
+		// two-step rank structure: one 128-byte line per 896 rows and pair of bases (2.29 bytes/symbol); an accelerator like the
+		// q-mer table -- without it the search takes single steps
+		uint64_t n_lines = (v.seq_len + kPlane2Rows - 1) / kPlane2Rows;
+		size_t bytes = (size_t)n_lines * 16 * 128;
+		uint64_t *t2_dev = nullptr;
+		if (hipMalloc((void **)&ix->d_planes2, bytes) == hipSuccess) {
+			HIP_TRY(hipMalloc((void **)&t2_dev, 16 * 8));
+			HIP_TRY(launch_build_planes2(v, ix->d_planes2, n_lines, t2_dev, nullptr));
+			HIP_TRY(hipMemcpy(v.t2, t2_dev, 16 * 8, hipMemcpyDeviceToHost));
+			HIP_TRY(hipFree(t2_dev));
+			v.planes2 = ix->d_planes2;
+			ix->device_bytes += bytes;
+		} else (void)hipGetLastError();
+	}
 	v.fsa32 = nullptr;
 	v.fsa64 = nullptr;
 	v.text = nullptr;
@@ -419,6 +438,7 @@ void kg_index_destroy(kg_index *ix)
 	(void)hipSetDevice(ix->device);
 	if (ix->d_occ) (void)hipFree(ix->d_occ);
 	if (ix->d_planes) (void)hipFree(ix->d_planes);
+	if (ix->d_planes2) (void)hipFree(ix->d_planes2);
 	if (ix->d_qtab) (void)hipFree(ix->d_qtab);
 	for (NwScratch *sc : ix->nw_pool) {
 		if (sc->done) { (void)hipEventSynchronize(sc->done); (void)hipEventDestroy(sc->done); }
@@ -570,6 +590,32 @@ int kg_workspace_traffic(kg_workspace *ws, kg_traffic_t *out)
 	out->text_rounds = ctl[20]; out->window_words = ctl[21]; out->rank_steps_two_lines_narrow = ctl[22];
 	out->sa_gathers = ctl[8]; out->hits = ctl[1]; out->searches = ctl[4];
 	out->sa_entry_bytes = (ws->ix->view.fsa32 ? 4 : 8);
+	out->double_steps = ctl[23]; out->double_steps_two_lines = ctl[24]; out->double_step_bytes = ctl[25];
+	return KG_OK;
+}
+
+int kg_workspace_set_single_steps(kg_workspace *ws, int enabled)
+{
+	if (!ws) return fail(KG_ERR_ARG, "kg_workspace_set_single_steps: null workspace");
+	ws->single_steps = enabled != 0;
+	return KG_OK;
+}
+
+int kg_index_selfcheck(kg_index *ix, int64_t samples, uint64_t seed, uint64_t *disagreements)
+{
+	if (!ix || !disagreements || samples < 0) return fail(KG_ERR_ARG, "kg_index_selfcheck: bad argument");
+	*disagreements = 0;
+	if (!ix->view.planes2) return fail(KG_ERR_ARG, "kg_index_selfcheck: the index holds no two-step rank structure");
+	HIP_TRY(hipSetDevice(ix->device));
+	unsigned long long *bad = nullptr;
+	HIP_TRY(hipMalloc((void **)&bad, 8));
+	HIP_TRY(hipMemset(bad, 0, 8));
+	hipError_t e = launch_planes2_check(ix->view, (uint64_t)samples, seed, bad, nullptr);
+	unsigned long long h = 0;
+	hipError_t e2 = hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
+	(void)hipFree(bad);
+	if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_index_selfcheck: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+	*disagreements = h;
 	return KG_OK;
 }
 
@@ -638,6 +684,7 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.min_seed_len = min_seed_len;
 	a.occ_thr = occ_thr;
 	a.packed = ws->d_packed;
+	a.single_steps = ws->single_steps ? 1 : 0;
 	a.read_order = nullptr; a.sort_keys = ws->d_sort_keys; a.sort_temp = ws->d_sort_temp; a.sort_temp_bytes = ws->sort_bytes;
 	a.hits = ws->d_hits;
 	a.max_hits = ws->max_hits;

@@ -14,6 +14,14 @@
 //           made the search kernel VALU-bound even with the index in L2).  1 byte/symbol: 9.3 MB
 //           for E. coli, 6.2 GB for hg38 -- cheap against 288 GB of HBM; every rank still touches
 //           exactly one 64-byte line.
+//   planes2: DEVICE-PRIVATE two-step rank structure built once at load (index_build.inc): for every ordered pair of
+//           bases (c1, c2) a bit-plane over the BWT rows: bit p set iff BWT[p] == c1 and BWT[LF(p)] == c2 (the two text
+//           characters in front of the row's suffix).  One 128-byte LINE = 896 rows of ONE pair: a 16-byte header
+//           { u64 count of the pair before the line's first row, 6 x 10-bit counts of the line's rows before its 2nd ..
+//           7th segment } and seven 16-byte segments of 128 rows; line index = (p / 896) * 16 + c1 * 4 + c2.  A rank =
+//           header + one segment (two 16-byte gathers from ONE line).  Two backward-search steps then cost one rank pair
+//           in one plane: both ends of an interval narrower than a line come out of the same line, wider ones out of two
+//           -- against (1 + 2 x 0.63) x 2 lines for the same two steps on `planes`.  2.29 bytes/symbol: 14.2 GB for hg38.
 //   sa    : u64 sample per 32 ranks, sa[0] = (u64)-1 (reference src/bwt_index.cpp:16-36).
 //   fsa   : optional full suffix array (u32 when 2L < 2^32, else u64), expanded on the device at
 //           load time; turns the ~31-step LF walk of bwt_sa() into one 4/8-byte gather.
@@ -25,6 +33,7 @@ namespace kg {
 
 struct FmView {
 	const uint4 *planes;   // device-private rank structure, see below
+	const uint4 *planes2;  // two-step rank structure (null: single steps only), see below
 	const uint32_t *occ;
 	const uint64_t *sa;
 	const uint32_t *fsa32;
@@ -45,7 +54,11 @@ struct FmView {
 	uint64_t primary;
 	uint64_t seq_len;
 	uint64_t L2[5];
+	// two steps at once (first c1, then c2): k'' = t2[c1 * 4 + c2] + rank2(k - 1), where t2 = L2[c2] + 1 + occ(L2[c1], c2)
+	uint64_t t2[16];
 };
+
+constexpr uint32_t kPlane2Rows = 896;   // rows per 128-byte line of planes2 (7 segments of 128)
 
 constexpr int kQmerMin = 8, kQmerMax = 16;
 
@@ -78,6 +91,27 @@ __device__ __forceinline__ uint64_t lf_step_plane(const FmView &ix, uint64_t k)
 	uint64_t m = (2ull << pos) - 1;
 	uint64_t l2 = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
 	return l2 + cnt + (uint64_t)__popcll(bits & m);
+}
+
+// rank of row `pos` (0..895, inclusive) within one planes2 line, from its header and the segment holding the row
+__device__ __forceinline__ uint64_t rank2_line(uint4 hdr, uint4 sg, uint32_t pos)
+{
+	uint64_t cnt = ((uint64_t)hdr.y << 32) | hdr.x, subs = ((uint64_t)hdr.w << 32) | hdr.z;
+	uint32_t s = pos >> 7, w = pos & 127;
+	uint32_t sub = s ? (uint32_t)(subs >> (10 * (s - 1))) & 1023u : 0u;
+	uint64_t lo = ((uint64_t)sg.y << 32) | sg.x, hi = ((uint64_t)sg.w << 32) | sg.z;
+	uint64_t mlo = w >= 64 ? ~0ull : (2ull << w) - 1;                 // (w = 63: 2 << 63 wraps to 0, minus 1 = all ones)
+	uint64_t mhi = w < 64 ? 0ull : (2ull << (w - 64)) - 1;
+	return cnt + sub + (uint64_t)(__popcll(lo & mlo) + __popcll(hi & mhi));
+}
+
+// occurrences of the pair (c1, c2) in rows [0..kk] ($-less coordinate)
+__device__ __forceinline__ uint64_t rank2_plane(const FmView &ix, uint64_t kk, int pair)
+{
+	uint64_t blk = kk / kPlane2Rows;
+	uint32_t pos = (uint32_t)(kk - blk * kPlane2Rows);
+	const uint4 *line = ix.planes2 + (((blk << 4) + (uint64_t)pair) << 3);
+	return rank2_line(line[0], line[1 + (pos >> 7)], pos);
 }
 
 }  // namespace kg

@@ -23,8 +23,8 @@ struct Hit {
 //   [12..16] reads on the sort work lists: 9..16, 17..32, 33..64 seeds (4 / 2 / 1 lists per wave), 65..256 (small LDS),
 //            > 256 (large LDS)
 //   [17..21] what the search kernel itself fetched: q-mer table lookups, rank steps executed, those touching two 128-byte
-//            lines, text-comparison rounds, packed window words, two-line rank steps on intervals below 960 (kg_workspace_traffic)
-constexpr int kCtlWords = 23;
+//            lines, text-comparison rounds, packed window words, two-line rank steps on intervals below 960, double steps, those with two lines, bytes their ranks read (kg_workspace_traffic)
+constexpr int kCtlWords = 26;
 
 struct SeedArgs {
 	FmView ix;
@@ -38,6 +38,7 @@ struct SeedArgs {
 	uint64_t *packed;    // 4-bit read codes, 16 per word, read r at word (read_off[r] >> 4) + 3 r
 	// EXPERIMENT (KG_SORT_READS): the order in which the search kernel's lanes draw the reads -- sorted by the first 16 bases, so
 	// that lanes of a wave start in neighbouring q-mer table entries / rank lines; null = input order
+	int single_steps;         // 1: never take two steps at once (the reference's per-step block accounting, counters lf1 / lf2, is then exact)
 	int32_t *read_order;
 	uint32_t *sort_keys;      // [4 * max_reads]: keys in, keys out, ids in, ids out
 	void *sort_temp;
@@ -57,6 +58,8 @@ size_t sort_temp_bytes(int64_t max_reads);
 // ev: optional array of 5 events recorded before/after the four phases (search | scan | locate | sort)
 hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream, hipEvent_t *ev);
 hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *planes, hipStream_t stream);
+hipError_t launch_build_planes2(FmView ix, uint4 *planes2, uint64_t n_lines, uint64_t *t2_dev, hipStream_t stream);
+hipError_t launch_planes2_check(const FmView &ix, uint64_t samples, uint64_t seed, unsigned long long *bad_dev, hipStream_t stream);
 hipError_t launch_build_text(const uint8_t *pac, uint64_t l_pac, uint8_t *text, uint64_t n_bytes, hipStream_t stream);
 hipError_t launch_build_qtab(const FmView &ix, int q, uint2 *t32, uint64_t *t64, hipStream_t stream);
 hipError_t launch_rank_sa(const FmView &ix, const uint64_t *ks, int64_t n, uint64_t *occ4, uint64_t *sa_walk, uint64_t *sa_full, hipStream_t stream);

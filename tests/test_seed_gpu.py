@@ -36,6 +36,7 @@ def test_counters_match_oracle(golden, gpu_index, oracle_small):
     oracle_small.seed_batch(golden["fast_enc"], golden["fast_off"], 0)
     want = oracle_small.counters(reset=True)
     ws = gpu_index.workspace(len(golden["fast_off"]) - 1, len(golden["fast_enc"]))
+    ws.set_single_steps(True)         # (double steps keep lf1 + lf2, not the split: second test below)
     ws.seed_batch(golden["fast_enc"], golden["fast_off"], 0)
     got = ws.counters().as_dict()
     # the kernel walks LF from the ranks of the reverse-complement interval (x[1]+i) while the
@@ -55,11 +56,41 @@ def test_counters_with_text_comparison(golden, gpu_index_full, oracle_small):
     oracle_small.seed_batch(golden["fast_enc"], golden["fast_off"], 0)
     want = oracle_small.counters(reset=True)
     ws = gpu_index_full.workspace(len(golden["fast_off"]) - 1, len(golden["fast_enc"]))
+    ws.set_single_steps(True)
     ws.seed_batch(golden["fast_enc"], golden["fast_off"], 0)
     got = ws.counters().as_dict()
     assert got["searches"] == want["searches"] and got["seeds"] == want["seeds"] and got["bases"] == want["bases"]
     assert got["lf1"] + got["lf2"] == want["lf1"] + want["lf2"]
     assert got["lf2"] <= want["lf2"] and want["lf2"] - got["lf2"] < 0.02 * (want["lf1"] + want["lf2"])
+
+
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_double_steps_keep_the_step_count_and_the_seeds(golden, which, mode, request):
+    """two extension steps at once on the pair planes (the default): same seeds and the same total of the reference's steps as
+    with single steps (whose counters test_counters_match_oracle pins to the oracle), and the kernel reports double steps"""
+    ix = request.getfixturevalue(which)
+    enc, off = (golden["fast_enc"], golden["fast_off"]) if mode == 0 else (golden["sens_enc"], golden["sens_off"])
+    res = []
+    for single in (False, True):
+        ws = ix.workspace(len(off) - 1, len(enc))
+        ws.set_single_steps(single)
+        o, seeds = ws.seed_batch(enc, off, mode)
+        res.append((o.copy(), seeds.copy(), ws.counters().as_dict(), ws.traffic().as_dict()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    a, b = res[0][2], res[1][2]
+    assert a["lf1"] + a["lf2"] == b["lf1"] + b["lf2"] and a["searches"] == b["searches"] and a["seeds"] == b["seeds"]
+    assert res[0][3]["double_steps"] > 0 and res[1][3]["double_steps"] == 0
+    assert res[0][3]["rank_steps"] < res[1][3]["rank_steps"]
+
+
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full"])
+def test_pair_planes_known_answers(which, request):
+    """device KAT of the two-step rank structure: 4 M pseudo-random intervals of every width x every pair of bases, one double
+    step == two single BWT_Search steps (src/bwt_search.cpp:157-168) on the plain rank structure"""
+    ix = request.getfixturevalue(which)
+    for seed in (1, 2, 3):
+        assert ix.selfcheck(1 << 22, seed) == 0
 
 
 def test_empty_and_tiny_batches(gpu_index):

@@ -30,6 +30,13 @@ def run(tag, exe, t):
         if line.startswith(("stage seconds", "worker thread-seconds", "All the", "device report", "CHECK_ALIGN", "chunks re-mapped", "cpu seconds")):
             res[tag].setdefault("log", []).append(line.strip())
 run("kart_amd", "kart_amd/bin/kart-amd", threads)
+for i, setting in enumerate(filter(None, os.environ.get("E2E_SWEEP", "").split(";"))):       # e.g. "KART_AMD_WRITER_AHEAD=1;;KART_AMD_WRITER_MODE=0"
+    kv = dict(x.split("=", 1) for x in setting.split(",") if "=" in x)
+    os.environ.update(kv)
+    run("sweep%d" % i, "kart_amd/bin/kart-amd", threads)
+    res["sweep%d" % i]["setting"] = setting
+    for k in kv:
+        del os.environ[k]
 if os.environ.get("E2E_CHECK_ALIGN"):      # every device record against the host's text for the same read (slow: the host maps everything too)
     os.environ["KART_AMD_CHECK_ALIGN"] = "1"
     run("kart_amd_check_align", "kart_amd/bin/kart-amd", threads)
