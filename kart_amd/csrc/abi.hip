@@ -968,7 +968,7 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		HIP_TRY(hipMalloc((void **)&ws->d_jobs, sizeof(NwJobDesc) * (size_t)ws->job_capacity));
 		HIP_TRY(hipMalloc((void **)&ws->d_job_ops, (size_t)ws->ops_capacity + 1024));
 		HIP_TRY(hipMalloc((void **)&ws->d_job_len, 4 * (size_t)ws->job_capacity));
-		HIP_TRY(hipMalloc((void **)&ws->d_plans, sizeof(AlnPlan) * (size_t)ws->job_capacity + sizeof(AlnPiece) * 4 * (size_t)ws->job_capacity));
+		HIP_TRY(hipMalloc((void **)&ws->d_plans, sizeof(AlnPlan) * (size_t)ws->job_capacity + sizeof(AlnPiece) * 4 * (size_t)ws->job_capacity + 16 + sizeof(PartTask) * (size_t)ws->job_capacity));
 		ws->aln_read_capacity = cap;
 	}
 	if (n_chunks > ws->chunk_capacity) {
@@ -997,6 +997,7 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 	a.genome_size = ix->l_pac; a.two_genome_size = 2 * ix->l_pac;
 	a.est_distance = est_distance; a.max_insert = max_insert; a.max_gaps = max_gaps;
 	a.multi_hit = multi_hit ? 1 : 0; a.unset_flag = unset_flag;
+	{ static const bool nopart = getenv("KG_DBG_NO_PARTITION") != nullptr; a.dbg_no_partition = nopart ? 1 : 0; }
 	a.extra_capacity = 0;                                  // (set below, once the pinned array of this call is known)
 	a.mapq_tab = ix->d_mapq_tab;
 	{
@@ -1031,6 +1032,7 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 	a.ctl = ws->d_aln_ctl;
 	a.nw_ops = ws->d_job_ops; a.nw_len = ws->d_job_len;
 	a.plans = (AlnPlan *)ws->d_plans; a.pieces = (AlnPiece *)((char *)ws->d_plans + sizeof(AlnPlan) * (size_t)ws->job_capacity);
+	a.part_tasks = (PartTask *)((char *)a.pieces + ((sizeof(AlnPiece) * 4 * (size_t)ws->job_capacity + 15) & ~(size_t)15));
 	a.chunk_stats = ws->d_chunk_stats;
 	HIP_TRY(launch_align_front(a, ix->n_cu, st));
 	// ---- gap closing: the NW kernels on the job descriptors, fragments read in place --------------------------------------------

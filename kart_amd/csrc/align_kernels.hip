@@ -838,7 +838,7 @@ __device__ int finish_tail(const AlnArgs &a, const Columns &c, int &gLen, int &r
 }
 
 // what pass 1 decided for a pair
-enum : uint8_t { W_NONE = 0, W_SIMPLE = 1, W_IMMEDIATE = 2, W_JOB = 3, W_PLAN = 4 };
+enum : uint8_t { W_NONE = 0, W_SIMPLE = 1, W_IMMEDIATE = 2, W_JOB = 3, W_PLAN = 4, W_PENDING = 5 };
 struct Work {
 	uint8_t kind[kAlnMaxPairs];
 	uint8_t op[kAlnMaxPairs];
@@ -987,23 +987,130 @@ __device__ __forceinline__ int mismatches(const AlnArgs &a, const uint8_t *rd, i
 
 }  // namespace
 
+struct __attribute__((packed, aligned(1))) AlnU64u { uint64_t v; };
+
+// 32 bases of the 2-bit text from position p (base i in bits 2 i); beyond the end of the text: zeros
+__device__ __forceinline__ uint64_t text_word32(const AlnArgs &a, int64_t p)
+{
+	if (p > a.two_genome_size) return 0;                 // (the text buffer has 16 bytes of slack behind its last base)
+	const uint8_t *tp = a.ix.text + ((uint64_t)p >> 2);
+	uint64_t lo = reinterpret_cast<const AlnU64u *>(tp)->v, hi = tp[8];
+	int sh = ((int)p & 3) << 1;
+	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
+// The runs plan_partition's scalar loop finds, bit-parallel: the read fragment (<= 256 characters) and the text around the
+// genome fragment as 2 bits per base in registers; per diagonal one XOR per 32 bases, the equality bits compressed to one per
+// base (256-bit vector), the positions where 8 consecutive bits are set by shift-and doubling, the maximal runs read off in
+// increasing read position.  Same runs, same order as the scalar loop (which stays for MaxGaps > 32 and for fragments at
+// the very start of the text).  -1: a non-ACGT character in the read fragment, or more runs than the envelope takes.
+__device__ int partition_runs_packed(const AlnArgs &a, const uint8_t *f1, int64_t g, int rL, int gL, int mg, Pairs &v)
+{
+	uint64_t RD[8], TW[10];
+	bool ok = true;
+	const uint64_t k7f = 0x7F7F7F7F7F7F7F7Full;
+#pragma unroll
+	for (int w = 0; w < 8; ++w) {
+		uint64_t acc = 0;
+#pragma unroll
+		for (int h = 0; h < 4; ++h) {
+			const int t0 = 32 * w + 8 * h;
+			if (t0 < rL) {
+				uint64_t x = reinterpret_cast<const AlnU64u *>(f1 + t0)->v;                 // 8 characters (the buffer has slack behind the last read)
+				const int nv = rL - t0;
+				const uint64_t keep = nv >= 8 ? ~0ull : (1ull << (8 * nv)) - 1;
+				uint64_t u = x & 0xDFDFDFDFDFDFDFDFull;
+				// 0x80 in every byte that equals the constant (exact per byte, no borrow between bytes)
+				uint64_t ya = u ^ 0x4141414141414141ull, yc = u ^ 0x4343434343434343ull, yg = u ^ 0x4747474747474747ull, yt = u ^ 0x5454545454545454ull;
+				uint64_t good = ~((((ya & k7f) + k7f) | ya) & (((yc & k7f) + k7f) | yc) & (((yg & k7f) + k7f) | yg) & (((yt & k7f) + k7f) | yt)) & 0x8080808080808080ull;
+				if ((good & keep) != (0x8080808080808080ull & keep)) ok = false;
+				uint64_t c2 = (x >> 1) & 0x0303030303030303ull;                              // A 0, C 1, G 3, T 2 ...
+				c2 ^= (c2 >> 1) & 0x0101010101010101ull;                                     // ... one Gray step from the codes 0..3
+				c2 &= keep;
+				c2 = (c2 | (c2 >> 6)) & 0x000F000F000F000Full;
+				c2 = (c2 | (c2 >> 12)) & 0x000000FF000000FFull;
+				c2 = (c2 | (c2 >> 24)) & 0xFFFFull;
+				acc |= c2 << (16 * h);
+			}
+		}
+		RD[w] = acc;
+	}
+	if (!ok) return -1;
+	const int64_t g0 = g - (int64_t)(mg - 1);
+	const int words = (rL + 31) >> 5;
+#pragma unroll
+	for (int k = 0; k < 10; ++k) TW[k] = k <= words + 1 ? text_word32(a, g0 + 32 * k) : 0;
+	for (int d = -(mg - 1); d <= mg - 1; ++d) {
+		const int t_lo = d < 0 ? -d : 0;
+		const int t_hi = rL < gL - d ? rL : gL - d;
+		if (t_hi - t_lo < 8) continue;
+		const int s = d + mg - 1;
+		const bool far = (s >> 5) != 0;
+		const int sb = (s & 31) << 1;
+		uint64_t E[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int w = 0; w < 8; ++w) {
+			const int base = w << 5;
+			if (base >= t_hi || base + 32 <= t_lo) continue;
+			uint64_t lo = far ? TW[w + 1] : TW[w], hi = far ? TW[w + 2] : TW[w + 1];
+			uint64_t tw = sb ? (lo >> sb) | (hi << (64 - sb)) : lo;
+			uint64_t diff = RD[w] ^ tw;
+			uint64_t eq = ~(diff | (diff >> 1)) & 0x5555555555555555ull;             // bit 2b set: base b equal
+			int b0 = t_lo > base ? t_lo - base : 0, b1 = t_hi - base < 32 ? t_hi - base : 32;
+			eq &= (b1 >= 32 ? ~0ull : ((1ull << (b1 << 1)) - 1)) & ~((1ull << (b0 << 1)) - 1);
+			uint64_t x = eq;
+			x = (x | (x >> 1)) & 0x3333333333333333ull;
+			x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+			x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+			x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+			x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+			E[w >> 1] |= x << ((w & 1) << 5);
+		}
+		auto shr = [](const uint64_t *q, int k, uint64_t *o) {     // o = q >> k over 256 bits, 0 < k < 64
+			o[0] = (q[0] >> k) | (q[1] << (64 - k)); o[1] = (q[1] >> k) | (q[2] << (64 - k)); o[2] = (q[2] >> k) | (q[3] << (64 - k)); o[3] = q[3] >> k;
+		};
+		uint64_t T[4], R[4];
+		shr(E, 1, T);
+		for (int i = 0; i < 4; ++i) R[i] = E[i] & T[i];             // >= 2
+		shr(R, 2, T);
+		for (int i = 0; i < 4; ++i) R[i] &= T[i];                   // >= 4
+		shr(R, 4, T);
+		for (int i = 0; i < 4; ++i) R[i] &= T[i];                   // >= 8
+		while ((R[0] | R[1] | R[2] | R[3]) != 0) {
+			int pos = R[0] ? __ffsll((unsigned long long)R[0]) - 1 : R[1] ? 64 + __ffsll((unsigned long long)R[1]) - 1
+			        : R[2] ? 128 + __ffsll((unsigned long long)R[2]) - 1 : 192 + __ffsll((unsigned long long)R[3]) - 1;
+			int e = pos + 8;                                        // extend while the bases stay equal
+			while (e < 256 && ((E[e >> 6] >> (e & 63)) & 1)) e++;
+			if (v.num == kAlnMaxSeeds) return -1;
+			int k = v.num++;
+			v.rPos[k] = pos; v.gPos[k] = pos + d; v.rLen[k] = v.gLen[k] = e - pos; v.simple[k] = 1;
+			for (int c = pos; c < e; ++c) R[c >> 6] &= ~(1ull << (c & 63));   // (positions of this run cannot start another)
+		}
+	}
+	return v.num;
+}
+
 // GenerateNormalPairAlignment for a fragment pair with both sides > 30 (src/tools.cpp:146-212; non-PacBio: MaxShift = MaxGaps):
 // GenerateSimplePairsFromFragmentPair -- the common 8-mers of the two fragments whose positions differ by less than MaxShift,
 // merged into exact matches of at least 8 bases (src/KmerAnalysis.cpp:104-179) -- then IdentifyNormalPairs(rLen, gLen, ...) on
 // them, and per resulting piece either a literal stretch or a sub-fragment alignment.
-// Returns 1: the pair is planned (w.kind[j] = W_PLAN); 0: the partition is empty (the caller aligns the whole fragment);
+// Returns 1: the pair is planned (plan_index); 0: the partition is empty (the caller aligns the whole fragment);
 // -1: outside the envelope (host); -2: a device list is full (host).
-__device__ int plan_partition(const AlnArgs &a, int64_t enc_off, const uint8_t *f1, int64_t g, int rL, int gL, Work &w, int j)
+__device__ int plan_partition(const AlnArgs &a, int64_t enc_off, const uint8_t *f1, int64_t g, int rL, int gL, int32_t &plan_index)
 {
+	Pairs v;
+	v.num = 0;
+	const int mg = a.max_gaps;
+	if (mg >= 1 && mg <= 32 && g >= (int64_t)(mg - 1) && rL <= 256) {
+		int rc = partition_runs_packed(a, f1, g, rL, gL, mg, v);
+		if (rc < 0) return -1;
+	} else {
 	// the 8-mer code maps characters through nst_nt4_table and skips 'N': plain A/C/G/T (either case) is what the comparison
 	// of 2-bit codes below reproduces
 	for (int i = 0; i < rL; ++i) {
 		unsigned u = f1[i] & 0xDFu;
 		if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) return -1;
 	}
-	Pairs v;
-	v.num = 0;
-	const int mg = a.max_gaps;
 	// runs of at least 8 equal bases along the diagonals |gpos - rpos| < MaxShift, in (diagonal, read position) order
 	for (int d = -(mg - 1); d <= mg - 1; ++d) {
 		int t_lo = d < 0 ? -d : 0;
@@ -1027,6 +1134,7 @@ __device__ int plan_partition(const AlnArgs &a, int64_t enc_off, const uint8_t *
 				run = 0;
 			}
 		}
+	}
 	}
 	if (v.num == 0) return 0;
 	// sort(SimplePairVec, CompByGenomePos), src/KmerAnalysis.cpp:177
@@ -1081,7 +1189,7 @@ __device__ int plan_partition(const AlnArgs &a, int64_t enc_off, const uint8_t *
 		}
 		a.pieces[piece_at + pk++] = pc;
 	}
-	w.kind[j] = W_PLAN; w.val[j] = (int32_t)plan_at;
+	plan_index = (int32_t)plan_at;
 	return 1;
 }
 
@@ -1124,7 +1232,7 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 		if (!coordinates_valid(a, v)) { a.c_score[cand] = -1; continue; }      // no report, and no best/second-best step (:647)
 		Work w;
 		const int num = v.num;
-		bool host = false, jobs = false;
+		bool host = false, jobs = false, pending = false;
 		int why = WHY_PARTITION;
 		for (int j = 0; j < num && !host; ++j) {
 			w.kind[j] = W_NONE; w.op[j] = 0; w.op_len[j] = 0; w.val[j] = 0;
@@ -1162,11 +1270,13 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			}
 			if (rL > kAlnMaxFrag || gL > kAlnMaxFrag || rL <= 0 || gL <= 0) { host = true; break; }
 			if (rL > 30 && gL > 30) {
-				// GenerateNormalPairAlignment's 8-mer partition, src/tools.cpp:146-212
-				int pr = plan_partition(a, rbase + v.rPos[j], f1, v.gPos[j], rL, gL, w, j);
-				if (pr < 0) { host = true; why = pr == -2 ? WHY_CAPACITY : WHY_PARTITION; break; }
-				if (pr == 1) { jobs = true; continue; }
-				// (0: no common 8-mer survived: the whole fragment is one alignment, below)
+				if (a.dbg_no_partition) { host = true; break; }
+				// GenerateNormalPairAlignment's 8-mer partition, src/tools.cpp:146-212: about one candidate in thirteen has such a
+				// pair, so almost every wave would walk the long path for a few lanes -- the pair is handed to the dense
+				// aln_partition_kernel instead (one task per lane), which writes its outcome into the parked candidate
+				w.kind[j] = W_PENDING;
+				jobs = true; pending = true;
+				continue;
 			}
 			// nw_alignment(rL, frag1, gL, frag2): a job for the NW kernels
 			unsigned long long slot = atomicAdd(&a.ctl[1], 1ull);
@@ -1195,6 +1305,41 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			q.val = w.val[j]; q.kind = w.kind[j]; q.op = w.op[j]; q.op_len = (int16_t)w.op_len[j];
 			o.p[j] = q;
 		}
+		if (pending) {
+			for (int j = 0; j < num; ++j) {
+				if (w.kind[j] != W_PENDING) continue;
+				unsigned long long t = atomicAdd(&a.ctl[3], 1ull);
+				if (t >= (unsigned long long)a.job_capacity) { flag_host(a, r, WHY_CAPACITY); break; }
+				PartTask pt;
+				pt.enc_off = rbase + v.rPos[j]; pt.g = v.gPos[j]; pt.spill = (int32_t)sp; pt.j = j; pt.read = (int32_t)r;
+				pt.rL = (int16_t)v.rLen[j]; pt.gL = (int16_t)v.gLen[j];
+				a.part_tasks[t] = pt;
+			}
+		}
+	}
+}
+
+// ---- pass 1b: the 8-mer partitions, one task per lane (dense) -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void aln_partition_kernel(AlnArgs a)
+{
+	unsigned long long n = a.ctl[3];
+	if (n > (unsigned long long)a.job_capacity) n = (unsigned long long)a.job_capacity;
+	for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * blockDim.x) {
+		const PartTask pt = a.part_tasks[t];
+		if (a.r_host[pt.read]) continue;
+		AlnSpillPair &q = a.spill[pt.spill].p[pt.j];
+		int32_t plan_index = 0;
+		int pr = plan_partition(a, pt.enc_off, a.enc + pt.enc_off, pt.g, pt.rL, pt.gL, plan_index);
+		if (pr < 0) { flag_host(a, pt.read, pr == -2 ? WHY_CAPACITY : WHY_PARTITION); continue; }
+		if (pr == 1) { q.kind = W_PLAN; q.val = plan_index; continue; }
+		// no common 8-mer survived: the whole fragment is one alignment (src/tools.cpp:214-221)
+		unsigned long long slot = atomicAdd(&a.ctl[1], 1ull);
+		unsigned long long ops_at = atomicAdd(&a.ctl[2], (unsigned long long)(pt.rL + pt.gL));
+		if (slot >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(pt.rL + pt.gL) > (unsigned long long)a.ops_capacity) { flag_host(a, pt.read, WHY_CAPACITY); continue; }
+		NwJobDesc jd;
+		jd.o1 = pt.enc_off; jd.o2 = pt.g; jd.ops = (int64_t)ops_at; jd.m = pt.rL; jd.n = pt.gL;
+		a.jobs[slot] = jd;
+		q.kind = W_JOB; q.val = (int32_t)slot;
 	}
 }
 
@@ -1520,7 +1665,11 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 __global__ void aln_reset_kernel(AlnArgs a)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < 8) a.ctl[i] = 0;       // (ctl[8..23]: running tallies of why pairs went back to the host, never reset)
+	// (ctl[8..23]: running tallies, never reset: [8..20] why pairs went back to the host; [21..23] parked candidates, NW jobs and
+	// partition plans of the batches before this one)
+	if (i == 0) { a.ctl[21] += a.ctl[0]; a.ctl[22] += a.ctl[1]; a.ctl[23] += a.ctl[5]; }
+	__syncthreads();
+	if (i < 8) a.ctl[i] = 0;
 	for (int c = i; c < a.n_chunks; c += gridDim.x * blockDim.x) {
 		kg_chunk_stats z;
 		z.paired = 0; z.distance = 0; z.lo = -1; z.hi = 0x7fffffffffffffffll; z.unmapped = 0; z.unique = 0; z.host_pairs = 0; z.rescue_wanted = 0;
@@ -1543,7 +1692,10 @@ hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 	hipLaunchKernelGGL(aln_pair_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
 	hipLaunchKernelGGL(aln_rescue_kernel, dim3(grid_for_aln(a.task_capacity, 1, n_cu * 32)), dim3(64), 0, stream, a);
 	hipLaunchKernelGGL(aln_post_rescue_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
-	if (a.n_cands > 0) hipLaunchKernelGGL(aln_plan_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	if (a.n_cands > 0) {
+		hipLaunchKernelGGL(aln_plan_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
+		hipLaunchKernelGGL(aln_partition_kernel, dim3(grid_for_aln(a.n_cands / 8 + 1, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	}
 	return hipGetLastError();
 }
 

@@ -43,6 +43,15 @@ struct AlnPlan {
 	int32_t first, count; // pieces
 };
 
+// A fragment pair of a parked candidate that waits for its 8-mer partition (aln_partition_kernel: dense, one task per lane)
+struct PartTask {
+	int64_t enc_off;      // the read fragment's offset in the batch's characters
+	int64_t g;            // the genome fragment's text position
+	int32_t spill, j;     // whose pair it is
+	int32_t read;
+	int16_t rL, gL;
+};
+
 struct AlnSpill {
 	int32_t cand;         // dense candidate index
 	int32_t num;
@@ -91,6 +100,7 @@ struct AlnArgs {
 	int est_distance, max_insert, max_gaps;
 	int multi_hit;                  // -m: every candidate the reference's output loops print (src/Mapping.cpp:194-223, 242-263, 293)
 	int unset_flag;                 // what a never-assigned SamFlag prints as
+	int dbg_no_partition;           // diagnostics (KG_DBG_NO_PARTITION): fragments that need the 8-mer partition go back to the host
 	int64_t extra_capacity;         // records beyond one per read: records[n_reads .. n_reads + extra_capacity), handed out through ctl[7]
 	const uint8_t *mapq_tab;        // [(kAlnMaxScore + 1) * 6]: EvaluateMAPQ's libm branch, tabulated by the host
 	// per-candidate state
@@ -117,7 +127,8 @@ struct AlnArgs {
 	int64_t job_capacity, ops_capacity;
 	AlnPlan *plans;                 // [job_capacity]
 	AlnPiece *pieces;               // [4 * job_capacity]
-	unsigned long long *ctl;        // [0] spill count, [1] job count, [2] ops bytes, [3] unused, [4] rescue tasks, [5] plans, [6] pieces, [7] extra records (-m)
+	PartTask *part_tasks;           // [job_capacity], handed out through ctl[3]
+	unsigned long long *ctl;        // [0] spill count, [1] job count, [2] ops bytes, [3] partition tasks, [4] rescue tasks, [5] plans, [6] pieces, [7] extra records (-m)
 	uint8_t *nw_ops;
 	int32_t *nw_len;
 	// outputs

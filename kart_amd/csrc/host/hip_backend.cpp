@@ -100,6 +100,8 @@ public:
 		std::string s(tb);
 		for (int i = 0; i < 13; ++i)
 			if (w[i]) s += std::string(name[i]) + " " + std::to_string((unsigned long long)w[i]) + ", ";
+		s += "| before the last batch: parked candidates " + std::to_string((unsigned long long)w[13]) + ", NW jobs " + std::to_string((unsigned long long)w[14]) +
+		     ", partition plans " + std::to_string((unsigned long long)w[15]);
 		return s;
 	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
