@@ -29,7 +29,7 @@ def test_golden_sam(case, product_binary, tmp_path):
     assert got == want
 
 
-@pytest.mark.parametrize("flags", [[], ["-m"]])
+@pytest.mark.parametrize("flags", [[], ["-m"], ["-g", "40"]])       # (-g 40: MaxGaps beyond what the packed partition scan takes -- its scalar form)
 def test_live_reference_30k_pairs(flags, product_binary, tmp_path):
     if not os.path.exists(KART_REF):
         pytest.skip("oracle/_ref/kart not present on this machine")
