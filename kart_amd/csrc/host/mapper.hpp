@@ -40,7 +40,8 @@ struct Options {
 	int shard_rank = 0, shard_count = 1;   // this process maps shard_rank of shard_count contiguous chunk ranges of the library ...
 	std::string rendezvous;         // ... coordinating with the other processes through this shared-memory file
 	int sa_mode = KG_SA_FULL;
-	int64_t batch_reads = 400000;   // reads seeded per GPU call (a whole number of 4000-read chunks)
+	int64_t batch_reads = default_batch_reads();   // reads seeded per GPU call (a whole number of 4000-read chunks; KART_AMD_BATCH_READS overrides)
+	static int64_t default_batch_reads() { const char *e = getenv("KART_AMD_BATCH_READS"); long long v = e ? atoll(e) : 0; return v >= 4000 ? (int64_t)v : 400000; }
 };
 
 // The gap-closing jobs of one chunk, flat: fragments concatenated (read side f1, genome side f2) with
