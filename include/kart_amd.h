@@ -102,6 +102,7 @@ typedef struct {
 	uint64_t rank_steps_two_lines_narrow;   /* two-line rank steps on an interval of fewer than 960 suffixes (what a 960-symbols-per-line plane layout would serve from one line) */
 	uint64_t double_steps;                  /* two extension steps taken at once on the pair planes (one or two 128-byte lines, 896 rows of one pair of bases each) */
 	uint64_t double_steps_two_lines;        /* ... whose interval ends lie in different lines */
+	uint64_t triple_steps;                  /* ... of double_steps, those that took three steps (the index holds the 64 triple planes: devices with room for 9 bytes/symbol) */
 	uint64_t double_step_bytes;             /* bytes those ranks read: per line its 16-byte header and the 16-byte segment(s) holding the rows asked for */
 } kg_traffic_t;
 

@@ -73,7 +73,7 @@ class Traffic(C.Structure):
     """kg_traffic_t: what the search kernel itself fetched in the last batch (the implemented algorithm)."""
     _fields_ = [(n, C.c_uint64) for n in ("table_lookups", "rank_steps", "rank_steps_two_lines", "sa_gathers", "text_rounds", "window_words",
                                           "hits", "searches", "sa_entry_bytes", "rank_steps_two_lines_narrow", "double_steps", "double_steps_two_lines",
-                                          "double_step_bytes")]
+                                          "triple_steps", "double_step_bytes")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

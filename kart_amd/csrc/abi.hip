@@ -109,6 +109,7 @@ struct kg_index {
 	uint32_t *d_occ = nullptr;
 	uint4 *d_planes = nullptr;
 	uint4 *d_planes2 = nullptr;        // two-step rank structure (fm_device.hpp)
+	uint4 *d_planes3 = nullptr;        // three-step rank structure
 	void *d_qtab = nullptr;
 	uint64_t *d_sa = nullptr;
 	void *d_fsa = nullptr;
@@ -359,18 +360,21 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		ix->device_bytes += plane_bytes;
 	}
 	v.planes2 = nullptr;
+	v.planes3 = nullptr;
 	for (int i = 0; i < 16; ++i) v.t2[i] = 0;
+	for (int i = 0; i < 64; ++i) v.t3[i] = 0;
 	if (!getenv("KG_NO_PLANES2")) {
 		// two-step rank structure: one 128-byte line per 896 rows and pair of bases (2.29 bytes/symbol); an accelerator like the
 		// q-mer table -- without it the search takes single steps
 		uint64_t n_lines = (v.seq_len + kPlane2Rows - 1) / kPlane2Rows;
 		size_t bytes = (size_t)n_lines * 16 * 128;
-		uint64_t *t2_dev = nullptr;
+		uint64_t *t_dev = nullptr;
 		if (hipMalloc((void **)&ix->d_planes2, bytes) == hipSuccess) {
-			HIP_TRY(hipMalloc((void **)&t2_dev, 16 * 8));
-			HIP_TRY(launch_build_planes2(v, ix->d_planes2, n_lines, t2_dev, nullptr));
-			HIP_TRY(hipMemcpy(v.t2, t2_dev, 16 * 8, hipMemcpyDeviceToHost));
-			HIP_TRY(hipFree(t2_dev));
+			HIP_TRY(hipMalloc((void **)&t_dev, (16 + 64) * 8));
+			HIP_TRY(launch_build_planes_k(v, 2, ix->d_planes2, n_lines, t_dev, t_dev + 16, nullptr));
+			HIP_TRY(hipMemcpy(v.t2, t_dev, 16 * 8, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(v.t3, t_dev + 16, 64 * 8, hipMemcpyDeviceToHost));
+			HIP_TRY(hipFree(t_dev));
 			v.planes2 = ix->d_planes2;
 			ix->device_bytes += bytes;
 		} else (void)hipGetLastError();
@@ -428,6 +432,18 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		if (narrow) v.qtab32 = (const uint2 *)ix->d_qtab; else v.qtab64 = (const uint64_t *)ix->d_qtab;
 		ix->device_bytes += tab_bytes;
 	}
+	// three-step rank structure (9.14 bytes/symbol: 56.7 GB for hg38), last and only where the device keeps room for the
+	// workspaces after it (a 288 GB device does, with the 111 GB of everything else): searches then take three bases per rank pair
+	if (v.planes2 && !getenv("KG_NO_PLANES3")) {
+		uint64_t n_lines = (v.seq_len + kPlane2Rows - 1) / kPlane2Rows;
+		size_t bytes = (size_t)n_lines * 64 * 128, free_b = 0, total_b = 0;
+		const size_t reserve = (size_t)48 << 30;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > bytes + reserve && hipMalloc((void **)&ix->d_planes3, bytes) == hipSuccess) {
+			HIP_TRY(launch_build_planes_k(v, 3, ix->d_planes3, n_lines, nullptr, nullptr, nullptr));
+			v.planes3 = ix->d_planes3;
+			ix->device_bytes += bytes;
+		} else (void)hipGetLastError();
+	}
 	*out = ix.release();
 	return KG_OK;
 }
@@ -439,6 +455,7 @@ void kg_index_destroy(kg_index *ix)
 	if (ix->d_occ) (void)hipFree(ix->d_occ);
 	if (ix->d_planes) (void)hipFree(ix->d_planes);
 	if (ix->d_planes2) (void)hipFree(ix->d_planes2);
+	if (ix->d_planes3) (void)hipFree(ix->d_planes3);
 	if (ix->d_qtab) (void)hipFree(ix->d_qtab);
 	for (NwScratch *sc : ix->nw_pool) {
 		if (sc->done) { (void)hipEventSynchronize(sc->done); (void)hipEventDestroy(sc->done); }
@@ -590,7 +607,7 @@ int kg_workspace_traffic(kg_workspace *ws, kg_traffic_t *out)
 	out->text_rounds = ctl[20]; out->window_words = ctl[21]; out->rank_steps_two_lines_narrow = ctl[22];
 	out->sa_gathers = ctl[8]; out->hits = ctl[1]; out->searches = ctl[4];
 	out->sa_entry_bytes = (ws->ix->view.fsa32 ? 4 : 8);
-	out->double_steps = ctl[23]; out->double_steps_two_lines = ctl[24]; out->double_step_bytes = ctl[25];
+	out->double_steps = ctl[23]; out->double_steps_two_lines = ctl[24]; out->double_step_bytes = ctl[25]; out->triple_steps = ctl[26];
 	return KG_OK;
 }
 

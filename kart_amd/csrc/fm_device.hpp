@@ -34,6 +34,7 @@ namespace kg {
 struct FmView {
 	const uint4 *planes;   // device-private rank structure, see below
 	const uint4 *planes2;  // two-step rank structure (null: single steps only), see below
+	const uint4 *planes3;  // three-step rank structure (null: at most double steps): the same lines for the 64 triples of bases
 	const uint32_t *occ;
 	const uint64_t *sa;
 	const uint32_t *fsa32;
@@ -56,6 +57,7 @@ struct FmView {
 	uint64_t L2[5];
 	// two steps at once (first c1, then c2): k'' = t2[c1 * 4 + c2] + rank2(k - 1), where t2 = L2[c2] + 1 + occ(L2[c1], c2)
 	uint64_t t2[16];
+	uint64_t t3[64];       // three steps: k3 = t3[c1 * 16 + c2 * 4 + c3] + rank3(k - 1), t3 = L2[c3] + 1 + occ(t2[c1 c2] - 1, c3)
 };
 
 constexpr uint32_t kPlane2Rows = 896;   // rows per 128-byte line of planes2 (7 segments of 128)
@@ -105,12 +107,12 @@ __device__ __forceinline__ uint64_t rank2_line(uint4 hdr, uint4 sg, uint32_t pos
 	return cnt + sub + (uint64_t)(__popcll(lo & mlo) + __popcll(hi & mhi));
 }
 
-// occurrences of the pair (c1, c2) in rows [0..kk] ($-less coordinate)
-__device__ __forceinline__ uint64_t rank2_plane(const FmView &ix, uint64_t kk, int pair)
+// occurrences of the pair (c1, c2) -- or, on planes3 with sh = 6, of the triple (c1, c2, c3) -- in rows [0..kk] ($-less coordinate)
+__device__ __forceinline__ uint64_t rank2_plane(const uint4 *planes_k, int sh, uint64_t kk, int code)
 {
 	uint64_t blk = kk / kPlane2Rows;
 	uint32_t pos = (uint32_t)(kk - blk * kPlane2Rows);
-	const uint4 *line = ix.planes2 + (((blk << 4) + (uint64_t)pair) << 3);
+	const uint4 *line = planes_k + (((blk << sh) + (uint64_t)code) << 3);
 	return rank2_line(line[0], line[1 + (pos >> 7)], pos);
 }
 

@@ -24,7 +24,7 @@ struct Hit {
 //            > 256 (large LDS)
 //   [17..21] what the search kernel itself fetched: q-mer table lookups, rank steps executed, those touching two 128-byte
 //            lines, text-comparison rounds, packed window words, two-line rank steps on intervals below 960, double steps, those with two lines, bytes their ranks read (kg_workspace_traffic)
-constexpr int kCtlWords = 26;
+constexpr int kCtlWords = 27;
 
 struct SeedArgs {
 	FmView ix;
@@ -58,7 +58,7 @@ size_t sort_temp_bytes(int64_t max_reads);
 // ev: optional array of 5 events recorded before/after the four phases (search | scan | locate | sort)
 hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream, hipEvent_t *ev);
 hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *planes, hipStream_t stream);
-hipError_t launch_build_planes2(FmView ix, uint4 *planes2, uint64_t n_lines, uint64_t *t2_dev, hipStream_t stream);
+hipError_t launch_build_planes_k(FmView ix, int k_steps, uint4 *planes_k, uint64_t n_lines, uint64_t *t2_dev, uint64_t *t3_dev, hipStream_t stream);
 hipError_t launch_planes2_check(const FmView &ix, uint64_t samples, uint64_t seed, unsigned long long *bad_dev, hipStream_t stream);
 hipError_t launch_build_text(const uint8_t *pac, uint64_t l_pac, uint8_t *text, uint64_t n_bytes, hipStream_t stream);
 hipError_t launch_build_qtab(const FmView &ix, int q, uint2 *t32, uint64_t *t64, hipStream_t stream);
