@@ -612,7 +612,7 @@ def seeding_leg(args, api, prefix, codes, dev, n_reads_leg, oracle_sample):
                      "traffic_GBps": (traffic / (search_ms * 1e-3) / 1e9) if traffic else None,
                      "traffic_over_algorithmic": (traffic / useful) if traffic else None,
                      "note": "achieved = bytes the IMPLEMENTED search needs (kg_workspace_traffic: 8 B per q-mer table entry, 2 x 16 B rank segments per single "
-                             "step, header + segment (16 B each) per rank of a double step on the pair planes, one SA entry, 48 B per text-comparison round, packed read "
+                             "step, header + segment (16 B each) per rank of a double / triple step on the pair / triple planes, one SA entry, 48 B per text-comparison round, packed read "
                              "words, hit records) / HIP-event time of search_kernel.  reference_algorithm_per_read: lf1 + lf2 is exact, the split only with single steps.  Every gather "
                              "costs a whole 128-byte line of HBM traffic: min_line_bytes is the line traffic this layout cannot avoid, traffic the measured one (PMC)."}})
     if not args.no_cpu_baseline and args.leg == "all":
