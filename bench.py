@@ -8,7 +8,7 @@
 Metric (BASELINE.json): mapped reads/sec of the whole job, 150 bp paired-end on hg38 (configs[2]).  There is no network for
 the real FASTA, so a seeded hg38-SIZED synthetic genome stands in (3.1 Gbp in 24 contigs behind a 2 kb decoy, 45 % of it
 mutated copies of a 300 bp and a 6 kb repeat family, generated on the device); its FM-index (2L = 6.2 G symbols) is built by
-kart_amd.index_build on the GPU and loaded with the full suffix array, the 2-bit text and the 4^16-entry q-mer table (97 GB
+kart_amd.index_build on the GPU and loaded with the full suffix array, the 2-bit text, the 4^16-entry q-mer table and the two- / three-step rank planes (168 GB
 of HBM per GPU).  10 M read pairs (20 M reads, 1 % substitution errors + 0.1 % haplotype substitutions) are written as two
 FASTQ files.  `KART_REF_FASTA=<fa>` benchmarks a real reference instead; `--genome-len` selects another synthetic size; if the
 large index cannot be built on the machine a single-rank run falls back to configs[1] and says so in config.fallback.
