@@ -14,7 +14,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("env,sa,reads", [({"KG_FORCE_U64": "1"}, "full", 1_000_000), ({}, "full", 400_000), ({"KG_FORCE_U64": "1"}, "sampled", 200_000)])
+@pytest.mark.parametrize("env,sa,reads", [({"KG_FORCE_U64": "1"}, "full", 1_000_000), ({}, "full", 400_000), ({"KG_FORCE_U64": "1"}, "sampled", 200_000),
+                                          ({"KG_FORCE_U64": "1", "KG_NO_PLANES3": "1"}, "full", 200_000),      # at most double steps
+                                          ({"KG_FORCE_U64": "1", "KG_NO_PLANES2": "1"}, "full", 200_000)])     # single steps only
 def test_50mbp_index_gpu_equals_oracle(env, sa, reads, tmp_path_factory):
     wd = str(tmp_path_factory.getbasetemp() / "large50")          # the three cases share one index
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_large.py"), "--genome-len", "50000000", "--reads", str(reads), "--sa", sa,
@@ -22,4 +24,12 @@ def test_50mbp_index_gpu_equals_oracle(env, sa, reads, tmp_path_factory):
     assert r.returncode == 0, (r.stdout.decode()[-600:], r.stderr.decode()[-1200:])
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert res["seeds_identical"] and res["candidates_identical"] and res["reads"] == reads and res["seeds"] > reads
-    assert res["force_u64"] == bool(env)
+    assert res["force_u64"] == ("KG_FORCE_U64" in env)
+    # the search took the steps the index allows: triples where the three-step planes are resident, doubles without them
+    st = res["steps"]
+    if "KG_NO_PLANES2" in env:
+        assert st["double_steps"] == 0 and st["rank_steps"] > 0
+    elif "KG_NO_PLANES3" in env:
+        assert st["double_steps"] > 0 and st["triple_steps"] == 0
+    else:
+        assert st["triple_steps"] > 0

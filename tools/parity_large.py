@@ -38,6 +38,7 @@ ix = api.Index(prefix, 0, api.KG_SA_FULL if args.sa == "full" else api.KG_SA_SAM
 enc_h, off_h = enc.cpu().numpy(), off.cpu().numpy()
 ws = ix.workspace(n_reads, len(enc_h))
 t = time.time(); so_g, s_g = ws.seed_batch(enc_h, off_h, 0); tg = time.time() - t
+traffic = ws.traffic().as_dict()
 orc = O.Oracle(prefix)
 t = time.time(); so_o, s_o = orc.seed_batch(enc_h, off_h, 0, threads=bench.effective_cores()); to = time.time() - t
 same = bool((so_g == so_o).all() and (s_g == s_o.astype(api.SEED_DT)).all())
@@ -55,7 +56,7 @@ if k:
             cand_same = False
             break
     wsk.close()
-print(json.dumps({"genome_len": L, "reads": n_reads, "seeds": int(so_o[-1]), "seeds_identical": same, "candidate_reads": k, "candidates_identical": cand_same,
+print(json.dumps({"steps": {k_: traffic[k_] for k_ in ("rank_steps", "double_steps", "triple_steps")}, "genome_len": L, "reads": n_reads, "seeds": int(so_o[-1]), "seeds_identical": same, "candidate_reads": k, "candidates_identical": cand_same,
                   "sa": args.sa, "force_u64": bool(os.environ.get("KG_FORCE_U64")), "qmer": os.environ.get("KG_QMER"),
                   "gpu_host_form_s": round(tg, 2), "oracle_s": round(to, 1)}))
 sys.exit(0 if same and cand_same else 1)
