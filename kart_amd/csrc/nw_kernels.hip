@@ -250,23 +250,31 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 		for (int i = lane; i <= m; i += 64) bSR[i] = i == 0 ? make_int2(0, 0) : make_int2(-2 - i, NEG);
 		for (int i = lane; i < m; i += 64) s1c[i] = (unsigned char)nt4_code((unsigned char)a.f1[o1 + i]);
 		__syncthreads();
-		const int n_stripes = (n + 63) >> 6;
-		const int steps = m + 63;                          // anti-diagonal steps of one stripe
-		// direction bits: per stripe and step one pair of 64-bit lane masks (s == r, s == t) -- the compare results themselves
+		// Two columns per lane: a stripe is 128 columns wide, lane l owns columns 2l+1 and 2l+2 of it and computes both cells of its
+		// row in one step (the second takes the first as its left neighbour) -- the per-step work that does not depend on the
+		// number of cells (lane shifts, boundary fetch, mask stores, loop) is paid once per 128 cells, and fragments of up to 128
+		// columns need one sweep instead of two.
+		const int n_stripes = (n + 127) >> 7;
+		const int steps = m + 63;                          // anti-diagonal steps of one (full) stripe
+		// direction bits: per stripe and step four 64-bit lane masks (first column: s == r, s == t; second column: likewise) --
+		// the compare results themselves
 		uint64_t *dir64 = reinterpret_cast<uint64_t *>(dir);
 		for (int st = 0; st < n_stripes; ++st) {
-			const int j = st * 64 + lane + 1;    // 1-based column of this lane
-			const int c2 = j <= n ? nw_code2(a, o2 + j - 1) : 9;
-			int up_s = -2 - j, up_t = NEG;       // row 0
-			int res_s = 0, res_r = 0;            // this lane's last result (what lane+1 sees as "left")
-			int prev_left_s = 0;                 // S(i-1, j-1): the left neighbour's value of the previous step
+			const int ja = st * 128 + 2 * lane + 1, jb = ja + 1;    // 1-based columns of this lane
+			const int c2a = ja <= n ? nw_code2(a, o2 + ja - 1) : 9, c2b = jb <= n ? nw_code2(a, o2 + jb - 1) : 10;
+			int upa_s = -2 - ja, upa_t = NEG, upb_s = -2 - jb, upb_t = NEG;       // row 0
+			int res_s = 0, res_r = 0;            // this lane's last result of its second column (what lane+1 sees as "left")
+			int prev_left_s = 0;                 // S(i-1, ja-1): the left neighbour's value of the previous step
 			int c1 = 15;                         // sequence-1 code of this lane's row, handed on from lane to lane
-			uint64_t *dw = dir64 + (int64_t)st * steps * 2;
+			uint64_t *dw = dir64 + (int64_t)st * steps * 4;
 			// lane 0's inputs of a step (boundary values and the code of the row entering the stripe) are fetched one step ahead,
 			// so that the LDS latency is off the dependent chain
 			int2 b = bSR[m >= 1 ? 1 : 0];
 			int code_in = s1c[0];
-			for (int d = 1; d <= steps; ++d) {
+			// (a stripe narrower than 128 columns is done once its last column has reached row m)
+			const int width = n - st * 128 < 128 ? n - st * 128 : 128;
+			const int steps_here = m + ((width + 1) >> 1) - 1;
+			for (int d = 1; d <= steps_here; ++d) {
 				const int i = d - lane;
 				// what comes in from the left: lane-1's result of the previous step (a wave shift by one lane); lane 0 takes the
 				// boundary column instead
@@ -278,27 +286,34 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 					code_in = s1c[bn - 1];
 				}
 				const bool valid = (unsigned)(i - 1) < (unsigned)m;
-				const int diag_s = i == 1 ? (j == 1 ? 0 : -2 - (j - 1)) : prev_left_s;
-				const int r = max(left_r - 1, left_s - 3);
-				const int tt = max(up_t - 1, up_s - 3);
-				const int dd = diag_s + (c1 == c2 ? 3 : -3);
-				const int s = max(dd, max(r, tt));
+				// first column
+				const int diag_a = i == 1 ? (ja == 1 ? 0 : -2 - (ja - 1)) : prev_left_s;
+				const int ra = max(left_r - 1, left_s - 3);
+				const int ta = max(upa_t - 1, upa_s - 3);
+				const int sa = max(diag_a + (c1 == c2a ? 3 : -3), max(ra, ta));
+				// second column: its left neighbour is the cell just computed, its diagonal the first column's previous row
+				const int diag_b = i == 1 ? -2 - ja : upa_s;
+				const int rb = max(ra - 1, sa - 3);
+				const int tb = max(upb_t - 1, upb_s - 3);
+				const int sb = max(diag_b + (c1 == c2b ? 3 : -3), max(rb, tb));
 				const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);                  // (compare results are the lane masks: scalar ANDs, no VALU)
-				const uint64_t mr = __builtin_amdgcn_ballot_w64(s == r) & vm, mt = __builtin_amdgcn_ballot_w64(s == tt) & vm;
-				if (lane == 0) { dw[2 * (d - 1)] = mr; dw[2 * (d - 1) + 1] = mt; }
-				prev_left_s = left_s;            // cell (i, j-1) is the diagonal of the next row
-				if (valid) { up_s = s; up_t = tt; }      // (a lane that has not started keeps row 0)
-				res_s = s; res_r = r;
-				// lane 63 publishes its column as the next stripe's boundary (row i of column 64*(st+1))
-				if (lane == 63 && valid) bSR[i] = make_int2(s, r);
+				const uint64_t mra = __builtin_amdgcn_ballot_w64(sa == ra) & vm, mta = __builtin_amdgcn_ballot_w64(sa == ta) & vm;
+				const uint64_t mrb = __builtin_amdgcn_ballot_w64(sb == rb) & vm, mtb = __builtin_amdgcn_ballot_w64(sb == tb) & vm;
+				if (lane == 0) { uint64_t *o = dw + 4 * (d - 1); o[0] = mra; o[1] = mta; o[2] = mrb; o[3] = mtb; }
+				prev_left_s = left_s;            // cell (i, ja-1) is the diagonal of the next row
+				if (valid) { upa_s = sa; upa_t = ta; upb_s = sb; upb_t = tb; }      // (a lane that has not started keeps row 0)
+				res_s = sb; res_r = rb;
+				// lane 63 publishes its second column as the next stripe's boundary (row i of column 128*(st+1))
+				if (lane == 63 && valid) bSR[i] = make_int2(sb, rb);
 			}
 			// row 0 of the next boundary column
-			if (lane == 63) bSR[0] = make_int2(-2 - (st * 64 + 64), -2 - (st * 64 + 64));
+			if (lane == 63) bSR[0] = make_int2(-2 - (st * 128 + 128), -2 - (st * 128 + 128));
 			__syncthreads();
 		}
 		// Traceback, wave-cooperative: the path is one dependent chain; all lanes walk the same (uniform) path.  Cell (i, j) of
-		// stripe st was computed by lane (j-1) & 63 at step i + lane: the mask pairs of the 64 steps below the current one are
-		// loaded by the 64 lanes at once and read by lane shuffle; every move lowers the step by one or two.
+		// stripe st was computed by lane ((j-1) & 127) >> 1 at step i + lane: the mask quadruples of the 64 steps below the current
+		// one are loaded by the 64 lanes at once and read lane by lane; every move lowers the step by one or two (or keeps it, from
+		// a lane's second column to its first).
 		uint8_t *ops = a.ops + q.oo;
 		int len = 0;
 		{
@@ -314,20 +329,23 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 					len += i; i = 0;
 					break;
 				}
-				const int st = (jj - 1) >> 6;
-				const int d_hi = i + ((jj - 1) & 63);
-				const uint64_t *dw = dir64 + (int64_t)st * steps * 2;
-				uint64_t cr = 0, ct = 0;
-				if (d_hi - lane >= 1) { cr = dw[2 * (d_hi - lane - 1)]; ct = dw[2 * (d_hi - lane - 1) + 1]; }
-				while (i > 0 && jj > 0 && ((jj - 1) >> 6) == st) {
-					const int cl = (jj - 1) & 63, d = i + cl;
+				const int st = (jj - 1) >> 7;
+				const int d_hi = i + (((jj - 1) & 127) >> 1);
+				const uint64_t *dw = dir64 + (int64_t)st * steps * 4;
+				uint64_t cra = 0, cta = 0, crb = 0, ctb = 0;
+				if (d_hi - lane >= 1) { const uint64_t *o = dw + 4 * (d_hi - lane - 1); cra = o[0]; cta = o[1]; crb = o[2]; ctb = o[3]; }
+				while (i > 0 && jj > 0 && ((jj - 1) >> 7) == st) {
+					const int col = (jj - 1) & 127, cl = col >> 1, d = i + cl;
 					const int src = d_hi - d;
 					if (src > 63) break;
-					const uint32_t lo_r = (uint32_t)__shfl((int)(uint32_t)cr, src), hi_r = (uint32_t)__shfl((int)(uint32_t)(cr >> 32), src);
-					const uint32_t lo_t = (uint32_t)__shfl((int)(uint32_t)ct, src), hi_t = (uint32_t)__shfl((int)(uint32_t)(ct >> 32), src);
-					const uint64_t wr_ = ((uint64_t)hi_r << 32) | lo_r, wt_ = ((uint64_t)hi_t << 32) | lo_t;
-					const bool g1 = (wr_ >> cl) & 1;
-					const bool g2 = !g1 && ((wt_ >> cl) & 1);
+					// (the path is wave-uniform: the source lane and the bit are scalars, v_readlane instead of a shuffle through the
+					//  LDS crossbar -- the walk is one dependent chain, its length is the alignment's)
+					const int us = __builtin_amdgcn_readfirstlane(src), ub = __builtin_amdgcn_readfirstlane(cl), second = __builtin_amdgcn_readfirstlane(col & 1);
+					const uint64_t wr = second ? crb : cra, wt = second ? ctb : cta;
+					const uint32_t half_r = ub < 32 ? (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wr, us) : (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wr >> 32), us);
+					const uint32_t half_t = ub < 32 ? (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wt, us) : (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wt >> 32), us);
+					const bool g1 = (half_r >> (ub & 31)) & 1;
+					const bool g2 = !g1 && ((half_t >> (ub & 31)) & 1);
 					if (lane == 0) ops[len] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
 					len++;
 					if (g1) jj--; else if (g2) i--; else { i--; jj--; }
