@@ -224,6 +224,134 @@ __global__ __launch_bounds__(256) void nw_small32_kernel(NwArgs a)
 // LDS per wave: boundary column S,R for rows 0..m (column 64*stripe), updated in place: lane 63
 // rewrites row i 63 steps after lane 0 consumed it.
 
+// K columns per lane: a stripe is 64 K columns wide, lane l owns columns K l + 1 .. K l + K of it and computes the K cells of its
+// row in one step (each takes the one before as its left neighbour) -- the per-step work that does not depend on the number of
+// cells (lane shifts, boundary fetch, mask stores, loop) is paid once per 64 K cells, and a fragment of up to 64 K columns needs
+// one sweep.  Direction bits: per stripe and step 2 K 64-bit lane masks (column k: s == r, s == t) -- the compare results
+// themselves.
+template <int K>
+__device__ __forceinline__ void nw_sweep(const NwArgs &a, int lane, int m, int n, int64_t o2, int2 *bSR, const unsigned char *s1c, uint64_t *dir64)
+{
+	constexpr int W = 64 * K;
+	const int n_stripes = (n + W - 1) / W;
+	const int steps = m + 63;                          // anti-diagonal steps of one (full) stripe
+	for (int st = 0; st < n_stripes; ++st) {
+		const int j0 = st * W + K * lane + 1;           // 1-based first column of this lane
+		int c2[K], up_s[K], up_t[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			c2[k] = j0 + k <= n ? nw_code2(a, o2 + j0 + k - 1) : 9 + k;
+			up_s[k] = -2 - (j0 + k); up_t[k] = NEG;     // row 0
+		}
+		int res_s = 0, res_r = 0;            // this lane's last result of its last column (what lane+1 sees as "left")
+		int prev_left_s = 0;                 // S(i-1, j0-1): the left neighbour's value of the previous step
+		int c1 = 15;                         // sequence-1 code of this lane's row, handed on from lane to lane
+		uint64_t *dw = dir64 + (int64_t)st * steps * (2 * K);
+		// lane 0's inputs of a step (boundary values and the code of the row entering the stripe) are fetched one step ahead,
+		// so that the LDS latency is off the dependent chain
+		int2 b = bSR[m >= 1 ? 1 : 0];
+		int code_in = s1c[0];
+		// (a stripe narrower than 64 K columns is done once its last column has reached row m)
+		const int width = n - st * W < W ? n - st * W : W;
+		const int steps_here = m + (width + K - 1) / K - 1;
+		for (int d = 1; d <= steps_here; ++d) {
+			const int i = d - lane;
+			// what comes in from the left: lane-1's result of the previous step (a wave shift by one lane); lane 0 takes the
+			// boundary column instead
+			const int left_s = wave_shr1(res_s, b.x), left_r = wave_shr1(res_r, b.y);
+			c1 = wave_shr1(c1, code_in);
+			{
+				const int bn = d + 1 <= m ? d + 1 : m;             // next step's boundary row
+				b = bSR[bn];
+				code_in = s1c[bn - 1];
+			}
+			const bool valid = (unsigned)(i - 1) < (unsigned)m;
+			int sv[K], rv[K], tv[K];
+			uint64_t mr[K], mt[K];
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				// column k: its left neighbour is the cell just computed (column 0: what came in), its diagonal the previous
+				// column's previous row (row 0 while the lane has not started: up_s still holds it)
+				const int ls = k == 0 ? left_s : sv[k - 1], lr = k == 0 ? left_r : rv[k - 1];
+				const int diag = k == 0 ? (i == 1 ? (j0 == 1 ? 0 : -2 - (j0 - 1)) : prev_left_s) : up_s[k - 1];
+				rv[k] = max(lr - 1, ls - 3);
+				tv[k] = max(up_t[k] - 1, up_s[k] - 3);
+				sv[k] = max(diag + (c1 == c2[k] ? 3 : -3), max(rv[k], tv[k]));
+				mr[k] = __builtin_amdgcn_ballot_w64(sv[k] == rv[k]);       // (rows outside 1..m are never visited by the traceback)
+				mt[k] = __builtin_amdgcn_ballot_w64(sv[k] == tv[k]);
+			}
+			if (lane == 0) {
+				uint64_t *o = dw + (2 * K) * (d - 1);
+#pragma unroll
+				for (int k = 0; k < K; ++k) { o[2 * k] = mr[k]; o[2 * k + 1] = mt[k]; }
+			}
+			prev_left_s = left_s;            // cell (i, j0-1) is the diagonal of the next row
+			if (valid) {                     // (a lane that has not started keeps row 0)
+#pragma unroll
+				for (int k = 0; k < K; ++k) { up_s[k] = sv[k]; up_t[k] = tv[k]; }
+			}
+			res_s = sv[K - 1]; res_r = rv[K - 1];
+			// lane 63 publishes its last column as the next stripe's boundary (row i of column W (st+1))
+			if (lane == 63 && valid) bSR[i] = make_int2(sv[K - 1], rv[K - 1]);
+		}
+		// row 0 of the next boundary column
+		if (lane == 63) bSR[0] = make_int2(-2 - (st * W + W), -2 - (st * W + W));
+		__syncthreads();
+	}
+}
+
+// Traceback, wave-cooperative: the path is one dependent chain; all lanes walk the same (uniform) path.  Cell (i, j) of stripe st
+// was computed by lane ((j-1) mod 64 K) / K at step i + lane: the masks of the 64 steps below the current one are loaded by the 64
+// lanes at once and read lane by lane (v_readlane on scalar lane / bit indices); every move lowers the step by one or two (or keeps
+// it, between columns of one lane).  Returns the number of ops written (in reverse order).
+template <int K>
+__device__ __forceinline__ int nw_walk(int lane, int m, int n, const uint64_t *dir64, uint8_t *ops)
+{
+	constexpr int W = 64 * K;
+	const int steps = m + 63;
+	int len = 0, i = m, jj = n;
+	while (i > 0 || jj > 0) {
+		if (i == 0) {                                         // the rest of the top row: gaps in sequence 1
+			for (int x = lane; x < jj; x += 64) ops[len + x] = KG_OP_GAP1;
+			len += jj; jj = 0;
+			break;
+		}
+		if (jj == 0) {
+			for (int x = lane; x < i; x += 64) ops[len + x] = KG_OP_GAP2;
+			len += i; i = 0;
+			break;
+		}
+		const int st = (jj - 1) / W;
+		const int d_hi = i + ((jj - 1) % W) / K;
+		const uint64_t *dw = dir64 + (int64_t)st * steps * (2 * K);
+		uint64_t cr[K], ct[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) { cr[k] = 0; ct[k] = 0; }
+		if (d_hi - lane >= 1) {
+			const uint64_t *o = dw + (2 * K) * (d_hi - lane - 1);
+#pragma unroll
+			for (int k = 0; k < K; ++k) { cr[k] = o[2 * k]; ct[k] = o[2 * k + 1]; }
+		}
+		while (i > 0 && jj > 0 && (jj - 1) / W == st) {
+			const int col = (jj - 1) % W, cl = col / K, d = i + cl;
+			const int src = d_hi - d;
+			if (src > 63) break;
+			const int us = __builtin_amdgcn_readfirstlane(src), ub = __builtin_amdgcn_readfirstlane(cl), kk = __builtin_amdgcn_readfirstlane(col % K);
+			uint64_t wr = cr[0], wt = ct[0];
+#pragma unroll
+			for (int k = 1; k < K; ++k) { if (kk == k) { wr = cr[k]; wt = ct[k]; } }
+			const uint32_t half_r = ub < 32 ? (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wr, us) : (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wr >> 32), us);
+			const uint32_t half_t = ub < 32 ? (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wt, us) : (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wt >> 32), us);
+			const bool g1 = (half_r >> (ub & 31)) & 1;
+			const bool g2 = !g1 && ((half_t >> (ub & 31)) & 1);
+			if (lane == 0) ops[len] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
+			len++;
+			if (g1) jj--; else if (g2) i--; else { i--; jj--; }
+		}
+	}
+	return len;
+}
+
 // kGlobal: fragments longer than kNwMaxLen -- the boundary column and the sequence-1 codes no longer fit the LDS and
 // live in a per-wave HBM slab behind the direction words instead (same sweep; the reference's nw_alignment has no length
 // limit, src/nw_alignment.cpp:24-33, so neither has this path).
@@ -250,109 +378,13 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 		for (int i = lane; i <= m; i += 64) bSR[i] = i == 0 ? make_int2(0, 0) : make_int2(-2 - i, NEG);
 		for (int i = lane; i < m; i += 64) s1c[i] = (unsigned char)nt4_code((unsigned char)a.f1[o1 + i]);
 		__syncthreads();
-		// Two columns per lane: a stripe is 128 columns wide, lane l owns columns 2l+1 and 2l+2 of it and computes both cells of its
-		// row in one step (the second takes the first as its left neighbour) -- the per-step work that does not depend on the
-		// number of cells (lane shifts, boundary fetch, mask stores, loop) is paid once per 128 cells, and fragments of up to 128
-		// columns need one sweep instead of two.
-		const int n_stripes = (n + 127) >> 7;
-		const int steps = m + 63;                          // anti-diagonal steps of one (full) stripe
-		// direction bits: per stripe and step four 64-bit lane masks (first column: s == r, s == t; second column: likewise) --
-		// the compare results themselves
 		uint64_t *dir64 = reinterpret_cast<uint64_t *>(dir);
-		for (int st = 0; st < n_stripes; ++st) {
-			const int ja = st * 128 + 2 * lane + 1, jb = ja + 1;    // 1-based columns of this lane
-			const int c2a = ja <= n ? nw_code2(a, o2 + ja - 1) : 9, c2b = jb <= n ? nw_code2(a, o2 + jb - 1) : 10;
-			int upa_s = -2 - ja, upa_t = NEG, upb_s = -2 - jb, upb_t = NEG;       // row 0
-			int res_s = 0, res_r = 0;            // this lane's last result of its second column (what lane+1 sees as "left")
-			int prev_left_s = 0;                 // S(i-1, ja-1): the left neighbour's value of the previous step
-			int c1 = 15;                         // sequence-1 code of this lane's row, handed on from lane to lane
-			uint64_t *dw = dir64 + (int64_t)st * steps * 4;
-			// lane 0's inputs of a step (boundary values and the code of the row entering the stripe) are fetched one step ahead,
-			// so that the LDS latency is off the dependent chain
-			int2 b = bSR[m >= 1 ? 1 : 0];
-			int code_in = s1c[0];
-			// (a stripe narrower than 128 columns is done once its last column has reached row m)
-			const int width = n - st * 128 < 128 ? n - st * 128 : 128;
-			const int steps_here = m + ((width + 1) >> 1) - 1;
-			for (int d = 1; d <= steps_here; ++d) {
-				const int i = d - lane;
-				// what comes in from the left: lane-1's result of the previous step (a wave shift by one lane); lane 0 takes the
-				// boundary column instead
-				const int left_s = wave_shr1(res_s, b.x), left_r = wave_shr1(res_r, b.y);
-				c1 = wave_shr1(c1, code_in);
-				{
-					const int bn = d + 1 <= m ? d + 1 : m;             // next step's boundary row
-					b = bSR[bn];
-					code_in = s1c[bn - 1];
-				}
-				const bool valid = (unsigned)(i - 1) < (unsigned)m;
-				// first column
-				const int diag_a = i == 1 ? (ja == 1 ? 0 : -2 - (ja - 1)) : prev_left_s;
-				const int ra = max(left_r - 1, left_s - 3);
-				const int ta = max(upa_t - 1, upa_s - 3);
-				const int sa = max(diag_a + (c1 == c2a ? 3 : -3), max(ra, ta));
-				// second column: its left neighbour is the cell just computed, its diagonal the first column's previous row
-				const int diag_b = i == 1 ? -2 - ja : upa_s;
-				const int rb = max(ra - 1, sa - 3);
-				const int tb = max(upb_t - 1, upb_s - 3);
-				const int sb = max(diag_b + (c1 == c2b ? 3 : -3), max(rb, tb));
-				const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);                  // (compare results are the lane masks: scalar ANDs, no VALU)
-				const uint64_t mra = __builtin_amdgcn_ballot_w64(sa == ra) & vm, mta = __builtin_amdgcn_ballot_w64(sa == ta) & vm;
-				const uint64_t mrb = __builtin_amdgcn_ballot_w64(sb == rb) & vm, mtb = __builtin_amdgcn_ballot_w64(sb == tb) & vm;
-				if (lane == 0) { uint64_t *o = dw + 4 * (d - 1); o[0] = mra; o[1] = mta; o[2] = mrb; o[3] = mtb; }
-				prev_left_s = left_s;            // cell (i, ja-1) is the diagonal of the next row
-				if (valid) { upa_s = sa; upa_t = ta; upb_s = sb; upb_t = tb; }      // (a lane that has not started keeps row 0)
-				res_s = sb; res_r = rb;
-				// lane 63 publishes its second column as the next stripe's boundary (row i of column 128*(st+1))
-				if (lane == 63 && valid) bSR[i] = make_int2(sb, rb);
-			}
-			// row 0 of the next boundary column
-			if (lane == 63) bSR[0] = make_int2(-2 - (st * 128 + 128), -2 - (st * 128 + 128));
-			__syncthreads();
-		}
-		// Traceback, wave-cooperative: the path is one dependent chain; all lanes walk the same (uniform) path.  Cell (i, j) of
-		// stripe st was computed by lane ((j-1) & 127) >> 1 at step i + lane: the mask quadruples of the 64 steps below the current
-		// one are loaded by the 64 lanes at once and read lane by lane; every move lowers the step by one or two (or keeps it, from
-		// a lane's second column to its first).
 		uint8_t *ops = a.ops + q.oo;
-		int len = 0;
-		{
-			int i = m, jj = n;
-			while (i > 0 || jj > 0) {
-				if (i == 0) {                                         // the rest of the top row: gaps in sequence 1
-					for (int x = lane; x < jj; x += 64) ops[len + x] = KG_OP_GAP1;
-					len += jj; jj = 0;
-					break;
-				}
-				if (jj == 0) {
-					for (int x = lane; x < i; x += 64) ops[len + x] = KG_OP_GAP2;
-					len += i; i = 0;
-					break;
-				}
-				const int st = (jj - 1) >> 7;
-				const int d_hi = i + (((jj - 1) & 127) >> 1);
-				const uint64_t *dw = dir64 + (int64_t)st * steps * 4;
-				uint64_t cra = 0, cta = 0, crb = 0, ctb = 0;
-				if (d_hi - lane >= 1) { const uint64_t *o = dw + 4 * (d_hi - lane - 1); cra = o[0]; cta = o[1]; crb = o[2]; ctb = o[3]; }
-				while (i > 0 && jj > 0 && ((jj - 1) >> 7) == st) {
-					const int col = (jj - 1) & 127, cl = col >> 1, d = i + cl;
-					const int src = d_hi - d;
-					if (src > 63) break;
-					// (the path is wave-uniform: the source lane and the bit are scalars, v_readlane instead of a shuffle through the
-					//  LDS crossbar -- the walk is one dependent chain, its length is the alignment's)
-					const int us = __builtin_amdgcn_readfirstlane(src), ub = __builtin_amdgcn_readfirstlane(cl), second = __builtin_amdgcn_readfirstlane(col & 1);
-					const uint64_t wr = second ? crb : cra, wt = second ? ctb : cta;
-					const uint32_t half_r = ub < 32 ? (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wr, us) : (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wr >> 32), us);
-					const uint32_t half_t = ub < 32 ? (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wt, us) : (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wt >> 32), us);
-					const bool g1 = (half_r >> (ub & 31)) & 1;
-					const bool g2 = !g1 && ((half_t >> (ub & 31)) & 1);
-					if (lane == 0) ops[len] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
-					len++;
-					if (g1) jj--; else if (g2) i--; else { i--; jj--; }
-				}
-			}
-			if (lane == 0) a.aln_len[p] = len;
-		}
+		int len;
+		// two columns per lane up to 128 columns (one sweep), four beyond
+		if (n <= 128) { nw_sweep<2>(a, lane, m, n, o2, bSR, s1c, dir64); len = nw_walk<2>(lane, m, n, dir64, ops); }
+		else { nw_sweep<4>(a, lane, m, n, o2, bSR, s1c, dir64); len = nw_walk<4>(lane, m, n, dir64, ops); }
+		if (lane == 0) a.aln_len[p] = len;
 		__threadfence_block();
 		__syncthreads();
 		for (int x = lane; x < len / 2; x += 64) {
