@@ -268,6 +268,88 @@ int  kg_nw_batch_device(kg_index *ix, const char *d_frag1, const int64_t *d_off1
                         const int64_t *d_off2, int64_t n, int64_t max_len, uint8_t *d_ops,
                         int32_t *d_aln_len, void *stream);
 
+/* ---- FASTQ text in, SAM text out ------------------------------------------------------------------------------------ */
+/* The reference's worker takes a chunk of reads from GetNextChunk (src/GetData.cpp:109-143: four getline() calls per record,
+ * the name cut out of the header by IdentifyHeaderBegPos / EndPos, mate 2 reverse-complemented), maps it, and prints every
+ * record with fprintf (OutputPairedAlignments / OutputSingledAlignments, src/Mapping.cpp:177-315).  A stream does the same for
+ * a whole batch on the device, so that the caller only moves bytes: it uploads the text of the input file(s) as it lies there
+ * and receives the text of the SAM records.  `lanes` batches are in flight at once (the reference's N worker threads each on
+ * their own chunk, src/Mapping.cpp:716-717): every lane owns a workspace, device text windows, page-locked staging and
+ * result buffers and a HIP stream; the calls of one lane must not overlap, different lanes may be driven from different threads.
+ * Short reads, plain 4-line FASTQ, the Illumina configuration (not -pacbio).
+ *
+ *   per batch:  fill kg_stream_staging(lane, f) -> kg_stream_upload (any number of pieces) -> kg_stream_parse -> kg_stream_map
+ */
+typedef struct kg_stream kg_stream;
+typedef struct {
+	int64_t max_reads;       /* reads per batch the lanes are sized for */
+	int64_t max_window;      /* bytes of FASTQ text per file and batch (the staging buffers' size) */
+	int32_t lanes;           /* batches in flight */
+} kg_stream_config;
+int   kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out);
+void  kg_stream_close(kg_stream *s);
+/* page-locked staging buffer of input file `file` (0 / 1) in lane `lane`, *capacity = max_window bytes */
+char *kg_stream_staging(kg_stream *s, int lane, int file, int64_t *capacity);
+/* staging[file][from, to) -> the lane's device window, asynchronously: a caller reads the next piece meanwhile */
+int   kg_stream_upload(kg_stream *s, int lane, int file, int64_t from, int64_t to);
+
+typedef struct {
+	int64_t begin[2], end[2];    /* the window of file f is staging[f][begin, end); begin lies on a record boundary */
+	int32_t eof[2];              /* the window ends where the file ends */
+	int32_t two_files;           /* -f / -f2: read 2q comes from file 0, read 2q+1 from file 1; else every read from file 0 */
+	int32_t paired;              /* the second read of every pair is held reverse-complemented, qualities reversed (src/GetData.cpp:125-135) */
+	int32_t chunk_reads;         /* ReadChunkSize (src/structure.h:21): 4000 */
+	int64_t want_reads;          /* take at most this many reads (a multiple of chunk_reads, <= max_reads) */
+} kg_stream_window;
+#define KG_STREAM_STOP_NONE      0
+#define KG_STREAM_STOP_IRREGULAR 1   /* behind the reads taken lies a record the device parser leaves to the caller's own reader: an
+                                        empty read (it ends a chunk early, src/GetData.cpp:117,121), a NUL byte, an overlong header */
+#define KG_STREAM_STOP_TAIL      2   /* the file ends in less than a chunk that is not regular (a lone mate, a partial record) */
+typedef struct {
+	int64_t n_reads, n_chunks, n_bases;   /* whole chunks of chunk_reads reads, or everything up to a regular end of the file(s) */
+	int64_t used[2];                       /* the next window of file f starts at staging offset used[f] of this one */
+	int32_t stop;                          /* KG_STREAM_STOP_*: != NONE: after this batch the caller's own reader continues at used[] */
+	int32_t done;                          /* the files ended regularly with this batch */
+} kg_stream_parsed;
+/* GetNextChunk for the whole window: lines, records, the reads as the reference holds them (left on the device for kg_stream_map) */
+int   kg_stream_parse(kg_stream *s, int lane, const kg_stream_window *w, kg_stream_parsed *out);
+
+typedef struct {
+	int32_t est_distance, max_insert, max_gaps, multi_hit, unset_flag;   /* as kg_align_batch */
+} kg_stream_params;
+typedef struct {
+	int64_t n_reads, n_chunks;
+	const char *sam;                 /* the SAM lines of the reads decided on the device, in read order (page-locked, the lane's) */
+	int64_t sam_bytes;
+	const int64_t *sam_off;          /* [n_reads + 1]: the lines of read r are sam[sam_off[r], sam_off[r+1]) -- empty for a read handed back */
+	const kg_aln_record *records;    /* [n_records] as kg_align_batch (the first n_reads are the reads' own) */
+	int64_t n_records;
+	const kg_chunk_stats *chunk_stats;   /* [n_chunks] */
+	const int32_t *host_reads;       /* reads whose record is KG_ALN_HOST, ascending */
+	int64_t n_host_reads;
+	const int64_t *cand_off;         /* [n_reads + 1] the candidates of read r: cands[cand_off[r], cand_off[r+1]) (kg_candidates_batch) */
+	const kg_candidate *cands;
+	const kg_seed *cand_seeds;
+	const uint32_t *rec_start[2];    /* staging offset of the header line of record j of file f (read r = record r/2 of file r%2 with two files) */
+} kg_stream_result;
+/* seeding (FastMode), chaining, the per-read report (kg_align_batch) and the SAM text for the batch kg_stream_parse left in the
+ * lane.  The result's arrays belong to the lane: valid until its next kg_stream_parse. */
+int   kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream_result *out);
+/* test aid: the reads of the parsed batch as the seeding stage sees them (characters, offsets[n_reads + 1]); enc may be NULL */
+int   kg_stream_fetch_reads(kg_stream *s, int lane, uint8_t *enc, int64_t *read_off);
+
+/* device time since the stream was opened (or last reset), summed over the batches of all lanes: HIP events on each lane's
+ * stream around its stages, the search kernel's own launches, and the bytes that kernel fetched (kg_workspace_traffic's formula) */
+typedef struct {
+	int64_t batches, reads;
+	double parse_ms, seed_ms, chain_ms, align_ms, format_ms, copy_ms;
+	double search_kernel_ms;
+	int64_t search_kernel_launches;
+	double search_useful_bytes;
+	double text_in_bytes, text_out_bytes;
+} kg_stream_timing_t;
+int   kg_stream_timing(kg_stream *s, kg_stream_timing_t *out, int reset);
+
 #ifdef __cplusplus
 }
 #endif

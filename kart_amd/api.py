@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "kg_last_error", "kg_device_count", "kg_index_load", "kg_index_destroy", "kg_index_info",
     "kg_index_contig", "kg_host_alloc", "kg_host_free", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters", "kg_workspace_traffic",
     "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_set_single_steps", "kg_index_selfcheck", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_align_batch", "kg_align_reasons", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
+    "kg_stream_open", "kg_stream_close", "kg_stream_staging", "kg_stream_upload", "kg_stream_parse", "kg_stream_map", "kg_stream_fetch_reads", "kg_stream_timing",
 )
 
 
@@ -91,6 +92,37 @@ class Traffic(C.Structure):
                    + (8 * self.window_words + 20 * n_reads + 32 * self.hits) / 128)
 
 
+class StreamConfig(C.Structure):
+    _fields_ = [("max_reads", C.c_int64), ("max_window", C.c_int64), ("lanes", C.c_int32)]
+
+
+class StreamWindow(C.Structure):
+    _fields_ = [("begin", C.c_int64 * 2), ("end", C.c_int64 * 2), ("eof", C.c_int32 * 2), ("two_files", C.c_int32), ("paired", C.c_int32),
+                ("chunk_reads", C.c_int32), ("want_reads", C.c_int64)]
+
+
+class StreamParsed(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_chunks", C.c_int64), ("n_bases", C.c_int64), ("used", C.c_int64 * 2), ("stop", C.c_int32), ("done", C.c_int32)]
+
+
+class StreamParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("est_distance", "max_insert", "max_gaps", "multi_hit", "unset_flag")]
+
+
+class StreamResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_chunks", C.c_int64), ("sam", C.c_void_p), ("sam_bytes", C.c_int64), ("sam_off", C.POINTER(C.c_int64)),
+                ("records", C.c_void_p), ("n_records", C.c_int64), ("chunk_stats", C.c_void_p), ("host_reads", C.POINTER(C.c_int32)), ("n_host_reads", C.c_int64),
+                ("cand_off", C.POINTER(C.c_int64)), ("cands", C.c_void_p), ("cand_seeds", C.c_void_p), ("rec_start", C.POINTER(C.c_uint32) * 2)]
+
+
+class StreamTiming(C.Structure):
+    _fields_ = [("batches", C.c_int64), ("reads", C.c_int64)] + [(n, C.c_double) for n in ("parse_ms", "seed_ms", "chain_ms", "align_ms", "format_ms", "copy_ms", "search_kernel_ms")] + \
+               [("search_kernel_launches", C.c_int64)] + [(n, C.c_double) for n in ("search_useful_bytes", "text_in_bytes", "text_out_bytes")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 _lib = None
 
 
@@ -130,6 +162,16 @@ def load_library() -> C.CDLL:
     L.kg_nw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.kg_nw_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kg_stream_open.argtypes = [C.c_void_p, C.POINTER(StreamConfig), C.POINTER(C.c_void_p)]
+    L.kg_stream_close.argtypes = [C.c_void_p]
+    L.kg_stream_close.restype = None
+    L.kg_stream_staging.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    L.kg_stream_staging.restype = C.c_void_p
+    L.kg_stream_upload.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64]
+    L.kg_stream_parse.argtypes = [C.c_void_p, C.c_int, C.POINTER(StreamWindow), C.POINTER(StreamParsed)]
+    L.kg_stream_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(StreamParams), C.POINTER(StreamResult)]
+    L.kg_stream_fetch_reads.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.kg_stream_timing.argtypes = [C.c_void_p, C.POINTER(StreamTiming), C.c_int]
     _lib = L
     return L
 

@@ -3,8 +3,7 @@
 // Host side of the boundary: index files -> HBM, per-batch workspaces, kernel launches.  No
 // CPU implementation of the kernels lives here: without a usable HIP device every entry point
 // returns KG_ERR_NO_DEVICE.
-#include "seed_kernels.hpp"
-#include "align_kernels.hpp"
+#include "abi_internal.hpp"
 #include <cmath>
 
 #include <algorithm>
@@ -18,13 +17,13 @@
 #include <thread>
 #include <vector>
 
-using namespace kg;
-
 namespace {
 
 thread_local char g_err[512] = "";
 
-int fail(int code, const char *fmt, ...)
+}  // namespace
+
+int kg_fail(int code, const char *fmt, ...)
 {
 	va_list ap;
 	va_start(ap, fmt);
@@ -32,13 +31,9 @@ int fail(int code, const char *fmt, ...)
 	va_end(ap);
 	return code;
 }
+#define fail kg_fail
 
-#define HIP_TRY(expr)                                                                                  \
-	do {                                                                                               \
-		hipError_t e_ = (expr);                                                                        \
-		if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? KG_ERR_NOMEM : KG_ERR_NO_DEVICE, \
-		                                  "%s: %s", #expr, hipGetErrorString(e_));                     \
-	} while (0)
+namespace {
 
 // a whole file in memory, without the zero fill a std::vector would do first (the .bwt of hg38 is 3.1 GB)
 struct FileBuf {
@@ -68,129 +63,7 @@ bool read_file(const std::string &path, FileBuf &buf)
 	return got == (size_t)sz;
 }
 
-struct ContigRec {
-	std::string name;
-	int64_t fwd_start, rev_start, len;
-};
-
 }  // namespace
-
-// Scratch of one in-flight kg_nw_batch* call.  Cached in the index handle and recycled once the event
-// recorded behind the call's last kernel has completed: steady state allocates nothing, and the
-// device-pointer entry stays asynchronous.  (hipMallocAsync/hipFreeAsync were used first; with calls of
-// varying size on the null stream the recycled pool blocks produced intermittently empty work lists.)
-struct NwScratch {
-	int32_t *lists = nullptr;
-	size_t list_words = 0;
-	unsigned long long *queue = nullptr;
-	uint32_t *dir = nullptr;
-	size_t dir_words = 0;
-	hipEvent_t done = nullptr;
-	bool busy = false;
-	bool pending = false;     // acquired, but the event behind its kernels is not recorded yet: `done` still reports the PREVIOUS use
-	// staging of the host-buffer entry (kg_nw_batch): inputs, offsets and outputs, grown on demand
-	char *io = nullptr;
-	size_t io_bytes = 0;
-	bool io_busy = false;
-};
-
-struct kg_index {
-	std::mutex nw_mu;
-	std::vector<NwScratch *> nw_pool;
-	int device = 0;
-	int n_cu = 256;
-	int sa_mode = KG_SA_SAMPLED;
-	FmView view{};
-	int64_t l_pac = 0;
-	uint64_t n_sa = 0;
-	std::vector<ContigRec> contigs;
-	std::vector<uint8_t> pac;   // forward strand, 2 bits/base (host copy)
-	// device allocations
-	uint32_t *d_occ = nullptr;
-	uint4 *d_planes = nullptr;
-	uint4 *d_planes2 = nullptr;        // two-step rank structure (fm_device.hpp)
-	uint4 *d_planes3 = nullptr;        // three-step rank structure
-	void *d_qtab = nullptr;
-	uint64_t *d_sa = nullptr;
-	void *d_fsa = nullptr;
-	uint8_t *d_text = nullptr;
-	uint8_t *d_pac = nullptr;
-	int64_t *d_contig_end = nullptr;   // ChrLocMap keys, ascending
-	int n_ends = 0;
-	int32_t *d_end_chr = nullptr;      // contig of every key
-	int64_t *d_chr_tab = nullptr;      // [3 * n_contigs]: FowardLocation, ReverseLocation, len
-	uint8_t *d_mapq_tab = nullptr;     // EvaluateMAPQ's libm branch, tabulated (kg_align_batch)
-	uint64_t device_bytes = 0;
-};
-
-struct kg_workspace {
-	kg_index *ix = nullptr;
-	int64_t max_reads = 0, max_bases = 0, max_hits = 0;
-	// device scratch
-	Hit *d_hits = nullptr;
-	uint64_t *d_packed = nullptr;
-	int32_t *d_seeds_per_read = nullptr;
-	unsigned long long *d_ctl = nullptr;
-	void *d_scan_temp = nullptr;
-	size_t scan_bytes = 0;
-	uint32_t *d_sort_keys = nullptr;    // EXPERIMENT (KG_SORT_READS)
-	bool single_steps = false;          // kg_workspace_set_single_steps
-	void *d_sort_temp = nullptr;
-	size_t sort_bytes = 0;
-	// staging for the host-buffer entry point
-	uint8_t *d_enc = nullptr;
-	int64_t *d_read_off = nullptr;
-	int64_t *d_seed_off = nullptr;
-	kg_seed *d_seeds = nullptr;
-	int64_t seed_capacity = 0;
-	int64_t last_reads = 0, last_seeds = 0;   // batch the staging buffers currently hold (kg_seed_batch)
-	kg_candidate *d_cands = nullptr;
-	kg_seed *d_cand_seeds = nullptr;
-	int32_t *d_n_cands = nullptr;
-	uint8_t *d_taken = nullptr;
-	int32_t *d_used = nullptr;
-	int64_t *d_cand_off = nullptr, *d_cseed_off = nullptr;
-	kg_candidate *d_dense_cands = nullptr, *h_cands = nullptr;
-	kg_seed *d_dense_seeds = nullptr, *h_cand_seeds = nullptr;
-	int64_t h_cand_capacity = 0;
-	// The pinned arrays kg_candidates_batch / kg_align_batch hand out rotate through kRing sets, so that a result stays valid
-	// while the next kRing - 1 batches go through the workspace (a pipelined caller keeps several batches in flight and need
-	// not copy anything out)
-	static constexpr int kRing = 4;
-	kg_candidate *ring_cands[kRing] = {nullptr, nullptr, nullptr, nullptr};
-	kg_seed *ring_seeds[kRing] = {nullptr, nullptr, nullptr, nullptr};
-	int64_t ring_cand_capacity[kRing] = {0, 0, 0, 0};
-	kg_aln_record *ring_records[kRing] = {nullptr, nullptr, nullptr, nullptr};
-	int64_t ring_record_capacity[kRing] = {0, 0, 0, 0};
-	int ring_at = 0, ring_rec_at = 0;
-	int64_t cand_capacity = 0, ncand_capacity = 0;
-	kg_seed *h_seeds = nullptr;     // pinned
-	int64_t h_seed_capacity = 0;
-	// alignment stage (kg_align_batch)
-	int64_t last_cands = -1;            // candidates the last kg_candidates_batch left on the device
-	bool last_ascii = false;            // the resident reads are characters (KG_INPUT_ASCII)
-	void *d_aln_cand = nullptr;         // per-candidate state, one block
-	int64_t aln_cand_capacity = 0;
-	void *d_aln_read = nullptr;         // per-read state (host flags, records), one block
-	int64_t aln_read_capacity = 0;
-	kg_aln_record *h_records = nullptr; // pinned
-	AlnSpill *d_spill = nullptr;
-	NwJobDesc *d_jobs = nullptr;
-	uint8_t *d_job_ops = nullptr;
-	int32_t *d_job_len = nullptr;
-	int64_t spill_capacity = 0, job_capacity = 0, ops_capacity = 0;
-	void *d_plans = nullptr;            // partition plans + pieces, one block
-	void *d_tasks = nullptr;            // rescue windows and the candidates they yield, one block
-	int64_t task_capacity = 0;
-	int64_t *d_chunk_off = nullptr;
-	uint8_t *d_chunk_paired = nullptr;
-	kg_chunk_stats *d_chunk_stats = nullptr;
-	int chunk_capacity = 0;
-	unsigned long long *d_aln_ctl = nullptr;
-	hipStream_t stream = nullptr;
-	bool profiling = false;
-	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-};
 
 extern "C" {
 
@@ -561,6 +434,7 @@ int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_w
 		HIP_TRY(hipMalloc(&ws->d_sort_temp, ws->sort_bytes ? ws->sort_bytes : 256));
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+	HIP_TRY(hipHostMalloc((void **)&ws->h_small, 8 * 16, hipHostMallocDefault));
 	*out = ws.release();
 	return KG_OK;
 }
@@ -579,6 +453,8 @@ void kg_workspace_destroy(kg_workspace *ws)
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (ws->h_seeds) (void)hipHostFree(ws->h_seeds);
+	if (ws->h_small) (void)hipHostFree(ws->h_small);
+	if (ws->sync_ev) (void)hipEventDestroy(ws->sync_ev);
 	for (hipEvent_t e : ws->ev)
 		if (e) (void)hipEventDestroy(e);
 	delete ws;
@@ -718,6 +594,57 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	return KG_OK;
 }
 
+// waits for everything enqueued on the workspace's stream.  The wait sleeps on an interrupt (hipEventBlockingSync) instead of
+// spinning: several device threads wait at once in a pipelined run and the host's cores are the scarce resource there
+hipError_t kgi_sync(kg_workspace *ws)
+{
+	static const bool spin = getenv("KG_SPIN_SYNC") != nullptr;
+	if (spin) return hipStreamSynchronize(ws->stream);
+	if (!ws->sync_ev) {
+		hipError_t e = hipEventCreateWithFlags(&ws->sync_ev, hipEventBlockingSync | hipEventDisableTiming);
+		if (e != hipSuccess) return e;
+	}
+	hipError_t e = hipEventRecord(ws->sync_ev, ws->stream);
+	if (e != hipSuccess) return e;
+	return hipEventSynchronize(ws->sync_ev);
+}
+
+// seeding of the batch resident in ws->d_enc / ws->d_read_off: the seeds stay in ws->d_seeds / ws->d_seed_off.  The output
+// capacity grows on demand: run, and if the batch overflowed, re-run once with the exact size.
+int kgi_seed_resident(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, int64_t n_reads, int64_t n_bases, int64_t *total_out)
+{
+	int rc = check_seed_args(ws, mode, min_seed_len, occ_thr, n_reads, n_bases);
+	if (rc != KG_OK) return rc;
+	int64_t want = std::max<int64_t>(ws->seed_capacity, 8 * n_reads + 1024);
+	int64_t total = 0;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		if (want > ws->seed_capacity) {
+			if (ws->d_seeds) HIP_TRY(hipFree(ws->d_seeds));
+			ws->d_seeds = nullptr;
+			HIP_TRY(hipMalloc((void **)&ws->d_seeds, sizeof(kg_seed) * (size_t)want));
+			ws->seed_capacity = want;
+		}
+		rc = kg_seed_batch_device(ws, mode, min_seed_len, occ_thr, ws->d_enc, ws->d_read_off, n_reads, n_bases,
+		                          ws->d_seed_off, ws->d_seeds, ws->seed_capacity, ws->stream);
+		if (rc != KG_OK) return rc;
+		unsigned long long *h = ws->h_small;           // (page-locked: the two copies below are truly asynchronous)
+		HIP_TRY(hipMemcpyAsync(&h[0], ws->d_seed_off + n_reads, 8, hipMemcpyDeviceToHost, ws->stream));
+		HIP_TRY(hipMemcpyAsync(&h[1], ws->d_ctl + 11, 8, hipMemcpyDeviceToHost, ws->stream));
+		HIP_TRY(kgi_sync(ws));
+		if (h[1] == (~0ull >> 1)) return fail(KG_ERR_CAPACITY, "kg_seed_batch: the hit list of the workspace overflowed");
+		total = (int64_t)h[0];
+		if (total <= ws->seed_capacity) break;
+		want = total;
+		if (attempt == 1) return fail(KG_ERR_CAPACITY, "kg_seed_batch: seed buffer overflow persisted");
+	}
+	ws->last_reads = n_reads;
+	ws->last_seeds = total;
+	ws->last_cands = -1;
+	ws->last_ascii = (mode & KG_INPUT_ASCII) != 0;
+	*total_out = total;
+	return KG_OK;
+}
+
 int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, const uint8_t *enc_bases,
                   const int64_t *read_offsets, int64_t n_reads, int64_t *seed_offsets, const kg_seed **seeds)
 {
@@ -736,32 +663,11 @@ int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, con
 	}
 	HIP_TRY(hipMemcpyAsync(ws->d_enc, enc_bases, (size_t)n_bases, hipMemcpyHostToDevice, ws->stream));
 	HIP_TRY(hipMemcpyAsync(ws->d_read_off, read_offsets, 8 * (size_t)(n_reads + 1), hipMemcpyHostToDevice, ws->stream));
-	// output capacity grows on demand: run, and if the batch overflowed, re-run once with the exact size
-	int64_t want = std::max<int64_t>(ws->seed_capacity, 8 * n_reads + 1024);
-	for (int attempt = 0; attempt < 2; ++attempt) {
-		if (want > ws->seed_capacity) {
-			if (ws->d_seeds) HIP_TRY(hipFree(ws->d_seeds));
-			ws->d_seeds = nullptr;
-			HIP_TRY(hipMalloc((void **)&ws->d_seeds, sizeof(kg_seed) * (size_t)want));
-			ws->seed_capacity = want;
-		}
-		rc = kg_seed_batch_device(ws, mode, min_seed_len, occ_thr, ws->d_enc, ws->d_read_off, n_reads, n_bases,
-		                          ws->d_seed_off, ws->d_seeds, ws->seed_capacity, ws->stream);
-		if (rc != KG_OK) return rc;
-		HIP_TRY(hipMemcpyAsync(seed_offsets, ws->d_seed_off, 8 * (size_t)(n_reads + 1), hipMemcpyDeviceToHost, ws->stream));
-		unsigned long long over = 0;
-		HIP_TRY(hipMemcpyAsync(&over, ws->d_ctl + 11, 8, hipMemcpyDeviceToHost, ws->stream));
-		HIP_TRY(hipStreamSynchronize(ws->stream));
-		if (over == (~0ull >> 1)) return fail(KG_ERR_CAPACITY, "kg_seed_batch: the hit list of the workspace overflowed");
-		if (seed_offsets[n_reads] <= ws->seed_capacity) break;
-		want = seed_offsets[n_reads];
-		if (attempt == 1) return fail(KG_ERR_CAPACITY, "kg_seed_batch: seed buffer overflow persisted");
-	}
-	int64_t total = seed_offsets[n_reads];
-	ws->last_reads = n_reads;
-	ws->last_seeds = total;
-	ws->last_cands = -1;
-	ws->last_ascii = (mode & KG_INPUT_ASCII) != 0;
+	int64_t total = 0;
+	rc = kgi_seed_resident(ws, mode, min_seed_len, occ_thr, n_reads, n_bases, &total);
+	if (rc != KG_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(seed_offsets, ws->d_seed_off, 8 * (size_t)(n_reads + 1), hipMemcpyDeviceToHost, ws->stream));
+	HIP_TRY(kgi_sync(ws));
 	if (!seeds) return KG_OK;             // the caller only wants the candidates: the seeds stay on the device
 	if (total > ws->h_seed_capacity) {
 		if (ws->h_seeds) HIP_TRY(hipHostFree(ws->h_seeds));
@@ -772,7 +678,7 @@ int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, con
 	}
 	if (total > 0) {
 		HIP_TRY(hipMemcpyAsync(ws->h_seeds, ws->d_seeds, sizeof(kg_seed) * (size_t)total, hipMemcpyDeviceToHost, ws->stream));
-		HIP_TRY(hipStreamSynchronize(ws->stream));
+		HIP_TRY(kgi_sync(ws));
 	}
 	*seeds = ws->h_seeds;
 	ws->last_reads = n_reads;
@@ -782,17 +688,10 @@ int kg_seed_batch(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, con
 
 // Replaces GenerateAlignmentCandidateForIlluminaSeq / ForPacBioSeq (reference src/AlignmentCandidates.cpp:82-130,
 // 171-224) for every read of the batch the last kg_seed_batch call left on the device.
-int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_reads, int64_t n_seeds, int32_t *n_cands,
-                         const kg_candidate **cands, int64_t *n_cands_total, const kg_seed **cand_seeds, int64_t *n_cand_seeds_total)
+// chaining of the batch the last seeding call left on the device; totals[0] candidates, totals[1] candidate seeds (dense arrays
+// ws->d_dense_cands / d_dense_seeds, per-read ranges ws->d_cand_off)
+int kgi_chain_resident(kg_workspace *ws, int pacbio, int max_gaps, int64_t totals[2])
 {
-	if (!ws || !n_cands || !cands || !n_cands_total || !cand_seeds || !n_cand_seeds_total) return fail(KG_ERR_ARG, "kg_candidates_batch: null argument");
-	*cands = nullptr; *cand_seeds = nullptr; *n_cands_total = 0; *n_cand_seeds_total = 0;
-	if (ws->last_reads <= 0) return fail(KG_ERR_ARG, "kg_candidates_batch: no seeded batch on this workspace (call kg_seed_batch first)");
-	if (max_gaps < 0) return fail(KG_ERR_ARG, "kg_candidates_batch: negative max_gaps");
-	if (n_reads != ws->last_reads || n_seeds != ws->last_seeds)
-		return fail(KG_ERR_ARG, "kg_candidates_batch: batch shape (%lld reads, %lld seeds) is not the one kg_seed_batch left on this workspace (%lld, %lld)",
-		            (long long)n_reads, (long long)n_seeds, (long long)ws->last_reads, (long long)ws->last_seeds);
-	HIP_TRY(hipSetDevice(ws->ix->device));
 	int64_t n = ws->last_reads, m = ws->last_seeds;
 	if (m + 1 > ws->cand_capacity) {
 		for (void *p : {(void *)ws->d_cands, (void *)ws->d_cand_seeds, (void *)ws->d_taken, (void *)ws->d_dense_cands, (void *)ws->d_dense_seeds})
@@ -824,11 +723,30 @@ int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_re
 	a.n_cands = ws->d_n_cands; a.used = ws->d_used; a.cands = ws->d_cands; a.cand_seeds = ws->d_cand_seeds; a.taken = ws->d_taken;
 	a.cand_off = ws->d_cand_off; a.cseed_off = ws->d_cseed_off; a.dense_cands = ws->d_dense_cands; a.dense_seeds = ws->d_dense_seeds;
 	HIP_TRY(launch_chain_batch(a, ws->d_scan_temp, ws->scan_bytes, ws->ix->n_cu, ws->stream));
+	unsigned long long *h = ws->h_small;
+	HIP_TRY(hipMemcpyAsync(&h[0], ws->d_cand_off + n, 8, hipMemcpyDeviceToHost, ws->stream));
+	HIP_TRY(hipMemcpyAsync(&h[1], ws->d_cseed_off + n, 8, hipMemcpyDeviceToHost, ws->stream));
+	HIP_TRY(kgi_sync(ws));
+	totals[0] = (int64_t)h[0]; totals[1] = (int64_t)h[1];
+	ws->last_cands = totals[0];
+	return KG_OK;
+}
+
+int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_reads, int64_t n_seeds, int32_t *n_cands,
+                         const kg_candidate **cands, int64_t *n_cands_total, const kg_seed **cand_seeds, int64_t *n_cand_seeds_total)
+{
+	if (!ws || !n_cands || !cands || !n_cands_total || !cand_seeds || !n_cand_seeds_total) return fail(KG_ERR_ARG, "kg_candidates_batch: null argument");
+	*cands = nullptr; *cand_seeds = nullptr; *n_cands_total = 0; *n_cand_seeds_total = 0;
+	if (ws->last_reads <= 0) return fail(KG_ERR_ARG, "kg_candidates_batch: no seeded batch on this workspace (call kg_seed_batch first)");
+	if (max_gaps < 0) return fail(KG_ERR_ARG, "kg_candidates_batch: negative max_gaps");
+	if (n_reads != ws->last_reads || n_seeds != ws->last_seeds)
+		return fail(KG_ERR_ARG, "kg_candidates_batch: batch shape (%lld reads, %lld seeds) is not the one kg_seed_batch left on this workspace (%lld, %lld)",
+		            (long long)n_reads, (long long)n_seeds, (long long)ws->last_reads, (long long)ws->last_seeds);
+	HIP_TRY(hipSetDevice(ws->ix->device));
+	const int64_t n = ws->last_reads;
 	int64_t totals[2] = {0, 0};
-	HIP_TRY(hipMemcpyAsync(n_cands, ws->d_n_cands, 4 * (size_t)n, hipMemcpyDeviceToHost, ws->stream));
-	HIP_TRY(hipMemcpyAsync(&totals[0], ws->d_cand_off + n, 8, hipMemcpyDeviceToHost, ws->stream));
-	HIP_TRY(hipMemcpyAsync(&totals[1], ws->d_cseed_off + n, 8, hipMemcpyDeviceToHost, ws->stream));
-	HIP_TRY(hipStreamSynchronize(ws->stream));
+	int rc = kgi_chain_resident(ws, pacbio, max_gaps, totals);
+	if (rc != KG_OK) return rc;
 	int64_t need = std::max(totals[0], totals[1]);
 	const int slot = ws->ring_at;
 	ws->ring_at = (ws->ring_at + 1) % kg_workspace::kRing;
@@ -843,12 +761,12 @@ int kg_candidates_batch(kg_workspace *ws, int pacbio, int max_gaps, int64_t n_re
 		ws->ring_cand_capacity[slot] = cap;
 	}
 	ws->h_cands = ws->ring_cands[slot]; ws->h_cand_seeds = ws->ring_seeds[slot];
+	HIP_TRY(hipMemcpyAsync(n_cands, ws->d_n_cands, 4 * (size_t)n, hipMemcpyDeviceToHost, ws->stream));
 	if (totals[0] > 0) HIP_TRY(hipMemcpyAsync(ws->h_cands, ws->d_dense_cands, sizeof(kg_candidate) * (size_t)totals[0], hipMemcpyDeviceToHost, ws->stream));
 	if (totals[1] > 0) HIP_TRY(hipMemcpyAsync(ws->h_cand_seeds, ws->d_dense_seeds, sizeof(kg_seed) * (size_t)totals[1], hipMemcpyDeviceToHost, ws->stream));
-	HIP_TRY(hipStreamSynchronize(ws->stream));
+	HIP_TRY(kgi_sync(ws));
 	*cands = ws->h_cands; *cand_seeds = ws->h_cand_seeds;
 	*n_cands_total = totals[0]; *n_cand_seeds_total = totals[1];
-	ws->last_cands = totals[0];
 	return KG_OK;
 }
 
@@ -938,21 +856,14 @@ static int nw_run(kg_index *ix, const char *d_frag1, const int64_t *d_off1, cons
 	return KG_OK;
 }
 
-// Replaces, for a batch, what ReadMapping() does per read between chaining and the SAM text (reference src/Mapping.cpp:542-578);
-// see align_kernels.hip for the kernel <-> reference correspondence.
-int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks, int est_distance, int max_insert,
-                   int max_gaps, int multi_hit, int unset_flag, const kg_aln_record **records, kg_chunk_stats *chunk_stats)
+// The alignment stage (align_kernels.hip) for the chained batch resident on the workspace: buffers grown on demand, every kernel
+// enqueued on the workspace's stream, nothing copied back.  `a` receives the argument block (a.records: n reads + the extra
+// records of -m, as many as `host_record_capacity` -- the caller's destination array -- and the device array hold).
+int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks, int est_distance, int max_insert,
+                       int max_gaps, int multi_hit, int unset_flag, int64_t host_record_capacity, AlnArgs &a)
 {
-	if (!ws || !chunk_off || !chunk_paired || !records || !chunk_stats || n_chunks <= 0) return fail(KG_ERR_ARG, "kg_align_batch: bad argument");
-	*records = nullptr;
-	if (ws->last_reads <= 0 || ws->last_cands < 0) return fail(KG_ERR_ARG, "kg_align_batch: no chained batch on this workspace (kg_seed_batch + kg_candidates_batch first)");
 	kg_index *ix = ws->ix;
 	const int64_t n = ws->last_reads, nc = ws->last_cands;
-	if (chunk_off[0] != 0 || chunk_off[n_chunks] != n) return fail(KG_ERR_ARG, "kg_align_batch: the chunks do not cover the %lld reads of the batch", (long long)n);
-	for (int c = 0; c < n_chunks; ++c) {
-		if (chunk_off[c + 1] < chunk_off[c]) return fail(KG_ERR_ARG, "kg_align_batch: chunk offsets must not decrease");
-		if (chunk_paired[c] && ((chunk_off[c + 1] - chunk_off[c]) & 1)) return fail(KG_ERR_ARG, "kg_align_batch: a paired chunk holds an odd number of reads");
-	}
 	if (!ix->d_text) return fail(KG_ERR_ARG, "kg_align_batch: the index holds no text");
 	if (!ws->last_ascii) return fail(KG_ERR_ARG, "kg_align_batch: the batch must have been seeded from read characters (KG_INPUT_ASCII): mismatch counting and CIGAR scoring compare raw characters");
 	HIP_TRY(hipSetDevice(ix->device));
@@ -1002,7 +913,6 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 	HIP_TRY(hipMemcpyAsync(ws->d_chunk_off, chunk_off, 8 * (size_t)(n_chunks + 1), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(ws->d_chunk_paired, chunk_paired, (size_t)n_chunks, hipMemcpyHostToDevice, st));
 	// ---- arguments ------------------------------------------------------------------------------------------------------------
-	AlnArgs a;
 	a.ix = ix->view;
 	a.ix.text = ix->d_text;
 	a.enc = ws->d_enc; a.read_off = ws->d_read_off; a.n_reads = n;
@@ -1072,6 +982,29 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 		hipError_t e2 = nw_submitted(ix, sc, st);
 		if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_align_batch: %s", hipGetErrorString(e != hipSuccess ? e : e2));
 	}
+	// -m: the further records of a read take slots behind the n per-read ones, as many as both arrays hold
+	if (multi_hit) a.extra_capacity = std::max<int64_t>(0, std::min<int64_t>(ws->aln_read_capacity, host_record_capacity) - n);
+	HIP_TRY(launch_align_back(a, ix->n_cu, st));
+	return KG_OK;
+}
+
+// Replaces, for a batch, what ReadMapping() does per read between chaining and the SAM text (reference src/Mapping.cpp:542-578);
+// see align_kernels.hip for the kernel <-> reference correspondence.
+int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks, int est_distance, int max_insert,
+                   int max_gaps, int multi_hit, int unset_flag, const kg_aln_record **records, kg_chunk_stats *chunk_stats)
+{
+	if (!ws || !chunk_off || !chunk_paired || !records || !chunk_stats || n_chunks <= 0) return fail(KG_ERR_ARG, "kg_align_batch: bad argument");
+	*records = nullptr;
+	if (ws->last_reads <= 0 || ws->last_cands < 0) return fail(KG_ERR_ARG, "kg_align_batch: no chained batch on this workspace (kg_seed_batch + kg_candidates_batch first)");
+	kg_index *ix = ws->ix;
+	const int64_t n = ws->last_reads;
+	if (chunk_off[0] != 0 || chunk_off[n_chunks] != n) return fail(KG_ERR_ARG, "kg_align_batch: the chunks do not cover the %lld reads of the batch", (long long)n);
+	for (int c = 0; c < n_chunks; ++c) {
+		if (chunk_off[c + 1] < chunk_off[c]) return fail(KG_ERR_ARG, "kg_align_batch: chunk offsets must not decrease");
+		if (chunk_paired[c] && ((chunk_off[c + 1] - chunk_off[c]) & 1)) return fail(KG_ERR_ARG, "kg_align_batch: a paired chunk holds an odd number of reads");
+	}
+	HIP_TRY(hipSetDevice(ix->device));
+	hipStream_t st = ws->stream;
 	{
 		const int slot = ws->ring_rec_at;
 		ws->ring_rec_at = (ws->ring_rec_at + 1) % kg_workspace::kRing;
@@ -1083,20 +1016,21 @@ int kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *ch
 			ws->ring_record_capacity[slot] = cap;
 		}
 		ws->h_records = ws->ring_records[slot];
-		// -m: the further records of a read take slots behind the n per-read ones, as many as both arrays hold
-		if (multi_hit) a.extra_capacity = std::min<int64_t>(ws->aln_read_capacity, ws->ring_record_capacity[slot]) - n;
 	}
-	HIP_TRY(launch_align_back(a, ix->n_cu, st));
+	AlnArgs a;
+	int rc = kgi_align_resident(ws, chunk_off, chunk_paired, n_chunks, est_distance, max_insert, max_gaps, multi_hit, unset_flag,
+	                            ws->ring_record_capacity[(ws->ring_rec_at + kg_workspace::kRing - 1) % kg_workspace::kRing], a);
+	if (rc != KG_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(ws->h_records, a.records, sizeof(kg_aln_record) * (size_t)n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(chunk_stats, ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)n_chunks, hipMemcpyDeviceToHost, st));
 	if (multi_hit) {
-		unsigned long long extra = 0;
-		HIP_TRY(hipMemcpyAsync(&extra, ws->d_aln_ctl + 7, 8, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		int64_t k = (int64_t)std::min<unsigned long long>(extra, (unsigned long long)a.extra_capacity);
+		unsigned long long *h = ws->h_small;
+		HIP_TRY(hipMemcpyAsync(&h[0], ws->d_aln_ctl + 7, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(kgi_sync(ws));
+		int64_t k = (int64_t)std::min<unsigned long long>(h[0], (unsigned long long)a.extra_capacity);
 		if (k > 0) HIP_TRY(hipMemcpyAsync(ws->h_records + n, a.records + n, sizeof(kg_aln_record) * (size_t)k, hipMemcpyDeviceToHost, st));
 	}
-	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(kgi_sync(ws));
 	*records = ws->h_records;
 	return KG_OK;
 }

@@ -1,0 +1,414 @@
+// abi_stream.hip -- kg_stream_*: FASTQ text in, SAM text out (declared in include/kart_amd.h).
+//
+// One call chain per batch replaces what the reference's worker loop does for a chunk from GetNextChunk to the fprintf of its SAM
+// lines (src/Mapping.cpp:488-637; src/GetData.cpp:109-143): the caller uploads the bytes of the input files as they lie there,
+// and receives the text of the records.  A stream owns `lanes` independent lanes -- workspace, device text windows, page-locked
+// staging and result buffers, one HIP stream each -- so that several batches are in flight on the device at once (the analogue of
+// the reference's N workers each on their own chunk, src/Mapping.cpp:716-717).
+#include "abi_internal.hpp"
+#include "stream_kernels.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#define fail kg_fail
+
+namespace {
+
+struct Lane {
+	kg_workspace *ws = nullptr;
+	// device
+	uint8_t *d_text[2] = {nullptr, nullptr};
+	int32_t *d_tile[2] = {nullptr, nullptr};
+	uint32_t *d_line_end[2] = {nullptr, nullptr};
+	uint32_t *d_rec[2] = {nullptr, nullptr};           // six arrays of rec_capacity words: hdr, name, seq, qual, rlen, qlen
+	int64_t *d_meta = nullptr;
+	int32_t *d_read_len = nullptr;
+	void *d_scan = nullptr;
+	size_t scan_bytes = 0;
+	int32_t *d_sam_len = nullptr, *d_host_list = nullptr;
+	int64_t *d_sam_off = nullptr;
+	unsigned long long *d_sam_ctl = nullptr;
+	uint8_t *d_sam = nullptr;
+	int64_t d_sam_capacity = 0;
+	// page-locked
+	char *h_text[2] = {nullptr, nullptr};
+	int64_t *h_meta = nullptr;                         // [FQM_WORDS] + [8] spare words for totals
+	char *h_sam = nullptr;
+	int64_t h_sam_capacity = 0;
+	int64_t *h_sam_off = nullptr, *h_cand_off = nullptr;
+	int32_t *h_host_list = nullptr;
+	uint32_t *h_rec_hdr[2] = {nullptr, nullptr};
+	kg_aln_record *h_records = nullptr;
+	int64_t record_capacity = 0;
+	kg_chunk_stats *h_chunk_stats = nullptr;
+	int64_t chunk_capacity = 0;
+	kg_candidate *h_cands = nullptr;
+	kg_seed *h_cand_seeds = nullptr;
+	int64_t h_cand_capacity = 0;
+	unsigned long long *h_ctl = nullptr;               // [kCtlWords] the search kernel's counters of the batch
+	// the batch in the lane
+	kg_stream_window win{};
+	kg_stream_parsed parsed{};
+	bool have_batch = false;
+	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+}  // namespace
+
+struct kg_stream {
+	kg_index *ix = nullptr;
+	kg_stream_config cfg{};
+	int64_t text_capacity = 0, line_capacity = 0, rec_capacity = 0;
+	std::vector<Lane> lanes;
+	uint8_t *d_chr_names = nullptr;
+	int32_t *d_chr_name_off = nullptr;
+	int min_seed_len = 13;
+	std::mutex mu;
+	kg_stream_timing_t total{};
+};
+
+namespace {
+
+void free_lane(Lane &l)
+{
+	if (l.ws) kg_workspace_destroy(l.ws);
+	for (int f = 0; f < 2; ++f) {
+		if (l.d_text[f]) (void)hipFree(l.d_text[f]);
+		if (l.d_tile[f]) (void)hipFree(l.d_tile[f]);
+		if (l.d_line_end[f]) (void)hipFree(l.d_line_end[f]);
+		if (l.d_rec[f]) (void)hipFree(l.d_rec[f]);
+		if (l.h_text[f]) (void)hipHostFree(l.h_text[f]);
+		if (l.h_rec_hdr[f]) (void)hipHostFree(l.h_rec_hdr[f]);
+	}
+	for (void *p : {(void *)l.d_meta, (void *)l.d_read_len, l.d_scan, (void *)l.d_sam_len, (void *)l.d_host_list, (void *)l.d_sam_off, (void *)l.d_sam_ctl, (void *)l.d_sam})
+		if (p) (void)hipFree(p);
+	for (void *p : {(void *)l.h_meta, (void *)l.h_sam, (void *)l.h_sam_off, (void *)l.h_cand_off, (void *)l.h_host_list, (void *)l.h_records, (void *)l.h_chunk_stats,
+	                (void *)l.h_cands, (void *)l.h_cand_seeds, (void *)l.h_ctl})
+		if (p) (void)hipHostFree(p);
+	for (hipEvent_t e : l.ev)
+		if (e) (void)hipEventDestroy(e);
+	l = Lane();
+}
+
+FqWindow window_of(const kg_stream *s, const Lane &l, int f)
+{
+	FqWindow w;
+	w.text = l.d_text[f];
+	w.begin = l.win.begin[f]; w.end = l.win.end[f]; w.eof = l.win.eof[f];
+	w.tile_lines = l.d_tile[f];
+	w.line_end = l.d_line_end[f];
+	w.line_capacity = s->line_capacity;
+	uint32_t *r = l.d_rec[f];
+	const size_t c = (size_t)s->rec_capacity;
+	w.rec_hdr = r; w.rec_name = r + c; w.rec_seq = r + 2 * c; w.rec_qual = r + 3 * c;
+	w.rec_rlen = (int32_t *)(r + 4 * c); w.rec_qlen = (int32_t *)(r + 5 * c);
+	return w;
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b)
+{
+	float ms = 0;
+	if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return ms;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out)
+{
+	if (!ix || !cfg || !out) return fail(KG_ERR_ARG, "kg_stream_open: null argument");
+	*out = nullptr;
+	if (cfg->lanes < 1 || cfg->lanes > 16 || cfg->max_reads < 2 || cfg->max_window < 4096 || cfg->max_window > 0xF0000000ll)
+		return fail(KG_ERR_ARG, "kg_stream_open: bad configuration (%d lanes, %lld reads, %lld bytes per window)", cfg->lanes, (long long)cfg->max_reads, (long long)cfg->max_window);
+	if (!ix->d_text) return fail(KG_ERR_ARG, "kg_stream_open: the index holds no text");
+	HIP_TRY(hipSetDevice(ix->device));
+	std::unique_ptr<kg_stream, void (*)(kg_stream *)> s(new kg_stream(), kg_stream_close);
+	s->ix = ix;
+	s->cfg = *cfg;
+	s->text_capacity = (cfg->max_window + 4096 + 255) & ~255ll;
+	// a line of FASTQ text is rarely shorter than 16 bytes on average (header, sequence, '+', qualities); a window with more lines
+	// than this goes back to the caller's reader (FQ_STOP_IRREGULAR)
+	s->line_capacity = cfg->max_window / 16 + 4096;
+	s->rec_capacity = s->line_capacity / 4 + 1;
+	{
+		kg_index_info_t info;
+		kg_index_info(ix, &info);
+		s->min_seed_len = info.min_seed_len;
+		std::vector<int32_t> off{0};
+		std::string names;
+		for (const ContigRec &c : ix->contigs) { names += c.name; off.push_back((int32_t)names.size()); }
+		HIP_TRY(hipMalloc((void **)&s->d_chr_names, names.size() + 16));
+		HIP_TRY(hipMalloc((void **)&s->d_chr_name_off, 4 * off.size()));
+		HIP_TRY(hipMemcpy(s->d_chr_names, names.data(), names.size(), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(s->d_chr_name_off, off.data(), 4 * off.size(), hipMemcpyHostToDevice));
+	}
+	s->lanes.resize((size_t)cfg->lanes);
+	const int64_t n = cfg->max_reads;
+	for (Lane &l : s->lanes) {
+		// bases of a batch: what two windows can hold (every read costs its characters twice plus a header)
+		int rc = kg_workspace_create(ix, n + 8, cfg->max_window + 4096, &l.ws);
+		if (rc != KG_OK) return rc;
+		kg_workspace *ws = l.ws;
+		HIP_TRY(hipMalloc((void **)&ws->d_enc, (size_t)ws->max_bases + 64));
+		HIP_TRY(hipMalloc((void **)&ws->d_read_off, 8 * (size_t)(ws->max_reads + 1)));
+		HIP_TRY(hipMalloc((void **)&ws->d_seed_off, 8 * (size_t)(ws->max_reads + 1)));
+		(void)kg_workspace_set_profiling(ws, 1);
+		const int64_t n_tiles = s->text_capacity / kFqTile + 2;
+		for (int f = 0; f < 2; ++f) {
+			HIP_TRY(hipMalloc((void **)&l.d_text[f], (size_t)s->text_capacity));
+			HIP_TRY(hipMalloc((void **)&l.d_tile[f], 4 * (size_t)(n_tiles + 1)));
+			HIP_TRY(hipMalloc((void **)&l.d_line_end[f], 4 * (size_t)s->line_capacity));
+			HIP_TRY(hipMalloc((void **)&l.d_rec[f], 4 * 6 * (size_t)s->rec_capacity));
+			HIP_TRY(hipHostMalloc((void **)&l.h_text[f], (size_t)s->text_capacity, hipHostMallocDefault));
+			HIP_TRY(hipHostMalloc((void **)&l.h_rec_hdr[f], 4 * (size_t)(n + 8), hipHostMallocDefault));
+		}
+		HIP_TRY(hipMalloc((void **)&l.d_meta, 8 * FQM_WORDS));
+		HIP_TRY(hipMalloc((void **)&l.d_read_len, 4 * (size_t)(n + 8)));
+		l.scan_bytes = fq_scan_temp_bytes(std::max<int64_t>(n + 8, n_tiles + 1));
+		HIP_TRY(hipMalloc(&l.d_scan, l.scan_bytes ? l.scan_bytes : 256));
+		HIP_TRY(hipMalloc((void **)&l.d_sam_len, 4 * (size_t)(n + 8)));
+		HIP_TRY(hipMalloc((void **)&l.d_host_list, 4 * (size_t)(n + 8)));
+		HIP_TRY(hipMalloc((void **)&l.d_sam_off, 8 * (size_t)(n + 8)));
+		HIP_TRY(hipMalloc((void **)&l.d_sam_ctl, 8 * 4));
+		HIP_TRY(hipHostMalloc((void **)&l.h_meta, 8 * (FQM_WORDS + 8), hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void **)&l.h_sam_off, 8 * (size_t)(n + 8), hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void **)&l.h_cand_off, 8 * (size_t)(n + 8), hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void **)&l.h_host_list, 4 * (size_t)(n + 8), hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void **)&l.h_ctl, 8 * kCtlWords, hipHostMallocDefault));
+		// the text of a batch: its input's bytes and a little more per read (FLAG .. TLEN and the tags against '+' and the mate suffix)
+		l.d_sam_capacity = 2 * cfg->max_window + 64 * n + 4096;
+		HIP_TRY(hipMalloc((void **)&l.d_sam, (size_t)l.d_sam_capacity));
+		l.h_sam_capacity = l.d_sam_capacity;
+		HIP_TRY(hipHostMalloc((void **)&l.h_sam, (size_t)l.h_sam_capacity, hipHostMallocDefault));
+		l.record_capacity = n + n / 4 + 4096;
+		HIP_TRY(hipHostMalloc((void **)&l.h_records, sizeof(kg_aln_record) * (size_t)l.record_capacity, hipHostMallocDefault));
+		for (hipEvent_t &e : l.ev) HIP_TRY(hipEventCreate(&e));
+	}
+	*out = s.release();
+	return KG_OK;
+}
+
+void kg_stream_close(kg_stream *s)
+{
+	if (!s) return;
+	(void)hipSetDevice(s->ix->device);
+	for (Lane &l : s->lanes) free_lane(l);
+	if (s->d_chr_names) (void)hipFree(s->d_chr_names);
+	if (s->d_chr_name_off) (void)hipFree(s->d_chr_name_off);
+	delete s;
+}
+
+char *kg_stream_staging(kg_stream *s, int lane, int file, int64_t *capacity)
+{
+	if (!s || lane < 0 || lane >= (int)s->lanes.size() || file < 0 || file > 1) return nullptr;
+	if (capacity) *capacity = s->cfg.max_window;
+	return s->lanes[(size_t)lane].h_text[file];
+}
+
+int kg_stream_upload(kg_stream *s, int lane, int file, int64_t from, int64_t to)
+{
+	if (!s || lane < 0 || lane >= (int)s->lanes.size() || file < 0 || file > 1) return fail(KG_ERR_ARG, "kg_stream_upload: bad argument");
+	if (from < 0 || to < from || to > s->cfg.max_window) return fail(KG_ERR_ARG, "kg_stream_upload: range [%lld, %lld) outside the staging buffer", (long long)from, (long long)to);
+	if (to == from) return KG_OK;
+	Lane &l = s->lanes[(size_t)lane];
+	HIP_TRY(hipSetDevice(s->ix->device));
+	HIP_TRY(hipMemcpyAsync(l.d_text[file] + from, l.h_text[file] + from, (size_t)(to - from), hipMemcpyHostToDevice, l.ws->stream));
+	return KG_OK;
+}
+
+int kg_stream_parse(kg_stream *s, int lane, const kg_stream_window *w, kg_stream_parsed *out)
+{
+	if (!s || !w || !out || lane < 0 || lane >= (int)s->lanes.size()) return fail(KG_ERR_ARG, "kg_stream_parse: bad argument");
+	Lane &l = s->lanes[(size_t)lane];
+	const int nf = w->two_files ? 2 : 1;
+	for (int f = 0; f < nf; ++f)
+		if (w->begin[f] < 0 || w->end[f] < w->begin[f] || w->end[f] > s->cfg.max_window) return fail(KG_ERR_ARG, "kg_stream_parse: window %d outside the staging buffer", f);
+	if (w->chunk_reads < 2 || (w->chunk_reads & 1) || w->want_reads < w->chunk_reads || w->want_reads > s->cfg.max_reads || w->want_reads % w->chunk_reads)
+		return fail(KG_ERR_ARG, "kg_stream_parse: want_reads must be a multiple of chunk_reads (an even number) within the stream's batch size");
+	HIP_TRY(hipSetDevice(s->ix->device));
+	l.win = *w;
+	l.have_batch = false;
+	kg_workspace *ws = l.ws;
+	FqArgs a;
+	a.w[0] = window_of(s, l, 0);
+	a.w[1] = window_of(s, l, 1);
+	if (!w->two_files) { a.w[1].begin = a.w[1].end = 0; a.w[1].eof = 1; }
+	a.two_files = w->two_files ? 1 : 0;
+	a.paired = w->paired ? 1 : 0;
+	a.chunk_reads = w->chunk_reads;
+	a.max_reads = s->cfg.max_reads;
+	a.want_reads = w->want_reads;
+	a.meta = l.d_meta;
+	a.read_len = l.d_read_len;
+	a.read_off = ws->d_read_off;
+	a.enc = ws->d_enc;
+	a.n_reads = 0;
+	hipStream_t st = ws->stream;
+	HIP_TRY(hipEventRecord(l.ev[0], st));
+	HIP_TRY(launch_fq_parse(a, l.d_scan, l.scan_bytes, s->ix->n_cu, st));
+	HIP_TRY(hipMemcpyAsync(l.h_meta, l.d_meta, 8 * FQM_WORDS, hipMemcpyDeviceToHost, st));
+	HIP_TRY(kgi_sync(ws));
+	kg_stream_parsed &p = l.parsed;
+	p.n_reads = l.h_meta[FQM_READS]; p.n_chunks = l.h_meta[FQM_CHUNKS]; p.n_bases = l.h_meta[FQM_BASES];
+	p.used[0] = l.h_meta[FQM_USED0]; p.used[1] = w->two_files ? l.h_meta[FQM_USED1] : 0;
+	p.stop = (int32_t)l.h_meta[FQM_STOP]; p.done = (int32_t)l.h_meta[FQM_DONE];
+	if (p.n_bases > ws->max_bases) return fail(KG_ERR_CAPACITY, "kg_stream_parse: %lld bases exceed the lane's workspace (%lld)", (long long)p.n_bases, (long long)ws->max_bases);
+	if (p.n_reads > 0) {
+		a.n_reads = p.n_reads;
+		HIP_TRY(launch_fq_materialise(a, s->ix->n_cu, st));
+		// where every record of the batch starts in its window: the caller re-reads the few reads that come back as KG_ALN_HOST
+		const int64_t r0 = w->two_files ? p.n_reads / 2 : p.n_reads;
+		HIP_TRY(hipMemcpyAsync(l.h_rec_hdr[0], a.w[0].rec_hdr, 4 * (size_t)r0, hipMemcpyDeviceToHost, st));
+		if (w->two_files) HIP_TRY(hipMemcpyAsync(l.h_rec_hdr[1], a.w[1].rec_hdr, 4 * (size_t)r0, hipMemcpyDeviceToHost, st));
+	}
+	HIP_TRY(hipEventRecord(l.ev[1], st));
+	l.have_batch = p.n_reads > 0;
+	*out = p;
+	return KG_OK;
+}
+
+int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream_result *out)
+{
+	if (!s || !prm || !out || lane < 0 || lane >= (int)s->lanes.size()) return fail(KG_ERR_ARG, "kg_stream_map: bad argument");
+	Lane &l = s->lanes[(size_t)lane];
+	if (!l.have_batch) return fail(KG_ERR_ARG, "kg_stream_map: no parsed batch in lane %d (kg_stream_parse first)", lane);
+	memset(out, 0, sizeof(*out));
+	kg_index *ix = s->ix;
+	kg_workspace *ws = l.ws;
+	hipStream_t st = ws->stream;
+	HIP_TRY(hipSetDevice(ix->device));
+	const int64_t n = l.parsed.n_reads;
+	const int n_chunks = (int)l.parsed.n_chunks;
+	// ---- seeding (IdentifySeedPairs_FastMode) and chaining on the resident characters ---------------------------------------
+	int64_t n_seeds = 0, totals[2] = {0, 0};
+	int rc = kgi_seed_resident(ws, KG_MODE_FAST | KG_INPUT_ASCII, s->min_seed_len, KG_OCC_THR_DEFAULT, n, l.parsed.n_bases, &n_seeds);
+	if (rc != KG_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(l.h_ctl, ws->d_ctl, 8 * kCtlWords, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(l.ev[2], st));
+	rc = kgi_chain_resident(ws, 0, prm->max_gaps, totals);
+	if (rc != KG_OK) return rc;
+	HIP_TRY(hipEventRecord(l.ev[3], st));
+	// ---- the per-read report ------------------------------------------------------------------------------------------------
+	std::vector<int64_t> chunk_off((size_t)n_chunks + 1);
+	std::vector<uint8_t> chunk_paired((size_t)n_chunks, (uint8_t)(l.win.paired ? 1 : 0));
+	for (int c = 0; c <= n_chunks; ++c) chunk_off[(size_t)c] = std::min<int64_t>(n, (int64_t)c * l.win.chunk_reads);
+	if (n_chunks > l.chunk_capacity) {
+		if (l.h_chunk_stats) HIP_TRY(hipHostFree(l.h_chunk_stats));
+		l.h_chunk_stats = nullptr;
+		l.chunk_capacity = n_chunks + n_chunks / 2 + 64;
+		HIP_TRY(hipHostMalloc((void **)&l.h_chunk_stats, sizeof(kg_chunk_stats) * (size_t)l.chunk_capacity, hipHostMallocDefault));
+	}
+	AlnArgs a;
+	rc = kgi_align_resident(ws, chunk_off.data(), chunk_paired.data(), n_chunks, prm->est_distance, prm->max_insert, prm->max_gaps, prm->multi_hit,
+	                        prm->unset_flag, l.record_capacity, a);
+	if (rc != KG_OK) return rc;
+	HIP_TRY(hipEventRecord(l.ev[4], st));
+	// ---- the text -----------------------------------------------------------------------------------------------------------
+	SamArgs q;
+	q.w[0] = window_of(s, l, 0); q.w[1] = window_of(s, l, 1);
+	q.two_files = l.win.two_files ? 1 : 0; q.paired = l.win.paired ? 1 : 0;
+	q.enc = ws->d_enc; q.read_off = ws->d_read_off; q.n_reads = n;
+	q.records = a.records;
+	q.chr_names = s->d_chr_names; q.chr_name_off = s->d_chr_name_off;
+	q.sam_len = l.d_sam_len; q.sam_off = l.d_sam_off; q.sam = l.d_sam; q.sam_capacity = l.d_sam_capacity;
+	q.host_list = l.d_host_list; q.ctl = l.d_sam_ctl;
+	HIP_TRY(launch_sam_size(q, l.d_scan, l.scan_bytes, ix->n_cu, st));
+	int64_t *tot = l.h_meta + FQM_WORDS;              // [0] text bytes, [1] reads handed back, [2] format errors, [3] extra records of -m
+	HIP_TRY(hipMemcpyAsync(&tot[0], l.d_sam_off + n, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&tot[1], l.d_sam_ctl, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&tot[3], ws->d_aln_ctl + 7, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(kgi_sync(ws));
+	const int64_t sam_bytes = tot[0], n_host = tot[1];
+	const int64_t extra = prm->multi_hit ? std::min<int64_t>(tot[3], a.extra_capacity) : 0;
+	if (sam_bytes > l.d_sam_capacity) {
+		// (never seen: the estimate in kg_stream_open is generous; -m on a repeat-rich genome could get here)
+		HIP_TRY(hipFree(l.d_sam)); l.d_sam = nullptr;
+		l.d_sam_capacity = sam_bytes + sam_bytes / 4;
+		HIP_TRY(hipMalloc((void **)&l.d_sam, (size_t)l.d_sam_capacity));
+		q.sam = l.d_sam; q.sam_capacity = l.d_sam_capacity;
+	}
+	if (sam_bytes > l.h_sam_capacity) {
+		HIP_TRY(hipHostFree(l.h_sam)); l.h_sam = nullptr;
+		l.h_sam_capacity = sam_bytes + sam_bytes / 4;
+		HIP_TRY(hipHostMalloc((void **)&l.h_sam, (size_t)l.h_sam_capacity, hipHostMallocDefault));
+	}
+	const int64_t cand_need = std::max(totals[0], totals[1]);
+	if (cand_need > l.h_cand_capacity) {
+		if (l.h_cands) HIP_TRY(hipHostFree(l.h_cands));
+		if (l.h_cand_seeds) HIP_TRY(hipHostFree(l.h_cand_seeds));
+		l.h_cands = nullptr; l.h_cand_seeds = nullptr;
+		l.h_cand_capacity = std::max<int64_t>(cand_need + cand_need / 4 + 1024, 3 * s->cfg.max_reads);
+		HIP_TRY(hipHostMalloc((void **)&l.h_cands, sizeof(kg_candidate) * (size_t)l.h_cand_capacity, hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void **)&l.h_cand_seeds, sizeof(kg_seed) * (size_t)l.h_cand_capacity, hipHostMallocDefault));
+	}
+	HIP_TRY(launch_sam_format(q, ix->n_cu, st));
+	HIP_TRY(hipEventRecord(l.ev[5], st));
+	if (sam_bytes > 0) HIP_TRY(hipMemcpyAsync(l.h_sam, l.d_sam, (size_t)sam_bytes, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(l.h_sam_off, l.d_sam_off, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(l.h_records, a.records, sizeof(kg_aln_record) * (size_t)(n + extra), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(l.h_chunk_stats, ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)n_chunks, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(l.h_cand_off, ws->d_cand_off, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
+	// the candidates travel with every batch: the reads handed back need them, and so does a pair the caller maps again because its
+	// speculated EstDistance did not hold
+	if (n_host > 0) HIP_TRY(hipMemcpyAsync(l.h_host_list, l.d_host_list, 4 * (size_t)n_host, hipMemcpyDeviceToHost, st));
+	if (totals[0] > 0) HIP_TRY(hipMemcpyAsync(l.h_cands, ws->d_dense_cands, sizeof(kg_candidate) * (size_t)totals[0], hipMemcpyDeviceToHost, st));
+	if (totals[1] > 0) HIP_TRY(hipMemcpyAsync(l.h_cand_seeds, ws->d_dense_seeds, sizeof(kg_seed) * (size_t)totals[1], hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&tot[2], l.d_sam_ctl + 1, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(l.ev[6], st));
+	HIP_TRY(kgi_sync(ws));
+	if (tot[2] != 0) return fail(KG_ERR_NO_DEVICE, "kg_stream_map: %lld records were formatted to a size other than the one announced", (long long)tot[2]);
+	std::sort(l.h_host_list, l.h_host_list + n_host);
+	out->n_reads = n; out->n_chunks = n_chunks;
+	out->sam = l.h_sam; out->sam_bytes = sam_bytes; out->sam_off = l.h_sam_off;
+	out->records = l.h_records; out->n_records = n + extra;
+	out->chunk_stats = l.h_chunk_stats;
+	out->host_reads = l.h_host_list; out->n_host_reads = n_host;
+	out->cand_off = l.h_cand_off; out->cands = l.h_cands; out->cand_seeds = l.h_cand_seeds;
+	out->rec_start[0] = l.h_rec_hdr[0]; out->rec_start[1] = l.win.two_files ? l.h_rec_hdr[1] : nullptr;
+	l.have_batch = false;
+	{
+		// what the batch cost on the device, stage by stage, and what its search kernel fetched (kg_workspace_traffic's formula)
+		float sk = 0;
+		if (ws->profiling && ws->ev[0]) sk = elapsed(ws->ev[0], ws->ev[1]);
+		const unsigned long long *c = l.h_ctl;
+		const double sa_bytes = ix->view.fsa32 ? 4.0 : 8.0;
+		const double useful = 8.0 * (double)c[17] + 32.0 * (double)c[18] + sa_bytes * (double)c[8] + 48.0 * (double)c[20] + 8.0 * (double)c[21] + 20.0 * (double)n + 32.0 * (double)c[1];
+		std::lock_guard<std::mutex> lk(s->mu);
+		kg_stream_timing_t &t = s->total;
+		t.batches += 1; t.reads += n;
+		t.parse_ms += elapsed(l.ev[0], l.ev[1]); t.seed_ms += elapsed(l.ev[1], l.ev[2]); t.chain_ms += elapsed(l.ev[2], l.ev[3]);
+		t.align_ms += elapsed(l.ev[3], l.ev[4]); t.format_ms += elapsed(l.ev[4], l.ev[5]); t.copy_ms += elapsed(l.ev[5], l.ev[6]);
+		t.search_kernel_ms += sk; t.search_kernel_launches += 1; t.search_useful_bytes += useful;
+		t.text_in_bytes += (double)((l.parsed.used[0] - l.win.begin[0]) + (l.win.two_files ? l.parsed.used[1] - l.win.begin[1] : 0));
+		t.text_out_bytes += (double)sam_bytes;
+	}
+	return KG_OK;
+}
+
+int kg_stream_fetch_reads(kg_stream *s, int lane, uint8_t *enc, int64_t *read_off)
+{
+	if (!s || lane < 0 || lane >= (int)s->lanes.size() || !read_off) return fail(KG_ERR_ARG, "kg_stream_fetch_reads: bad argument");
+	Lane &l = s->lanes[(size_t)lane];
+	if (!l.have_batch) return fail(KG_ERR_ARG, "kg_stream_fetch_reads: no parsed batch in lane %d", lane);
+	HIP_TRY(hipSetDevice(s->ix->device));
+	HIP_TRY(kgi_sync(l.ws));
+	HIP_TRY(hipMemcpy(read_off, l.ws->d_read_off, 8 * (size_t)(l.parsed.n_reads + 1), hipMemcpyDeviceToHost));
+	if (enc && l.parsed.n_bases > 0) HIP_TRY(hipMemcpy(enc, l.ws->d_enc, (size_t)l.parsed.n_bases, hipMemcpyDeviceToHost));
+	return KG_OK;
+}
+
+int kg_stream_timing(kg_stream *s, kg_stream_timing_t *out, int reset)
+{
+	if (!s || !out) return fail(KG_ERR_ARG, "kg_stream_timing: null argument");
+	std::lock_guard<std::mutex> lk(s->mu);
+	*out = s->total;
+	if (reset) s->total = kg_stream_timing_t{};
+	return KG_OK;
+}
+
+}  // extern "C"

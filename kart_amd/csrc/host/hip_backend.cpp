@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -31,6 +32,46 @@ static double now_sec()
 	return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+class HipStream : public StreamBackend {
+public:
+	HipStream(kg_stream *s, const kg_stream_config &cfg) : s_(s), cfg_(cfg) {}
+	~HipStream() override { kg_stream_close(s_); }
+	int lanes() const override { return cfg_.lanes; }
+	int64_t max_reads() const override { return cfg_.max_reads; }
+	int64_t max_window() const override { return cfg_.max_window; }
+	char *staging(int lane, int file) override { return kg_stream_staging(s_, lane, file, nullptr); }
+	void upload(int lane, int file, int64_t from, int64_t to) override
+	{
+		if (kg_stream_upload(s_, lane, file, from, to) != KG_OK) die("kg_stream_upload");
+	}
+	bool parse(int lane, const kg_stream_window &w, kg_stream_parsed &out) override
+	{
+		int rc = kg_stream_parse(s_, lane, &w, &out);
+		if (rc == KG_ERR_CAPACITY) return false;
+		if (rc != KG_OK) die("kg_stream_parse");
+		return true;
+	}
+	void map(int lane, const kg_stream_params &p, kg_stream_result &out) override
+	{
+		if (kg_stream_map(s_, lane, &p, &out) != KG_OK) die("kg_stream_map");
+	}
+	std::string timing(bool reset) override
+	{
+		kg_stream_timing_t t;
+		if (kg_stream_timing(s_, &t, reset ? 1 : 0) != KG_OK || t.batches == 0) return std::string();
+		char b[640];
+		snprintf(b, sizeof(b), "device stream: %lld batches, %lld reads | stage ms (summed over lanes, stages of different lanes overlap): parse %.1f, seed %.1f (search_kernel %.2f in %lld launches, %.1f useful MB), chain %.1f, align %.1f, format %.1f, copy-out %.1f | text in %.1f MB, out %.1f MB",
+		         (long long)t.batches, (long long)t.reads, t.parse_ms, t.seed_ms, t.search_kernel_ms, (long long)t.search_kernel_launches, t.search_useful_bytes / 1e6, t.chain_ms, t.align_ms,
+		         t.format_ms, t.copy_ms, t.text_in_bytes / 1e6, t.text_out_bytes / 1e6);
+		return std::string(b);
+	}
+	kg_stream *handle() const { return s_; }
+
+private:
+	kg_stream *s_;
+	kg_stream_config cfg_;
+};
+
 class HipBackend : public KernelBackend {
 public:
 	double t_seed = 0, t_cands = 0, t_copy = 0, t_align = 0, t_reccopy = 0;   // KART_AMD_VERBOSE: where the per-batch device stage spends its time
@@ -42,8 +83,26 @@ public:
 	}
 	~HipBackend() override
 	{
+		stream_.reset();
+		for (std::pair<kg_workspace *, int> &r : retired_) kg_workspace_destroy(r.first);
 		kg_workspace_destroy(ws_);
 		kg_index_destroy(ix_);
+	}
+	StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes) override
+	{
+		static const bool off = getenv("KART_AMD_NO_STREAM") != nullptr;      // A/B aid: the host parses and prints, as before
+		if (off) return nullptr;
+		if (stream_ && stream_->max_reads() >= max_reads && stream_->max_window() >= max_window && stream_->lanes() >= lanes) return stream_.get();
+		stream_.reset();
+		kg_stream_config cfg;
+		cfg.max_reads = max_reads; cfg.max_window = max_window; cfg.lanes = lanes;
+		kg_stream *s = nullptr;
+		if (kg_stream_open(ix_, &cfg, &s) != KG_OK) {
+			fprintf(stderr, "Warning! no device stream (%s): the host parses and prints\n", kg_last_error());
+			return nullptr;
+		}
+		stream_.reset(new HipStream(s, cfg));
+		return stream_.get();
 	}
 	int min_seed_len() const override { return info_.min_seed_len; }
 	void *host_alloc(size_t bytes) override { return kg_host_alloc(bytes); }
@@ -135,8 +194,14 @@ private:
 	// the seeding workspace grows with the largest batch seen (long-read batches are far larger in bases)
 	void reserve(int64_t reads, int64_t bases)
 	{
+		// a workspace that was outgrown is retired, not destroyed: its page-locked result arrays (candidates, records) are still
+		// being read by the stages of up to kRing - 1 earlier batches; it is freed once that many further batches have passed
+		for (size_t i = 0; i < retired_.size();) {
+			if (--retired_[i].second <= 0) { kg_workspace_destroy(retired_[i].first); retired_.erase(retired_.begin() + (std::ptrdiff_t)i); }
+			else ++i;
+		}
 		if (ws_ && reads <= cap_reads_ && bases <= cap_bases_) return;
-		if (ws_) kg_workspace_destroy(ws_);
+		if (ws_) retired_.emplace_back(ws_, 4);
 		ws_ = nullptr;
 		cap_reads_ = std::max(cap_reads_, reads + reads / 4 + 1024);
 		cap_bases_ = std::max(cap_bases_, bases + bases / 4 + 65536);
@@ -152,6 +217,8 @@ private:
 	std::vector<int32_t> len_;
 	std::vector<int64_t> seed_off_;
 	kg_workspace *ws_ = nullptr;
+	std::vector<std::pair<kg_workspace *, int>> retired_;   // outgrown workspaces and the batches left until their arrays are unused
+	std::unique_ptr<HipStream> stream_;
 	kg_index_info_t info_;
 };
 

@@ -8,6 +8,7 @@
 
 #include <fcntl.h>
 #include <immintrin.h>
+#include <sys/file.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
@@ -48,6 +49,7 @@ namespace {
 #include "detail/reader.inc"
 #include "detail/shard.inc"
 #include "detail/pipeline.inc"
+#include "detail/stream.inc"
 
 }  // namespace
 
@@ -211,6 +213,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		tot.t_lib += now_s() - tl;
 	}
 	const bool last_writer = !shard.active() || (shard.solo ? shard.rank == 0 : shard.rank == shard.count - 1);
+	const size_t bam_eof_bytes = 28;                     // (an empty BGZF block)
 	if (opt.bam && last_writer) {                       // the empty BGZF block that marks the end of the file (SAMv1 4.1.2)
 		std::string eof_block;
 		bgzf_append_block((const unsigned char *)"", 0, eof_block);
@@ -221,7 +224,17 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	if (shard.active()) {
 		// the run is complete when every shard's text is in the file
 		Rendezvous *rv = shard.rdv;
-		if (shard.rank == 0) shard.wait([&]() { for (int q = 0; q < shard.count; ++q) if (!rv->written[q].load()) return false; return true; }, "waiting for the other shards");
+		if (shard.rank == 0) {
+			shard.wait([&]() { for (int q = 0; q < shard.count; ++q) if (!rv->written[q].load()) return false; return true; }, "waiting for the other shards");
+			// every shard's text is in place and nobody extends the file any more (the writers grow it in large steps): its exact size
+			int64_t total = rv->header_bytes.load() + (opt.bam ? (int64_t)bam_eof_bytes : 0);
+			for (int q = 0; q < shard.count; ++q) total += rv->out_bytes[q].load();
+			struct stat sb;
+			if (out && fstat(fileno(out), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > total) {
+				fflush(out);
+				if (ftruncate(fileno(out), (off_t)total) != 0) perror("ftruncate");
+			}
+		}
 	}
 	stats.paired = tot.iPaired;
 	stats.distance = tot.iDistance;

@@ -41,6 +41,8 @@ struct Options {
 	std::string rendezvous;         // ... coordinating with the other processes through this shared-memory file
 	int sa_mode = KG_SA_FULL;
 	int64_t batch_reads = default_batch_reads();   // reads seeded per GPU call (a whole number of 4000-read chunks; KART_AMD_BATCH_READS overrides)
+	int64_t stream_reads = default_stream_reads();   // reads per batch of the device's FASTQ-in / SAM-out stream (KART_AMD_STREAM_READS overrides)
+	static int64_t default_stream_reads() { const char *e = getenv("KART_AMD_STREAM_READS"); long long v = e ? atoll(e) : 0; return v >= 4000 ? (int64_t)v : 1000000; }
 	static int64_t default_batch_reads() { const char *e = getenv("KART_AMD_BATCH_READS"); long long v = e ? atoll(e) : 0; return v >= 4000 ? (int64_t)v : 400000; }
 };
 
@@ -67,8 +69,24 @@ struct NwJobs {
 	}
 };
 
+// FASTQ text in, SAM text out (kg_stream_*, include/kart_amd.h): `lanes` batches in flight on the device, the host only moves
+// bytes.  The calls of one lane must not overlap; different lanes are driven from different threads.
+struct StreamBackend {
+	virtual ~StreamBackend() {}
+	virtual int lanes() const = 0;
+	virtual int64_t max_reads() const = 0;
+	virtual int64_t max_window() const = 0;
+	virtual char *staging(int lane, int file) = 0;                                   // page-locked, max_window() bytes
+	virtual void upload(int lane, int file, int64_t from, int64_t to) = 0;           // asynchronous
+	virtual bool parse(int lane, const kg_stream_window &w, kg_stream_parsed &out) = 0;   // false: the window does not fit the lane (the caller's own reader takes over)
+	virtual void map(int lane, const kg_stream_params &p, kg_stream_result &out) = 0;
+	virtual std::string timing(bool reset) { (void)reset; return std::string(); }    // KART_AMD_VERBOSE: device time per stage
+};
+
 struct KernelBackend {
 	virtual ~KernelBackend() {}
+	// a stream with at least this capacity (kept by the backend across runs), or null: the backend has no such path
+	virtual StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes) { (void)max_reads; (void)max_window; (void)lanes; return nullptr; }
 	// index constants the host needs
 	virtual int min_seed_len() const = 0;
 	// IdentifySeedPairs_{Fast,Sensitive}Mode + GenerateAlignmentCandidateFor{Illumina,PacBio}Seq for a batch: enc = the concatenated
@@ -116,6 +134,7 @@ struct Stats {
 	int64_t total_reads = 0, unmapped = 0, unique = 0, paired = 0, distance = 0;
 	double map_seconds = 0;     // first read in -> last SAM byte handed to the writer (index load excluded)
 	int64_t respeculated = 0;   // chunks re-mapped because their speculated EstDistance did not hold
+	int64_t stream_reads = 0;   // reads that went through the device's FASTQ-in / SAM-out stream
 	bool sharded = false;       // the totals above are this process's shard only (kart::shard_totals() gives the run's)
 };
 

@@ -1,0 +1,464 @@
+// stream_kernels.hip -- FASTQ text in, SAM text out, on the device (gfx950).
+//
+// Input side = GetNextChunk / GetNextEntry (reference src/GetData.cpp:29-143) for a whole window of text at once:
+//   fq_count_kernel / fq_index_kernel   the lines of the window: every '\n' ends one (getline); byte-parallel, 16 bytes per lane,
+//                                       per-tile counts -> scan -> scatter of the line ends in order.
+//   fq_record_kernel                    four lines = one record (header, sequence, '+', qualities) with the reference's own
+//                                       arithmetic: name = IdentifyHeaderBegPos/EndPos (:29-49), rlen = sequence line length - 1
+//                                       (the last character of a line is taken to be the newline, :66-69), qualities cut to rlen.
+//   fq_plan_kernel                      how many whole chunks of ReadChunkSize reads the window yields (GetNextChunk's loop, :109-143),
+//                                       where the next window starts, and whether something the device path does not take lies ahead
+//                                       (an empty read ends a chunk early in the reference; such windows go to the host's reader).
+//   fq_materialise_kernel               the reads as the reference holds them: characters as in the file, the second read of a
+//                                       pair reverse-complemented (:125-135; GetComplementarySeq, src/tools.cpp:3-29).
+// Output side = OutputPairedAlignments / OutputSingledAlignments (src/Mapping.cpp:177-315) for every kg_aln_record of the batch:
+//   sam_size_kernel                     exact byte count of the line(s) of every read -> scan -> offsets
+//   sam_format_kernel                   one wave per read: name, FLAG .. TLEN, sequence (reverse-complemented for a record shown on
+//                                       the other strand), qualities (reversed likewise), NM / AS / XS.
+// Byte work, HBM-bound, no MFMA.  Everything is integer / character arithmetic; results are bit-identical to the host pipeline's
+// text (tests/test_stream_gpu.py, and every SAM parity test runs through this path).
+#include "stream_kernels.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+namespace kg {
+
+namespace {
+
+// 4-bit mask of the bytes of x equal to the byte replicated in pat (bit i = byte i, lowest address first)
+__device__ __forceinline__ uint32_t eq_mask4(uint32_t x, uint32_t pat)
+{
+	uint32_t t = x ^ pat;
+	uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);       // 0x80 in every zero byte of t, exactly
+	return ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u);
+}
+
+// the 16 bytes of this thread: newline mask (and whether a NUL byte lies among them), restricted to the window
+__device__ __forceinline__ uint32_t newline_mask16(const FqWindow &w, int64_t p, bool &nul)
+{
+	nul = false;
+	if (p >= w.end || p + 16 <= w.begin) return 0;
+	const uint4 v = *reinterpret_cast<const uint4 *>(w.text + p);
+	uint32_t nl = eq_mask4(v.x, 0x0A0A0A0Au) | (eq_mask4(v.y, 0x0A0A0A0Au) << 4) | (eq_mask4(v.z, 0x0A0A0A0Au) << 8) | (eq_mask4(v.w, 0x0A0A0A0Au) << 12);
+	uint32_t z = eq_mask4(v.x, 0u) | (eq_mask4(v.y, 0u) << 4) | (eq_mask4(v.z, 0u) << 8) | (eq_mask4(v.w, 0u) << 12);
+	int lo = (int)(w.begin > p ? w.begin - p : 0), hi = (int)(w.end - p < 16 ? w.end - p : 16);
+	uint32_t keep = (hi >= 16 ? 0xFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+	nul = (z & keep) != 0;
+	return nl & keep;
+}
+
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+	const int lane = threadIdx.x & 63;
+	for (int d = 1; d < 64; d <<= 1) {
+		int t = __shfl_up(v, d);
+		if (lane >= d) v += t;
+	}
+	return v;
+}
+
+}  // namespace
+
+// ---- lines ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fq_count_kernel(FqArgs a, int f, int64_t n_tiles)
+{
+	const FqWindow &w = a.w[f];
+	const int64_t ta = w.begin & ~(int64_t)15;
+	__shared__ int wave_sum[4];
+	for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+		bool nul;
+		uint32_t m = newline_mask16(w, ta + t * kFqTile + (int64_t)threadIdx.x * 16, nul);
+		if (nul) a.meta[FQM_NUL] = 1;
+		int c = __popc(m);
+		for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+		if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
+		__syncthreads();
+		if (threadIdx.x == 0) w.tile_lines[t] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+		__syncthreads();
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) w.tile_lines[n_tiles] = 0;
+}
+
+__global__ __launch_bounds__(256) void fq_index_kernel(FqArgs a, int f, int64_t n_tiles)
+{
+	const FqWindow &w = a.w[f];
+	const int64_t ta = w.begin & ~(int64_t)15;
+	__shared__ int wave_sum[4];
+	for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+		bool nul;
+		const int64_t p = ta + t * kFqTile + (int64_t)threadIdx.x * 16;
+		uint32_t m = newline_mask16(w, p, nul);
+		int c = __popc(m);
+		int incl = wave_inclusive_scan(c);
+		if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+		__syncthreads();
+		int64_t at = (int64_t)w.tile_lines[t] + (incl - c);
+		for (int q = 0; q < (int)(threadIdx.x >> 6); ++q) at += wave_sum[q];
+		while (m) {
+			int b = __ffs(m) - 1;
+			m &= m - 1;
+			if (at < w.line_capacity) w.line_end[at] = (uint32_t)(p + b + 1);
+			else a.meta[FQM_OVERFLOW] = 1;
+			at++;
+		}
+		__syncthreads();
+	}
+	// the total, and the last line of a file that does not end in a newline (getline returns it as it is)
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		int64_t lines = w.tile_lines[n_tiles];
+		if (w.eof && w.end > w.begin && w.text[w.end - 1] != '\n') {
+			if (lines < w.line_capacity) w.line_end[lines] = (uint32_t)w.end;
+			else a.meta[FQM_OVERFLOW] = 1;
+			lines++;
+		}
+		a.meta[FQM_LINES0 + f] = lines;
+	}
+}
+
+// ---- records -------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fq_record_kernel(FqArgs a, int f)
+{
+	const FqWindow &w = a.w[f];
+	// (launched behind fq_index_kernel of the same window on the same stream: the line count is final)
+	int64_t lines = a.meta[FQM_LINES0 + f];
+	if (lines > w.line_capacity) lines = w.line_capacity;
+	const int64_t recs = lines >> 2;
+	for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < recs; j += (int64_t)gridDim.x * blockDim.x) {
+		const uint32_t l0 = j == 0 ? (uint32_t)w.begin : w.line_end[4 * j - 1], l1 = w.line_end[4 * j], l2 = w.line_end[4 * j + 1],
+		               l3 = w.line_end[4 * j + 2], l4 = w.line_end[4 * j + 3];
+		// IdentifyHeaderBegPos / IdentifyHeaderEndPos on the header line (its newline included), src/GetData.cpp:29-49
+		const int len = (int)(l1 - l0);
+		const uint8_t *h = w.text + l0;
+		int p1 = len - 1, p2 = len - 1;
+		bool f1 = false, f2 = false;
+		for (int i = 1; i < len && !(f1 && f2); ++i) {
+			const uint8_t c = h[i];
+			if (!f1 && c != '>' && c != '@') { p1 = i; f1 = true; }
+			if (!f2 && (c == ' ' || c == '/' || c == '\t')) { p2 = i; f2 = true; }
+		}
+		const int name_len = p2 > p1 ? p2 - p1 : 0;
+		const int rlen = (int)(l2 - l1) - 1;
+		int qlen = (int)(l4 - l3);
+		if (qlen > rlen) qlen = rlen;
+		if (qlen < 0) qlen = 0;
+		w.rec_hdr[j] = l0;
+		w.rec_name[j] = (uint32_t)(p1 & 0xFFFF) | ((uint32_t)name_len << 16);
+		w.rec_seq[j] = l1;
+		w.rec_qual[j] = l3;
+		w.rec_rlen[j] = rlen;
+		w.rec_qlen[j] = qlen;
+		// an empty read ends a chunk early in the reference (src/GetData.cpp:117,121); a header too long for the 16-bit fields,
+		// a read beyond any short-read length: not taken here
+		if (rlen <= 0 || rlen > (1 << 20) || p1 > 0xFFFF || name_len > 0xFFFF) atomicMin((long long *)&a.meta[FQM_BAD0 + f], (long long)j);
+		const int64_t i = a.two_files ? 2 * j + f : j;
+		if (i < a.max_reads) a.read_len[i] = rlen > 0 ? rlen : 0;
+	}
+}
+
+__global__ void fq_reset_kernel(FqArgs a)
+{
+	const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i0 < FQM_WORDS) a.meta[i0] = (i0 == FQM_BAD0 || i0 == FQM_BAD1) ? 0x7fffffffffffffffll : 0;
+	for (int64_t i = i0; i <= a.max_reads; i += (int64_t)gridDim.x * blockDim.x) a.read_len[i] = 0;
+}
+
+// GetNextChunk's loop over the window: whole chunks only, unless the files end here in a regular way
+__global__ void fq_plan_kernel(FqArgs a)
+{
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	const int64_t kNone = 0x7fffffffffffffffll;
+	const int64_t L0 = a.meta[FQM_LINES0], L1 = a.two_files ? a.meta[FQM_LINES1] : 0;
+	const int64_t recs0 = L0 >> 2, recs1 = L1 >> 2;
+	int64_t avail, bad = kNone;
+	if (a.two_files) {
+		avail = 2 * (recs0 < recs1 ? recs0 : recs1);
+		if (a.meta[FQM_BAD0] != kNone) bad = 2 * a.meta[FQM_BAD0];
+		if (a.meta[FQM_BAD1] != kNone && 2 * a.meta[FQM_BAD1] + 1 < bad) bad = 2 * a.meta[FQM_BAD1] + 1;
+	} else {
+		avail = recs0;
+		bad = a.meta[FQM_BAD0];
+	}
+	const bool at_eof = a.w[0].eof && (!a.two_files || a.w[1].eof);
+	const bool regular_end = at_eof && (L0 & 3) == 0 && (!a.two_files || ((L1 & 3) == 0 && recs0 == recs1)) && (!(a.paired && !a.two_files) || (recs0 & 1) == 0);
+	int64_t take = avail < a.want_reads ? avail : a.want_reads;
+	int64_t stop = FQ_STOP_NONE;
+	if (bad < take) { take = bad; stop = FQ_STOP_IRREGULAR; }
+	if (a.meta[FQM_NUL] || a.meta[FQM_OVERFLOW]) { take = 0; stop = FQ_STOP_IRREGULAR; }
+	const bool full = stop == FQ_STOP_NONE && take == avail && regular_end;
+	if (!full) {
+		take = take / a.chunk_reads * a.chunk_reads;
+		// the rest of the file is less than a chunk and does not end in the regular way (a lone mate, a partial record): the host's
+		// reader takes it from here
+		if (stop == FQ_STOP_NONE && at_eof && avail - take < a.chunk_reads) stop = FQ_STOP_TAIL;
+	}
+	const int64_t t0 = a.two_files ? take >> 1 : take, t1 = a.two_files ? take >> 1 : 0;
+	a.meta[FQM_READS] = take;
+	a.meta[FQM_CHUNKS] = (take + a.chunk_reads - 1) / a.chunk_reads;
+	a.meta[FQM_BASES] = a.read_off[take];
+	a.meta[FQM_USED0] = t0 ? (int64_t)a.w[0].line_end[4 * t0 - 1] : a.w[0].begin;
+	a.meta[FQM_USED1] = a.two_files ? (t1 ? (int64_t)a.w[1].line_end[4 * t1 - 1] : a.w[1].begin) : 0;
+	a.meta[FQM_STOP] = stop;
+	a.meta[FQM_DONE] = full ? 1 : 0;
+}
+
+// GetComplementaryBase, src/tools.cpp:3-17
+__device__ __forceinline__ uint8_t comp_char(uint8_t c)
+{
+	const uint8_t u = c & 0xDFu;
+	return u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : 'N';
+}
+
+// one wave per read: its characters into the batch's character array, reverse-complemented for the second read of a pair
+__global__ __launch_bounds__(256) void fq_materialise_kernel(FqArgs a)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+	for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < a.n_reads; i += waves) {
+		const int f = a.two_files ? (int)(i & 1) : 0;
+		const int64_t j = a.two_files ? i >> 1 : i;
+		const FqWindow &w = a.w[f];
+		const uint8_t *src = w.text + w.rec_seq[j];
+		const int n = w.rec_rlen[j];
+		uint8_t *dst = a.enc + a.read_off[i];
+		if (a.paired && (i & 1)) {
+			for (int k = lane; k < n; k += 64) dst[k] = comp_char(src[n - 1 - k]);
+		} else {
+			for (int k = lane; k < n; k += 64) dst[k] = src[k];
+		}
+	}
+}
+
+// ---- SAM text ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int int_chars(long long v)            // characters "%d" / "%lld" print
+{
+	int n = v < 0 ? 2 : 1;
+	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+	while (u >= 10) { u /= 10; n++; }
+	return n;
+}
+
+__device__ __forceinline__ char *put_int(char *p, long long v)
+{
+	const int n = int_chars(v);
+	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+	if (v < 0) p[0] = '-';
+	for (int i = n - 1; i >= (v < 0 ? 1 : 0); --i) { p[i] = (char)('0' + (int)(u % 10)); u /= 10; }
+	return p + n;
+}
+
+__device__ __forceinline__ char *put_lit(char *p, const char *s, int n)
+{
+	for (int i = 0; i < n; ++i) p[i] = s[i];
+	return p + n;
+}
+
+struct ReadText {                      // where the name and the qualities of read r lie, and its length
+	const uint8_t *name, *qual;
+	int name_len, qlen, rlen;
+	bool held_reversed;                // the second read of a pair: held reverse-complemented, its qualities reversed
+};
+
+__device__ __forceinline__ ReadText read_text(const SamArgs &a, int64_t r)
+{
+	const int f = a.two_files ? (int)(r & 1) : 0;
+	const int64_t j = a.two_files ? r >> 1 : r;
+	const FqWindow &w = a.w[f];
+	ReadText t;
+	const uint32_t nm = w.rec_name[j];
+	t.name = w.text + w.rec_hdr[j] + (nm & 0xFFFFu);
+	t.name_len = (int)(nm >> 16);
+	t.qual = w.text + w.rec_qual[j];
+	t.qlen = w.rec_qlen[j];
+	t.rlen = (int)(a.read_off[r + 1] - a.read_off[r]);
+	t.held_reversed = a.paired && (r & 1);
+	return t;
+}
+
+#define SAM_UNMAPPED_MID "\t*\t0\t0\t*\t*\t0\t0\t"
+#define SAM_UNMAPPED_TAIL "\tAS:i:0\tXS:i:0\n"
+
+// the bytes of one record's line (src/Mapping.cpp:181-186 / 225-230 unmapped, :199-223 / 246-262 / 297-302 mapped)
+__device__ int record_size(const SamArgs &a, const ReadText &t, const kg_aln_record &rec)
+{
+	if (rec.kind == KG_ALN_UNMAPPED)
+		return t.name_len + 1 + int_chars(rec.flag) + (int)(sizeof(SAM_UNMAPPED_MID) - 1) + t.rlen + 1 + t.qlen + (int)(sizeof(SAM_UNMAPPED_TAIL) - 1);
+	if (rec.kind != KG_ALN_MAPPED) return 0;
+	int n = t.name_len + 1 + int_chars(rec.flag) + 1 + (a.chr_name_off[rec.chr + 1] - a.chr_name_off[rec.chr]) + 1 + int_chars(rec.pos) + 1 + int_chars(rec.mapq) + 1 + rec.cigar_len;
+	n += rec.has_mate ? 3 + int_chars(rec.mate_pos) + 1 + int_chars(rec.tlen) + 1 : 7;
+	n += t.rlen + 1 + t.qlen;
+	n += 6 + int_chars(t.rlen - rec.score) + 6 + int_chars(rec.score) + 6 + int_chars(rec.sub_score) + 1;
+	return n;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void sam_size_kernel(SamArgs a)
+{
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+		const kg_aln_record &first = a.records[r];
+		int n = 0;
+		if (first.kind == KG_ALN_HOST) {
+			a.host_list[atomicAdd(&a.ctl[0], 1ull)] = (int32_t)r;
+		} else {
+			const ReadText t = read_text(a, r);
+			for (int64_t at = r; at >= 0; at = a.records[at].next) n += record_size(a, t, a.records[at]);
+		}
+		a.sam_len[r] = n;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) a.sam_len[a.n_reads] = 0;
+}
+
+// one wave per read.  Lane 0 prints the numeric fields into the wave's LDS block; all lanes then move the pieces: name, contig
+// name, sequence and qualities straight from the FASTQ text / the read characters to the output.
+__global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
+{
+	__shared__ char lds[256];
+	__shared__ int len[3];
+	char *const A = lds, *const B = lds + 16, *const T = lds + 176;     // "\tFLAG\t" | "\tPOS\tMAPQ\tCIGAR\t=\tPNEXT\tTLEN\t" | the tags
+	const int lane = threadIdx.x;
+	for (int64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+		if (a.records[r].kind == KG_ALN_HOST) continue;
+		const ReadText t = read_text(a, r);
+		const uint8_t *const seq = a.enc + a.read_off[r];
+		uint8_t *p = a.sam + a.sam_off[r];
+		const int64_t room = a.sam_off[r + 1];
+		if (room > a.sam_capacity) { if (lane == 0) atomicAdd(&a.ctl[1], 1ull); continue; }
+		for (int64_t at = r; at >= 0; at = a.records[at].next) {
+			const kg_aln_record &rec = a.records[at];
+			if (rec.kind != KG_ALN_UNMAPPED && rec.kind != KG_ALN_MAPPED) continue;
+			const bool mapped = rec.kind == KG_ALN_MAPPED;
+			if (lane == 0) {
+				char *q = A;
+				*q++ = '\t'; q = put_int(q, rec.flag);
+				if (mapped) *q++ = '\t';
+				len[0] = (int)(q - A);
+				q = B;
+				if (mapped) {
+					*q++ = '\t'; q = put_int(q, rec.pos); *q++ = '\t'; q = put_int(q, rec.mapq); *q++ = '\t';
+					for (int i = 0; i < rec.cigar_len; ++i) *q++ = rec.cigar[i];
+					if (rec.has_mate) { q = put_lit(q, "\t=\t", 3); q = put_int(q, rec.mate_pos); *q++ = '\t'; q = put_int(q, rec.tlen); *q++ = '\t'; }
+					else q = put_lit(q, "\t*\t0\t0\t", 7);
+				} else q = put_lit(q, SAM_UNMAPPED_MID, (int)(sizeof(SAM_UNMAPPED_MID) - 1));
+				len[1] = (int)(q - B);
+				q = T;
+				if (mapped) {
+					q = put_lit(q, "\tNM:i:", 6); q = put_int(q, t.rlen - rec.score);
+					q = put_lit(q, "\tAS:i:", 6); q = put_int(q, rec.score);
+					q = put_lit(q, "\tXS:i:", 6); q = put_int(q, rec.sub_score);
+					*q++ = '\n';
+				} else q = put_lit(q, SAM_UNMAPPED_TAIL, (int)(sizeof(SAM_UNMAPPED_TAIL) - 1));
+				len[2] = (int)(q - T);
+			}
+			__syncthreads();
+			const int nA = len[0], nB = len[1], nT = len[2];
+			for (int k = lane; k < t.name_len; k += 64) p[k] = t.name[k];
+			p += t.name_len;
+			if (lane < nA) p[lane] = (uint8_t)A[lane];
+			p += nA;
+			if (mapped) {
+				const uint8_t *cn = a.chr_names + a.chr_name_off[rec.chr];
+				const int nc = a.chr_name_off[rec.chr + 1] - a.chr_name_off[rec.chr];
+				for (int k = lane; k < nc; k += 64) p[k] = cn[k];
+				p += nc;
+			}
+			for (int k = lane; k < nB; k += 64) p[k] = (uint8_t)B[k];
+			p += nB;
+			// the read as the record shows it: as held, or its reverse complement (GetComplementarySeq) with the qualities reversed
+			const bool flip = mapped && rec.flip;
+			if (flip) { for (int k = lane; k < t.rlen; k += 64) p[k] = comp_char(seq[t.rlen - 1 - k]); }
+			else { for (int k = lane; k < t.rlen; k += 64) p[k] = seq[k]; }
+			p += t.rlen;
+			if (lane == 0) *p = '\t';
+			p += 1;
+			if (flip != t.held_reversed) { for (int k = lane; k < t.qlen; k += 64) p[k] = t.qual[t.qlen - 1 - k]; }
+			else { for (int k = lane; k < t.qlen; k += 64) p[k] = t.qual[k]; }
+			p += t.qlen;
+			if (lane < nT) p[lane] = (uint8_t)T[lane];
+			p += nT;
+			__syncthreads();
+		}
+		if (lane == 0 && (int64_t)(p - a.sam) != room) atomicAdd(&a.ctl[1], 1ull);
+	}
+}
+
+__global__ void sam_reset_kernel(SamArgs a)
+{
+	if (threadIdx.x < 2) a.ctl[threadIdx.x] = 0;
+}
+
+// ---- launches ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Widen32 {
+	__host__ __device__ __forceinline__ int64_t operator()(const int32_t &x) const { return (int64_t)x; }
+};
+using Wide32Iter = hipcub::TransformInputIterator<int64_t, Widen32, const int32_t *>;
+
+inline int grid_of(int64_t items, int block, int max_blocks)
+{
+	int64_t g = (items + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > max_blocks) g = max_blocks;
+	return (int)g;
+}
+
+}  // namespace
+
+size_t fq_scan_temp_bytes(int64_t max_items)
+{
+	size_t b1 = 0, b2 = 0;
+	Wide32Iter it((const int32_t *)nullptr, Widen32());
+	(void)hipcub::DeviceScan::ExclusiveSum(nullptr, b1, it, (int64_t *)nullptr, (int)max_items);
+	(void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, (const int32_t *)nullptr, (int32_t *)nullptr, (int)max_items);
+	return b1 > b2 ? b1 : b2;
+}
+
+hipError_t launch_fq_parse(const FqArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream)
+{
+	hipError_t e;
+	hipLaunchKernelGGL(fq_reset_kernel, dim3(grid_of(a.max_reads + 1, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	for (int f = 0; f < (a.two_files ? 2 : 1); ++f) {
+		const FqWindow &w = a.w[f];
+		const int64_t ta = w.begin & ~(int64_t)15;
+		const int64_t n_tiles = w.end > ta ? (w.end - ta + kFqTile - 1) / kFqTile : 0;
+		hipLaunchKernelGGL(fq_count_kernel, dim3(grid_of(n_tiles, 1, n_cu * 64)), dim3(256), 0, stream, a, f, n_tiles);
+		size_t tb = scan_temp_bytes;
+		if ((e = hipcub::DeviceScan::ExclusiveSum(scan_temp, tb, (const int32_t *)w.tile_lines, w.tile_lines, (int)(n_tiles + 1), stream)) != hipSuccess) return e;
+		hipLaunchKernelGGL(fq_index_kernel, dim3(grid_of(n_tiles, 1, n_cu * 64)), dim3(256), 0, stream, a, f, n_tiles);
+		hipLaunchKernelGGL(fq_record_kernel, dim3(grid_of(w.line_capacity / 4, 256, n_cu * 16)), dim3(256), 0, stream, a, f);
+	}
+	size_t tb = scan_temp_bytes;
+	Wide32Iter it(a.read_len, Widen32());
+	if ((e = hipcub::DeviceScan::ExclusiveSum(scan_temp, tb, it, a.read_off, (int)(a.max_reads + 1), stream)) != hipSuccess) return e;
+	hipLaunchKernelGGL(fq_plan_kernel, dim3(1), dim3(64), 0, stream, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_fq_materialise(const FqArgs &a, int n_cu, hipStream_t stream)
+{
+	if (a.n_reads <= 0) return hipSuccess;
+	hipLaunchKernelGGL(fq_materialise_kernel, dim3(grid_of(a.n_reads, 4, n_cu * 32)), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_sam_size(const SamArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream)
+{
+	hipLaunchKernelGGL(sam_reset_kernel, dim3(1), dim3(64), 0, stream, a);
+	hipLaunchKernelGGL(sam_size_kernel, dim3(grid_of(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	size_t tb = scan_temp_bytes;
+	Wide32Iter it(a.sam_len, Widen32());
+	hipError_t e = hipcub::DeviceScan::ExclusiveSum(scan_temp, tb, it, a.sam_off, (int)(a.n_reads + 1), stream);
+	if (e != hipSuccess) return e;
+	return hipGetLastError();
+}
+
+hipError_t launch_sam_format(const SamArgs &a, int n_cu, hipStream_t stream)
+{
+	if (a.n_reads <= 0) return hipSuccess;
+	hipLaunchKernelGGL(sam_format_kernel, dim3(grid_of(a.n_reads, 1, n_cu * 64)), dim3(64), 0, stream, a);
+	return hipGetLastError();
+}
+
+}  // namespace kg
