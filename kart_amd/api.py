@@ -377,6 +377,68 @@ class Index:
         return out
 
 
+class Stream:
+    """kg_stream_*: FASTQ text in, SAM text out (GetNextChunk ... Output*Alignments of the reference on the device)."""
+
+    def __init__(self, index: "Index", max_reads: int = 16000, max_window: int = 8 << 20, lanes: int = 1):
+        self.lib = load_library()
+        self.index = index
+        cfg = StreamConfig(max_reads, max_window, lanes)
+        h = C.c_void_p()
+        _check(self.lib.kg_stream_open(index.h, C.byref(cfg), C.byref(h)), "kg_stream_open")
+        self.h = h
+        self.max_window = max_window
+
+    def close(self):
+        if self.h:
+            self.lib.kg_stream_close(self.h)
+            self.h = None
+
+    def parse(self, text1: bytes, text2: bytes | None = None, paired: bool = True, chunk_reads: int = 4000, want_reads: int | None = None,
+              eof=(True, True), begin=(0, 0), lane: int = 0) -> StreamParsed:
+        """uploads the window(s) (placed at staging offset begin[f]) and runs GetNextChunk's arithmetic on the device"""
+        w = StreamWindow()
+        texts = [text1] + ([text2] if text2 is not None else [])
+        for f, t in enumerate(texts):
+            cap = C.c_int64()
+            p = self.lib.kg_stream_staging(self.h, lane, f, C.byref(cap))
+            assert p and begin[f] + len(t) <= cap.value
+            C.memmove(p + begin[f], t, len(t))
+            w.begin[f], w.end[f], w.eof[f] = begin[f], begin[f] + len(t), 1 if eof[f] else 0
+            _check(self.lib.kg_stream_upload(self.h, lane, f, begin[f], begin[f] + len(t)), "kg_stream_upload")
+        w.two_files = 1 if text2 is not None else 0
+        w.paired = 1 if paired else 0
+        w.chunk_reads = chunk_reads
+        w.want_reads = want_reads if want_reads is not None else chunk_reads
+        out = StreamParsed()
+        _check(self.lib.kg_stream_parse(self.h, lane, C.byref(w), C.byref(out)), "kg_stream_parse")
+        return out
+
+    def fetch_reads(self, parsed: StreamParsed, lane: int = 0):
+        """the reads of the parsed batch as the seeding stage sees them: list of bytes"""
+        off = np.zeros(parsed.n_reads + 1, dtype=np.int64)
+        enc = np.zeros(max(1, parsed.n_bases), dtype=np.uint8)
+        _check(self.lib.kg_stream_fetch_reads(self.h, lane, _ptr(enc), _ptr(off)), "kg_stream_fetch_reads")
+        raw = enc.tobytes()
+        return [raw[off[i]:off[i + 1]] for i in range(parsed.n_reads)]
+
+    def map(self, est_distance: int = 1500, max_insert: int = 1500, max_gaps: int = 5, multi_hit: bool = False, unset_flag: int = 0, lane: int = 0):
+        """seeding .. SAM text for the parsed batch: (text per read, indices of the reads handed back)"""
+        prm = StreamParams(est_distance, max_insert, max_gaps, 1 if multi_hit else 0, unset_flag)
+        res = StreamResult()
+        _check(self.lib.kg_stream_map(self.h, lane, C.byref(prm), C.byref(res)), "kg_stream_map")
+        n = res.n_reads
+        off = np.ctypeslib.as_array(res.sam_off, shape=(n + 1,)).copy()
+        sam = C.string_at(res.sam, res.sam_bytes)
+        host = [int(res.host_reads[i]) for i in range(res.n_host_reads)]
+        return [sam[off[i]:off[i + 1]] for i in range(n)], host
+
+    def timing(self, reset: bool = False) -> dict:
+        t = StreamTiming()
+        _check(self.lib.kg_stream_timing(self.h, C.byref(t), 1 if reset else 0), "kg_stream_timing")
+        return t.as_dict()
+
+
 def apply_ops(s1: bytes, s2: bytes, ops: np.ndarray):
     """Re-insert the gaps described by an op string (what nw_alignment does in place)."""
     a, b = bytearray(), bytearray()

@@ -615,7 +615,8 @@ int kgi_seed_resident(kg_workspace *ws, int mode, int min_seed_len, int occ_thr,
 {
 	int rc = check_seed_args(ws, mode, min_seed_len, occ_thr, n_reads, n_bases);
 	if (rc != KG_OK) return rc;
-	int64_t want = std::max<int64_t>(ws->seed_capacity, 8 * n_reads + 1024);
+	// (sized for the workspace's largest batch at once: a reallocation synchronises the whole device, and batches grow while a run ramps up)
+	int64_t want = std::max<int64_t>(ws->seed_capacity, 8 * std::max(n_reads, ws->max_reads) + 1024);
 	int64_t total = 0;
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		if (want > ws->seed_capacity) {
@@ -697,7 +698,7 @@ int kgi_chain_resident(kg_workspace *ws, int pacbio, int max_gaps, int64_t total
 		for (void *p : {(void *)ws->d_cands, (void *)ws->d_cand_seeds, (void *)ws->d_taken, (void *)ws->d_dense_cands, (void *)ws->d_dense_seeds})
 			if (p) HIP_TRY(hipFree(p));
 		ws->d_cands = nullptr; ws->d_cand_seeds = nullptr; ws->d_taken = nullptr; ws->d_dense_cands = nullptr; ws->d_dense_seeds = nullptr;
-		int64_t cap = m + m / 4 + 1024;
+		int64_t cap = std::max<int64_t>(m + m / 4, 8 * ws->max_reads) + 1024;
 		HIP_TRY(hipMalloc((void **)&ws->d_cands, sizeof(kg_candidate) * (size_t)cap));
 		HIP_TRY(hipMalloc((void **)&ws->d_cand_seeds, sizeof(kg_seed) * (size_t)cap));
 		HIP_TRY(hipMalloc((void **)&ws->d_taken, (size_t)cap));
@@ -709,7 +710,7 @@ int kgi_chain_resident(kg_workspace *ws, int pacbio, int max_gaps, int64_t total
 		for (void *p : {(void *)ws->d_n_cands, (void *)ws->d_used, (void *)ws->d_cand_off, (void *)ws->d_cseed_off})
 			if (p) HIP_TRY(hipFree(p));
 		ws->d_n_cands = nullptr; ws->d_used = nullptr; ws->d_cand_off = nullptr; ws->d_cseed_off = nullptr;
-		int64_t cap = n + 1024;
+		int64_t cap = std::max(n, ws->max_reads) + 1024;
 		HIP_TRY(hipMalloc((void **)&ws->d_n_cands, 4 * (size_t)cap));
 		HIP_TRY(hipMalloc((void **)&ws->d_used, 4 * (size_t)cap));
 		HIP_TRY(hipMalloc((void **)&ws->d_cand_off, 8 * (size_t)cap));
@@ -874,7 +875,7 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 	if (nc + task_cap + 1 > ws->aln_cand_capacity) {
 		if (ws->d_aln_cand) HIP_TRY(hipFree(ws->d_aln_cand));
 		ws->d_aln_cand = nullptr;
-		int64_t cap = nc + nc / 4 + task_cap + task_cap / 4 + 4096;
+		int64_t cap = std::max<int64_t>(nc + nc / 4, 3 * ws->max_reads) + task_cap + task_cap / 4 + ws->max_reads / 4 + 4096;
 		HIP_TRY(hipMalloc(&ws->d_aln_cand, up(4 * (size_t)cap) * 5 + up(8 * (size_t)cap) + up((size_t)cap) * 2 + up((size_t)cap * KG_ALN_CIGAR_MAX)));
 		ws->aln_cand_capacity = cap;
 	}
@@ -883,7 +884,7 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 		for (void *p : {(void *)ws->d_spill, (void *)ws->d_jobs, (void *)ws->d_job_ops, (void *)ws->d_job_len, (void *)ws->d_tasks, (void *)ws->d_plans})
 			if (p) HIP_TRY(hipFree(p));
 		ws->d_aln_read = nullptr; ws->d_spill = nullptr; ws->d_jobs = nullptr; ws->d_job_ops = nullptr; ws->d_job_len = nullptr; ws->d_tasks = nullptr; ws->d_plans = nullptr;
-		int64_t cap = n + n / 4 + 4096;
+		int64_t cap = std::max(n, ws->max_reads); cap += cap / 4 + 4096;
 		HIP_TRY(hipMalloc(&ws->d_aln_read, 3 * up((size_t)cap) + up(4 * (size_t)cap) + sizeof(kg_aln_record) * (size_t)cap));
 		ws->task_capacity = cap / 4 + 4096;
 		HIP_TRY(hipMalloc(&ws->d_tasks, up(sizeof(RescueTask) * (size_t)ws->task_capacity) + up(8 * (size_t)ws->task_capacity) + up(4 * (size_t)ws->task_capacity) +

@@ -90,7 +90,7 @@ public:
 	}
 	StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes) override
 	{
-		static const bool off = getenv("KART_AMD_NO_STREAM") != nullptr;      // A/B aid: the host parses and prints, as before
+		static const bool off = getenv("KART_AMD_NO_STREAM") != nullptr || getenv("KART_AMD_HOST_ALIGN") != nullptr;      // A/B aids: the host parses and prints, as before
 		if (off) return nullptr;
 		if (stream_ && stream_->max_reads() >= max_reads && stream_->max_window() >= max_window && stream_->lanes() >= lanes) return stream_.get();
 		stream_.reset();

@@ -266,11 +266,3 @@ def test_single_contig_genome_live_reference(product_binary, tmp_path):
     assert int(dev.split()[2]) > 9000, dev
 
 
-@pytest.mark.parametrize("case", ["pe", "pe_g2", "se", "edge_pe"])
-def test_direct_output_mode(case, product_binary, tmp_path):
-    """KART_AMD_DIRECT_OUT: device-decided records formatted straight into the mapped output file (exact size pass, then the bytes)"""
-    from test_host_pipeline import materialise
-    args = [materialise(str(tmp_path), a) if a.endswith((".fq", ".fa", ".gz")) else a for a in CASES[case]]
-    out = str(tmp_path / "o.sam")
-    _run_verbose(product_binary, args, out, {"KART_AMD_DIRECT_OUT": "1"})
-    assert open(out, "rb").read() == gzip.open(os.path.join(GOLDEN, "sam", case + ".sam.gz")).read()
