@@ -8,6 +8,8 @@
 
 #include <fcntl.h>
 #include <immintrin.h>
+#include <sched.h>
+#include <pthread.h>
 #include <sys/file.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
@@ -144,6 +146,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	g_sections = getenv("KART_AMD_VERBOSE") != nullptr;
 	if (const char *uf = getenv("KART_AMD_UNSET_FLAG")) g_unset_flag = atoi(uf);
 	g_check_align = getenv("KART_AMD_CHECK_ALIGN") != nullptr;
+	g_io_cpus = detect_io_cpus(std::max(0, opt.shard_rank));
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	Options &o = const_cast<Options &>(opt);
 	RunTotals tot;
@@ -248,6 +251,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		auto secs = [](const timeval &a, const timeval &b) { return (double)(a.tv_sec - b.tv_sec) + 1e-6 * (double)(a.tv_usec - b.tv_usec); };
 		fprintf(stdout, "cpu seconds of the mapping phase: user %.2f, system %.2f (wall %.2f)\n", secs(ru1.ru_utime, ru0.ru_utime), secs(ru1.ru_stime, ru0.ru_stime), stats.map_seconds);
 	}
+	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "i/o threads: %s (%d CPUs)\n", g_io_cpus.valid ? "kept on the CPUs of one last-level cache" : "not pinned", g_io_cpus.count);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: %lld reads decided on the device, %lld mapped by the host stages\n", (long long)tot.dev_reads, (long long)tot.host_reads);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: read_batch total %.3f s (line index %.3f, views %.3f, views + chunk assembly %.3f, materialise + characters %.3f) | %s\n", 1e-9 * (double)g_read_ns.load(),
 		        1e-9 * (double)g_read_part_ns[0].load(), 1e-9 * (double)g_read_part_ns[1].load(), 1e-9 * (double)g_read_part_ns[2].load(), 1e-9 * (double)g_read_part_ns[3].load(), kern.align_diagnostics().c_str());

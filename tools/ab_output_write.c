@@ -22,6 +22,35 @@ static char *map;
 static size_t next_piece;
 static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
 
+// modes 6..8: A allocator threads run ahead of the copiers: fallocate a 64 MB step, then (7, 8) MADV_POPULATE_WRITE it
+static volatile size_t alloc_done[8];
+static int A = 1;
+static size_t step = 64 << 20;
+static void *allocator(void *arg)
+{
+	int me = (int)(long)arg;
+	for (size_t at = (size_t)me * step; at < total; at += (size_t)A * step) {
+		size_t n = at + step <= total ? step : total - at;
+		if (mode != 8 && fallocate(fd, 0, (off_t)at, (off_t)n) != 0) { perror("fallocate"); exit(1); }
+#ifdef MADV_POPULATE_WRITE
+		if (mode >= 7 && madvise(map + at, n, MADV_POPULATE_WRITE) != 0) { perror("madvise"); exit(1); }
+#endif
+		__atomic_store_n(&alloc_done[me], at + n, __ATOMIC_RELEASE);
+	}
+	__atomic_store_n(&alloc_done[me], (size_t)-1, __ATOMIC_RELEASE);
+	return NULL;
+}
+static int allocated(size_t at, size_t n)
+{
+	// the step holding [at, at + n) belongs to allocator (at / step) % A
+	size_t s0 = at / step, s1 = (at + n - 1) / step;
+	for (size_t s = s0; s <= s1; ++s) {
+		size_t d = __atomic_load_n(&alloc_done[s % (size_t)A], __ATOMIC_ACQUIRE);
+		if (d != (size_t)-1 && d < (s + 1) * step && d < total) return 0;
+	}
+	return 1;
+}
+
 static void *worker(void *arg)
 {
 	(void)arg;
@@ -31,6 +60,7 @@ static void *worker(void *arg)
 		next_piece += piece;
 		pthread_mutex_unlock(&mu);
 		if (at >= total) return NULL;
+		if (mode >= 6) while (!allocated(at, at + piece <= total ? piece : total - at)) usleep(50);
 		size_t n = at + piece <= total ? piece : total - at;
 		if (mode == 1) { if (pwrite(fd, src + (at % (64 << 20)), n, (off_t)at) != (ssize_t)n) { perror("pwrite"); exit(1); } }
 		else memcpy(map + at, src + (at % (64 << 20)), n);
@@ -39,7 +69,7 @@ static void *worker(void *arg)
 
 int main(int argc, char **argv)
 {
-	if (argc < 5) { fprintf(stderr, "usage: %s FILE GBYTES THREADS mode(0 mmap,1 pwrite,2 falloc+mmap,3 mmap+hugepage,4 reuse+mmap,5 mmap+populate_write)\n", argv[0]); return 2; }
+	if (argc < 5) { fprintf(stderr, "usage: %s FILE GBYTES THREADS mode(0 mmap,1 pwrite,2 falloc+mmap,3 mmap+hugepage,4 reuse+mmap,5 mmap+populate_write,6 allocator threads: fallocate ahead,7 ... + populate,8 populate only) [allocators]\n", argv[0]); return 2; }
 	const char *path = argv[1];
 	total = (size_t)(atof(argv[2]) * (1 << 30));
 	T = atoi(argv[3]);
@@ -70,9 +100,12 @@ int main(int argc, char **argv)
 #endif
 	}
 	double t1 = now();
-	pthread_t th[64];
+	pthread_t th[64], ath[8];
+	if (argc > 5) A = atoi(argv[5]);
+	if (mode >= 6) for (long i = 0; i < A; ++i) pthread_create(&ath[i], NULL, allocator, (void *)i);
 	for (int i = 0; i < T; ++i) pthread_create(&th[i], NULL, worker, NULL);
 	for (int i = 0; i < T; ++i) pthread_join(th[i], NULL);
+	if (mode >= 6) for (int i = 0; i < A; ++i) pthread_join(ath[i], NULL);
 	double t2 = now();
 	if (mode != 1) munmap(map, total);
 	close(fd);
