@@ -20,10 +20,11 @@ file -- through the host library (include/kart_host.h: index resident across run
 20 M reads are split into N contiguous chunk ranges, one process + one GPU + one index replica each (strong scaling), the
 output byte-identical to one process mapping everything; RCCL carries only the final counter all-reduce.
 
-The line also carries: `roofline` for the dominant GPU kernel (search_kernel: bytes the IMPLEMENTED search needs -- exported
-by the kernel itself, kg_workspace_traffic -- over its HIP-event time, against the 8 TB/s HBM peak; `traffic` from the
-committed PMC passes of `bench.py --leg seeding`), `seeding_stage` (the GPU seeding step alone on HBM-resident reads -- last
-round's headline, now a sub-field), `cpu_baseline` (the unmodified reference binary at -t <host quota> on a bounded prefix of
+The line also carries: `roofline` for the dominant GPU kernel, taken FROM THE TIMED REGION (search_kernel: bytes the IMPLEMENTED
+search needs -- exported by the kernel itself, kg_workspace_traffic -- summed over the launches of the timed steps, over the sum
+of their HIP-event durations on the lanes' streams, against the 8 TB/s HBM peak; `traffic` from the committed PMC pass of this
+command when there is one), `seeding_stage` (the GPU seeding step alone on HBM-resident reads in ONE launch of 20 M reads -- a
+sub-field with its own roofline), `other_configs` (configs[4] -m and configs[3] -pacbio through the same session), `cpu_baseline` (the unmodified reference binary at -t <host quota> on a bounded prefix of
 the same files, same box, same run) and `parity` (SAM byte identity with the reference's -t 1 on a 0.5 M-read prefix, and
 GPU seeds == CPU oracle on a random 200 k-read sample).  Rank 0 at N = 1 only for everything but `value`.
 """
@@ -186,7 +187,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs of the whole job (split over the ranks)")
+    ap.add_argument("--pairs", type=int, default=None, help="read pairs of the whole job (split over the ranks); default 50 M = the 100 M reads of configs[2] "
+                                                             "when the work directory holds them and their SAM, else 10 M")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] sub-lines")
     ap.add_argument("--leg", choices=["all", "seeding"], default="all", help="seeding: only the GPU seeding step on resident reads (what the rocprofv3 passes profile)")
     ap.add_argument("--seed-steps", type=int, default=5, help="timed launches of the seeding-stage leg")
     ap.add_argument("--sa", choices=["sampled", "full"], default="full", help="suffix array placement of the seeding-stage leg")
@@ -319,6 +322,24 @@ def run(args, fallback_note):
     barrier()
     from kart_amd import api, shard
 
+    if args.pairs is None:
+        # configs[2] names 100 M reads: 32 GB of FASTQ and 38 GB of SAM per step, page-cache resident
+        full = 50_000_000
+        need = 2 * full * REC_BYTES + (args.steps + args.warmup + 1) * 2 * full * 400 + (40 << 30)
+        wd_probe = pick_workdir(need)
+        big = args.genome_len >= 300_000_000 and wd_probe.startswith("/dev/shm")
+        if big:
+            try:
+                os.makedirs(wd_probe, exist_ok=True)
+                big = shutil.disk_usage(wd_probe).free > need
+            except OSError:
+                big = False
+        pick = [1 if big else 0]
+        if world > 1:
+            from kart_amd import shard as _sh
+            pick = _sh.allreduce_counters([0 if big else 1], device=None if share else dev)       # any rank without room: the small job for all
+            pick = [1 if pick[0] == 0 else 0]
+        args.pairs = full if pick[0] else 10_000_000
     n_pairs = args.pairs
     n_reads = 2 * n_pairs
     workdir = pick_workdir(2 * n_pairs * REC_BYTES + n_reads * 450 + (12 << 30))
@@ -403,7 +424,14 @@ def run(args, fallback_note):
         return 0
 
     assert totals[0] == n_reads * args.steps, "the ranks together mapped %d reads per step, expected %d" % (totals[0] // max(1, args.steps), n_reads)
-    value = float(totals[0]) / elapsed
+    value = float(totals[1]) / elapsed           # MAPPED reads of the whole job per second (BASELINE.json's metric)
+    sw = np.sort(np.array(step_wall))
+    # the dominant kernel inside the timed region: every search_kernel launch of the timed steps (HIP events on the lanes' streams)
+    sk_ms = sum(float(st.search_kernel_ms) for st in stats)
+    sk_n = sum(int(st.search_kernel_launches) for st in stats)
+    sk_bytes = sum(float(st.search_useful_bytes) for st in stats)
+    stage_names = ("parse", "seed", "chain", "align", "format", "copy_out")
+    stage_ms = {nm: sum(float(st.stage_ms[i]) for st in stats) / args.steps for i, nm in enumerate(stage_names)}
     line = {
         "metric": "mapped reads/sec (whole node), 150 bp PE",
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -419,7 +447,22 @@ def run(args, fallback_note):
         "mapped_reads_per_step": totals[1] // args.steps, "mapped_fraction": totals[1] / max(1, totals[0]),
         "chunks_remapped_per_step": totals[2] / args.steps,
         "rank0_step_seconds": [round(x, 3) for x in step_wall], "rank0_map_seconds": [round(st.map_seconds, 3) for st in stats],
+        "reads_per_sec_total": float(totals[0]) / elapsed,
+        "step_seconds": {"min": float(sw[0]), "p10": float(np.percentile(sw, 10)), "median": float(np.median(sw)), "p90": float(np.percentile(sw, 90)), "max": float(sw[-1]),
+                         "mean": float(sw.mean())},
+        "device_ms_per_step": dict(stage_ms, what="rank 0: HIP-event time of the stages of all batches of a step, summed over the lanes (stages of different lanes overlap); "
+                                                  "reads through the device stream per step: %d" % (sum(int(st.stream_reads) for st in stats) // args.steps)),
     }
+    if sk_n > 0 and sk_ms > 0:
+        achieved = sk_bytes / (sk_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(0, args, tag="timed")
+        line["roofline"] = {"bound": "hbm", "kernel": "search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": traffic, "traffic_source": traffic_src,
+                            "source": "the timed region: %d launches in %d steps on rank 0, %.0f reads per launch on average" % (sk_n, args.steps, reads_here / max(1, sk_n)),
+                            "launches": sk_n, "avg_launch_ms": sk_ms / sk_n, "algorithmic_bytes_per_launch": sk_bytes / sk_n,
+                            "algorithmic_bytes_per_read": sk_bytes / max(1, reads_here), "search_kernel_ms_per_step": sk_ms / args.steps,
+                            "note": "achieved = bytes the IMPLEMENTED search needs (kg_workspace_traffic's formula, summed over the launches) / the sum of the launches' HIP-event "
+                                    "durations.  The lanes' kernels share the device, so a launch's duration includes what other lanes' kernels took from it."}
 
     if world == 1:
         # ---- parity + CPU baseline on a prefix of the very files that were timed ------------------------------------------
@@ -432,6 +475,11 @@ def run(args, fallback_note):
         if "cpu_baseline" in ref_legs:
             line["cpu_baseline"] = ref_legs.pop("cpu_baseline")
         line["parity"] = ref_legs
+        if large and not args.no_other_configs:
+            try:
+                line["other_configs"] = other_configs(args, sess, prefix, workdir, codes, dev, threads, cores)
+            except Exception as exc:      # a side measurement must never cost the line
+                line["other_configs"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     sess.close()
     for f in outs + [f1, f2]:
         try:
@@ -442,7 +490,10 @@ def run(args, fallback_note):
     if world == 1 and not args.no_seeding_leg:
         seed = seeding_leg(args, api, prefix, codes, dev, n_reads_leg=min(n_reads, 20_000_000), oracle_sample=0 if args.no_parity else 200_000)
         line["seeding_stage"] = seed
-        line["roofline"] = seed.pop("roofline")
+        if "roofline" in line:
+            seed["roofline_single_launch"] = seed.pop("roofline")
+        else:
+            line["roofline"] = seed.pop("roofline")
         if "oracle_sample" in seed:
             line.setdefault("parity", {})["seeds_vs_oracle"] = seed.pop("oracle_sample")
         if not args.no_cpu_baseline:
@@ -625,6 +676,116 @@ def seeding_leg(args, api, prefix, codes, dev, n_reads_leg, oracle_sample):
     return out
 
 
+def other_configs(args, sess, prefix, workdir, codes, dev, threads, cores):
+    """configs[4] (-m, 2.1 % error) and configs[3] (-pacbio, 7 kb reads at 15 % error) through the same session, one run each, with
+    SAM identity against the reference's -t 1 on a prefix (for -m: up to the FLAGs the reference never assigns, App. B-12)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "kart")
+    out = {}
+    UNSET = 1 << 20
+
+    def ref_run(flags, files, sam, t):
+        t0 = time.perf_counter()
+        a = [ref, "-silent", "-i", prefix, "-f", files[0]] + (["-f2", files[1]] if len(files) > 1 else []) + flags + ["-o", sam, "-t", str(t)]
+        r = subprocess.run(a, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return r.returncode, time.perf_counter() - t0
+
+    def head(src, dst, n_lines):
+        with open(src, "rb") as fi, open(dst, "wb") as fo:
+            for _ in range(n_lines):
+                l = fi.readline()
+                if not l:
+                    break
+                fo.write(l)
+
+    # ---- configs[4]: -m ------------------------------------------------------------------------------------------------
+    n_mh = 10_000_000
+    f1, f2 = os.path.join(workdir, "cfg4_1.fq"), os.path.join(workdir, "cfg4_2.fq")
+    write_fastq_pairs(codes, n_mh, 41, f1, f2, dev, err=0.021)
+    sam = os.path.join(workdir, "cfg4.sam")
+    sess.map(["-silent", "-f", f1, "-f2", f2, "-m", "-o", sam])          # (warm-up: the stream's buffers grow for -m's extra records)
+    os.remove(sam)
+    st = sess.map(["-silent", "-f", f1, "-f2", f2, "-m", "-o", sam])
+    c4 = {"workload": "configs[4]: %d x 150 bp paired-end reads at 2.1 %% error, -m (multi-hit output), hg38-sized index" % (2 * n_mh),
+          "value": (st.total_reads - st.unmapped) / st.map_seconds, "unit": "mapped reads/s", "map_seconds": round(st.map_seconds, 3),
+          "reads_through_the_device_stream": int(st.stream_reads), "sam_bytes": os.path.getsize(sam)}
+    os.remove(sam)
+    if os.path.exists(ref) and not args.no_parity:
+        k = 100_000
+        p1, p2 = os.path.join(workdir, "cfg4_p1.fq"), os.path.join(workdir, "cfg4_p2.fq")
+        head(f1, p1, 4 * k); head(f2, p2, 4 * k)
+        sa, sr = os.path.join(workdir, "cfg4_p_amd.sam"), os.path.join(workdir, "cfg4_p_ref.sam")
+        os.environ["KART_AMD_UNSET_FLAG"] = str(UNSET)
+        try:
+            sess.map(["-silent", "-f", p1, "-f2", p2, "-m", "-o", sa])
+        finally:
+            del os.environ["KART_AMD_UNSET_FLAG"]
+        rc, _ = ref_run(["-m"], [p1, p2], sr, 1)
+        la, lb = open(sr, "rb").read().split(b"\n"), open(sa, "rb").read().split(b"\n")
+        ok, masked = rc == 0 and len(la) == len(lb), 0
+        for x, y in zip(la, lb) if ok else ():
+            if x == y:
+                continue
+            fx, fy = x.split(b"\t"), y.split(b"\t")
+            if len(fy) < 2 or int(fy[1]) != UNSET or fx[:1] + fx[2:] != fy[:1] + fy[2:]:
+                ok = False
+                break
+            masked += 1
+        c4["sam_vs_reference_t1"] = {"reads": 2 * k, "identical_up_to_never_assigned_flags": bool(ok), "records_with_never_assigned_flag": masked}
+        for f in (p1, p2, sa, sr):
+            os.remove(f)
+    out["configs[4]"] = c4
+    for f in (f1, f2):
+        os.remove(f)
+
+    # ---- configs[3]: -pacbio -------------------------------------------------------------------------------------------
+    n_long, read_len = 1_000_000, 7000
+    fq = os.path.join(workdir, "cfg3_long.fq")
+    g = torch.Generator(device=dev); g.manual_seed(31)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    ar = torch.arange(read_len, device=dev)
+    L = codes.numel()
+    with open(fq, "wb") as fh:
+        for s in range(0, n_long, 20000):
+            m = min(20000, n_long - s)
+            pos = DECOY_LEN + (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * (L - DECOY_LEN - read_len - 1)).long()
+            r = codes[pos[:, None] + ar]
+            flip = torch.rand(m, generator=g, device=dev) < 0.5
+            r = torch.where(flip[:, None], (3 - r).flip(1), r)
+            e = torch.rand(r.shape, generator=g, device=dev) < 0.15
+            r = torch.where(e, (r + torch.randint(1, 4, r.shape, generator=g, device=dev, dtype=torch.uint8)) & 3, r)
+            # records assembled on the device: "@L<9 digits>\n" + bases + "\n+\n" + qualities + "\n"
+            rec = torch.empty((m, 11 + read_len + 3 + read_len + 1), dtype=torch.uint8, device=dev)
+            rec[:, 0] = 64; rec[:, 1] = 76
+            idx = torch.arange(s, s + m, device=dev, dtype=torch.int64)
+            pow10 = torch.tensor([10 ** (8 - d) for d in range(9)], device=dev, dtype=torch.int64)
+            rec[:, 2:11] = ((idx[:, None] // pow10) % 10 + 48).to(torch.uint8)
+            rec[:, 11] = 10
+            rec[:, 12:12 + read_len] = acgt[r.long()]
+            rec[:, 12 + read_len] = 10; rec[:, 13 + read_len] = 43; rec[:, 14 + read_len] = 10
+            rec[:, 15 + read_len:15 + 2 * read_len] = 53
+            rec[:, 15 + 2 * read_len] = 10
+            fh.write(memoryview(rec.cpu().numpy()).cast("B"))
+    sam = os.path.join(workdir, "cfg3.sam")
+    st = sess.map(["-silent", "-f", fq, "-pacbio", "-o", sam])
+    c3 = {"workload": "configs[3]: %d x %d bp single-end reads at 15 %% error, -pacbio, hg38-sized index" % (n_long, read_len),
+          "value": (st.total_reads - st.unmapped) / st.map_seconds, "unit": "mapped reads/s", "map_seconds": round(st.map_seconds, 3), "sam_bytes": os.path.getsize(sam)}
+    os.remove(sam)
+    if os.path.exists(ref) and not args.no_parity:
+        k = 1000
+        pq = os.path.join(workdir, "cfg3_p.fq")
+        head(fq, pq, 4 * k)
+        sa, sr = os.path.join(workdir, "cfg3_p_amd.sam"), os.path.join(workdir, "cfg3_p_ref.sam")
+        sess.map(["-silent", "-f", pq, "-pacbio", "-o", sa])
+        rc, dt = ref_run(["-pacbio"], [pq], sr, 1)              # (-t 1: with more threads the reference prints the chunks in completion order)
+        c3["sam_vs_reference_t1"] = {"reads": k, "identical": bool(rc == 0 and open(sa, "rb").read() == open(sr, "rb").read()),
+                                     "reference_t1_seconds_whole_process": round(dt, 1)}
+        for f in (pq, sa, sr):
+            os.remove(f)
+    out["configs[3]"] = c3
+    os.remove(fq)
+    return out
+
+
 def effective_cores():
     """CPUs this process can actually use: the cgroup CPU quota when there is one (the GPU boxes expose 256
     logical CPUs under a 16-core quota), else the affinity mask / CPU count."""
@@ -638,7 +799,7 @@ def effective_cores():
     return n
 
 
-def measured_traffic(n_reads, args):
+def measured_traffic(n_reads, args, tag=None):
     """HBM/fabric bytes per search_kernel launch from the committed PMC passes of this exact command
     (rocprofv3 --pmc, separate passes; profiles/*_pmc_summary.json, corrected for gfx950 as
     MI355X_MICROARCH.md prescribes).  bench.py cannot run the profiler on itself, so the figure is
@@ -652,7 +813,7 @@ def measured_traffic(n_reads, args):
                 t = json.load(open(os.path.join(ROOT, "profiles", f))).get("_search_traffic")
             except Exception:
                 t = None
-            if t and t.get("reads_per_launch") == n_reads and t.get("genome_len", GENOME_LEN) == args.genome_len:
+            if t and t.get("tag") == tag and (tag is not None or t.get("reads_per_launch") == n_reads) and t.get("genome_len", GENOME_LEN) == args.genome_len:
                 best = (t["traffic_bytes_per_launch"], "profiles/" + f)
     return best if best else (None, None)
 

@@ -36,6 +36,15 @@ typedef struct {
 	int64_t respeculated;    /* chunks re-mapped because a speculated EstDistance did not hold */
 	double  map_seconds;     /* first read in -> last output byte written (index load excluded) */
 	int32_t sharded;         /* 1: the counts are this process's shard of a -shard r/N run */
+	int32_t pad;
+	/* the run's batches on the device (kg_stream_timing_t, include/kart_amd.h): HIP events on the lanes' streams, summed */
+	int64_t stream_reads;    /* reads that went through the device's FASTQ-in / SAM-out stream */
+	int64_t stream_batches;
+	double  stage_ms[6];     /* parse, seed, chain, align, format, copy-out */
+	double  search_kernel_ms;        /* search_kernel's own launches (events around each) */
+	int64_t search_kernel_launches;
+	double  search_useful_bytes;     /* bytes the implemented search fetched in them (kg_traffic_t's formula) */
+	double  text_in_bytes, text_out_bytes;
 } kh_stats_t;
 
 const char *kh_last_error(void);

@@ -457,7 +457,9 @@ def apply_ops(s1: bytes, s2: bytes, ops: np.ndarray):
 # ---- the host pipeline as a library (include/kart_host.h): bwa_idx_load once, Mapping() many times -------------------------
 class HostStats(C.Structure):
     _fields_ = [("total_reads", C.c_int64), ("unmapped", C.c_int64), ("unique", C.c_int64), ("paired", C.c_int64), ("distance", C.c_int64),
-                ("respeculated", C.c_int64), ("map_seconds", C.c_double), ("sharded", C.c_int32)]
+                ("respeculated", C.c_int64), ("map_seconds", C.c_double), ("sharded", C.c_int32), ("pad", C.c_int32),
+                ("stream_reads", C.c_int64), ("stream_batches", C.c_int64), ("stage_ms", C.c_double * 6), ("search_kernel_ms", C.c_double),
+                ("search_kernel_launches", C.c_int64), ("search_useful_bytes", C.c_double), ("text_in_bytes", C.c_double), ("text_out_bytes", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

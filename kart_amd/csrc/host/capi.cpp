@@ -89,6 +89,13 @@ int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
 	if (stats) {
 		stats->total_reads = st.total_reads; stats->unmapped = st.unmapped; stats->unique = st.unique; stats->paired = st.paired;
 		stats->distance = st.distance; stats->respeculated = st.respeculated; stats->map_seconds = st.map_seconds; stats->sharded = st.sharded ? 1 : 0;
+		stats->pad = 0;
+		stats->stream_reads = st.stream_reads; stats->stream_batches = st.device.batches;
+		const double ms[6] = {st.device.parse_ms, st.device.seed_ms, st.device.chain_ms, st.device.align_ms, st.device.format_ms, st.device.copy_ms};
+		for (int i = 0; i < 6; ++i) stats->stage_ms[i] = ms[i];
+		stats->search_kernel_ms = st.device.search_kernel_ms; stats->search_kernel_launches = st.device.search_kernel_launches;
+		stats->search_useful_bytes = st.device.search_useful_bytes;
+		stats->text_in_bytes = st.device.text_in_bytes; stats->text_out_bytes = st.device.text_out_bytes;
 	}
 	return rc == 0 ? 0 : fail("kh_map: mapping failed");
 }

@@ -55,16 +55,7 @@ public:
 	{
 		if (kg_stream_map(s_, lane, &p, &out) != KG_OK) die("kg_stream_map");
 	}
-	std::string timing(bool reset) override
-	{
-		kg_stream_timing_t t;
-		if (kg_stream_timing(s_, &t, reset ? 1 : 0) != KG_OK || t.batches == 0) return std::string();
-		char b[640];
-		snprintf(b, sizeof(b), "device stream: %lld batches, %lld reads | stage ms (summed over lanes, stages of different lanes overlap): parse %.1f, seed %.1f (search_kernel %.2f in %lld launches, %.1f useful MB), chain %.1f, align %.1f, format %.1f, copy-out %.1f | text in %.1f MB, out %.1f MB",
-		         (long long)t.batches, (long long)t.reads, t.parse_ms, t.seed_ms, t.search_kernel_ms, (long long)t.search_kernel_launches, t.search_useful_bytes / 1e6, t.chain_ms, t.align_ms,
-		         t.format_ms, t.copy_ms, t.text_in_bytes / 1e6, t.text_out_bytes / 1e6);
-		return std::string(b);
-	}
+	bool timing(kg_stream_timing_t &t, bool reset) override { return kg_stream_timing(s_, &t, reset ? 1 : 0) == KG_OK; }
 	kg_stream *handle() const { return s_; }
 
 private:

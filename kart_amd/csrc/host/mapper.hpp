@@ -80,7 +80,7 @@ struct StreamBackend {
 	virtual void upload(int lane, int file, int64_t from, int64_t to) = 0;           // asynchronous
 	virtual bool parse(int lane, const kg_stream_window &w, kg_stream_parsed &out) = 0;   // false: the window does not fit the lane (the caller's own reader takes over)
 	virtual void map(int lane, const kg_stream_params &p, kg_stream_result &out) = 0;
-	virtual std::string timing(bool reset) { (void)reset; return std::string(); }    // KART_AMD_VERBOSE: device time per stage
+	virtual bool timing(kg_stream_timing_t &t, bool reset) { (void)t; (void)reset; return false; }   // device time per stage since the last reset
 };
 
 struct KernelBackend {
@@ -135,6 +135,7 @@ struct Stats {
 	double map_seconds = 0;     // first read in -> last SAM byte handed to the writer (index load excluded)
 	int64_t respeculated = 0;   // chunks re-mapped because their speculated EstDistance did not hold
 	int64_t stream_reads = 0;   // reads that went through the device's FASTQ-in / SAM-out stream
+	kg_stream_timing_t device{};   // ... and what their batches cost on the device (HIP events on the lanes' streams, summed)
 	bool sharded = false;       // the totals above are this process's shard only (kart::shard_totals() gives the run's)
 };
 
