@@ -754,7 +754,7 @@ def other_configs(args, sess, prefix, workdir, codes, dev, threads, cores):
             e = torch.rand(r.shape, generator=g, device=dev) < 0.15
             r = torch.where(e, (r + torch.randint(1, 4, r.shape, generator=g, device=dev, dtype=torch.uint8)) & 3, r)
             # records assembled on the device: "@L<9 digits>\n" + bases + "\n+\n" + qualities + "\n"
-            rec = torch.empty((m, 11 + read_len + 3 + read_len + 1), dtype=torch.uint8, device=dev)
+            rec = torch.empty((m, 12 + read_len + 3 + read_len + 1), dtype=torch.uint8, device=dev)
             rec[:, 0] = 64; rec[:, 1] = 76
             idx = torch.arange(s, s + m, device=dev, dtype=torch.int64)
             pow10 = torch.tensor([10 ** (8 - d) for d in range(9)], device=dev, dtype=torch.int64)

@@ -400,7 +400,9 @@ int kg_rank_sa_batch(kg_index *ix, const uint64_t *k, int64_t n, uint64_t *occ4,
 void *kg_host_alloc(size_t bytes)
 {
 	void *p = nullptr;
-	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	// (portable: page-locked for every device, whichever one the calling thread happens to have current -- the reader threads
+	//  of a -gpu N run call this without ever selecting the index's device)
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
 	return p;
 }
 

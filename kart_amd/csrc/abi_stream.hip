@@ -377,7 +377,7 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 		if (ws->profiling && ws->ev[0]) sk = elapsed(ws->ev[0], ws->ev[1]);
 		const unsigned long long *c = l.h_ctl;
 		const double sa_bytes = ix->view.fsa32 ? 4.0 : 8.0;
-		const double useful = 8.0 * (double)c[17] + 32.0 * (double)c[18] + sa_bytes * (double)c[8] + 48.0 * (double)c[20] + 8.0 * (double)c[21] + 20.0 * (double)n + 32.0 * (double)c[1];
+		const double useful = 8.0 * (double)c[17] + 32.0 * (double)c[18] + (double)c[25] + sa_bytes * (double)c[8] + 48.0 * (double)c[20] + 8.0 * (double)c[21] + 20.0 * (double)n + 32.0 * (double)c[1];
 		std::lock_guard<std::mutex> lk(s->mu);
 		kg_stream_timing_t &t = s->total;
 		t.batches += 1; t.reads += n;

@@ -77,12 +77,16 @@ int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
 	FILE *out = nullptr;
 	if (opt.shard_rank == 0) {
 		out = kart::open_output(opt.out_name);
-		if (!out) return fail("kh_map: cannot open [%s]", opt.out_name.c_str());
+		if (!out) {
+			if (opt.shard_count > 1) kart::shard_mark_failed(opt.rendezvous);
+			return fail("kh_map: cannot open [%s]", opt.out_name.c_str());
+		}
 	}
 	kart::Stats st;
 	auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
 	double t0 = now();
 	rc = kart::run_mapping(opt, s->ref, *s->kern, out, st);
+	if (rc != 0 && opt.shard_count > 1) kart::shard_mark_failed(opt.rendezvous);     // the other shards stop waiting for this one
 	double t1 = now();
 	if (out) fclose(out);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "kh_map: run_mapping %.3f s (its own mapping seconds %.3f), closing the output %.3f s\n", t1 - t0, st.map_seconds, now() - t1);

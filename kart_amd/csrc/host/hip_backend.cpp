@@ -70,7 +70,10 @@ public:
 	{
 		kg_index_info(ix_, &info_);
 		int64_t max_reads = std::max<int64_t>(opt.batch_reads, 4000ll * 4 * std::max(1, opt.threads)) + 8192;
-		reserve(max_reads, max_reads * 256);
+		// (KART_AMD_TINY_WORKSPACE: test aid -- start far too small, so that the workspace is outgrown and retired several times
+		//  while results of earlier batches are still being read)
+		if (getenv("KART_AMD_TINY_WORKSPACE")) reserve(2048, 1 << 16);
+		else reserve(max_reads, max_reads * 256);
 	}
 	~HipBackend() override
 	{

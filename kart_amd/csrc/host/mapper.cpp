@@ -9,6 +9,7 @@
 #include <fcntl.h>
 #include <immintrin.h>
 #include <sched.h>
+#include <signal.h>
 #include <pthread.h>
 #include <sys/file.h>
 #include <sys/mman.h>

@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT, SMALL_PREFIX
-from test_host_pipeline import CASES, UNSET_FLAG, assert_same_sam_up_to_unset_flags, run_case
+from test_host_pipeline import (CASES, UNSET_FLAG, assert_sam_equals_reference_with_its_own_mask, assert_same_sam_up_to_unset_flags,
+                                reference_sam_and_never_assigned_flags, run_case)
 
 pytestmark = pytest.mark.gpu
 KART_AMD = os.path.join(ROOT, "kart_amd", "bin", "kart-amd")
@@ -31,8 +32,7 @@ def test_golden_sam(case, product_binary, tmp_path):
 
 @pytest.mark.parametrize("flags", [[], ["-m"], ["-g", "40"]])       # (-g 40: MaxGaps beyond what the packed partition scan takes -- its scalar form)
 def test_live_reference_30k_pairs(flags, product_binary, tmp_path):
-    if not os.path.exists(KART_REF):
-        pytest.skip("oracle/_ref/kart not present on this machine")
+    assert os.path.exists(KART_REF), "oracle/_ref/kart did not travel to the GPU box: __graft_entry__.build() makes it where /root/reference exists"
     from kart_amd import synth
     from kart_amd.index_build import read_fasta
     genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
@@ -40,26 +40,23 @@ def test_live_reference_30k_pairs(flags, product_binary, tmp_path):
     f1, f2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
     synth.write_fastq(f1, names, r1, mate=1)
     synth.write_fastq(f2, names, r2, mate=2)
-    outs = []
-    for binary in (KART_REF, product_binary):
-        out = str(tmp_path / (os.path.basename(binary) + ".sam"))
-        extra = ["-t", "1"] if binary == KART_REF else []
-        # the product prints UNSET_FLAG wherever the reference never assigns SamFlag
-        subprocess.run([binary, "-silent", "-i", SMALL_PREFIX, "-f", f1, "-f2", f2, "-o", out] + extra + flags, check=True,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, KART_AMD_UNSET_FLAG=str(UNSET_FLAG)))
-        outs.append(open(out, "rb").read())
-    ref, got = outs
-    masked = assert_same_sam_up_to_unset_flags(ref, got)
+    # the records whose FLAG the reference never assigns come from the reference alone (two runs under different heap fill bytes);
+    # the product prints UNSET_FLAG on exactly those
+    ref_lines, never = reference_sam_and_never_assigned_flags(KART_REF, ["-i", SMALL_PREFIX, "-f", f1, "-f2", f2] + flags, str(tmp_path))
+    out = str(tmp_path / "amd.sam")
+    subprocess.run([product_binary, "-silent", "-i", SMALL_PREFIX, "-f", f1, "-f2", f2, "-o", out] + flags, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, KART_AMD_UNSET_FLAG=str(UNSET_FLAG)))
+    got = open(out, "rb").read()
+    masked = assert_sam_equals_reference_with_its_own_mask(ref_lines, never, got)
     if flags != ["-m"]:
         assert masked == 0          # without -m every printed FLAG is assigned by the reference: byte identity
-        assert got == ref
+        assert got == b"\n".join(ref_lines)
 
 
 def test_live_reference_pacbio_7kb(product_binary, tmp_path):
     """configs[3] in miniature: 7 kb reads at 15 % error with -pacbio (SensitiveMode seeding, recursive 8-mer
     partition, NW fragments of several hundred bases -> the wave-per-pair kernel with multiple stripes)."""
-    if not os.path.exists(KART_REF):
-        pytest.skip("oracle/_ref/kart not present on this machine")
+    assert os.path.exists(KART_REF), "oracle/_ref/kart did not travel to the GPU box: __graft_entry__.build() makes it where /root/reference exists"
     from kart_amd import synth
     from kart_amd.index_build import read_fasta
     genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
@@ -79,8 +76,7 @@ def test_live_reference_pacbio_7kb(product_binary, tmp_path):
 def test_live_reference_pacbio_unseeded_stretch_over_7000(product_binary, tmp_path):
     """a long read whose middle 7600 bases are N: no seeds and no 8-mers there, so the whole stretch reaches nw_alignment as one
     7600 x ~7600 fragment -- beyond what the wave-per-pair kernel's LDS holds (the run used to exit with "kg_nw_batch")"""
-    if not os.path.exists(KART_REF):
-        pytest.skip("oracle/_ref/kart not present on this machine")
+    assert os.path.exists(KART_REF), "oracle/_ref/kart did not travel to the GPU box: __graft_entry__.build() makes it where /root/reference exists"
     from kart_amd.index_build import read_fasta
     genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
     chrom = max(genome.values(), key=len)
@@ -158,8 +154,7 @@ def test_sharded_golden_sam(case, product_binary, tmp_path):
 def test_sharded_live_reference_160k_reads(product_binary, tmp_path):
     """40 chunks with drifting insert sizes (the estimate keeps moving): 1, 2, 3 processes -- and 2/4/8 real devices where the
     box has them -- all equal to the reference's -t 1"""
-    if not os.path.exists(KART_REF):
-        pytest.skip("oracle/_ref/kart not present on this machine")
+    assert os.path.exists(KART_REF), "oracle/_ref/kart did not travel to the GPU box: __graft_entry__.build() makes it where /root/reference exists"
     from kart_amd import synth
     from kart_amd.index_build import read_fasta
     genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
@@ -237,8 +232,7 @@ def test_device_report_on_30k_live_pairs_with_rescue_and_indels(product_binary, 
 def test_single_contig_genome_live_reference(product_binary, tmp_path):
     """a genome of ONE contig takes the n_chr == 1 branches of GenCoordinateInfo (src/AlignmentCandidates.cpp:523,541) -- on the
     device and on the host; reads keep 3 kb away from both ends (the reference's rescue windows index outside the text there, App. B-3)"""
-    if not os.path.exists(KART_REF):
-        pytest.skip("oracle/_ref/kart not present on this machine")
+    assert os.path.exists(KART_REF), "oracle/_ref/kart did not travel to the GPU box: __graft_entry__.build() makes it where /root/reference exists"
     from kart_amd import index_build, synth
     from kart_amd.index_build import read_fasta
     genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
@@ -266,3 +260,18 @@ def test_single_contig_genome_live_reference(product_binary, tmp_path):
     assert int(dev.split()[2]) > 9000, dev
 
 
+
+
+@pytest.mark.parametrize("case", ["pe", "pacbio", "edge_pe"])
+def test_outgrown_workspaces_are_retired_not_freed(case, product_binary, tmp_path):
+    """ADVICE round 2 (use-after-free): the backend's workspace starts far too small (KART_AMD_TINY_WORKSPACE), is outgrown while
+    the pipeline ramps its batches up and while the page-locked results of earlier batches are still being read; those must
+    survive (the outgrown workspace is retired, freed four batches later).  The host's reader / printer path (no device stream)."""
+    from test_host_pipeline import materialise
+    args = [materialise(str(tmp_path), a) if a.endswith((".fq", ".fa", ".gz")) else a for a in CASES[case]]
+    out = str(tmp_path / "o.sam")
+    for it in range(3):
+        r = subprocess.run([product_binary, "-silent", "-i", SMALL_PREFIX, "-t", "6", "-o", out] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           env=dict(os.environ, KART_AMD_TINY_WORKSPACE="1", KART_AMD_NO_STREAM="1", KART_AMD_BATCH_READS="4000"))
+        assert r.returncode == 0, r.stdout.decode()[-600:]
+        assert open(out, "rb").read() == gzip.open(os.path.join(GOLDEN, "sam", case + ".sam.gz")).read()
