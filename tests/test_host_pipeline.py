@@ -78,13 +78,13 @@ def assert_same_sam_up_to_unset_flags(ref: bytes, got: bytes) -> int:
 def reference_sam_and_never_assigned_flags(ref_bin, args, tmp):
     """The reference's -t 1 SAM, and -- derived from the reference alone -- the lines whose FLAG it never assigns: the records
     whose FLAG column differs between two runs under MALLOC_PERTURB_=85 and =170 (AlnReportArr is new-ed without initialising
-    SamFlag, src/AlignmentCandidates.cpp:636-640; glibc fills fresh heap blocks with the perturbation byte).  Every other
-    column of every line must agree between the two runs."""
+    SamFlag, src/AlignmentCandidates.cpp:636-640; glibc fills every block malloc hands out with the perturbation byte -- with the
+    thread cache switched off, whose fast path skips the fill).  Every other column of every line must agree between the two runs."""
     outs = []
     for perturb in (85, 170):
         out = os.path.join(tmp, "ref_%d.sam" % perturb)
         subprocess.run([ref_bin, "-silent", "-t", "1"] + list(args) + ["-o", out], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                       env=dict(os.environ, MALLOC_PERTURB_=str(perturb)))
+                       env=dict(os.environ, MALLOC_PERTURB_=str(perturb), GLIBC_TUNABLES="glibc.malloc.tcache_count=0"))
         outs.append(open(out, "rb").read().split(b"\n"))
     a, b = outs
     assert len(a) == len(b)
