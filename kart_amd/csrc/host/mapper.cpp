@@ -147,6 +147,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	g_sections = getenv("KART_AMD_VERBOSE") != nullptr;
 	if (const char *uf = getenv("KART_AMD_UNSET_FLAG")) g_unset_flag = atoi(uf);
 	g_check_align = getenv("KART_AMD_CHECK_ALIGN") != nullptr;
+	// (a sharded run: every process takes L3 domains of its own)
 	g_io_cpus = detect_io_cpus(std::max(0, opt.shard_rank));
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	Options &o = const_cast<Options &>(opt);

@@ -13,8 +13,9 @@
 //                                       pair reverse-complemented (:125-135; GetComplementarySeq, src/tools.cpp:3-29).
 // Output side = OutputPairedAlignments / OutputSingledAlignments (src/Mapping.cpp:177-315) for every kg_aln_record of the batch:
 //   sam_size_kernel                     exact byte count of the line(s) of every read -> scan -> offsets
-//   sam_format_kernel                   one wave per read: name, FLAG .. TLEN, sequence (reverse-complemented for a record shown on
-//                                       the other strand), qualities (reversed likewise), NM / AS / XS.
+//   sam_format_kernel                   one wave per 64 reads: every lane prints the numeric fields of one read into the LDS, then all
+//                                       lanes move each read's pieces -- name, FLAG .. TLEN, sequence (reverse-complemented for a
+//                                       record shown on the other strand), qualities (reversed likewise), NM / AS / XS.
 // Byte work, HBM-bound, no MFMA.  Everything is integer / character arithmetic; results are bit-identical to the host pipeline's
 // text (tests/test_stream_gpu.py, and every SAM parity test runs through this path).
 #include "stream_kernels.hpp"
@@ -231,8 +232,18 @@ __global__ __launch_bounds__(256) void fq_materialise_kernel(FqArgs a)
 // ---- SAM text ------------------------------------------------------------------------------------------------------------------
 namespace {
 
-__device__ __forceinline__ int int_chars(long long v)            // characters "%d" / "%lld" print
+// characters "%d" / "%lld" print.  Every number of a SAM line fits 32 bits in practice (positions are contig-relative, contig
+// lengths are 32-bit in the index format); 32-bit division by the constant 10 is a multiply, a 64-bit one a subroutine.
+__device__ __forceinline__ int u32_chars(uint32_t u)
 {
+	return u < 10u ? 1 : u < 100u ? 2 : u < 1000u ? 3 : u < 10000u ? 4 : u < 100000u ? 5 : u < 1000000u ? 6 : u < 10000000u ? 7 : u < 100000000u ? 8 : u < 1000000000u ? 9 : 10;
+}
+__device__ __forceinline__ int int_chars(long long v)
+{
+	if (v >= -2147483647ll && v <= 2147483647ll) {
+		const int x = (int)v;
+		return x < 0 ? 1 + u32_chars((uint32_t)(-x)) : u32_chars((uint32_t)x);
+	}
 	int n = v < 0 ? 2 : 1;
 	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
 	while (u >= 10) { u /= 10; n++; }
@@ -241,6 +252,14 @@ __device__ __forceinline__ int int_chars(long long v)            // characters "
 
 __device__ __forceinline__ char *put_int(char *p, long long v)
 {
+	if (v >= -2147483647ll && v <= 2147483647ll) {
+		const int x = (int)v;
+		uint32_t u = x < 0 ? (uint32_t)(-x) : (uint32_t)x;
+		if (x < 0) *p++ = '-';
+		const int n = u32_chars(u);
+		for (int i = n - 1; i >= 0; --i) { p[i] = (char)('0' + (int)(u % 10u)); u /= 10u; }
+		return p + n;
+	}
 	const int n = int_chars(v);
 	unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
 	if (v < 0) p[0] = '-';
@@ -310,76 +329,155 @@ __global__ __launch_bounds__(256) void sam_size_kernel(SamArgs a)
 	if (blockIdx.x == 0 && threadIdx.x == 0) a.sam_len[a.n_reads] = 0;
 }
 
-// one wave per read.  Lane 0 prints the numeric fields into the wave's LDS block; all lanes then move the pieces: name, contig
-// name, sequence and qualities straight from the FASTQ text / the read characters to the output.
+// One wave per 64 consecutive reads, two phases.
+//   1. lane l prints the numeric fields of read base + l ("\tFLAG\t", "\tPOS\tMAPQ\tCIGAR\t=\tPNEXT\tTLEN\t", the tags) into its own slot
+//      of the wave's LDS block and leaves there what the copy phase needs (where the name, the qualities, the characters and the
+//      contig name lie, where the line goes): 64 records are fetched and printed side by side, not one after the other.
+//   2. for each of the 64 reads all lanes move the pieces -- name, contig name, sequence and qualities straight from the FASTQ
+//      text / the read characters -- to the output; everything this phase needs per read comes from the LDS.
+// A read with further records chained behind it (-m) takes the record-by-record path (format_chain).
+namespace {
+
+constexpr int kFmtA = 16, kFmtB = 92, kFmtT = 52, kFmtSlot = kFmtA + kFmtB + kFmtT;     // bytes of a lane's strings
+
+struct FmtDesc {                       // what phase 2 needs for one read
+	const uint8_t *name, *qual, *seq, *chr;
+	uint8_t *out;
+	int32_t room_end_lo;               // (low bits of the end offset: checked against the bytes written)
+	int16_t name_len, n_chr, rlen, qlen;
+	uint8_t nA, nB, nT, flags;         // flags: 1 print, 2 reverse-complement, 4 qualities reversed, 8 chained records follow
+};
+
+// the fields of one record as text: A = "\tFLAG[\t]", B = the middle, T = the tags
+__device__ __forceinline__ void print_fields(const ReadText &t, const kg_aln_record &rec, char *A, char *B, char *T, int &nA, int &nB, int &nT)
+{
+	const bool mapped = rec.kind == KG_ALN_MAPPED;
+	char *q = A;
+	*q++ = '\t'; q = put_int(q, rec.flag);
+	if (mapped) *q++ = '\t';
+	nA = (int)(q - A);
+	q = B;
+	if (mapped) {
+		*q++ = '\t'; q = put_int(q, rec.pos); *q++ = '\t'; q = put_int(q, rec.mapq); *q++ = '\t';
+		for (int i = 0; i < rec.cigar_len; ++i) *q++ = rec.cigar[i];
+		if (rec.has_mate) { q = put_lit(q, "\t=\t", 3); q = put_int(q, rec.mate_pos); *q++ = '\t'; q = put_int(q, rec.tlen); *q++ = '\t'; }
+		else q = put_lit(q, "\t*\t0\t0\t", 7);
+	} else q = put_lit(q, SAM_UNMAPPED_MID, (int)(sizeof(SAM_UNMAPPED_MID) - 1));
+	nB = (int)(q - B);
+	q = T;
+	if (mapped) {
+		q = put_lit(q, "\tNM:i:", 6); q = put_int(q, t.rlen - rec.score);
+		q = put_lit(q, "\tAS:i:", 6); q = put_int(q, rec.score);
+		q = put_lit(q, "\tXS:i:", 6); q = put_int(q, rec.sub_score);
+		*q++ = '\n';
+	} else q = put_lit(q, SAM_UNMAPPED_TAIL, (int)(sizeof(SAM_UNMAPPED_TAIL) - 1));
+	nT = (int)(q - T);
+}
+
+// all lanes: one line from its pieces; returns the end
+__device__ __forceinline__ uint8_t *copy_line(uint8_t *__restrict__ p, int lane, const uint8_t *__restrict__ name, int name_len, const char *A, int nA,
+                                              const uint8_t *__restrict__ chr, int n_chr, const char *B, int nB, const uint8_t *__restrict__ seq, int rlen, bool flip,
+                                              const uint8_t *__restrict__ qual, int qlen, bool qrev, const char *T, int nT)
+{
+	// (every piece is at most a few wave-widths long: the loads of all pieces are issued before the first store is needed)
+	for (int k = lane; k < name_len; k += 64) p[k] = name[k];
+	p += name_len;
+	if (lane < nA) p[lane] = (uint8_t)A[lane];
+	p += nA;
+	for (int k = lane; k < n_chr; k += 64) p[k] = chr[k];
+	p += n_chr;
+	for (int k = lane; k < nB; k += 64) p[k] = (uint8_t)B[k];
+	p += nB;
+	// the read as the record shows it: as held, or its reverse complement (GetComplementarySeq) with the qualities reversed
+	if (flip) { for (int k = lane; k < rlen; k += 64) p[k] = comp_char(seq[rlen - 1 - k]); }
+	else { for (int k = lane; k < rlen; k += 64) p[k] = seq[k]; }
+	p += rlen;
+	if (lane == 0) *p = '\t';
+	p += 1;
+	if (qrev) { for (int k = lane; k < qlen; k += 64) p[k] = qual[qlen - 1 - k]; }
+	else { for (int k = lane; k < qlen; k += 64) p[k] = qual[k]; }
+	p += qlen;
+	if (lane < nT) p[lane] = (uint8_t)T[lane];
+	return p + nT;
+}
+
+}  // namespace
+
 __global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
 {
-	__shared__ char lds[256];
-	__shared__ int len[3];
-	char *const A = lds, *const B = lds + 16, *const T = lds + 176;     // "\tFLAG\t" | "\tPOS\tMAPQ\tCIGAR\t=\tPNEXT\tTLEN\t" | the tags
+	__shared__ char str[64 * kFmtSlot];
+	__shared__ FmtDesc desc[64];
+	__shared__ int chain_len[3];
 	const int lane = threadIdx.x;
-	for (int64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
-		if (a.records[r].kind == KG_ALN_HOST) continue;
-		const ReadText t = read_text(a, r);
-		const uint8_t *const seq = a.enc + a.read_off[r];
-		uint8_t *p = a.sam + a.sam_off[r];
-		const int64_t room = a.sam_off[r + 1];
-		if (room > a.sam_capacity) { if (lane == 0) atomicAdd(&a.ctl[1], 1ull); continue; }
-		for (int64_t at = r; at >= 0; at = a.records[at].next) {
-			const kg_aln_record &rec = a.records[at];
-			if (rec.kind != KG_ALN_UNMAPPED && rec.kind != KG_ALN_MAPPED) continue;
-			const bool mapped = rec.kind == KG_ALN_MAPPED;
-			if (lane == 0) {
-				char *q = A;
-				*q++ = '\t'; q = put_int(q, rec.flag);
-				if (mapped) *q++ = '\t';
-				len[0] = (int)(q - A);
-				q = B;
-				if (mapped) {
-					*q++ = '\t'; q = put_int(q, rec.pos); *q++ = '\t'; q = put_int(q, rec.mapq); *q++ = '\t';
-					for (int i = 0; i < rec.cigar_len; ++i) *q++ = rec.cigar[i];
-					if (rec.has_mate) { q = put_lit(q, "\t=\t", 3); q = put_int(q, rec.mate_pos); *q++ = '\t'; q = put_int(q, rec.tlen); *q++ = '\t'; }
-					else q = put_lit(q, "\t*\t0\t0\t", 7);
-				} else q = put_lit(q, SAM_UNMAPPED_MID, (int)(sizeof(SAM_UNMAPPED_MID) - 1));
-				len[1] = (int)(q - B);
-				q = T;
-				if (mapped) {
-					q = put_lit(q, "\tNM:i:", 6); q = put_int(q, t.rlen - rec.score);
-					q = put_lit(q, "\tAS:i:", 6); q = put_int(q, rec.score);
-					q = put_lit(q, "\tXS:i:", 6); q = put_int(q, rec.sub_score);
-					*q++ = '\n';
-				} else q = put_lit(q, SAM_UNMAPPED_TAIL, (int)(sizeof(SAM_UNMAPPED_TAIL) - 1));
-				len[2] = (int)(q - T);
+	const int64_t n_groups = (a.n_reads + 63) >> 6;
+	for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+		// ---- phase 1: lane = read -------------------------------------------------------------------------------------------
+		{
+			const int64_t r = (g << 6) + lane;
+			FmtDesc d;
+			d.flags = 0;
+			if (r < a.n_reads) {
+				const kg_aln_record &rec = a.records[r];
+				const int kind = rec.kind;
+				if (kind == KG_ALN_UNMAPPED || kind == KG_ALN_MAPPED || (kind != KG_ALN_HOST && rec.next >= 0)) {
+					const ReadText t = read_text(a, r);
+					const int64_t o0 = a.sam_off[r], o1 = a.sam_off[r + 1];
+					d.name = t.name; d.qual = t.qual; d.seq = a.enc + a.read_off[r];
+					d.out = a.sam + o0;
+					d.room_end_lo = (int32_t)(o1 - o0);
+					d.name_len = (int16_t)t.name_len; d.rlen = (int16_t)t.rlen; d.qlen = (int16_t)t.qlen;
+					d.chr = a.chr_names; d.n_chr = 0;
+					const bool mapped = kind == KG_ALN_MAPPED;
+					if (mapped) { d.chr = a.chr_names + a.chr_name_off[rec.chr]; d.n_chr = (int16_t)(a.chr_name_off[rec.chr + 1] - a.chr_name_off[rec.chr]); }
+					const bool flip = mapped && rec.flip;
+					int nA = 0, nB = 0, nT = 0;
+					// (reads beyond what the 16-bit fields and the output buffer hold take the record-by-record path, which checks)
+					const bool wide = t.rlen > 32000 || t.name_len > 32000 || o1 > a.sam_capacity;
+					const bool chained = rec.next >= 0 || wide || (kind != KG_ALN_UNMAPPED && kind != KG_ALN_MAPPED);
+					if (!chained) print_fields(t, rec, str + lane * kFmtSlot, str + lane * kFmtSlot + kFmtA, str + lane * kFmtSlot + kFmtA + kFmtB, nA, nB, nT);
+					d.nA = (uint8_t)nA; d.nB = (uint8_t)nB; d.nT = (uint8_t)nT;
+					d.flags = (uint8_t)(1 | (flip ? 2 : 0) | (flip != t.held_reversed ? 4 : 0) | (chained ? 8 : 0));
+				}
 			}
-			__syncthreads();
-			const int nA = len[0], nB = len[1], nT = len[2];
-			for (int k = lane; k < t.name_len; k += 64) p[k] = t.name[k];
-			p += t.name_len;
-			if (lane < nA) p[lane] = (uint8_t)A[lane];
-			p += nA;
-			if (mapped) {
-				const uint8_t *cn = a.chr_names + a.chr_name_off[rec.chr];
-				const int nc = a.chr_name_off[rec.chr + 1] - a.chr_name_off[rec.chr];
-				for (int k = lane; k < nc; k += 64) p[k] = cn[k];
-				p += nc;
-			}
-			for (int k = lane; k < nB; k += 64) p[k] = (uint8_t)B[k];
-			p += nB;
-			// the read as the record shows it: as held, or its reverse complement (GetComplementarySeq) with the qualities reversed
-			const bool flip = mapped && rec.flip;
-			if (flip) { for (int k = lane; k < t.rlen; k += 64) p[k] = comp_char(seq[t.rlen - 1 - k]); }
-			else { for (int k = lane; k < t.rlen; k += 64) p[k] = seq[k]; }
-			p += t.rlen;
-			if (lane == 0) *p = '\t';
-			p += 1;
-			if (flip != t.held_reversed) { for (int k = lane; k < t.qlen; k += 64) p[k] = t.qual[t.qlen - 1 - k]; }
-			else { for (int k = lane; k < t.qlen; k += 64) p[k] = t.qual[k]; }
-			p += t.qlen;
-			if (lane < nT) p[lane] = (uint8_t)T[lane];
-			p += nT;
-			__syncthreads();
+			desc[lane] = d;
 		}
-		if (lane == 0 && (int64_t)(p - a.sam) != room) atomicAdd(&a.ctl[1], 1ull);
+		__syncthreads();
+		// ---- phase 2: all lanes per read ------------------------------------------------------------------------------------
+		for (int i = 0; i < 64; ++i) {
+			const FmtDesc &d = desc[i];
+			if (!(d.flags & 1)) continue;
+			if (!(d.flags & 8)) {
+				const char *S = str + i * kFmtSlot;
+				uint8_t *e = copy_line(d.out, lane, d.name, d.name_len, S, d.nA, d.chr, d.n_chr, S + kFmtA, d.nB, d.seq, d.rlen, (d.flags & 2) != 0, d.qual, d.qlen, (d.flags & 4) != 0,
+				                       S + kFmtA + kFmtB, d.nT);
+				if (lane == 0 && (int32_t)(e - d.out) != d.room_end_lo) atomicAdd(&a.ctl[1], 1ull);
+				continue;
+			}
+			// -m: every record chained behind the read's own, one after the other (lane 0 prints the fields of each)
+			const int64_t r = (g << 6) + i;
+			const ReadText t = read_text(a, r);
+			const uint8_t *const seq = a.enc + a.read_off[r];
+			uint8_t *p = a.sam + a.sam_off[r];
+			const int64_t room = a.sam_off[r + 1];
+			if (room > a.sam_capacity) { if (lane == 0) atomicAdd(&a.ctl[1], 1ull); continue; }
+			char *S = str + i * kFmtSlot;                    // (the read's own slot is free: nothing was printed into it)
+			for (int64_t at = r; at >= 0; at = a.records[at].next) {
+				const kg_aln_record &rec = a.records[at];
+				if (rec.kind != KG_ALN_UNMAPPED && rec.kind != KG_ALN_MAPPED) continue;
+				const bool mapped = rec.kind == KG_ALN_MAPPED;
+				__syncthreads();
+				if (lane == 0) print_fields(t, rec, S, S + kFmtA, S + kFmtA + kFmtB, chain_len[0], chain_len[1], chain_len[2]);
+				__syncthreads();
+				const uint8_t *cn = a.chr_names;
+				int nc = 0;
+				if (mapped) { cn = a.chr_names + a.chr_name_off[rec.chr]; nc = a.chr_name_off[rec.chr + 1] - a.chr_name_off[rec.chr]; }
+				const bool flip = mapped && rec.flip;
+				p = copy_line(p, lane, t.name, t.name_len, S, chain_len[0], cn, nc, S + kFmtA, chain_len[1], seq, t.rlen, flip, t.qual, t.qlen, flip != t.held_reversed,
+				              S + kFmtA + kFmtB, chain_len[2]);
+			}
+			if (lane == 0 && (int64_t)(p - a.sam) != room) atomicAdd(&a.ctl[1], 1ull);
+		}
+		__syncthreads();
 	}
 }
 
@@ -457,7 +555,7 @@ hipError_t launch_sam_size(const SamArgs &a, void *scan_temp, size_t scan_temp_b
 hipError_t launch_sam_format(const SamArgs &a, int n_cu, hipStream_t stream)
 {
 	if (a.n_reads <= 0) return hipSuccess;
-	hipLaunchKernelGGL(sam_format_kernel, dim3(grid_of(a.n_reads, 1, n_cu * 64)), dim3(64), 0, stream, a);
+	hipLaunchKernelGGL(sam_format_kernel, dim3(grid_of((a.n_reads + 63) / 64, 1, n_cu * 64)), dim3(64), 0, stream, a);
 	return hipGetLastError();
 }
 
