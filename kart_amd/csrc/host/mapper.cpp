@@ -253,6 +253,9 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		auto secs = [](const timeval &a, const timeval &b) { return (double)(a.tv_sec - b.tv_sec) + 1e-6 * (double)(a.tv_usec - b.tv_usec); };
 		fprintf(stdout, "cpu seconds of the mapping phase: user %.2f, system %.2f (wall %.2f)\n", secs(ru1.ru_utime, ru0.ru_utime), secs(ru1.ru_stime, ru0.ru_stime), stats.map_seconds);
 	}
+	if (getenv("KART_AMD_VERBOSE") && shard.active())
+		fprintf(stdout, "shard %d/%d: %lld reads in %.3f s | waited %.3f s for the totals of the shard before | settled in %.3f s (%lld chunks mapped again) | writer drain %.3f s\n", shard.rank, shard.count,
+		        (long long)stats.total_reads, stats.map_seconds, tot.t_shard_wait, tot.t_shard_settle, (long long)stats.respeculated, tot.t_drain);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "i/o threads: %s (%d CPUs)\n", g_io_cpus.valid ? "kept on the CPUs of one last-level cache" : "not pinned", g_io_cpus.count);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: %lld reads decided on the device, %lld mapped by the host stages\n", (long long)tot.dev_reads, (long long)tot.host_reads);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: read_batch total %.3f s (line index %.3f, views %.3f, views + chunk assembly %.3f, materialise + characters %.3f) | %s\n", 1e-9 * (double)g_read_ns.load(),
