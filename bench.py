@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=None, help="read pairs of the whole job (split over the ranks); default 50 M = the 100 M reads of configs[2] "
                                                              "when the work directory holds them and their SAM, else 10 M")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] sub-lines")
+    ap.add_argument("--parts", action="store_true", help="N > 1: one output file per rank (kart-amd -parts; their concatenation is the single-process SAM) instead of one shared file")
     ap.add_argument("--leg", choices=["all", "seeding"], default="all", help="seeding: only the GPU seeding step on resident reads (what the rocprofv3 passes profile)")
     ap.add_argument("--seed-steps", type=int, default=5, help="timed launches of the seeding-stage leg")
     ap.add_argument("--sa", choices=["sampled", "full"], default="full", help="suffix array placement of the seeding-stage leg")
@@ -388,6 +389,8 @@ def run(args, fallback_note):
         a = ["-silent", "-f", f1, "-f2", f2, "-o", out]
         if world > 1:
             a += ["-shard", "%d/%d" % (rank, world), "-rendezvous", os.path.join(workdir, "rdv_%s" % tag)]
+            if args.parts:
+                a += ["-parts"]
         return sess.map(a)
 
     def clean_rendezvous():
@@ -442,7 +445,9 @@ def run(args, fallback_note):
                                "index resident" % n_reads,
                    "reads_per_step": n_reads, "reads_per_gpu_per_step": n_reads // world, "threads_per_rank": threads, "host_cpu_quota": cores,
                    "parallelism": "%d process(es), one GPU + index replica each, contiguous chunk ranges of the same input, SAM merged by file offset" % world,
-                   "files": "page-cache resident (%s)" % workdir, "sam_bytes_per_step": os.path.getsize(outs[-1]),
+                   "files": "page-cache resident (%s)" % workdir,
+                   "sam_bytes_per_step": sum(os.path.getsize(f) for f in ([outs[-1] + ".%d" % q for q in range(world)] if (args.parts and world > 1) else [outs[-1]])),
+                   "output": "one file per rank (-parts)" if (args.parts and world > 1) else "one SAM file",
                    "fallback": fallback_note, "index_build_s": round(t_build, 2), "index_load_s": round(t_load, 2), "fastq_write_s": round(t_fastq, 2)},
         "mapped_reads_per_step": totals[1] // args.steps, "mapped_fraction": totals[1] / max(1, totals[0]),
         "chunks_remapped_per_step": totals[2] / args.steps,
@@ -481,7 +486,7 @@ def run(args, fallback_note):
             except Exception as exc:      # a side measurement must never cost the line
                 line["other_configs"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     sess.close()
-    for f in outs + [f1, f2]:
+    for f in outs + [f1, f2] + [o + ".%d" % q for o in outs for q in range(world if args.parts else 0)]:
         try:
             os.remove(f)
         except OSError:

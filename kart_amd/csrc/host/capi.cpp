@@ -75,8 +75,8 @@ int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
 	opt.threads = s->base.threads;
 	if (opt.shard_count > 1 && opt.rendezvous.empty()) return fail("kh_map: -shard needs -rendezvous FILE");
 	FILE *out = nullptr;
-	if (opt.shard_rank == 0) {
-		out = kart::open_output(opt.out_name);
+	if (opt.shard_rank == 0 || opt.parts) {
+		out = kart::open_output(opt.parts && opt.shard_count > 1 ? opt.out_name + "." + std::to_string(opt.shard_rank) : opt.out_name);
 		if (!out) {
 			if (opt.shard_count > 1) kart::shard_mark_failed(opt.rendezvous);
 			return fail("kh_map: cannot open [%s]", opt.out_name.c_str());

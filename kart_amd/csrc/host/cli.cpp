@@ -32,6 +32,7 @@ static void usage(const char *prog)
 	fprintf(stdout, "         -p            paired-end reads are interlaced in the same file\n");
 	fprintf(stdout, "         -pacbio       pacbio data\n");
 	fprintf(stdout, "         -gpu INT[,INT..] HIP device [0]; a list runs one process per device on contiguous parts of the input\n");
+	fprintf(stdout, "         -parts        with a device list: one output file per device, Output.0 Output.1 ... (their concatenation is the alignment file)\n");
 	fprintf(stdout, "         -v            version\n\n");
 }
 
@@ -72,6 +73,7 @@ int parse_cli(int argc, char **argv, Options &opt)
 				return -2;
 			}
 		} else if (p == "-rendezvous" && i + 1 < argc) opt.rendezvous = argv[++i];
+		else if (p == "-parts") opt.parts = true;
 		else if (p == "-silent") opt.silent = true;
 		else if (p == "-pacbio") opt.pacbio = true;
 		else if (p == "-m") opt.multi_hit = true;
@@ -139,9 +141,10 @@ static int run_one(const Options &opt, KernelBackend *(*make_backend)(const Opti
 	if (!ref_ok) { fprintf(stdout, "\n\nError! Index files are corrupt! (%s)\n", ref_err.c_str()); delete kern; return 1; }
 	if (!kern) { fprintf(stderr, "Error! %s\n", err.c_str()); return 1; }
 	FILE *out = nullptr;
-	if (opt.shard_rank == 0) {                               // later shards open the file once shard 0 has created it
-		out = kart::open_output(opt.out_name);
-		if (!out) { fprintf(stderr, "Error! Cannot open file [%s]\n", opt.out_name.c_str()); delete kern; return 1; }
+	if (opt.shard_rank == 0 || opt.parts) {                  // later shards open the file once shard 0 has created it (-parts: each its own)
+		const std::string name = opt.parts && opt.shard_count > 1 ? opt.out_name + "." + std::to_string(opt.shard_rank) : opt.out_name;
+		out = kart::open_output(name);
+		if (!out) { fprintf(stderr, "Error! Cannot open file [%s]\n", name.c_str()); delete kern; return 1; }
 	}
 	if (opt.silent && !quiet) fprintf(stdout, "Start read mapping...\n");
 	int rc = run_mapping(opt, ref, *kern, out, st);

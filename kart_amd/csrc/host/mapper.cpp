@@ -229,7 +229,9 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	if (shard.active()) {
 		// the run is complete when every shard's text is in the file
 		Rendezvous *rv = shard.rdv;
-		if (shard.rank == 0) {
+		if (shard.rank == 0 && opt.parts)
+			shard.wait([&]() { for (int q = 0; q < shard.count; ++q) if (!rv->written[q].load()) return false; return true; }, "waiting for the other shards");
+		else if (shard.rank == 0) {
 			shard.wait([&]() { for (int q = 0; q < shard.count; ++q) if (!rv->written[q].load()) return false; return true; }, "waiting for the other shards");
 			// every shard's text is in place and nobody extends the file any more (the writers grow it in large steps): its exact size
 			int64_t total = rv->header_bytes.load() + (opt.bam ? (int64_t)bam_eof_bytes : 0);

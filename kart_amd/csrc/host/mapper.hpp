@@ -39,6 +39,9 @@ struct Options {
 	std::vector<int> devices;       // -gpu a,b,c: one process per listed device, the input sharded between them
 	int shard_rank = 0, shard_count = 1;   // this process maps shard_rank of shard_count contiguous chunk ranges of the library ...
 	std::string rendezvous;         // ... coordinating with the other processes through this shared-memory file
+	bool parts = false;             // -parts: a sharded run writes one file per shard, <out>.<r>; `cat <out>.0 <out>.1 ...` is the single-process file.
+	                                // One file takes ~10-13 GB/s of text on the 2-socket box however many processes write it: with several
+	                                // GPUs that is the run's ceiling; parts have no such common ceiling.
 	int sa_mode = KG_SA_FULL;
 	int64_t batch_reads = default_batch_reads();   // reads seeded per GPU call (a whole number of 4000-read chunks; KART_AMD_BATCH_READS overrides)
 	int64_t stream_reads = default_stream_reads();   // reads per batch of the device's FASTQ-in / SAM-out stream (KART_AMD_STREAM_READS overrides)

@@ -275,3 +275,14 @@ def test_outgrown_workspaces_are_retired_not_freed(case, product_binary, tmp_pat
                            env=dict(os.environ, KART_AMD_TINY_WORKSPACE="1", KART_AMD_NO_STREAM="1", KART_AMD_BATCH_READS="4000"))
         assert r.returncode == 0, r.stdout.decode()[-600:]
         assert open(out, "rb").read() == gzip.open(os.path.join(GOLDEN, "sam", case + ".sam.gz")).read()
+
+
+def test_sharded_parts_on_the_device(product_binary, tmp_path):
+    """-gpu 0,0,0 -parts: three processes through the device stream, one output file each; concatenated = the reference's SAM"""
+    from test_host_pipeline import materialise
+    args = [materialise(str(tmp_path), a) if a.endswith((".fq", ".fa", ".gz")) else a for a in CASES["pe_plain"]]
+    out = str(tmp_path / "o.sam")
+    r = subprocess.run([product_binary, "-silent", "-i", SMALL_PREFIX, "-t", "6", "-o", out, "-gpu", "0,0,0", "-parts"] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-600:]
+    got = b"".join(open("%s.%d" % (out, q), "rb").read() for q in range(3))
+    assert got == gzip.open(os.path.join(GOLDEN, "sam", "pe.sam.gz")).read()

@@ -68,3 +68,17 @@ def test_a_failing_shard_ends_the_run(host_oracle_binary, tmp_path):
         open(bad + e, "w").write("")
     r = subprocess.run([host_oracle_binary, "-silent", "-i", bad, "-f", fq, "-o", str(tmp_path / "o.sam"), "-gpu", "0,1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("devices", ["0,1", "0,1,2,3"])
+@pytest.mark.parametrize("case", ["pe_plain", "edge_se", "pe"])
+def test_sharded_parts_concatenate_to_the_golden_file(case, devices, host_oracle_binary, tmp_path):
+    """-parts: one output file per shard (<out>.<r>); their concatenation is the single-process file byte for byte"""
+    args = [materialise(str(tmp_path), a) if a.endswith((".fq", ".fa", ".gz")) else a for a in CASES[case]]
+    out = str(tmp_path / "o.sam")
+    r = subprocess.run([host_oracle_binary, "-silent", "-i", SMALL_PREFIX] + args + ["-o", out, "-gpu", devices, "-parts", "-t", "6"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-500:]
+    n = len(devices.split(","))
+    got = b"".join(open("%s.%d" % (out, q), "rb").read() for q in range(n))
+    from test_host_pipeline import GOLD_OF, SAM
+    assert got == gzip.open(os.path.join(SAM, GOLD_OF.get(case, case) + ".sam.gz")).read()
