@@ -24,6 +24,9 @@ namespace kg {
 
 constexpr int NEG = -(1 << 20);
 
+struct __attribute__((packed, aligned(1))) NwU64u { uint64_t v; };
+struct __attribute__((packed, aligned(1))) NwU32u { uint32_t v; };
+
 __device__ __forceinline__ int nt4_code(unsigned char ch)  // nst_nt4_table, src/BWT_Index/bntseq.c:40-57
 {
 	unsigned u = ch & 0xDFu;
@@ -125,9 +128,19 @@ __global__ __launch_bounds__(256) void nw_small8_kernel(NwArgs a)
 		const NwPair q = nw_pair(a, p);
 		const int64_t o1 = q.o1, o2 = q.o2;
 		const int m = q.m, n = q.n;
+		// descriptor mode (the alignment stage's jobs): both sequences lie in buffers with slack behind them (the read characters,
+		// the 2-bit text), so each is ONE unaligned load instead of up to eight byte gathers
+		const bool packed = a.desc != nullptr && a.text2 != nullptr;
+		uint64_t w1 = 0;
+		uint32_t tw = 0;
+		if (packed) {
+			w1 = reinterpret_cast<const NwU64u *>(a.f1 + o1)->v;
+			const uint32_t raw = reinterpret_cast<const NwU32u *>(a.text2 + ((uint64_t)o2 >> 2))->v;
+			tw = raw >> (((uint32_t)o2 & 3) << 1);                      // (8 bases = 16 bits, at most 6 bits of shift: 22 bits needed)
+		}
 		int c2[8];
 #pragma unroll
-		for (int j = 0; j < 8; ++j) c2[j] = j < n ? nw_code2(a, o2 + j) : 8 + j;
+		for (int j = 0; j < 8; ++j) c2[j] = j < n ? (packed ? (int)((tw >> (2 * j)) & 3u) : nw_code2(a, o2 + j)) : 8 + j;
 		int S[9], T[9];
 		S[0] = 0; T[0] = 0;
 #pragma unroll
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(256) void nw_small8_kernel(NwArgs a)
 #pragma unroll
 		for (int i = 1; i <= 8; ++i) {
 			if (i <= m) {
-				int c1 = nt4_code((unsigned char)a.f1[o1 + i - 1]);
+				int c1 = nt4_code(packed ? (unsigned char)(w1 >> (8 * (i - 1))) : (unsigned char)a.f1[o1 + i - 1]);
 				int diag = S[0];
 				S[0] = -2 - i;
 				int left_s = S[0], left_r = NEG;
@@ -153,16 +166,39 @@ __global__ __launch_bounds__(256) void nw_small8_kernel(NwArgs a)
 				}
 			}
 		}
+		// the traceback yields the columns right to left: they are collected in registers from the top byte of a 16-byte word down
+		// (at most m + n <= 16 columns), shifted into place at the end and stored once -- no read-modify-write of the op string
 		uint8_t *ops = a.ops + q.oo;
 		int i = m, j = n, len = 0;
+		uint64_t lo = 0, hi = 0;                                        // bytes 0..7 | 8..15 of the word
 		while (i > 0 || j > 0) {
 			int bit = 8 * (i - 1) + (j - 1);
 			bool g1 = i == 0 || (j > 0 && ((fr >> bit) & 1));
 			bool g2 = !g1 && (j == 0 || ((ft >> bit) & 1));
-			ops[len++] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
+			const uint64_t op = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
+			const int at = 15 - len;
+			if (at >= 8) hi |= op << (8 * (at - 8)); else lo |= op << (8 * at);
+			len++;
 			if (g1) j--; else if (g2) i--; else { i--; j--; }
 		}
-		reverse_ops(ops, len);
+		if (len > 0) {
+			const int sh = 16 - len;                                    // bytes to shift down
+			if (sh >= 8) { lo = sh == 8 ? hi : hi >> (8 * (sh - 8)); hi = 0; }
+			else if (sh > 0) { lo = (lo >> (8 * sh)) | (hi << (8 * (8 - sh))); hi >>= 8 * sh; }
+			// overlapping stores that never leave [0, len): the neighbouring jobs' op strings start right behind
+			if (len >= 8) {
+				reinterpret_cast<NwU64u *>(ops)->v = lo;
+				if (len > 8) {
+					const int t8 = len - 8;                             // the last eight bytes, bytes t8 .. t8 + 7 of the word
+					reinterpret_cast<NwU64u *>(ops + t8)->v = t8 == 8 ? hi : (lo >> (8 * t8)) | (hi << (8 * (8 - t8)));
+				}
+			} else if (len >= 4) {
+				reinterpret_cast<NwU32u *>(ops)->v = (uint32_t)lo;
+				if (len > 4) reinterpret_cast<NwU32u *>(ops + len - 4)->v = (uint32_t)(lo >> (8 * (len - 4)));
+			} else {
+				for (int k = 0; k < len; ++k) ops[k] = (uint8_t)(lo >> (8 * k));
+			}
+		}
 		a.aln_len[p] = len;
 	}
 }
