@@ -268,6 +268,17 @@ int  kg_nw_batch_device(kg_index *ix, const char *d_frag1, const int64_t *d_off1
                         const int64_t *d_off2, int64_t n, int64_t max_len, uint8_t *d_ops,
                         int32_t *d_aln_len, void *stream);
 
+/* GenerateNormalPairAlignment (src/tools.cpp:142-223) for n fragment pairs: the read fragment i is frag1[off1[i], off1[i+1])
+ * (raw characters, host buffer), the genome fragment the glen[i] bases of the indexed text at coordinate gpos[i].  Fragments with
+ * both sides above 30 are partitioned at their common 8-mers (shift limit: min(50, 20 %% of the longer side) with pacbio != 0,
+ * else max_gaps), IdentifyNormalPairs(rLen, gLen, ...) runs on the matches, the pieces between them are aligned by
+ * nw_alignment, and with pacbio != 0 a piece with a side above 300 goes through the same procedure again (:197).  The result
+ * is the alignment as kg_nw_batch reports one: aln_len[i] op codes at ops[ops_off[i] ...], where ops_off[i] must be the
+ * number of columns (rLen + gLen) of the requests before i.  status[i] != 0: the request lies outside the kernels' envelope (a
+ * read character other than A/C/G/T, more than 255 matches, a side above 4096) -- the caller plans it itself. */
+int  kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t *off1, const int64_t *gpos, const int32_t *glen, int64_t n,
+                        int pacbio, int max_gaps, uint8_t *ops, const int64_t *ops_off, int32_t *aln_len, uint8_t *status);
+
 /* ---- FASTQ text in, SAM text out ------------------------------------------------------------------------------------ */
 /* The reference's worker takes a chunk of reads from GetNextChunk (src/GetData.cpp:109-143: four getline() calls per record,
  * the name cut out of the header by IdentifyHeaderBegPos / EndPos, mate 2 reverse-complemented), maps it, and prints every

@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "kg_last_error", "kg_device_count", "kg_index_load", "kg_index_destroy", "kg_index_info",
     "kg_index_contig", "kg_host_alloc", "kg_host_free", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters", "kg_workspace_traffic",
     "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_set_single_steps", "kg_index_selfcheck", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_align_batch", "kg_align_reasons", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
+    "kg_fragments_batch",
     "kg_stream_open", "kg_stream_close", "kg_stream_staging", "kg_stream_upload", "kg_stream_parse", "kg_stream_map", "kg_stream_fetch_reads", "kg_stream_timing",
 )
 

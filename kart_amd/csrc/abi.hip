@@ -824,6 +824,14 @@ static int nw_run(kg_index *ix, const char *d_frag1, const int64_t *d_off1, cons
 	NwArgs a;
 	a.f1 = d_frag1; a.off1 = d_off1; a.f2 = d_frag2; a.off2 = d_off2; a.n = n;
 	a.ops = d_ops; a.aln_len = d_aln_len;
+	return kgi_nw_launch(ix, a, max_len, st);
+}
+
+// the NW kernels for the pairs `a` names (offset arrays, or job descriptors written on the device): scratch for the longest pair
+// from the index's pool, launch, hand the scratch back once the kernels are through
+int kgi_nw_launch(kg_index *ix, NwArgs &a, int64_t max_len, hipStream_t st)
+{
+	const int64_t n = a.n;
 	a.dir_scratch = nullptr;
 	a.dir_words_per_wave = 0;
 	a.big_waves = 0;

@@ -1,0 +1,463 @@
+// frag_kernels.hip -- GenerateNormalPairAlignment for long fragments on the device (gfx950): the -pacbio branch.
+//
+// For a read fragment and a genome fragment that both exceed 30 bases the reference (src/tools.cpp:142-223) finds their common
+// 8-mers within a shift limit -- min(50, 20 % of the longer side) for -pacbio, MaxGaps otherwise -- merges them into exact matches
+// (GenerateSimplePairsFromFragmentPair, src/KmerAnalysis.cpp:104-179), runs IdentifyNormalPairs(rLen, gLen, ...) on those
+// (src/AlignmentCandidates.cpp:420-490 with its three seed filters, :235-418), and aligns what lies between them: literal
+// stretches, nw_alignment for the sub-fragments, and -- -pacbio only -- the same procedure again for a sub-fragment with a side
+// above 300 (the recursion at :197).  aln_partition_kernel (align_kernels.hip) does this for short-read fragments (<= 255
+// bases, <= 12 matches, no recursion); this file is the general form:
+//   frag_partition_kernel  one wave per task (a fragment pair).  The read fragment and the text window go into the LDS as 2-bit
+//                          codes; every lane scans diagonals for runs of >= 8 equal bases (32 bases per step); the runs are
+//                          rank-sorted by (gPos, rPos); lane 0 runs the reference's IdentifyNormalPairs on the LDS arrays (the
+//                          filters are sequential by nature) and writes the task's pieces: literal columns, NW jobs (for the
+//                          NW kernels, nw_kernels.hip), sub-tasks for the next level.
+//   frag_stitch_kernel     one lane per request: the op string of the whole fragment from its pieces, depth first (what the
+//                          reference leaves in frag1 / frag2 at the end of GenerateNormalPairAlignment).
+// Integer / bit work, no MFMA.  Outside the envelope (a read character other than A/C/G/T, more than kFragMaxRuns matches,
+// fragments beyond kFragMaxLen, recursion deeper than kFragMaxDepth) the request is handed back (status 1) and the caller
+// plans it with its own implementation of the same reference code.
+#include "frag_kernels.hpp"
+
+namespace kg {
+
+namespace {
+
+struct __attribute__((packed, aligned(1))) FrU64u { uint64_t v; };
+
+__device__ __forceinline__ uint64_t text_word32_at(const uint8_t *text, int64_t two_l, int64_t p)     // 32 bases of the 2-bit text from position p
+{
+	if (p < 0 || p > two_l) return 0;
+	const uint8_t *tp = text + ((uint64_t)p >> 2);
+	uint64_t lo = reinterpret_cast<const FrU64u *>(tp)->v, hi = tp[8];
+	int sh = ((int)p & 3) << 1;
+	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
+// 32 codes (2 bits each) starting at base `at` of a packed LDS array of 64-bit words (32 bases per word); `at` may be negative
+// or beyond the end: bases outside [0, n) read as 0 (the caller masks them)
+__device__ __forceinline__ uint64_t codes32(const uint64_t *w, int n_words, int at)
+{
+	const int wi = at >> 5, sh = (at & 31) << 1;          // (arithmetic shift: at = -1 -> word -1)
+	uint64_t lo = (wi >= 0 && wi < n_words) ? w[wi] : 0, hi = (wi + 1 >= 0 && wi + 1 < n_words) ? w[wi + 1] : 0;
+	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
+__device__ __forceinline__ bool key_less(int g1, int r1, int g2, int r2) { return g1 == g2 ? r1 < r2 : g1 < g2; }   // CompByGenomePos
+
+// vector<SeedPair_t> of one fragment in the LDS (fragment-relative coordinates)
+struct FragPairs {
+	int32_t *gPos, *rPos, *rLen, *gLen;
+	uint8_t *simple;
+	int num;
+};
+
+__device__ void erase_empty(FragPairs &v)
+{
+	int w = 0;
+	for (int i = 0; i < v.num; ++i)
+		if (v.rLen[i] != 0) {
+			if (w != i) { v.gPos[w] = v.gPos[i]; v.rPos[w] = v.rPos[i]; v.rLen[w] = v.rLen[i]; v.gLen[w] = v.gLen[i]; v.simple[w] = v.simple[i]; }
+			w++;
+		}
+	v.num = w;
+}
+
+// CheckSeedOverlapping, src/AlignmentCandidates.cpp:323-373
+__device__ bool resolve_overlap(FragPairs &v, int i, int j)
+{
+	bool master = true;
+	int ov;
+	if ((ov = v.rPos[i] + v.rLen[i] - v.rPos[j]) > 0) {
+		if (v.rLen[i] < v.rLen[j]) {
+			master = false;
+			if (v.rLen[i] > ov) v.gLen[i] = (v.rLen[i] -= ov);
+			else v.rLen[i] = v.gLen[i] = 0;
+		} else if (v.rLen[j] > ov) {
+			v.rPos[j] += ov; v.gPos[j] += ov; v.gLen[j] = (v.rLen[j] -= ov);
+		} else v.rLen[j] = v.gLen[j] = 0;
+	}
+	if (v.rLen[i] > 0 && v.rLen[j] > 0 && (ov = v.gPos[i] + v.gLen[i] - v.gPos[j]) > 0) {
+		if (v.gLen[i] < v.gLen[j]) {
+			master = false;
+			if (v.rLen[i] > ov) v.gLen[i] = (v.rLen[i] -= ov);
+			else v.rLen[i] = v.gLen[i] = 0;
+		} else if (v.rLen[j] > ov) {
+			v.rPos[j] += ov; v.gPos[j] += ov; v.gLen[j] = (v.rLen[j] -= ov);
+		} else v.rLen[j] = v.gLen[j] = 0;
+	}
+	return master;
+}
+
+// IdentifyNormalPairs(rlen, glen, v) for a fragment (glen > 0), src/AlignmentCandidates.cpp:420-490, by ONE lane on the LDS arrays.
+// byr: scratch of v.num entries (read-position order).  false: more pairs than `cap`.
+__device__ bool identify_normal_pairs(int rlen, int glen, FragPairs &v, uint16_t *byr, int cap)
+{
+	if (v.num > 1) {
+		// RemoveTandemRepeatSeeds, :235-260: every read position hit by more than one seed goes
+		{
+			bool any = false;
+			for (int i = 0; i < v.num; ++i) byr[i] = 0;
+			for (int i = 0; i < v.num; ++i)
+				for (int j = i + 1; j < v.num; ++j)
+					if (v.rPos[i] == v.rPos[j]) { byr[i] = byr[j] = 1; any = true; }
+			if (any) {
+				for (int i = 0; i < v.num; ++i)
+					if (byr[i]) v.rLen[i] = v.gLen[i] = 0;
+				erase_empty(v);
+			}
+		}
+		// RemoveTranslocatedSeeds, :262-321: byr[k] = index (in genome order) of the seed with the k-th smallest read position
+		if (v.num > 1) {
+			const int num = v.num;
+			for (int i = 0; i < num; ++i) {
+				int p = i;
+				while (p > 0 && v.rPos[byr[p - 1]] > v.rPos[i]) { byr[p] = byr[p - 1]; --p; }
+				byr[p] = (uint16_t)i;
+			}
+			bool any = false;
+			for (int i = 0; i < num; ++i) {
+				if (byr[i] == i) continue;
+				any = true;
+				int hi = byr[i];
+				for (int j = i + 1; j <= hi; ++j)
+					if (byr[j] > hi) hi = byr[j];
+				int s1 = 0, s2 = 0;
+				for (int k = i; k <= hi; ++k) {
+					if (k < byr[k]) s1 += v.rLen[byr[k]];
+					else s2 += v.rLen[byr[k]];
+				}
+				for (int k = i; k <= hi; ++k) {
+					bool drop = s1 > s2 ? k > byr[k] : k < byr[k];
+					if (drop) v.rLen[byr[k]] = v.gLen[byr[k]] = 0;
+				}
+				i = hi;
+			}
+			if (any) erase_empty(v);
+		}
+		// CheckOverlappingSeeds, :375-418
+		if (v.num > 1) {
+			const int num = v.num;
+			bool any = false;
+			for (int i = 0; i < num;) {
+				if (v.rLen[i] > 0) {
+					int r_end = v.rPos[i] + v.rLen[i] - 1, g_end = v.gPos[i] + v.gLen[i] - 1;
+					for (int j = i + 1; j < num; ++j) {
+						if (v.rLen[j] == 0) continue;
+						if (r_end < v.rPos[j] && g_end < v.gPos[j]) break;
+						if (!resolve_overlap(v, i, j)) break;
+					}
+					if (v.rLen[i] == 0) {
+						any = true;
+						int q = i - 1;
+						while (q > 0 && v.rLen[q] == 0) q--;
+						i = q < 0 ? 0 : q;
+					} else i++;
+				} else {
+					any = true;
+					i++;
+				}
+			}
+			if (any) erase_empty(v);
+		}
+		// the gaps between consecutive seeds, appended and then moved to their place in (gPos, rPos) order (:437-455; the keys are distinct)
+		const int num = v.num;
+		int added = 0;
+		for (int i = 0, j = 1; j < num; ++i, ++j) {
+			int r_gap = v.rPos[j] - (v.rPos[i] + v.rLen[i]);
+			if (r_gap < 0) r_gap = 0;
+			int g_gap = v.gPos[j] - (v.gPos[i] + v.gLen[i]);
+			if (g_gap < 0) g_gap = 0;
+			if (r_gap > 0 || g_gap > 0) {
+				if (num + added >= cap) return false;
+				int t = num + added++;
+				v.simple[t] = 0;
+				v.rPos[t] = v.rPos[i] + v.rLen[i];
+				v.gPos[t] = v.gPos[i] + v.gLen[i];
+				v.rLen[t] = r_gap; v.gLen[t] = g_gap;
+			}
+		}
+		for (int t = num; t < num + added; ++t) {
+			int xg = v.gPos[t], xr = v.rPos[t], xrl = v.rLen[t], xgl = v.gLen[t];
+			uint8_t xs = v.simple[t];
+			int p = t;
+			while (p > 0 && key_less(xg, xr, v.gPos[p - 1], v.rPos[p - 1])) {
+				v.gPos[p] = v.gPos[p - 1]; v.rPos[p] = v.rPos[p - 1]; v.rLen[p] = v.rLen[p - 1]; v.gLen[p] = v.gLen[p - 1]; v.simple[p] = v.simple[p - 1];
+				--p;
+			}
+			v.gPos[p] = xg; v.rPos[p] = xr; v.rLen[p] = xrl; v.gLen[p] = xgl; v.simple[p] = xs;
+		}
+		v.num = num + added;
+	}
+	if (v.num > 0) {
+		if (v.num + 2 > cap) return false;
+		int r_gap = v.rPos[0] > 0 ? v.rPos[0] : 0;
+		int g_gap = glen > 0 ? v.gPos[0] : r_gap;
+		if (r_gap > 0 || g_gap > 0) {
+			for (int p = v.num; p > 0; --p) {
+				v.gPos[p] = v.gPos[p - 1]; v.rPos[p] = v.rPos[p - 1]; v.rLen[p] = v.rLen[p - 1]; v.gLen[p] = v.gLen[p - 1]; v.simple[p] = v.simple[p - 1];
+			}
+			int g = v.gPos[1] - g_gap;
+			v.gPos[0] = g < 0 ? 0 : g;
+			v.rPos[0] = 0; v.rLen[0] = r_gap; v.gLen[0] = g_gap; v.simple[0] = 0;
+			v.num++;
+		}
+		int last = v.num - 1;
+		r_gap = rlen - (v.rPos[last] + v.rLen[last]);
+		g_gap = glen > 0 ? glen - (v.gPos[last] + v.gLen[last]) : r_gap;
+		if (r_gap > 0 || g_gap > 0) {
+			int t = v.num++;
+			v.simple[t] = 0;
+			v.rPos[t] = v.rPos[last] + v.rLen[last];
+			v.gPos[t] = v.gPos[last] + v.gLen[last];
+			v.rLen[t] = r_gap; v.gLen[t] = g_gap;
+		}
+	}
+	return true;
+}
+
+}  // namespace
+
+// One wave per task of the level [level_begin[level], level_begin[level + 1]).
+__global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int level)
+{
+	__shared__ uint64_t s_rd[kFragMaxLen / 32 + 2], s_tx[kFragMaxLen / 32 + 2];
+	__shared__ int32_t s_gPos[kFragMaxPairs], s_rPos[kFragMaxPairs], s_rLen[kFragMaxPairs], s_gLen[kFragMaxPairs];
+	__shared__ uint8_t s_simple[kFragMaxPairs];
+	__shared__ int32_t s_run_r[kFragMaxRuns], s_run_d[kFragMaxRuns], s_run_l[kFragMaxRuns];
+	__shared__ uint16_t s_byr[kFragMaxPairs];
+	__shared__ int s_n, s_bad;
+	const int lane = threadIdx.x;
+	const unsigned long long t0 = a.ctl[FC_LEVEL0 + level], t1 = a.ctl[FC_LEVEL0 + level + 1];
+	for (unsigned long long ti = t0 + blockIdx.x; ti < t1; ti += gridDim.x) {
+		FragTask &task = a.tasks[ti];
+		const int rL = task.rL, gL = task.gL;
+		const uint8_t *f1 = reinterpret_cast<const uint8_t *>(a.f1) + task.f1_off;
+		const int64_t g = task.g;
+		// lane 0 decides the task's pieces; everybody else helps with the runs
+		bool whole_job = !(rL > 30 && gL > 30);            // src/tools.cpp:146
+		bool host = false;
+		if (!whole_job && (rL > kFragMaxLen || gL > kFragMaxLen)) host = true;
+		int n_runs = 0;
+		if (!whole_job && !host) {
+			int max_shift;
+			if (a.pacbio) {                                // :149-153
+				max_shift = rL > gL ? (int)(rL * 0.2) : (int)(gL * 0.2);
+				if (max_shift > 50) max_shift = 50;
+			} else max_shift = a.max_gaps;
+			if (lane == 0) { s_n = 0; s_bad = 0; }
+			__syncthreads();
+			// ---- the two fragments as 2-bit codes (the 8-mer code maps characters through nst_nt4_table and skips 'N': plain
+			// A/C/G/T in either case is what a comparison of 2-bit codes reproduces; anything else goes back to the caller) ----
+			const int rw = (rL + 31) >> 5, gw = (gL + 31) >> 5;
+			for (int w = lane; w < rw; w += 64) {
+				uint64_t word = 0;
+				bool bad = false;
+				for (int k = 0; k < 32; ++k) {
+					const int i = (w << 5) + k;
+					if (i >= rL) break;
+					const unsigned ch = f1[i], u = ch & 0xDFu;
+					if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad = true;
+					unsigned c = (ch >> 1) & 3;
+					c ^= c >> 1;
+					word |= (uint64_t)c << (2 * k);
+				}
+				s_rd[w] = word;
+				if (bad) s_bad = 1;
+			}
+			for (int w = lane; w < gw; w += 64) s_tx[w] = text_word32_at(a.text, a.two_genome_size, g + ((int64_t)w << 5));
+			__syncthreads();
+			if (s_bad) host = true;
+			else {
+				// ---- runs of >= 8 equal bases along the diagonals |gpos - rpos| < max_shift (= the merged common 8-mers) ----
+				for (int d = -(max_shift - 1) + lane; d <= max_shift - 1; d += 64) {
+					const int t_lo = d < 0 ? -d : 0, t_hi = rL < gL - d ? rL : gL - d;      // read positions t with 0 <= t + d < gL
+					int run = 0;
+					for (int base = t_lo & ~31; base < t_hi; base += 32) {
+						const uint64_t x = codes32(s_rd, rw, base) ^ codes32(s_tx, gw, base + d);
+						uint64_t e = ~(x | (x >> 1)) & 0x5555555555555555ull;                 // 1 at the even bit of every equal base
+						e = (e | (e >> 1)) & 0x3333333333333333ull;
+						e = (e | (e >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+						e = (e | (e >> 4)) & 0x00FF00FF00FF00FFull;
+						e = (e | (e >> 8)) & 0x0000FFFF0000FFFFull;
+						e = (e | (e >> 16)) & 0x00000000FFFFFFFFull;
+						uint32_t m = (uint32_t)e;
+						const int lo = t_lo > base ? t_lo - base : 0, hi = t_hi - base < 32 ? t_hi - base : 32;
+						m &= (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+						int pos = 0;
+						while (pos < 32) {
+							const uint32_t rest = m >> pos;
+							if (rest & 1u) {
+								int ones = __ffs(~rest) - 1;                                    // (rest != all ones once shifted, or pos == 0 and m full)
+								if (ones < 0 || ones > 32 - pos) ones = 32 - pos;
+								run += ones; pos += ones;
+							} else {
+								if (run >= 8) {
+									int k = atomicAdd(&s_n, 1);
+									if (k < kFragMaxRuns) { s_run_r[k] = base + pos - run; s_run_d[k] = d; s_run_l[k] = run; }
+								}
+								run = 0;
+								if (rest == 0) break;
+								pos += __ffs(rest) - 1;
+							}
+						}
+					}
+					if (run >= 8) {
+						int k = atomicAdd(&s_n, 1);
+						if (k < kFragMaxRuns) { s_run_r[k] = t_hi - run; s_run_d[k] = d; s_run_l[k] = run; }
+					}
+				}
+				__syncthreads();
+				n_runs = s_n;
+				if (n_runs > kFragMaxRuns) host = true;
+			}
+			if (!host && n_runs > 0) {
+				// sort(SimplePairVec, CompByGenomePos), src/KmerAnalysis.cpp:177: rank of every run among the others (keys are distinct)
+				for (int i = lane; i < n_runs; i += 64) {
+					const int gi = s_run_r[i] + s_run_d[i], ri = s_run_r[i];
+					int rank = 0;
+					for (int j = 0; j < n_runs; ++j)
+						if (key_less(s_run_r[j] + s_run_d[j], s_run_r[j], gi, ri)) rank++;
+					s_gPos[rank] = gi; s_rPos[rank] = ri; s_rLen[rank] = s_gLen[rank] = s_run_l[i]; s_simple[rank] = 1;
+				}
+			}
+			__syncthreads();
+		}
+		if (lane == 0) {
+			FragPairs v;
+			v.gPos = s_gPos; v.rPos = s_rPos; v.rLen = s_rLen; v.gLen = s_gLen; v.simple = s_simple; v.num = n_runs;
+			if (!host && !whole_job && n_runs > 0 && !identify_normal_pairs(rL, gL, v, s_byr, kFragMaxPairs)) host = true;
+			if (!host && !whole_job && v.num == 0) whole_job = true;            // no common 8-mer survived: the whole fragment is one alignment (:214-221)
+			int first = 0, count = 0;
+			if (!host) {
+				int n_pieces = 0;
+				if (whole_job) n_pieces = 1;
+				else
+					for (int i = 0; i < v.num; ++i)
+						if (!(v.rLen[i] <= 0 && v.gLen[i] <= 0)) n_pieces++;
+				const unsigned long long at = atomicAdd(&a.ctl[FC_PIECES], (unsigned long long)n_pieces);
+				if (at + (unsigned long long)n_pieces > (unsigned long long)a.piece_capacity) host = true;
+				else {
+					first = (int)at;
+					auto nw_job = [&](int64_t o1, int64_t o2, int m, int n, FragPiece &pc) {
+						const unsigned long long slot = atomicAdd(&a.ctl[FC_JOBS], 1ull);
+						const unsigned long long ops_at = atomicAdd(&a.ctl[FC_OPS], (unsigned long long)(m + n));
+						if (slot >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(m + n) > (unsigned long long)a.ops_capacity) return false;
+						NwJobDesc jd;
+						jd.o1 = o1; jd.o2 = o2; jd.ops = (int64_t)ops_at; jd.m = m; jd.n = n;
+						a.jobs[slot] = jd;
+						pc.kind = FP_JOB; pc.v = (int32_t)slot;
+						return true;
+					};
+					if (whole_job) {
+						FragPiece pc;
+						if (!nw_job(task.f1_off, g, rL, gL, pc)) host = true;
+						else a.pieces[first + count++] = pc;
+					} else {
+						for (int i = 0; i < v.num && !host; ++i) {
+							const int prl = v.rLen[i], pgl = v.gLen[i];
+							if (prl <= 0 && pgl <= 0) continue;
+							FragPiece pc;
+							if (pgl == 0) { pc.kind = KG_OP_GAP2; pc.v = prl; }                         // read characters against '-' (:172-176)
+							else if (prl == 0) { pc.kind = KG_OP_GAP1; pc.v = pgl; }                    // '-' against genome characters (:177-181)
+							else if ((prl == 1 && pgl == 1) || v.simple[i]) { pc.kind = KG_OP_DIAG; pc.v = prl; }
+							else if (a.pacbio && (prl > 300 || pgl > 300)) {                          // the recursion, :197
+								const unsigned long long nt = atomicAdd(&a.ctl[FC_TASKS], 1ull);
+								if (nt >= (unsigned long long)a.task_capacity || level + 1 >= kFragMaxDepth) { host = true; break; }
+								FragTask sub;
+								sub.f1_off = task.f1_off + v.rPos[i]; sub.g = g + v.gPos[i]; sub.rL = prl; sub.gL = pgl;
+								sub.first = 0; sub.count = 0; sub.status = 0; sub.root = task.root;
+								a.tasks[nt] = sub;
+								pc.kind = FP_TASK; pc.v = (int32_t)nt;
+							} else if (!nw_job(task.f1_off + v.rPos[i], g + v.gPos[i], prl, pgl, pc)) { host = true; break; }
+							a.pieces[first + count++] = pc;
+						}
+					}
+				}
+			}
+			task.first = first; task.count = host ? 0 : count; task.status = host ? 1 : 0;
+			if (host) a.status[task.root] = 1;                                              // the whole request goes back to the caller
+		}
+		__syncthreads();
+	}
+}
+
+// the tasks appended while `level` was processed are the next level
+__global__ void frag_level_kernel(FragArgs a, int level)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		unsigned long long n = a.ctl[FC_TASKS];
+		if (n > (unsigned long long)a.task_capacity) n = (unsigned long long)a.task_capacity;
+		a.ctl[FC_LEVEL0 + level + 2] = n;
+	}
+}
+
+__global__ void frag_reset_kernel(FragArgs a)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i == 0) {
+		a.ctl[FC_TASKS] = (unsigned long long)a.n; a.ctl[FC_PIECES] = 0; a.ctl[FC_JOBS] = 0; a.ctl[FC_OPS] = 0;
+		a.ctl[FC_LEVEL0] = 0; a.ctl[FC_LEVEL0 + 1] = (unsigned long long)a.n;
+		for (int l = 2; l <= kFragMaxDepth + 1; ++l) a.ctl[FC_LEVEL0 + l] = (unsigned long long)a.n;
+	}
+	for (int64_t r = i; r < a.n; r += (int64_t)gridDim.x * blockDim.x) {
+		FragTask t;
+		t.f1_off = a.off1[r]; t.g = a.gpos[r]; t.rL = (int32_t)(a.off1[r + 1] - a.off1[r]); t.gL = a.glen[r];
+		t.first = 0; t.count = 0; t.status = 0; t.root = (int32_t)r;
+		a.tasks[r] = t;
+		a.status[r] = 0;
+	}
+}
+
+// One lane per request: its op string from the pieces, depth first
+__global__ __launch_bounds__(256) void frag_stitch_kernel(FragArgs a)
+{
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += (int64_t)gridDim.x * blockDim.x) {
+		if (a.status[r]) { a.aln_len[r] = 0; continue; }
+		uint8_t *out = a.ops + a.ops_off[r];
+		int at = 0;
+		int stack_task[kFragMaxDepth + 1], stack_piece[kFragMaxDepth + 1];
+		int sp = 0;
+		stack_task[0] = (int)r; stack_piece[0] = 0;
+		while (sp >= 0) {
+			const FragTask &t = a.tasks[stack_task[sp]];
+			if (stack_piece[sp] >= t.count) { sp--; continue; }
+			const FragPiece pc = a.pieces[t.first + stack_piece[sp]++];
+			if (pc.kind <= KG_OP_GAP2) { for (int k = 0; k < pc.v; ++k) out[at++] = (uint8_t)pc.kind; }
+			else if (pc.kind == FP_JOB) {
+				const uint8_t *src = a.job_ops + a.jobs[pc.v].ops;
+				const int L = a.job_len[pc.v];
+				for (int k = 0; k < L; ++k) out[at++] = src[k];
+			} else if (sp < kFragMaxDepth) { sp++; stack_task[sp] = pc.v; stack_piece[sp] = 0; }
+		}
+		a.aln_len[r] = at;
+	}
+}
+
+static inline int grid_of(int64_t items, int block, int max_blocks)
+{
+	int64_t g = (items + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > max_blocks) g = max_blocks;
+	return (int)g;
+}
+
+hipError_t launch_frag_partition(const FragArgs &a, int n_cu, hipStream_t stream)
+{
+	hipLaunchKernelGGL(frag_reset_kernel, dim3(grid_of(a.n, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	for (int level = 0; level < kFragMaxDepth; ++level) {
+		// (the level's task count lives on the device: the grid is sized for the requests at level 0 and for a share of them below)
+		const int64_t guess = level == 0 ? a.n : a.n / 4 + 1024;
+		hipLaunchKernelGGL(frag_partition_kernel, dim3(grid_of(guess, 1, n_cu * 32)), dim3(64), 0, stream, a, level);
+		hipLaunchKernelGGL(frag_level_kernel, dim3(1), dim3(64), 0, stream, a, level);
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_frag_stitch(const FragArgs &a, int n_cu, hipStream_t stream)
+{
+	hipLaunchKernelGGL(frag_stitch_kernel, dim3(grid_of(a.n, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+}  // namespace kg

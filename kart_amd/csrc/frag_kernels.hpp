@@ -1,0 +1,58 @@
+// frag_kernels.hpp -- argument block of the fragment-pair alignment kernels (frag_kernels.hip) shared with the C ABI.
+#pragma once
+#include "seed_kernels.hpp"
+
+namespace kg {
+
+constexpr int kFragMaxLen = 4096;        // longest side of a fragment the partition kernel takes (2-bit codes of both sides in the LDS)
+constexpr int kFragMaxRuns = 255;        // exact matches of >= 8 bases per fragment pair
+constexpr int kFragMaxPairs = 2 * kFragMaxRuns + 2;   // ... and the normal pairs IdentifyNormalPairs makes of them
+constexpr int kFragMaxDepth = 6;         // levels of the -pacbio recursion (src/tools.cpp:197)
+
+enum { FP_JOB = 3, FP_TASK = 4 };        // FragPiece::kind beyond the literal runs KG_OP_DIAG / KG_OP_GAP1 / KG_OP_GAP2
+enum { FC_TASKS = 0, FC_PIECES = 1, FC_JOBS = 2, FC_OPS = 3, FC_LEVEL0 = 4, FC_WORDS = FC_LEVEL0 + kFragMaxDepth + 2 };
+
+struct FragTask {
+	int64_t f1_off;       // the read fragment in the characters the caller uploaded
+	int64_t g;            // the genome fragment's text coordinate
+	int32_t rL, gL;
+	int32_t first, count; // its pieces
+	int32_t status;       // 1: outside the envelope
+	int32_t root;         // the request it belongs to
+};
+struct FragPiece {
+	int32_t kind;         // KG_OP_*: a literal run of v columns; FP_JOB: NW job v; FP_TASK: task v (a sub-fragment partitioned again)
+	int32_t v;
+};
+
+struct FragArgs {
+	// requests
+	const char *f1;                 // read fragments, concatenated
+	const int64_t *off1;            // [n + 1]
+	const int64_t *gpos;            // [n] text coordinate of the genome fragment
+	const int32_t *glen;            // [n]
+	int64_t n;
+	const uint8_t *text;            // 2-bit text of the index
+	int64_t two_genome_size;
+	int pacbio, max_gaps;
+	// work lists
+	FragTask *tasks;
+	int64_t task_capacity;
+	FragPiece *pieces;
+	int64_t piece_capacity;
+	NwJobDesc *jobs;
+	int64_t job_capacity, ops_capacity;
+	uint8_t *job_ops;
+	int32_t *job_len;
+	unsigned long long *ctl;        // [FC_WORDS]
+	// results
+	uint8_t *status;                // [n] 1: the caller plans this request itself
+	uint8_t *ops;                   // the op strings, request r at ops_off[r] (room for rLen + gLen columns)
+	const int64_t *ops_off;         // [n]
+	int32_t *aln_len;               // [n]
+};
+
+hipError_t launch_frag_partition(const FragArgs &a, int n_cu, hipStream_t stream);   // levels 0 .. kFragMaxDepth - 1: pieces, NW jobs
+hipError_t launch_frag_stitch(const FragArgs &a, int n_cu, hipStream_t stream);      // after the NW kernels: the requests' op strings
+
+}  // namespace kg

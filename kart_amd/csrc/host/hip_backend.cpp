@@ -157,6 +157,38 @@ public:
 		     ", partition plans " + std::to_string((unsigned long long)w[15]);
 		return s;
 	}
+	bool has_fragments() const override { static const bool off = getenv("KART_AMD_HOST_FRAGMENTS") != nullptr; return !off; }
+	bool fragments_batch(std::vector<FragJobs *> &parts, bool pacbio, int max_gaps) override
+	{
+		if (!has_fragments()) return false;
+		std::lock_guard<std::mutex> lk(frag_mu_);
+		// concatenate the parts (a few large copies), one kernel call, scatter the results back
+		int64_t n = 0, b1 = 0, cols = 0;
+		for (FragJobs *p : parts) { n += (int64_t)p->size(); b1 += (int64_t)p->f1.size(); cols += p->cols; }
+		if (n == 0) return true;
+		fr_f1_.resize((size_t)b1 + 1); fr_o1_.resize((size_t)n + 1); fr_g_.resize((size_t)n); fr_gl_.resize((size_t)n); fr_oo_.resize((size_t)n);
+		fr_ops_.resize((size_t)cols + 1); fr_len_.resize((size_t)n); fr_status_.resize((size_t)n);
+		int64_t at = 0, a1 = 0, ac = 0;
+		fr_o1_[0] = 0;
+		for (FragJobs *p : parts) {
+			memcpy(&fr_f1_[(size_t)a1], p->f1.data(), p->f1.size());
+			for (size_t j = 0; j < p->size(); ++j) {
+				fr_o1_[(size_t)at + j + 1] = a1 + p->o1[j + 1];
+				fr_g_[(size_t)at + j] = p->g[j]; fr_gl_[(size_t)at + j] = p->gl[j]; fr_oo_[(size_t)at + j] = ac + p->oo[j];
+			}
+			at += (int64_t)p->size(); a1 += (int64_t)p->f1.size(); ac += p->cols;
+		}
+		if (kg_fragments_batch(ix_, fr_f1_.data(), fr_o1_.data(), fr_g_.data(), fr_gl_.data(), n, pacbio ? 1 : 0, max_gaps, fr_ops_.data(), fr_oo_.data(), fr_len_.data(), fr_status_.data()) != KG_OK)
+			die("kg_fragments_batch");
+		at = 0; ac = 0;
+		for (FragJobs *p : parts) {
+			p->ops.assign(fr_ops_.begin() + ac, fr_ops_.begin() + ac + p->cols);
+			p->len.assign(fr_len_.begin() + at, fr_len_.begin() + at + (int64_t)p->size());
+			p->status.assign(fr_status_.begin() + at, fr_status_.begin() + at + (int64_t)p->size());
+			at += (int64_t)p->size(); ac += p->cols;
+		}
+		return true;
+	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
 	{
 		std::lock_guard<std::mutex> lk(nw_mu_);   // the staging vectors below are shared; calls from the commit path are rare
@@ -204,7 +236,11 @@ private:
 	int64_t cap_reads_ = 0, cap_bases_ = 0;
 	kg_index *ix_;
 	int threads_;
-	std::mutex nw_mu_;
+	std::mutex nw_mu_, frag_mu_;
+	std::vector<char> fr_f1_;
+	std::vector<int64_t> fr_o1_, fr_g_, fr_oo_;
+	std::vector<int32_t> fr_gl_, fr_len_;
+	std::vector<uint8_t> fr_ops_, fr_status_;
 	std::vector<char> f1_, f2_;
 	std::vector<int64_t> o1_, o2_;
 	std::vector<uint8_t> ops_;

@@ -150,6 +150,7 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	// (a sharded run: every process takes L3 domains of its own)
 	g_io_cpus = detect_io_cpus(std::max(0, opt.shard_rank));
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
+	cx.frag_service = opt.pacbio && kern.has_fragments();
 	Options &o = const_cast<Options &>(opt);
 	RunTotals tot;
 	// one process per GPU (shard.inc): this process maps shard_rank of shard_count chunk ranges of the library
@@ -258,6 +259,8 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	if (getenv("KART_AMD_VERBOSE") && shard.active())
 		fprintf(stdout, "shard %d/%d: %lld reads in %.3f s | waited %.3f s for the totals of the shard before | settled in %.3f s (%lld chunks mapped again) | writer drain %.3f s\n", shard.rank, shard.count,
 		        (long long)stats.total_reads, stats.map_seconds, tot.t_shard_wait, tot.t_shard_settle, (long long)stats.respeculated, tot.t_drain);
+	if (getenv("KART_AMD_VERBOSE") && g_frag_total.load() > 0)
+		fprintf(stdout, "fragment pairs (GenerateNormalPairAlignment) aligned by the device: %lld, of them handed back and planned here: %lld\n", (long long)g_frag_total.load(), (long long)g_frag_back.load());
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "i/o threads: %s (%d CPUs)\n", g_io_cpus.valid ? "kept on the CPUs of one last-level cache" : "not pinned", g_io_cpus.count);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: %lld reads decided on the device, %lld mapped by the host stages\n", (long long)tot.dev_reads, (long long)tot.host_reads);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "device report: read_batch total %.3f s (line index %.3f, views %.3f, views + chunk assembly %.3f, materialise + characters %.3f) | %s\n", 1e-9 * (double)g_read_ns.load(),

@@ -86,8 +86,36 @@ struct StreamBackend {
 	virtual bool timing(kg_stream_timing_t &t, bool reset) { (void)t; (void)reset; return false; }   // device time per stage since the last reset
 };
 
+// The fragment pairs of one chunk whose alignment GenerateNormalPairAlignment (src/tools.cpp:142-223) is to produce -- 8-mer partition,
+// the -pacbio recursion, nw_alignment of the pieces -- as ONE batched call (kg_fragments_batch): read fragments concatenated (f1
+// with offsets o1), genome fragments as text coordinates.  Results: op codes at ops[oo[j] ...), len[j] columns; status[j] != 0:
+// outside the kernels' envelope, the host plans that pair itself.
+struct FragJobs {
+	std::string f1;
+	std::vector<int64_t> o1{0}, g, oo;
+	std::vector<int32_t> gl;
+	std::vector<void *> owner;          // whoever waits for job j (the host's PairWork)
+	std::vector<uint8_t> ops, status;
+	std::vector<int32_t> len;
+	int64_t cols = 0;
+	int add(const char *a, int m, int64_t gpos, int n, void *who)
+	{
+		f1.append(a, (size_t)m);
+		o1.push_back((int64_t)f1.size());
+		g.push_back(gpos); gl.push_back(n); oo.push_back(cols); owner.push_back(who);
+		cols += m + n;
+		return (int)g.size() - 1;
+	}
+	size_t size() const { return g.size(); }
+	void clear() { f1.clear(); o1.assign(1, 0); g.clear(); oo.clear(); gl.clear(); owner.clear(); ops.clear(); status.clear(); len.clear(); cols = 0; }
+};
+
 struct KernelBackend {
 	virtual ~KernelBackend() {}
+	// GenerateNormalPairAlignment for the fragment pairs of several chunks in one call (fills ops / len / status of every part);
+	// false: this backend has no such stage -- the host plans every pair itself
+	virtual bool fragments_batch(std::vector<FragJobs *> &parts, bool pacbio, int max_gaps) { (void)parts; (void)pacbio; (void)max_gaps; return false; }
+	virtual bool has_fragments() const { return false; }
 	// a stream with at least this capacity (kept by the backend across runs), or null: the backend has no such path
 	virtual StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes) { (void)max_reads; (void)max_window; (void)lanes; return nullptr; }
 	// index constants the host needs

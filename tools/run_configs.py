@@ -52,7 +52,7 @@ def run(cmd, env=None):
     for line in r.stdout.decode().splitlines():
         if line.startswith("mapping seconds"):
             out["mapping_seconds"] = float(line.split(":")[1])
-        if line.startswith(("stage seconds", "worker thread-seconds", "device report", "All the", "chunks re-mapped")):
+        if line.startswith(("stage seconds", "worker thread-seconds", "device report", "All the", "chunks re-mapped", "fragment pairs", "cpu seconds")):
             out.setdefault("log", []).append(line.strip()[:400])
     return out
 
