@@ -3,6 +3,8 @@
 #include "frag_kernels.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #define fail kg_fail
 
@@ -88,6 +90,8 @@ extern "C" int kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t
 	a.n = n;
 	a.text = ix->d_text; a.two_genome_size = 2 * ix->l_pac;
 	a.pacbio = pacbio ? 1 : 0; a.max_gaps = max_gaps;
+	static const bool prof = getenv("KG_FRAG_PROF") != nullptr;
+	a.prof = prof ? 1 : 0;
 	a.tasks = (FragTask *)(sc->work + w_tasks); a.task_capacity = task_cap;
 	a.pieces = (FragPiece *)(sc->work + w_pieces); a.piece_capacity = piece_cap;
 	a.jobs = (NwJobDesc *)(sc->work + w_jobs); a.job_capacity = job_cap; a.ops_capacity = jops_cap;
@@ -110,7 +114,14 @@ extern "C" int kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t
 	HIP_TRY(hipMemcpyAsync(ops, a.ops, (size_t)cols, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(aln_len, a.aln_len, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(status, a.status, (size_t)n, hipMemcpyDeviceToHost, st));
+	unsigned long long pc[FC_WORDS];
+	if (prof) HIP_TRY(hipMemcpyAsync(pc, a.ctl, 8 * FC_WORDS, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipEventRecord(sc->done, st));
 	HIP_TRY(hipEventSynchronize(sc->done));
+	if (prof)
+		fprintf(stderr, "kg_fragments_batch: %lld requests, %llu tasks, %llu pieces, %llu NW jobs | wave cycles per task: load+pack %.0f, diagonal scan %.0f, sort %.0f, normal pairs %.0f, pieces %.0f | runs per task %.1f, columns per task %.0f\n",
+		        (long long)n, pc[FC_PROF + 5], pc[FC_PIECES], pc[FC_JOBS], (double)pc[FC_PROF] / std::max(1ull, pc[FC_PROF + 5]), (double)pc[FC_PROF + 1] / std::max(1ull, pc[FC_PROF + 5]),
+		        (double)pc[FC_PROF + 2] / std::max(1ull, pc[FC_PROF + 5]), (double)pc[FC_PROF + 3] / std::max(1ull, pc[FC_PROF + 5]), (double)pc[FC_PROF + 4] / std::max(1ull, pc[FC_PROF + 5]),
+		        (double)pc[FC_PROF + 6] / std::max(1ull, pc[FC_PROF + 5]), (double)pc[FC_PROF + 7] / std::max(1ull, pc[FC_PROF + 5]));
 	return KG_OK;
 }

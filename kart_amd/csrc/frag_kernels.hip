@@ -231,6 +231,8 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 	const unsigned long long t0 = a.ctl[FC_LEVEL0 + level], t1 = a.ctl[FC_LEVEL0 + level + 1];
 	for (unsigned long long ti = t0 + blockIdx.x; ti < t1; ti += gridDim.x) {
 		FragTask &task = a.tasks[ti];
+		const long long c0 = a.prof ? clock64() : 0;
+		long long c1 = c0, c2 = c0, c3 = c0, c4 = c0;
 		const int rL = task.rL, gL = task.gL;
 		const uint8_t *f1 = reinterpret_cast<const uint8_t *>(a.f1) + task.f1_off;
 		const int64_t g = task.g;
@@ -251,22 +253,32 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 			// A/C/G/T in either case is what a comparison of 2-bit codes reproduces; anything else goes back to the caller) ----
 			const int rw = (rL + 31) >> 5, gw = (gL + 31) >> 5;
 			for (int w = lane; w < rw; w += 64) {
-				uint64_t word = 0;
-				bool bad = false;
-				for (int k = 0; k < 32; ++k) {
-					const int i = (w << 5) + k;
-					if (i >= rL) break;
-					const unsigned ch = f1[i], u = ch & 0xDFu;
-					if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad = true;
-					unsigned c = (ch >> 1) & 3;
-					c ^= c >> 1;
-					word |= (uint64_t)c << (2 * k);
+				// 32 characters = four unaligned 8-byte loads (the uploaded characters have 64 bytes of slack behind them), converted
+				// eight at a time: code in bits 2:1 of the letter (Gray), packed to 2 bits per base
+				uint64_t word = 0, bad = 0;
+				for (int q = 0; q < 4; ++q) {
+					const int i0 = (w << 5) + 8 * q;
+					if (i0 >= rL) break;
+					const uint64_t c8 = reinterpret_cast<const FrU64u *>(f1 + i0)->v;
+					const uint64_t u = c8 & 0xDFDFDFDFDFDFDFDFull;
+					auto zero_bytes = [](uint64_t t) { return ~(((t & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | t | 0x7F7F7F7F7F7F7F7Full); };
+					uint64_t ok = zero_bytes(u ^ 0x4141414141414141ull) | zero_bytes(u ^ 0x4343434343434343ull) | zero_bytes(u ^ 0x4747474747474747ull) | zero_bytes(u ^ 0x5454545454545454ull);
+					const int n = rL - i0 < 8 ? rL - i0 : 8;
+					const uint64_t in = n >= 8 ? 0x8080808080808080ull : ((1ull << (8 * n)) - 1) & 0x8080808080808080ull;
+					bad |= ~ok & in;
+					uint64_t g2 = (c8 >> 1) & 0x0303030303030303ull;
+					uint64_t code = g2 ^ ((g2 >> 1) & 0x0101010101010101ull);                 // A 0, C 1, G 2, T 3
+					code = (code | (code >> 6)) & 0x000F000F000F000Full;
+					code = (code | (code >> 12)) & 0x000000FF000000FFull;
+					code = (code | (code >> 24)) & 0xFFFFull;
+					word |= code << (16 * q);
 				}
 				s_rd[w] = word;
 				if (bad) s_bad = 1;
 			}
 			for (int w = lane; w < gw; w += 64) s_tx[w] = text_word32_at(a.text, a.two_genome_size, g + ((int64_t)w << 5));
 			__syncthreads();
+			if (a.prof) c1 = clock64();
 			if (s_bad) host = true;
 			else {
 				// ---- runs of >= 8 equal bases along the diagonals |gpos - rpos| < max_shift (= the merged common 8-mers) ----
@@ -310,6 +322,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 				__syncthreads();
 				n_runs = s_n;
 				if (n_runs > kFragMaxRuns) host = true;
+				if (a.prof) c2 = clock64();
 			}
 			if (!host && n_runs > 0) {
 				// sort(SimplePairVec, CompByGenomePos), src/KmerAnalysis.cpp:177: rank of every run among the others (keys are distinct)
@@ -322,12 +335,14 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 				}
 			}
 			__syncthreads();
+			if (a.prof) c3 = clock64();
 		}
 		if (lane == 0) {
 			FragPairs v;
 			v.gPos = s_gPos; v.rPos = s_rPos; v.rLen = s_rLen; v.gLen = s_gLen; v.simple = s_simple; v.num = n_runs;
 			if (!host && !whole_job && n_runs > 0 && !identify_normal_pairs(rL, gL, v, s_byr, kFragMaxPairs)) host = true;
 			if (!host && !whole_job && v.num == 0) whole_job = true;            // no common 8-mer survived: the whole fragment is one alignment (:214-221)
+			if (a.prof) c4 = clock64();
 			int first = 0, count = 0;
 			if (!host) {
 				int n_pieces = 0;
@@ -339,14 +354,30 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 				if (at + (unsigned long long)n_pieces > (unsigned long long)a.piece_capacity) host = true;
 				else {
 					first = (int)at;
+					// the task's NW jobs and their op bytes in ONE reservation each (a same-address atomic per job from every wave was
+					// the kernel: 2 M jobs per batch against ~90 M atomics/s on one word)
+					int n_jobs = 0;
+					long long n_ops = 0;
+					if (whole_job) { n_jobs = 1; n_ops = rL + gL; }
+					else
+						for (int i = 0; i < v.num; ++i) {
+							const int prl = v.rLen[i], pgl = v.gLen[i];
+							if (prl <= 0 || pgl <= 0 || (prl == 1 && pgl == 1) || v.simple[i]) continue;
+							if (a.pacbio && (prl > 300 || pgl > 300)) continue;
+							n_jobs++; n_ops += prl + pgl;
+						}
+					unsigned long long job_at = n_jobs ? atomicAdd(&a.ctl[FC_JOBS], (unsigned long long)n_jobs) : 0;
+					const unsigned long long job_end = job_at + (unsigned long long)n_jobs;
+					unsigned long long ops_next = n_jobs ? atomicAdd(&a.ctl[FC_OPS], (unsigned long long)n_ops) : 0;
+					const bool room = job_at + (unsigned long long)n_jobs <= (unsigned long long)a.job_capacity && ops_next + (unsigned long long)n_ops <= (unsigned long long)a.ops_capacity;
 					auto nw_job = [&](int64_t o1, int64_t o2, int m, int n, FragPiece &pc) {
-						const unsigned long long slot = atomicAdd(&a.ctl[FC_JOBS], 1ull);
-						const unsigned long long ops_at = atomicAdd(&a.ctl[FC_OPS], (unsigned long long)(m + n));
-						if (slot >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(m + n) > (unsigned long long)a.ops_capacity) return false;
+						if (!room) return false;
 						NwJobDesc jd;
-						jd.o1 = o1; jd.o2 = o2; jd.ops = (int64_t)ops_at; jd.m = m; jd.n = n;
-						a.jobs[slot] = jd;
-						pc.kind = FP_JOB; pc.v = (int32_t)slot;
+						jd.o1 = o1; jd.o2 = o2; jd.ops = (int64_t)ops_next; jd.m = m; jd.n = n;
+						ops_next += (unsigned long long)(m + n);
+						a.jobs[job_at] = jd;
+						pc.kind = FP_JOB; pc.v = (int32_t)job_at;
+						job_at++;
 						return true;
 					};
 					if (whole_job) {
@@ -373,10 +404,20 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 							a.pieces[first + count++] = pc;
 						}
 					}
+					// (a task that gave up half way leaves reserved job slots behind: empty jobs, so that the NW kernels find nothing in them)
+					if (room)
+						for (; job_at < job_end; ++job_at) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[job_at] = jd; }
 				}
 			}
 			task.first = first; task.count = host ? 0 : count; task.status = host ? 1 : 0;
 			if (host) a.status[task.root] = 1;                                              // the whole request goes back to the caller
+			if (a.prof) {
+				const long long c5 = clock64();
+				atomicAdd(&a.ctl[FC_PROF + 0], (unsigned long long)(c1 - c0)); atomicAdd(&a.ctl[FC_PROF + 1], (unsigned long long)(c2 - c1));
+				atomicAdd(&a.ctl[FC_PROF + 2], (unsigned long long)(c3 - c2)); atomicAdd(&a.ctl[FC_PROF + 3], (unsigned long long)(c4 - c3));
+				atomicAdd(&a.ctl[FC_PROF + 4], (unsigned long long)(c5 - c4)); atomicAdd(&a.ctl[FC_PROF + 5], 1ull);
+				atomicAdd(&a.ctl[FC_PROF + 6], (unsigned long long)n_runs); atomicAdd(&a.ctl[FC_PROF + 7], (unsigned long long)(rL + gL));
+			}
 		}
 		__syncthreads();
 	}
@@ -398,6 +439,7 @@ __global__ void frag_reset_kernel(FragArgs a)
 	if (i == 0) {
 		a.ctl[FC_TASKS] = (unsigned long long)a.n; a.ctl[FC_PIECES] = 0; a.ctl[FC_JOBS] = 0; a.ctl[FC_OPS] = 0;
 		a.ctl[FC_LEVEL0] = 0; a.ctl[FC_LEVEL0 + 1] = (unsigned long long)a.n;
+		for (int k = 0; k < 8; ++k) a.ctl[FC_PROF + k] = 0;
 		for (int l = 2; l <= kFragMaxDepth + 1; ++l) a.ctl[FC_LEVEL0 + l] = (unsigned long long)a.n;
 	}
 	for (int64_t r = i; r < a.n; r += (int64_t)gridDim.x * blockDim.x) {

@@ -10,7 +10,7 @@ constexpr int kFragMaxPairs = 2 * kFragMaxRuns + 2;   // ... and the normal pair
 constexpr int kFragMaxDepth = 6;         // levels of the -pacbio recursion (src/tools.cpp:197)
 
 enum { FP_JOB = 3, FP_TASK = 4 };        // FragPiece::kind beyond the literal runs KG_OP_DIAG / KG_OP_GAP1 / KG_OP_GAP2
-enum { FC_TASKS = 0, FC_PIECES = 1, FC_JOBS = 2, FC_OPS = 3, FC_LEVEL0 = 4, FC_WORDS = FC_LEVEL0 + kFragMaxDepth + 2 };
+enum { FC_TASKS = 0, FC_PIECES = 1, FC_JOBS = 2, FC_OPS = 3, FC_LEVEL0 = 4, FC_PROF = FC_LEVEL0 + kFragMaxDepth + 2, FC_WORDS = FC_PROF + 8 };   // FC_PROF: wave cycles per phase (KG_FRAG_PROF)
 
 struct FragTask {
 	int64_t f1_off;       // the read fragment in the characters the caller uploaded
@@ -35,6 +35,7 @@ struct FragArgs {
 	const uint8_t *text;            // 2-bit text of the index
 	int64_t two_genome_size;
 	int pacbio, max_gaps;
+	int prof;                       // KG_FRAG_PROF: wave cycles per phase of the partition kernel into ctl[FC_PROF ..]
 	// work lists
 	FragTask *tasks;
 	int64_t task_capacity;

@@ -63,6 +63,24 @@ private:
 	kg_stream_config cfg_;
 };
 
+// a page-locked array that keeps its capacity (the batched calls below stage their inputs and outputs here: copies to and from the
+// device then run at the link's rate instead of through the runtime's own staging)
+template <class T> struct PinnedBuf {
+	T *p = nullptr;
+	size_t cap = 0;
+	~PinnedBuf() { if (p) kg_host_free(p); }
+	T *get(size_t n)
+	{
+		if (n > cap) {
+			if (p) kg_host_free(p);
+			cap = n + n / 4 + 1024;
+			p = (T *)kg_host_alloc(cap * sizeof(T));
+			if (!p) { fprintf(stderr, "Error! out of page-locked memory\n"); exit(1); }
+		}
+		return p;
+	}
+};
+
 class HipBackend : public KernelBackend {
 public:
 	double t_seed = 0, t_cands = 0, t_copy = 0, t_align = 0, t_reccopy = 0;   // KART_AMD_VERBOSE: where the per-batch device stage spends its time
@@ -166,25 +184,26 @@ public:
 		int64_t n = 0, b1 = 0, cols = 0;
 		for (FragJobs *p : parts) { n += (int64_t)p->size(); b1 += (int64_t)p->f1.size(); cols += p->cols; }
 		if (n == 0) return true;
-		fr_f1_.resize((size_t)b1 + 1); fr_o1_.resize((size_t)n + 1); fr_g_.resize((size_t)n); fr_gl_.resize((size_t)n); fr_oo_.resize((size_t)n);
-		fr_ops_.resize((size_t)cols + 1); fr_len_.resize((size_t)n); fr_status_.resize((size_t)n);
+		char *f1 = fr_f1_.get((size_t)b1 + 64);
+		int64_t *o1 = fr_o1_.get((size_t)n + 1), *g = fr_g_.get((size_t)n), *oo = fr_oo_.get((size_t)n);
+		int32_t *gl = fr_gl_.get((size_t)n), *len = fr_len_.get((size_t)n);
+		uint8_t *ops = fr_ops_.get((size_t)cols + 64), *status = fr_status_.get((size_t)n);
 		int64_t at = 0, a1 = 0, ac = 0;
-		fr_o1_[0] = 0;
+		o1[0] = 0;
 		for (FragJobs *p : parts) {
-			memcpy(&fr_f1_[(size_t)a1], p->f1.data(), p->f1.size());
+			memcpy(f1 + a1, p->f1.data(), p->f1.size());
 			for (size_t j = 0; j < p->size(); ++j) {
-				fr_o1_[(size_t)at + j + 1] = a1 + p->o1[j + 1];
-				fr_g_[(size_t)at + j] = p->g[j]; fr_gl_[(size_t)at + j] = p->gl[j]; fr_oo_[(size_t)at + j] = ac + p->oo[j];
+				o1[(size_t)at + j + 1] = a1 + p->o1[j + 1];
+				g[(size_t)at + j] = p->g[j]; gl[(size_t)at + j] = p->gl[j]; oo[(size_t)at + j] = ac + p->oo[j];
 			}
 			at += (int64_t)p->size(); a1 += (int64_t)p->f1.size(); ac += p->cols;
 		}
-		if (kg_fragments_batch(ix_, fr_f1_.data(), fr_o1_.data(), fr_g_.data(), fr_gl_.data(), n, pacbio ? 1 : 0, max_gaps, fr_ops_.data(), fr_oo_.data(), fr_len_.data(), fr_status_.data()) != KG_OK)
-			die("kg_fragments_batch");
+		if (kg_fragments_batch(ix_, f1, o1, g, gl, n, pacbio ? 1 : 0, max_gaps, ops, oo, len, status) != KG_OK) die("kg_fragments_batch");
 		at = 0; ac = 0;
 		for (FragJobs *p : parts) {
-			p->ops.assign(fr_ops_.begin() + ac, fr_ops_.begin() + ac + p->cols);
-			p->len.assign(fr_len_.begin() + at, fr_len_.begin() + at + (int64_t)p->size());
-			p->status.assign(fr_status_.begin() + at, fr_status_.begin() + at + (int64_t)p->size());
+			p->ops.assign(ops + ac, ops + ac + p->cols);
+			p->len.assign(len + at, len + at + (int64_t)p->size());
+			p->status.assign(status + at, status + at + (int64_t)p->size());
 			at += (int64_t)p->size(); ac += p->cols;
 		}
 		return true;
@@ -237,10 +256,10 @@ private:
 	kg_index *ix_;
 	int threads_;
 	std::mutex nw_mu_, frag_mu_;
-	std::vector<char> fr_f1_;
-	std::vector<int64_t> fr_o1_, fr_g_, fr_oo_;
-	std::vector<int32_t> fr_gl_, fr_len_;
-	std::vector<uint8_t> fr_ops_, fr_status_;
+	PinnedBuf<char> fr_f1_;
+	PinnedBuf<int64_t> fr_o1_, fr_g_, fr_oo_;
+	PinnedBuf<int32_t> fr_gl_, fr_len_;
+	PinnedBuf<uint8_t> fr_ops_, fr_status_;
 	std::vector<char> f1_, f2_;
 	std::vector<int64_t> o1_, o2_;
 	std::vector<uint8_t> ops_;
