@@ -3,6 +3,7 @@
 #include "frag_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -20,6 +21,7 @@ struct FragScratch {
 	char *work = nullptr;          // [tasks | pieces | jobs | job_ops | job_len | ctl | status | ops | aln_len]
 	size_t work_bytes = 0;
 };
+double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 std::mutex g_frag_mu;
 std::vector<FragScratch *> g_frag_pool;
 }  // namespace
@@ -27,6 +29,7 @@ std::vector<FragScratch *> g_frag_pool;
 extern "C" int kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t *off1, const int64_t *gpos, const int32_t *glen, int64_t n, int pacbio,
                                   int max_gaps, uint8_t *ops, const int64_t *ops_off, int32_t *aln_len, uint8_t *status)
 {
+	const double t_in = wall();
 	if (!ix) return fail(KG_ERR_ARG, "kg_fragments_batch: null index");
 	if (n < 0 || n > 0x7ffffff0) return fail(KG_ERR_ARG, "kg_fragments_batch: bad request count");
 	if (n == 0) return KG_OK;
@@ -80,6 +83,11 @@ extern "C" int kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t
 		HIP_TRY(hipMalloc((void **)&sc->work, sc->work_bytes));
 	}
 	hipStream_t st = sc->stream;
+	static const bool prof = getenv("KG_FRAG_PROF") != nullptr;
+	hipEvent_t pe[6] = {};
+	auto mark = [&](int k) { if (prof) { (void)hipEventCreate(&pe[k]); (void)hipEventRecord(pe[k], st); } };
+	const double t_q = prof ? wall() : 0;
+	mark(0);
 	HIP_TRY(hipMemcpyAsync(sc->in + p_f1, frag1, (size_t)b1, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(sc->in + p_off, off1, 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(sc->in + p_g, gpos, 8 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -90,7 +98,6 @@ extern "C" int kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t
 	a.n = n;
 	a.text = ix->d_text; a.two_genome_size = 2 * ix->l_pac;
 	a.pacbio = pacbio ? 1 : 0; a.max_gaps = max_gaps;
-	static const bool prof = getenv("KG_FRAG_PROF") != nullptr;
 	a.prof = prof ? 1 : 0;
 	a.tasks = (FragTask *)(sc->work + w_tasks); a.task_capacity = task_cap;
 	a.pieces = (FragPiece *)(sc->work + w_pieces); a.piece_capacity = piece_cap;
@@ -99,7 +106,9 @@ extern "C" int kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t
 	a.ctl = (unsigned long long *)(sc->work + w_ctl);
 	a.status = (uint8_t *)(sc->work + w_status);
 	a.ops = (uint8_t *)(sc->work + w_ops); a.ops_off = (const int64_t *)(sc->in + p_oo); a.aln_len = (int32_t *)(sc->work + w_len);
+	mark(1);
 	HIP_TRY(launch_frag_partition(a, ix->n_cu, st));
+	mark(2);
 	{
 		// nw_alignment for the jobs the partition wrote: read side from the uploaded characters, genome side from the 2-bit text
 		NwArgs w;
@@ -110,14 +119,23 @@ extern "C" int kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t
 		int rc = kgi_nw_launch(ix, w, max_len, st);
 		if (rc != KG_OK) return rc;
 	}
+	mark(3);
 	HIP_TRY(launch_frag_stitch(a, ix->n_cu, st));
+	mark(4);
 	HIP_TRY(hipMemcpyAsync(ops, a.ops, (size_t)cols, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(aln_len, a.aln_len, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(status, a.status, (size_t)n, hipMemcpyDeviceToHost, st));
 	unsigned long long pc[FC_WORDS];
 	if (prof) HIP_TRY(hipMemcpyAsync(pc, a.ctl, 8 * FC_WORDS, hipMemcpyDeviceToHost, st));
+	mark(5);
 	HIP_TRY(hipEventRecord(sc->done, st));
 	HIP_TRY(hipEventSynchronize(sc->done));
+	if (prof) {
+		float ms[5] = {};
+		for (int k = 0; k < 5; ++k) (void)hipEventElapsedTime(&ms[k], pe[k], pe[k + 1]);
+		for (int k = 0; k < 6; ++k) (void)hipEventDestroy(pe[k]);
+		fprintf(stderr, "kg_fragments_batch: the whole call %.2f ms, of it before the first copy %.2f ms | H2D %.2f ms (%.1f MB), partition %.2f ms, nw %.2f ms, stitch %.2f ms, D2H %.2f ms (%.1f MB)\n", 1e3 * (wall() - t_in), 1e3 * (t_q - t_in), ms[0], 1e-6 * (double)(b1 + 28 * n), ms[1], ms[2], ms[3], ms[4], 1e-6 * (double)(cols + 5 * n));
+	}
 	if (prof)
 		fprintf(stderr, "kg_fragments_batch: %lld requests, %llu tasks, %llu pieces, %llu NW jobs | wave cycles per task: load+pack %.0f, diagonal scan %.0f, sort %.0f, normal pairs %.0f, pieces %.0f | runs per task %.1f, columns per task %.0f\n",
 		        (long long)n, pc[FC_PROF + 5], pc[FC_PIECES], pc[FC_JOBS], (double)pc[FC_PROF] / std::max(1ull, pc[FC_PROF + 5]), (double)pc[FC_PROF + 1] / std::max(1ull, pc[FC_PROF + 5]),

@@ -83,6 +83,7 @@ template <class T> struct PinnedBuf {
 
 class HipBackend : public KernelBackend {
 public:
+	double t_frag_in = 0, t_frag_call = 0; int64_t n_frag_calls = 0;
 	double t_seed = 0, t_cands = 0, t_copy = 0, t_align = 0, t_reccopy = 0;   // KART_AMD_VERBOSE: where the per-batch device stage spends its time
 	HipBackend(kg_index *ix, const Options &opt) : ix_(ix), threads_(std::max(1, std::min(opt.threads, 16)))
 	{
@@ -169,6 +170,10 @@ public:
 		char tb[256];
 		snprintf(tb, sizeof(tb), "device stage seconds: seed (H2D + kernels) %.3f | chain + D2H %.3f | candidate copies %.3f | align (kernels + D2H) %.3f | record copy %.3f || ", t_seed, t_cands, t_copy, t_align, t_reccopy);
 		std::string s(tb);
+		if (n_frag_calls) {
+			snprintf(tb, sizeof(tb), "fragment service: %lld calls, copying the parts together %.3f s, kg_fragments_batch %.3f s || ", (long long)n_frag_calls, t_frag_in, t_frag_call);
+			s += tb;
+		}
 		for (int i = 0; i < 13; ++i)
 			if (w[i]) s += std::string(name[i]) + " " + std::to_string((unsigned long long)w[i]) + ", ";
 		s += "| before the last batch: parked candidates " + std::to_string((unsigned long long)w[13]) + ", NW jobs " + std::to_string((unsigned long long)w[14]) +
@@ -184,27 +189,45 @@ public:
 		int64_t n = 0, b1 = 0, cols = 0;
 		for (FragJobs *p : parts) { n += (int64_t)p->size(); b1 += (int64_t)p->f1.size(); cols += p->cols; }
 		if (n == 0) return true;
+		const double t0 = now_sec();
 		char *f1 = fr_f1_.get((size_t)b1 + 64);
 		int64_t *o1 = fr_o1_.get((size_t)n + 1), *g = fr_g_.get((size_t)n), *oo = fr_oo_.get((size_t)n);
-		int32_t *gl = fr_gl_.get((size_t)n), *len = fr_len_.get((size_t)n);
-		uint8_t *ops = fr_ops_.get((size_t)cols + 64), *status = fr_status_.get((size_t)n);
-		int64_t at = 0, a1 = 0, ac = 0;
-		o1[0] = 0;
-		for (FragJobs *p : parts) {
-			memcpy(f1 + a1, p->f1.data(), p->f1.size());
-			for (size_t j = 0; j < p->size(); ++j) {
-				o1[(size_t)at + j + 1] = a1 + p->o1[j + 1];
-				g[(size_t)at + j] = p->g[j]; gl[(size_t)at + j] = p->gl[j]; oo[(size_t)at + j] = ac + p->oo[j];
-			}
-			at += (int64_t)p->size(); a1 += (int64_t)p->f1.size(); ac += p->cols;
+		// two sets of result arrays in alternation: the results of a call stay valid during the next one (pipeline.inc reads batch k-1
+		// while the call of batch k runs)
+		const int set = (int)(n_frag_calls & 1);
+		int32_t *gl = fr_gl_.get((size_t)n), *len = fr_len_[set].get((size_t)n);
+		uint8_t *ops = fr_ops_[set].get((size_t)cols + 64), *status = fr_status_[set].get((size_t)n);
+		// where every part starts in the combined arrays, then the parts are copied side by side (1.3 GB of characters per 200 k long reads)
+		std::vector<int64_t> p_at(parts.size() + 1, 0), p_a1(parts.size() + 1, 0), p_ac(parts.size() + 1, 0);
+		for (size_t k = 0; k < parts.size(); ++k) {
+			p_at[k + 1] = p_at[k] + (int64_t)parts[k]->size(); p_a1[k + 1] = p_a1[k] + (int64_t)parts[k]->f1.size(); p_ac[k + 1] = p_ac[k] + parts[k]->cols;
 		}
+		o1[0] = 0;
+		auto copy_parts = [&](size_t k0, size_t k1) {
+			for (size_t k = k0; k < k1; ++k) {
+				const FragJobs *p = parts[k];
+				const int64_t at = p_at[k], a1 = p_a1[k], ac = p_ac[k];
+				memcpy(f1 + a1, p->f1.data(), p->f1.size());
+				for (size_t j = 0; j < p->size(); ++j) {
+					o1[(size_t)at + j + 1] = a1 + p->o1[j + 1];
+					g[(size_t)at + j] = p->g[j]; gl[(size_t)at + j] = p->gl[j]; oo[(size_t)at + j] = ac + p->oo[j];
+				}
+			}
+		};
+		{
+			const size_t nt = std::min<size_t>((size_t)std::max(1, threads_ / 2), std::max<size_t>(1, parts.size() / 8));
+			std::vector<std::thread> th;
+			for (size_t t = 1; t < nt; ++t) th.emplace_back(copy_parts, parts.size() * t / nt, parts.size() * (t + 1) / nt);
+			copy_parts(0, parts.size() / nt);
+			for (std::thread &x : th) x.join();
+		}
+		const double t1 = now_sec();
 		if (kg_fragments_batch(ix_, f1, o1, g, gl, n, pacbio ? 1 : 0, max_gaps, ops, oo, len, status) != KG_OK) die("kg_fragments_batch");
-		at = 0; ac = 0;
-		for (FragJobs *p : parts) {
-			p->ops.assign(ops + ac, ops + ac + p->cols);
-			p->len.assign(len + at, len + at + (int64_t)p->size());
-			p->status.assign(status + at, status + at + (int64_t)p->size());
-			at += (int64_t)p->size(); ac += p->cols;
+		t_frag_in += t1 - t0; t_frag_call += now_sec() - t1; n_frag_calls++;
+		// the results stay where the device wrote them: every part gets its window (valid until the call after the next)
+		for (size_t k = 0; k < parts.size(); ++k) {
+			FragJobs *p = parts[k];
+			p->ops = ops + p_ac[k]; p->len = len + p_at[k]; p->status = status + p_at[k];
 		}
 		return true;
 	}
@@ -258,8 +281,8 @@ private:
 	std::mutex nw_mu_, frag_mu_;
 	PinnedBuf<char> fr_f1_;
 	PinnedBuf<int64_t> fr_o1_, fr_g_, fr_oo_;
-	PinnedBuf<int32_t> fr_gl_, fr_len_;
-	PinnedBuf<uint8_t> fr_ops_, fr_status_;
+	PinnedBuf<int32_t> fr_gl_, fr_len_[2];
+	PinnedBuf<uint8_t> fr_ops_[2], fr_status_[2];
 	std::vector<char> f1_, f2_;
 	std::vector<int64_t> o1_, o2_;
 	std::vector<uint8_t> ops_;

@@ -95,8 +95,10 @@ struct FragJobs {
 	std::vector<int64_t> o1{0}, g, oo;
 	std::vector<int32_t> gl;
 	std::vector<void *> owner;          // whoever waits for job j (the host's PairWork)
-	std::vector<uint8_t> ops, status;
-	std::vector<int32_t> len;
+	// results: they stay in the backend's page-locked arrays (two sets in alternation: valid until the call after the next -- the stage that
+	// reads them runs during the next call at the latest, pipeline.inc); ops of job j at ops[oo[j] ...]
+	const uint8_t *ops = nullptr, *status = nullptr;
+	const int32_t *len = nullptr;
 	int64_t cols = 0;
 	int add(const char *a, int m, int64_t gpos, int n, void *who)
 	{
@@ -107,7 +109,7 @@ struct FragJobs {
 		return (int)g.size() - 1;
 	}
 	size_t size() const { return g.size(); }
-	void clear() { f1.clear(); o1.assign(1, 0); g.clear(); oo.clear(); gl.clear(); owner.clear(); ops.clear(); status.clear(); len.clear(); cols = 0; }
+	void clear() { f1.clear(); o1.assign(1, 0); g.clear(); oo.clear(); gl.clear(); owner.clear(); ops = status = nullptr; len = nullptr; cols = 0; }
 };
 
 struct KernelBackend {

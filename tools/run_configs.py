@@ -20,6 +20,8 @@ prefix = os.path.join(wd, "synth_v2_%d" % L)
 subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "1000000", "--leg", "seeding", "--seed-steps", "1"], stdout=subprocess.DEVNULL)   # builds + caches the index
 codes = bench.make_large_codes(L, 3, dev)
 exe, ref = os.path.join(ROOT, "kart_amd", "bin", "kart-amd"), os.path.join(ROOT, "oracle", "_ref", "kart")
+if os.environ.get("RUN_CONFIGS_NO_REF"):
+    ref = "/nonexistent"          # A/B runs of kart-amd alone
 cores = bench.effective_cores()
 UNSET = 1 << 20
 res = {"genome_len": L, "host_cpu_quota": cores}
@@ -46,7 +48,8 @@ def write_long_reads(path, n, read_len, err, seed):
 
 def run(cmd, env=None):
     t = time.perf_counter()
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=dict(os.environ, KART_AMD_VERBOSE="1", **(env or {})))
+    err = open(os.environ["RUN_CONFIGS_STDERR"], "ab") if os.environ.get("RUN_CONFIGS_STDERR") else subprocess.DEVNULL
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=err, env=dict(os.environ, KART_AMD_VERBOSE="1", **(env or {})))
     dt = time.perf_counter() - t
     out = {"rc": r.returncode, "process_seconds": round(dt, 2)}
     for line in r.stdout.decode().splitlines():
@@ -100,6 +103,9 @@ def config3():
         c3["prefix_identity_vs_reference_t1"] = {"reads": k, "identical": open(os.path.join(wd, "cfg3_p_amd.sam"), "rb").read() == open(os.path.join(wd, "cfg3_p_ref.sam"), "rb").read(),
                                                  "reference_t1_process_seconds": r1["process_seconds"]}
     res["configs[3] -pacbio"] = c3
+    if os.environ.get("RUN_CONFIGS_KEEP_INPUTS"):          # (profiling: the same command again under rocprofv3)
+        c3["command"] = [exe, "-silent", "-i", prefix, "-f", fq, "-pacbio", "-t", str(cores), "-o", os.path.join(wd, "cfg3_amd.sam")]
+        return
     for f in ("cfg3_long.fq", "cfg3_amd.sam", "cfg3_ref.sam", "cfg3_prefix.fq", "cfg3_p_amd.sam", "cfg3_p_ref.sam"):
         try: os.remove(os.path.join(wd, f))
         except OSError: pass
