@@ -580,6 +580,11 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.occ_thr = occ_thr;
 	a.packed = ws->d_packed;
 	a.single_steps = ws->single_steps ? 1 : 0;
+	{
+		// SensitiveMode: short searches (a 30-base window each) in a dependent chain per read -- lanes wait for each other at the refill
+		static const int sens_refill = getenv("KG_SENSITIVE_REFILL") ? atoi(getenv("KG_SENSITIVE_REFILL")) : 0;
+		a.refill = a.mode == KG_MODE_FAST ? 0 : sens_refill;
+	}
 	a.read_order = nullptr; a.sort_keys = ws->d_sort_keys; a.sort_temp = ws->d_sort_temp; a.sort_temp_bytes = ws->sort_bytes;
 	a.hits = ws->d_hits;
 	a.max_hits = ws->max_hits;

@@ -38,6 +38,7 @@ struct SeedArgs {
 	uint64_t *packed;    // 4-bit read codes, 16 per word, read r at word (read_off[r] >> 4) + 3 r
 	// EXPERIMENT (KG_SORT_READS): the order in which the search kernel's lanes draw the reads -- sorted by the first 16 bases, so
 	// that lanes of a wave start in neighbouring q-mer table entries / rank lines; null = input order
+	int refill;               // parked lanes that send a wave to the slow path (0: the kernel's default)
 	int single_steps;         // 1: never take two steps at once (the reference's per-step block accounting, counters lf1 / lf2, is then exact)
 	int32_t *read_order;
 	uint32_t *sort_keys;      // [4 * max_reads]: keys in, keys out, ids in, ids out

@@ -6,7 +6,7 @@ CMD=$(python3 -c "import json; print(' '.join(json.load(open('gpurun_out/pb_keep
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_pb
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-KART_AMD_VERBOSE=1 rocprofv3 --kernel-trace --stats -d $OUT -o pb -- $CMD > $OUT/run.log 2>&1
+KART_AMD_VERBOSE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o pb -- $CMD > $OUT/run.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
 import csv, glob
