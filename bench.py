@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--parts", action="store_true", help="N > 1: one output file per rank (kart-amd -parts; their concatenation is the single-process SAM) instead of one shared file")
     ap.add_argument("--leg", choices=["all", "seeding"], default="all", help="seeding: only the GPU seeding step on resident reads (what the rocprofv3 passes profile)")
     ap.add_argument("--seed-steps", type=int, default=5, help="timed launches of the seeding-stage leg")
-    ap.add_argument("--sa", choices=["sampled", "full"], default="full", help="suffix array placement of the seeding-stage leg")
+    ap.add_argument("--sa", choices=["sampled", "full", "compact", "dense4", "dense8"], default="full", help="suffix array placement (seeding-stage leg and, via KART_AMD_SA, the mapping runs): dense4 / dense8 = the smaller index")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the reference -t 1 identity leg and the oracle sample")
     ap.add_argument("--no-seeding-leg", action="store_true")
@@ -371,6 +371,8 @@ def run(args, fallback_note):
     cores = effective_cores()
     threads = args.threads or max(2, cores // world)
     t0 = time.time()
+    if args.sa != "full":
+        os.environ["KART_AMD_SA"] = args.sa          # (read by the host library when it loads the index)
     sess = api.HostSession(prefix, local, threads)
     t_load = time.time() - t0
     out_sam = os.path.join(workdir, "bench_out.sam")
@@ -594,7 +596,7 @@ def seeding_leg(args, api, prefix, codes, dev, n_reads_leg, oracle_sample):
     n_reads = n_reads_leg & ~1
     n_bases = n_reads * READ_LEN
     large = args.genome_len >= 300_000_000
-    ix = api.Index(prefix, dev.index or 0, api.KG_SA_FULL if args.sa == "full" else api.KG_SA_SAMPLED)
+    ix = api.Index(prefix, dev.index or 0, {"full": api.KG_SA_FULL, "sampled": api.KG_SA_SAMPLED, "compact": api.KG_SA_FULL40, "dense4": api.KG_SA_DENSE4, "dense8": api.KG_SA_DENSE8}[args.sa])
     batches = [gen_reads_device(codes, n_reads // 2, seed=1000 + b, err=0.011, dev=dev) for b in range(2)]
     seed_cap = (12 if large else 6) * n_reads + 1024
     d_seed_off = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)

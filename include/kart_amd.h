@@ -55,6 +55,13 @@ extern "C" {
  * src/bwt_search.cpp:128-138) or the full suffix array expanded once at load into HBM. */
 #define KG_SA_SAMPLED        0
 #define KG_SA_FULL           1
+/* the smaller index: every 4th / 8th entry of the suffix array resident (built at load from the full expansion, which is then
+ * freed), no triple planes; single-suffix searches still finish against the text after a walk of at most 3 / 7 rank steps */
+#define KG_SA_DENSE4         4
+#define KG_SA_DENSE8         8
+/* the compact index: the whole suffix array in 5-byte entries (4-byte ones where the text allows), a q-mer table of a quarter the
+ * size, no triple planes -- ~66 GB instead of ~168 GB for a human genome, no walks */
+#define KG_SA_FULL40         5
 
 typedef struct kg_index kg_index;
 typedef struct kg_workspace kg_workspace;
@@ -73,7 +80,7 @@ typedef struct {
 	uint64_t primary;
 	int32_t  n_contigs;
 	int32_t  min_seed_len;   /* 13..16, src/Mapping.cpp:645 */
-	int32_t  sa_mode;        /* KG_SA_SAMPLED / KG_SA_FULL */
+	int32_t  sa_mode;        /* KG_SA_SAMPLED / KG_SA_FULL / KG_SA_FULL40 / KG_SA_DENSE4 / KG_SA_DENSE8 */
 	int32_t  device;
 	uint64_t device_bytes;   /* HBM held by the index */
 } kg_index_info_t;

@@ -254,6 +254,10 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	}
 	v.fsa32 = nullptr;
 	v.fsa64 = nullptr;
+	v.fsa40 = nullptr;
+	v.dsa32 = nullptr;
+	v.dsa64 = nullptr;
+	v.dsa_shift = 0;
 	v.text = nullptr;
 	{
 		// the indexed text itself, 2 bits per base, forward + reverse complement: the alignment stage compares reads with it;
@@ -268,17 +272,23 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	v.qtab64 = nullptr;
 	v.qmer = 0;
 
-	if (sa_mode == KG_SA_FULL) {
+	const bool dense = sa_mode == KG_SA_DENSE4 || sa_mode == KG_SA_DENSE8;
+	const bool compact = sa_mode == KG_SA_FULL40;          // 5-byte entries, a smaller q-mer table, no triple planes
+	if (sa_mode == KG_SA_FULL || dense || compact) {
 		bool narrow = v.seq_len < 0xFFFFFFFFull && !getenv("KG_FORCE_U64");
-		size_t fsa_bytes = (size_t)(v.seq_len + 1) * (narrow ? 4 : 8);
+		const bool packed = compact && !narrow;
+		if (packed && v.seq_len >= (1ull << 40)) return fail(KG_ERR_ARG, "kg_index_load: KG_SA_FULL40 holds texts below 2^40 bases");
+		size_t fsa_bytes = packed ? (size_t)(v.seq_len + 1) * 5 + 8 : (size_t)(v.seq_len + 1) * (narrow ? 4 : 8);
 		HIP_TRY(hipMalloc(&ix->d_fsa, fsa_bytes));
 		uint32_t *f32 = narrow ? (uint32_t *)ix->d_fsa : nullptr;
-		uint64_t *f64 = narrow ? nullptr : (uint64_t *)ix->d_fsa;
-		HIP_TRY(launch_expand_sa(v, ix->n_sa, f32, f64, nullptr));
+		uint64_t *f64 = narrow || packed ? nullptr : (uint64_t *)ix->d_fsa;
+		uint8_t *f40 = packed ? (uint8_t *)ix->d_fsa : nullptr;
+		HIP_TRY(launch_expand_sa(v, ix->n_sa, f32, f64, f40, nullptr));
 		HIP_TRY(hipDeviceSynchronize());
 		v.fsa32 = f32;
 		v.fsa64 = f64;
-		ix->device_bytes += fsa_bytes;
+		v.fsa40 = f40;
+		if (!dense) ix->device_bytes += fsa_bytes;
 		if (!getenv("KG_NO_DIRECT")) v.text = ix->d_text;   // finishing single-suffix searches by comparison against the text
 	} else if (sa_mode != KG_SA_SAMPLED) {
 		return fail(KG_ERR_ARG, "kg_index_load: unknown sa_mode %d", sa_mode);
@@ -289,6 +299,7 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		bool narrow = v.seq_len < 0xFFFFFF00ull && !getenv("KG_FORCE_U64");
 		int q = kQmerMin;
 		while (q < kQmerMax && ((uint64_t)1 << (2 * q + 1)) <= v.seq_len) q++;      // round(log4(2L))
+		if (compact && q > kQmerMin) q--;                                           // a quarter of the table: one more rank step per search
 		if (const char *env = getenv("KG_QMER")) { int t = atoi(env); if (t >= kQmerMin && t <= kQmerMax) q = t; }   // tuning knob
 		size_t tab_bytes = ((size_t)1 << (2 * q)) * 8;
 		// the table is an accelerator, not a requirement: when the device cannot hold 4^q entries (34 GB at q = 16) take a smaller q
@@ -305,9 +316,26 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		if (narrow) v.qtab32 = (const uint2 *)ix->d_qtab; else v.qtab64 = (const uint64_t *)ix->d_qtab;
 		ix->device_bytes += tab_bytes;
 	}
+	if (dense) {
+		// the smaller index: keep every 4th / 8th entry of the expansion (the q-mer table above has taken the single suffixes it
+		// needs from the full array), free the rest
+		const int shift = sa_mode == KG_SA_DENSE4 ? 2 : 3;
+		const bool narrow = v.fsa32 != nullptr;
+		const uint64_t n_out = (v.seq_len >> shift) + 1;
+		const size_t bytes = (size_t)n_out * (narrow ? 4 : 8);
+		HIP_TRY(hipMalloc(&ix->d_dsa, bytes));
+		HIP_TRY(launch_sample_sa(v.fsa32, v.fsa64, n_out, shift, narrow ? (uint32_t *)ix->d_dsa : nullptr, narrow ? nullptr : (uint64_t *)ix->d_dsa, nullptr));
+		HIP_TRY(hipDeviceSynchronize());
+		HIP_TRY(hipFree(ix->d_fsa));
+		ix->d_fsa = nullptr;
+		v.fsa32 = nullptr; v.fsa64 = nullptr;
+		if (narrow) v.dsa32 = (const uint32_t *)ix->d_dsa; else v.dsa64 = (const uint64_t *)ix->d_dsa;
+		v.dsa_shift = shift;
+		ix->device_bytes += bytes;
+	}
 	// three-step rank structure (9.14 bytes/symbol: 56.7 GB for hg38), last and only where the device keeps room for the
 	// workspaces after it (a 288 GB device does, with the 111 GB of everything else): searches then take three bases per rank pair
-	if (v.planes2 && !getenv("KG_NO_PLANES3")) {
+	if (v.planes2 && !dense && !compact && !getenv("KG_NO_PLANES3")) {
 		uint64_t n_lines = (v.seq_len + kPlane2Rows - 1) / kPlane2Rows;
 		size_t bytes = (size_t)n_lines * 64 * 128, free_b = 0, total_b = 0;
 		const size_t reserve = (size_t)48 << 30;
@@ -340,6 +368,7 @@ void kg_index_destroy(kg_index *ix)
 	}
 	if (ix->d_sa) (void)hipFree(ix->d_sa);
 	if (ix->d_fsa) (void)hipFree(ix->d_fsa);
+	if (ix->d_dsa) (void)hipFree(ix->d_dsa);
 	if (ix->d_text) (void)hipFree(ix->d_text);
 	if (ix->d_pac) (void)hipFree(ix->d_pac);
 	if (ix->d_contig_end) (void)hipFree(ix->d_contig_end);
@@ -484,7 +513,7 @@ int kg_workspace_traffic(kg_workspace *ws, kg_traffic_t *out)
 	out->table_lookups = ctl[17]; out->rank_steps = ctl[18]; out->rank_steps_two_lines = ctl[19];
 	out->text_rounds = ctl[20]; out->window_words = ctl[21]; out->rank_steps_two_lines_narrow = ctl[22];
 	out->sa_gathers = ctl[8]; out->hits = ctl[1]; out->searches = ctl[4];
-	out->sa_entry_bytes = (ws->ix->view.fsa32 ? 4 : 8);
+	out->sa_entry_bytes = (ws->ix->view.fsa32 ? 4 : ws->ix->view.fsa40 ? 5 : 8);
 	out->double_steps = ctl[23]; out->double_steps_two_lines = ctl[24]; out->double_step_bytes = ctl[25]; out->triple_steps = ctl[26];
 	return KG_OK;
 }
@@ -580,11 +609,6 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.occ_thr = occ_thr;
 	a.packed = ws->d_packed;
 	a.single_steps = ws->single_steps ? 1 : 0;
-	{
-		// SensitiveMode: short searches (a 30-base window each) in a dependent chain per read -- lanes wait for each other at the refill
-		static const int sens_refill = getenv("KG_SENSITIVE_REFILL") ? atoi(getenv("KG_SENSITIVE_REFILL")) : 0;
-		a.refill = a.mode == KG_MODE_FAST ? 0 : sens_refill;
-	}
 	a.read_order = nullptr; a.sort_keys = ws->d_sort_keys; a.sort_temp = ws->d_sort_temp; a.sort_temp_bytes = ws->sort_bytes;
 	a.hits = ws->d_hits;
 	a.max_hits = ws->max_hits;

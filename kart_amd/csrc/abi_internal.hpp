@@ -62,6 +62,7 @@ struct kg_index {
 	void *d_qtab = nullptr;
 	uint64_t *d_sa = nullptr;
 	void *d_fsa = nullptr;
+	void *d_dsa = nullptr;          // KG_SA_DENSE4 / 8: every 4th / 8th entry of the expansion
 	uint8_t *d_text = nullptr;
 	uint8_t *d_pac = nullptr;
 	int64_t *d_contig_end = nullptr;   // ChrLocMap keys, ascending

@@ -39,6 +39,11 @@ struct FmView {
 	const uint64_t *sa;
 	const uint32_t *fsa32;
 	const uint64_t *fsa64;
+	const uint8_t *fsa40;  // KG_SA_FULL40: the expanded suffix array in 5-byte little-endian entries (entry k at byte 5 k)
+	// KG_SA_DENSE4 / 8: entry i = SA[i << dsa_shift] (null otherwise); SA[k] = dsa[k' >> shift] + steps after `steps` LF steps k -> k'
+	const uint32_t *dsa32;
+	const uint64_t *dsa64;
+	int dsa_shift;
 	// q-mer interval table (device-private, built at load): for the first `qmer` bases of a search, the
 	// interval after qmer-1 extension steps.  q grows with the text (4^q ~ 2L: 12 for E. coli, 16 for hg38)
 	// so that the jump lands on intervals of a few suffixes.  Entry = { k, n | sa << 27 | lf2 << 28 } (u32
@@ -59,6 +64,19 @@ struct FmView {
 	uint64_t t2[16];
 	uint64_t t3[64];       // three steps: k3 = t3[c1 * 16 + c2 * 4 + c3] + rank3(k - 1), t3 = L2[c3] + 1 + occ(t2[c1 c2] - 1, c3)
 };
+
+struct __attribute__((packed, aligned(1))) FsaU64u { uint64_t v; };
+
+// the expanded suffix array, whichever entry width is resident
+__device__ __forceinline__ bool fsa_resident(const FmView &ix) { return ix.fsa32 != nullptr || ix.fsa64 != nullptr || ix.fsa40 != nullptr; }
+__device__ __forceinline__ uint64_t fsa_entry40(const uint8_t *fsa40, uint64_t k)
+{
+	return reinterpret_cast<const FsaU64u *>(fsa40 + 5 * k)->v & 0xFFFFFFFFFFull;       // (the array ends with 8 spare bytes)
+}
+__device__ __forceinline__ uint64_t fsa_entry(const FmView &ix, uint64_t k)
+{
+	return ix.fsa32 ? (uint64_t)ix.fsa32[k] : ix.fsa40 ? fsa_entry40(ix.fsa40, k) : ix.fsa64[k];
+}
 
 constexpr uint32_t kPlane2Rows = 896;   // rows per 128-byte line of planes2 (7 segments of 128)
 

@@ -38,7 +38,6 @@ struct SeedArgs {
 	uint64_t *packed;    // 4-bit read codes, 16 per word, read r at word (read_off[r] >> 4) + 3 r
 	// EXPERIMENT (KG_SORT_READS): the order in which the search kernel's lanes draw the reads -- sorted by the first 16 bases, so
 	// that lanes of a wave start in neighbouring q-mer table entries / rank lines; null = input order
-	int refill;               // parked lanes that send a wave to the slow path (0: the kernel's default)
 	int single_steps;         // 1: never take two steps at once (the reference's per-step block accounting, counters lf1 / lf2, is then exact)
 	int32_t *read_order;
 	uint32_t *sort_keys;      // [4 * max_reads]: keys in, keys out, ids in, ids out
@@ -64,7 +63,8 @@ hipError_t launch_planes2_check(const FmView &ix, uint64_t samples, uint64_t see
 hipError_t launch_build_text(const uint8_t *pac, uint64_t l_pac, uint8_t *text, uint64_t n_bytes, hipStream_t stream);
 hipError_t launch_build_qtab(const FmView &ix, int q, uint2 *t32, uint64_t *t64, hipStream_t stream);
 hipError_t launch_rank_sa(const FmView &ix, const uint64_t *ks, int64_t n, uint64_t *occ4, uint64_t *sa_walk, uint64_t *sa_full, hipStream_t stream);
-hipError_t launch_expand_sa(const FmView &ix, uint64_t n_sa, uint32_t *fsa32, uint64_t *fsa64, hipStream_t stream);
+hipError_t launch_expand_sa(const FmView &ix, uint64_t n_sa, uint32_t *fsa32, uint64_t *fsa64, uint8_t *fsa40, hipStream_t stream);
+hipError_t launch_sample_sa(const uint32_t *fsa32, const uint64_t *fsa64, uint64_t n_out, int shift, uint32_t *d32, uint64_t *d64, hipStream_t stream);
 
 struct ChainArgs {
 	const int64_t *read_off;     // for rlen

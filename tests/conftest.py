@@ -66,5 +66,33 @@ def gpu_index_full(built_lib):
     ix.close()
 
 
+def _dense_index(built_lib, mode_name):
+    from kart_amd import api
+    if api.device_count() <= 0:
+        pytest.fail("no HIP device visible: -m gpu tests must run on the GPU box (there is no CPU fallback)")
+    return api.Index(SMALL_PREFIX, 0, getattr(api, mode_name))
+
+
+@pytest.fixture(scope="session")
+def gpu_index_dense4(built_lib):
+    ix = _dense_index(built_lib, "KG_SA_DENSE4")       # the smaller index: every 4th suffix-array entry resident
+    yield ix
+    ix.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_index_compact(built_lib):
+    ix = _dense_index(built_lib, "KG_SA_FULL40")       # the compact index: whole suffix array, a quarter of the q-mer table, no triple planes
+    yield ix
+    ix.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_index_dense8(built_lib):
+    ix = _dense_index(built_lib, "KG_SA_DENSE8")
+    yield ix
+    ix.close()
+
+
 def split(arr, off):
     return [arr[off[i]:off[i + 1]] for i in range(len(off) - 1)]

@@ -204,6 +204,22 @@ def test_device_report_equals_the_host_report_record_by_record(case, product_bin
     assert "device report: 0 reads decided on the device" in log
 
 
+@pytest.mark.parametrize("sa", ["compact", "dense4", "dense8", "sampled"])
+@pytest.mark.parametrize("case", ["pe", "edge_pe", "se_m", "pacbio"])
+def test_smaller_index_modes_give_the_same_sam(case, sa, product_binary, tmp_path):
+    """KART_AMD_SA: the compact index (under KG_FORCE_U64 its 5-byte entries), every 4th / 8th suffix-array entry resident (searches walk to a sampled row, then finish against the text), or only
+    the file's samples (no text finishing): the golden SAM byte for byte, and the load reports the mode"""
+    from test_host_pipeline import materialise
+    args = [materialise(str(tmp_path), a) if a.endswith((".fq", ".fa", ".gz")) else a for a in CASES[case]]
+    out = str(tmp_path / "o.sam")
+    want = gzip.open(os.path.join(GOLDEN, "sam", case + ".sam.gz")).read()
+    for env in ({}, {"KG_FORCE_U64": "1"}):
+        _run_verbose(product_binary, args, out, dict(env, KART_AMD_SA=sa))
+        assert open(out, "rb").read() == want, env
+    r = subprocess.run([product_binary, "-silent", "-i", SMALL_PREFIX] + args + ["-o", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KART_AMD_SA="half"))
+    assert r.returncode != 0 and b"KART_AMD_SA" in r.stdout + r.stderr
+
+
 def test_device_report_on_30k_live_pairs_with_rescue_and_indels(product_binary, tmp_path):
     """30 k pairs at 2 % error with indels and short inserts (rescue windows, gap fragments of every size, estimate below
     MaxInsertSize): most reads are decided on the device, every device record equals the host's text, and the SAM equals the

@@ -18,13 +18,13 @@ def _check_reads(ix, reads, want, mode):
         assert (g == w.astype(api.SEED_DT)).all(), i
 
 
-@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full"])
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_dense4", "gpu_index_dense8"])
 def test_fast_mode_golden(golden, which, request):
     ix = request.getfixturevalue(which)
     _check_reads(ix, split(golden["fast_enc"], golden["fast_off"]), split(golden["fast_seeds"], golden["fast_seed_off"]), 0)
 
 
-@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full"])
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_dense4", "gpu_index_dense8"])
 def test_sensitive_mode_golden(golden, which, request):
     ix = request.getfixturevalue(which)
     _check_reads(ix, split(golden["sens_enc"], golden["sens_off"]), split(golden["sens_seeds"], golden["sens_seed_off"]), 1)
@@ -99,7 +99,7 @@ def test_empty_and_tiny_batches(gpu_index):
     assert [len(o) for o in out] == [0, 0, 0]
 
 
-@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full"])
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_dense4", "gpu_index_dense8"])
 def test_random_pairs_vs_oracle(which, request, oracle_small):
     """20k reads of 150 bp with 2 % errors + N's, ragged lengths mixed in; both modes"""
     ix = request.getfixturevalue(which)
@@ -157,7 +157,7 @@ def test_wide_index_instantiation(golden, built_lib, gpu_index_full, tmp_path, r
         from kart_amd import api
         g = np.load(%r, allow_pickle=True)
         e = np.load(%r)
-        for sa_mode in (api.KG_SA_SAMPLED, api.KG_SA_FULL):
+        for sa_mode in (api.KG_SA_SAMPLED, api.KG_SA_FULL, api.KG_SA_FULL40, api.KG_SA_DENSE4, api.KG_SA_DENSE8):
             ix = api.Index(%r, 0, sa_mode)
             for mode, key in ((0, "fast"), (1, "sens")):
                 ws = ix.workspace(len(g[key + "_off"]) - 1, len(g[key + "_enc"]))
@@ -236,7 +236,7 @@ def test_candidates_need_the_seeded_batch(golden, gpu_index):
     ws.close()
 
 
-def test_long_reads_cover_every_sort_class(gpu_index_full, gpu_index, oracle_small, request):
+def test_long_reads_cover_every_sort_class(gpu_index_full, gpu_index, gpu_index_dense4, oracle_small, request):
     """reads of 200 bp .. 60 kb in SensitiveMode give seed lists of a handful up to several thousand per read: the register
     network, the wave bitonic, both LDS classes and the in-place Shell pass of the sort, and multi-round expansion in locate"""
     g = {}
@@ -261,14 +261,14 @@ def test_long_reads_cover_every_sort_class(gpu_index_full, gpu_index, oracle_sma
     so_o, s_o = oracle_small.seed_batch(enc, off, 1, threads=4)
     sizes = np.diff(so_o)
     assert sizes.max() > 2048 and ((sizes > 256) & (sizes <= 2048)).any() and ((sizes > 64) & (sizes <= 256)).any() and (sizes <= 64).any()
-    for ix in (gpu_index_full, gpu_index):
+    for ix in (gpu_index_full, gpu_index, gpu_index_dense4):
         ws = ix.workspace(len(reads), len(enc))
         so_g, s_g = ws.seed_batch(enc, off, 1)
         assert (so_g == so_o).all()
         assert (s_g == s_o.astype(api.SEED_DT)).all()
 
 
-def test_reads_at_the_ends_of_the_text(gpu_index_full, gpu_index, oracle_small, request):
+def test_reads_at_the_ends_of_the_text(gpu_index_full, gpu_index, gpu_index_dense4, gpu_index_dense8, oracle_small, request):
     """matches that run into the first / last base of the forward strand (= the last / first base of the indexed text
     on the other strand), across contig junctions and across the forward/reverse seam, with and without tails that
     cannot match: the text-comparison path must stop exactly where the reference's interval empties"""
@@ -299,7 +299,7 @@ def test_reads_at_the_ends_of_the_text(gpu_index_full, gpu_index, oracle_small, 
     for mode in (0, 1):
         so_o, s_o = oracle_small.seed_batch(enc, off, mode)
         assert so_o[-1] > 0
-        for ix in (gpu_index_full, gpu_index):
+        for ix in (gpu_index_full, gpu_index, gpu_index_dense4, gpu_index_dense8):    # (dense: walks through the primary row wrap, bwt_sa :128-138)
             ws = ix.workspace(len(reads), len(enc))
             so_g, s_g = ws.seed_batch(enc, off, mode)
             assert (so_g == so_o).all() and (s_g == s_o.astype(api.SEED_DT)).all(), mode
