@@ -15,6 +15,7 @@
 #include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
+#include <sys/statvfs.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -149,6 +150,9 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	g_check_align = getenv("KART_AMD_CHECK_ALIGN") != nullptr;
 	// (a sharded run: every process takes L3 domains of its own)
 	g_io_cpus = detect_io_cpus(std::max(0, opt.shard_rank));
+	g_lane_cpus = IoCpus();
+	if (const char *e = getenv("KART_AMD_LANE_CPUS"))
+		if (!strcmp(e, "next") && g_io_cpus.valid && opt.shard_count <= 1) g_lane_cpus = detect_io_cpus(1);
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	cx.frag_service = opt.pacbio && kern.has_fragments();
 	Options &o = const_cast<Options &>(opt);

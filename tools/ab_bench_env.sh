@@ -4,7 +4,7 @@ B="python bench.py --pairs ${PAIRS:-10000000} --steps ${STEPS:-5} --warmup 1 --n
 show() { echo "== $2: $(grep -o '"value": [0-9.]*' $1 | head -1) $(grep -o '"frac": [0-9.]*' $1 | head -1) $(grep -o '"search_kernel_ms_per_step": [0-9.]*' $1) $(grep -o '"device_ms_per_step": {[^w]*' $1) $(grep -o '"rank0_step_seconds": [^]]*]' $1)"; grep -E "cpu seconds" $1 | tail -3 | cut -c1-120; grep -E "^stream:|^i/o threads" $1 | tail -2 | cut -c1-330; }
 run() { label=$1; shift; env "$@" KART_AMD_VERBOSE=1 $B > gpurun_out/ab_$$.log 2>&1; show gpurun_out/ab_$$.log "$label"; }
 if [ -n "$1" ]; then
-  while [ -n "$1" ]; do run "$1" $1; shift; done
+  while [ -n "$1" ]; do run "$1" ${1//,/ }; shift; done      # (several assignments: A=1,B=2)
   exit 0
 fi
 run "default (pinned, prealloc)" X=1
