@@ -287,15 +287,29 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 					int run = 0;
 					for (int base = t_lo & ~31; base < t_hi; base += 32) {
 						const uint64_t x = codes32(s_rd, rw, base) ^ codes32(s_tx, gw, base + d);
-						uint64_t e = ~(x | (x >> 1)) & 0x5555555555555555ull;                 // 1 at the even bit of every equal base
+						const int lo = t_lo > base ? t_lo - base : 0, hi = t_hi - base < 32 ? t_hi - base : 32;
+						// 1 at the even bit of every equal base inside [lo, hi)
+						uint64_t e = ~(x | (x >> 1)) & 0x5555555555555555ull;
+						e &= (hi >= 32 ? ~0ull : ((1ull << (2 * hi)) - 1ull)) & ~((1ull << (2 * lo)) - 1ull);
+						// the common case -- 98 of 99 diagonals are not the alignment's -- has no 8 equal bases in a row in this word and the
+						// run carried in does not reach 8 either: only the equal bases at the top of the word are carried on
+						{
+							uint64_t e8 = e & (e >> 2);
+							e8 &= e8 >> 4;
+							e8 &= e8 >> 8;
+							const uint64_t ne = ~e & 0x5555555555555555ull;
+							const int low_ones = ne ? (__ffsll((unsigned long long)ne) - 1) >> 1 : 32;      // equal bases from position 0 up
+							if (e8 == 0 && run + low_ones < 8) {
+								run = ne ? (__clzll((long long)ne) >> 1) : 32;                               // equal bases at the top (position 31 down); ne != 0 here
+								continue;
+							}
+						}
 						e = (e | (e >> 1)) & 0x3333333333333333ull;
 						e = (e | (e >> 2)) & 0x0F0F0F0F0F0F0F0Full;
 						e = (e | (e >> 4)) & 0x00FF00FF00FF00FFull;
 						e = (e | (e >> 8)) & 0x0000FFFF0000FFFFull;
 						e = (e | (e >> 16)) & 0x00000000FFFFFFFFull;
-						uint32_t m = (uint32_t)e;
-						const int lo = t_lo > base ? t_lo - base : 0, hi = t_hi - base < 32 ? t_hi - base : 32;
-						m &= (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+						const uint32_t m = (uint32_t)e;
 						int pos = 0;
 						while (pos < 32) {
 							const uint32_t rest = m >> pos;
