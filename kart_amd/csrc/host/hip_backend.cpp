@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -184,19 +185,18 @@ public:
 	bool fragments_batch(std::vector<FragJobs *> &parts, bool pacbio, int max_gaps) override
 	{
 		if (!has_fragments()) return false;
-		std::lock_guard<std::mutex> lk(frag_mu_);
-		// concatenate the parts (a few large copies), one kernel call, scatter the results back
+		// one of kFragSets sets of page-locked arrays, in rotation: up to three calls may be in flight (pipeline.inc keeps at most
+		// frag_depth <= 3 slices pending) while the results of the call before them are still being read
 		int64_t n = 0, b1 = 0, cols = 0;
 		for (FragJobs *p : parts) { n += (int64_t)p->size(); b1 += (int64_t)p->f1.size(); cols += p->cols; }
 		if (n == 0) return true;
 		const double t0 = now_sec();
-		char *f1 = fr_f1_.get((size_t)b1 + 64);
-		int64_t *o1 = fr_o1_.get((size_t)n + 1), *g = fr_g_.get((size_t)n), *oo = fr_oo_.get((size_t)n);
-		// two sets of result arrays in alternation: the results of a call stay valid during the next one (pipeline.inc reads batch k-1
-		// while the call of batch k runs)
-		const int set = (int)(n_frag_calls & 1);
-		int32_t *gl = fr_gl_.get((size_t)n), *len = fr_len_[set].get((size_t)n);
-		uint8_t *ops = fr_ops_[set].get((size_t)cols + 64), *status = fr_status_[set].get((size_t)n);
+		FragIo &io = fr_[(size_t)(fr_next_.fetch_add(1) % kFragSets)];
+		std::lock_guard<std::mutex> lk(io.mu);
+		char *f1 = io.f1.get((size_t)b1 + 64);
+		int64_t *o1 = io.o1.get((size_t)n + 1), *g = io.g.get((size_t)n), *oo = io.oo.get((size_t)n);
+		int32_t *gl = io.gl.get((size_t)n), *len = io.len.get((size_t)n);
+		uint8_t *ops = io.ops.get((size_t)cols + 64), *status = io.status.get((size_t)n);
 		// where every part starts in the combined arrays, then the parts are copied side by side (1.3 GB of characters per 200 k long reads)
 		std::vector<int64_t> p_at(parts.size() + 1, 0), p_a1(parts.size() + 1, 0), p_ac(parts.size() + 1, 0);
 		for (size_t k = 0; k < parts.size(); ++k) {
@@ -223,8 +223,11 @@ public:
 		}
 		const double t1 = now_sec();
 		if (kg_fragments_batch(ix_, f1, o1, g, gl, n, pacbio ? 1 : 0, max_gaps, ops, oo, len, status) != KG_OK) die("kg_fragments_batch");
-		t_frag_in += t1 - t0; t_frag_call += now_sec() - t1; n_frag_calls++;
-		// the results stay where the device wrote them: every part gets its window (valid until the call after the next)
+		{
+			std::lock_guard<std::mutex> tl(frag_mu_);
+			t_frag_in += t1 - t0; t_frag_call += now_sec() - t1; n_frag_calls++;
+		}
+		// the results stay where the device wrote them: every part gets its window (valid until this set comes round again, kFragSets calls later)
 		for (size_t k = 0; k < parts.size(); ++k) {
 			FragJobs *p = parts[k];
 			p->ops = ops + p_ac[k]; p->len = len + p_at[k]; p->status = status + p_at[k];
@@ -279,10 +282,16 @@ private:
 	kg_index *ix_;
 	int threads_;
 	std::mutex nw_mu_, frag_mu_;
-	PinnedBuf<char> fr_f1_;
-	PinnedBuf<int64_t> fr_o1_, fr_g_, fr_oo_;
-	PinnedBuf<int32_t> fr_gl_, fr_len_[2];
-	PinnedBuf<uint8_t> fr_ops_[2], fr_status_[2];
+	static constexpr int kFragSets = 5;        // 3 calls in flight + the one whose results are being read + one spare
+	struct FragIo {
+		std::mutex mu;
+		PinnedBuf<char> f1;
+		PinnedBuf<int64_t> o1, g, oo;
+		PinnedBuf<int32_t> gl, len;
+		PinnedBuf<uint8_t> ops, status;
+	};
+	FragIo fr_[kFragSets];
+	std::atomic<uint64_t> fr_next_{0};
 	std::vector<char> f1_, f2_;
 	std::vector<int64_t> o1_, o2_;
 	std::vector<uint8_t> ops_;

@@ -95,7 +95,7 @@ struct FragJobs {
 	std::vector<int64_t> o1{0}, g, oo;
 	std::vector<int32_t> gl;
 	std::vector<void *> owner;          // whoever waits for job j (the host's PairWork)
-	// results: they stay in the backend's page-locked arrays (two sets in alternation: valid until the call after the next -- the stage that
+	// results: they stay in the backend's page-locked arrays (several sets in rotation: valid for the next few calls -- the stage that
 	// reads them runs during the next call at the latest, pipeline.inc); ops of job j at ops[oo[j] ...]
 	const uint8_t *ops = nullptr, *status = nullptr;
 	const int32_t *len = nullptr;
