@@ -165,6 +165,7 @@ def load_library() -> C.CDLL:
     L.kg_nw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.kg_nw_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kg_fragments_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kg_stream_open.argtypes = [C.c_void_p, C.POINTER(StreamConfig), C.POINTER(C.c_void_p)]
     L.kg_stream_close.argtypes = [C.c_void_p]
     L.kg_stream_close.restype = None
@@ -371,6 +372,34 @@ class Index:
         _check(self.lib.kg_nw_batch(self.h, _ptr(f1), _ptr(off1), _ptr(f2), _ptr(off2), n, _ptr(ops), _ptr(alen)), "kg_nw_batch")
         oo = off1 + off2
         return [ops[oo[i]:oo[i] + alen[i]].copy() for i in range(n)]
+
+    def fragments_ops(self, frags, gpos, glen, pacbio=True, max_gaps=5):
+        """kg_fragments_batch: GenerateNormalPairAlignment(rLen, frag1, gLen, frag2) for read fragments `frags` (bytes) against the
+        genome fragments [gpos[i], gpos[i] + glen[i]) of the indexed text.  Returns (list of uint8 op arrays, uint8 status array)."""
+        n = len(frags)
+        if n == 0:
+            return [], np.zeros(0, np.uint8)
+        off1 = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(a) for a in frags], out=off1[1:])
+        f1 = np.frombuffer(b"".join(frags) + b"\0" * 64, dtype=np.uint8).copy()
+        g = np.ascontiguousarray(gpos, dtype=np.int64)
+        gl = np.ascontiguousarray(glen, dtype=np.int32)
+        oo = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.diff(off1) + gl, out=oo[1:])
+        ops = np.zeros(int(oo[n]) + 64, dtype=np.uint8)
+        alen = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.uint8)
+        _check(self.lib.kg_fragments_batch(self.h, _ptr(f1), _ptr(off1), _ptr(g), _ptr(gl), n, int(pacbio), max_gaps, _ptr(ops), _ptr(oo), _ptr(alen), _ptr(status)), "kg_fragments_batch")
+        return [ops[oo[i]:oo[i] + alen[i]].copy() for i in range(n)], status
+
+    def GenerateNormalPairAlignment(self, frags, gpos, glen, text, pacbio=True, max_gaps=5):
+        """Mirror of GenerateNormalPairAlignment (src/tools.cpp:142): the two gapped strings per pair (None where the request was handed back);
+        `text` = the indexed text as characters (RefSequence), from which frag2 is cut as in the callers"""
+        ops, status = self.fragments_ops(frags, gpos, glen, pacbio, max_gaps)
+        out = []
+        for i, a in enumerate(frags):
+            out.append(None if status[i] else apply_ops(a, bytes(text[int(gpos[i]):int(gpos[i]) + int(glen[i])]), ops[i]))
+        return out, status
 
     def nw_alignment(self, pairs):
         """Mirror of nw_alignment(m, s1, n, s2): returns the two gapped strings for every pair."""

@@ -547,6 +547,128 @@ void normal_pairs(int rlen, int glen, std::vector<ko_pair> &v)
 	}
 }
 
+// ---- GenerateNormalPairAlignment and the 8-mer partition behind it --------------------------------------------------
+// CreateKmerVecFromReadSeq, src/KmerAnalysis.cpp:56-102 (KmerSize 8, KmerPower 0x3FFF, src/structure.h:23-24): the 8-mers of a
+// fragment as (id, position), ids rolled through nst_nt4_table -- so a character other than A/C/G/T/N adds 4 and carries into
+// the next base's bits, exactly as there; an 'N' restarts the window, and the character right behind the restarted window is
+// never shifted in (the loop header advances both ends once more, :93-98): both quirks are part of the observable behaviour.
+struct KmerAt { uint32_t wid, pos; };
+
+uint32_t kmer_id(const char *seq, uint32_t pos)   // CreateKmerID, :28-35
+{
+	uint32_t id = 0;
+	for (uint32_t i = pos; i < pos + 8; ++i) id = (id << 2) + (uint32_t)nt4((unsigned char)seq[i]);
+	return id;
+}
+
+void kmer_list(int len, const char *seq, std::vector<KmerAt> &out)
+{
+	out.clear();
+	uint32_t tail = 0, count = 0;
+	auto window = [&]() {        // advance tail until 8 consecutive non-'N' characters end right before it
+		while (count < 8 && tail < (uint32_t)len) {
+			if (seq[tail++] != 'N') count++;
+			else count = 0;
+		}
+		return count == 8;
+	};
+	if (!window()) return;
+	uint32_t head = tail - 8;
+	KmerAt k{kmer_id(seq, head), head};
+	out.push_back(k);
+	for (head += 1; tail < (uint32_t)len; ++head, ++tail) {
+		if (seq[tail] != 'N') {
+			k.pos = head;
+			k.wid = ((k.wid & 0x3FFFu) << 2) + (uint32_t)nt4((unsigned char)seq[tail]);
+			out.push_back(k);
+		} else {
+			count = 0;
+			tail++;
+			if (!window()) break;
+			head = tail - 8;
+			k.pos = head; k.wid = kmer_id(seq, head);
+			out.push_back(k);
+		}
+	}
+	std::stable_sort(out.begin(), out.end(), [](const KmerAt &a, const KmerAt &b) { return a.wid < b.wid; });   // (:100; ties do not reach the result: the pairs are re-sorted below)
+}
+
+// GenerateSimplePairsFromFragmentPair, :164-179 = IdentifyCommonKmers (:104-131) + GenerateSimplePairsFromCommonKmers (:133-162, at least 8 long) + sort by genome position
+void fragment_simple_pairs(int max_shift, int len1, const char *f1, int len2, const char *f2, std::vector<ko_pair> &out)
+{
+	out.clear();
+	std::vector<KmerAt> v1, v2;
+	kmer_list(len1, f1, v1);
+	kmer_list(len2, f2, v2);
+	struct Common { int diff; uint32_t r, g; };
+	std::vector<Common> common;
+	for (const KmerAt &a : v1) {
+		auto it = std::lower_bound(v2.begin(), v2.end(), a, [](const KmerAt &x, const KmerAt &y) { return x.wid < y.wid; });
+		for (; it != v2.end() && it->wid == a.wid; ++it) {
+			const bool near = it->pos >= a.pos ? it->pos - a.pos < (uint32_t)max_shift : a.pos - it->pos < (uint32_t)max_shift;    // (:118, unsigned compare as there)
+			if (near) common.push_back(Common{(int)(it->pos - a.pos), a.pos, it->pos});
+		}
+	}
+	std::sort(common.begin(), common.end(), [](const Common &a, const Common &b) { return a.diff == b.diff ? a.r < b.r : a.diff < b.diff; });
+	for (size_t i = 0; i < common.size();) {
+		size_t j = i + 1;
+		for (uint32_t next = common[i].r + 1; j < common.size() && common[j].r == next && common[j].diff == common[i].diff; ++j) next++;
+		const int l = 8 + (int)(j - 1 - i);
+		if (l >= 8) {
+			ko_pair p;
+			memset(&p, 0, sizeof(p));
+			p.bSimple = 1; p.rPos = (int32_t)common[i].r; p.gPos = common[i].g; p.PosDiff = common[i].diff; p.rLen = p.gLen = l;
+			out.push_back(p);
+		}
+		i = j;
+	}
+	std::sort(out.begin(), out.end(), pair_by_gpos);
+}
+
+// GenerateNormalPairAlignment, src/tools.cpp:142-223: both strings are replaced by their aligned forms
+void normal_pair_alignment(bool pacbio, int max_gaps, std::string &frag1, std::string &frag2)
+{
+	const int rlen = (int)frag1.size(), glen = (int)frag2.size();
+	bool run_nw = true;
+	if (rlen > 30 && glen > 30) {
+		int max_shift;
+		if (pacbio) {
+			max_shift = rlen > glen ? (int)(rlen * 0.2) : (int)(glen * 0.2);
+			if (max_shift > 50) max_shift = 50;
+		} else max_shift = max_gaps;
+		std::vector<ko_pair> part;
+		fragment_simple_pairs(max_shift, rlen, frag1.c_str(), glen, frag2.c_str(), part);
+		if (!part.empty()) normal_pairs(rlen, glen, part);
+		if (!part.empty()) {
+			run_nw = false;
+			std::string a1, a2;
+			for (const ko_pair &p : part) {
+				if (p.rLen <= 0 && p.gLen <= 0) continue;
+				if (p.gLen == 0) { a1 += frag1.substr((size_t)p.rPos, (size_t)p.rLen); a2.append((size_t)p.rLen, '-'); }
+				else if (p.rLen == 0) { a1.append((size_t)p.gLen, '-'); a2 += frag2.substr((size_t)p.gPos, (size_t)p.gLen); }
+				else {
+					std::string s1 = frag1.substr((size_t)p.rPos, (size_t)p.rLen), s2 = frag2.substr((size_t)p.gPos, (size_t)p.gLen);
+					if (!(p.rLen == 1 && p.gLen == 1) && !p.bSimple) {
+						if (pacbio && (p.rLen > 300 || p.gLen > 300)) normal_pair_alignment(pacbio, max_gaps, s1, s2);   // :197
+						else {
+							std::vector<char> o1((size_t)(p.rLen + p.gLen) + 1), o2((size_t)(p.rLen + p.gLen) + 1);
+							int l = nw_align(s1.data(), p.rLen, s2.data(), p.gLen, o1.data(), o2.data());
+							s1.assign(o1.data(), (size_t)l); s2.assign(o2.data(), (size_t)l);
+						}
+					}
+					a1 += s1; a2 += s2;
+				}
+			}
+			frag1.swap(a1); frag2.swap(a2);
+		}
+	}
+	if (run_nw) {
+		std::vector<char> o1((size_t)(rlen + glen) + 1), o2((size_t)(rlen + glen) + 1);
+		int l = nw_align(frag1.data(), rlen, frag2.data(), glen, o1.data(), o2.data());
+		frag1.assign(o1.data(), (size_t)l); frag2.assign(o2.data(), (size_t)l);
+	}
+}
+
 int emit_cands(std::vector<Cand> &cands, int *cand_off, int *score, int64_t *posdiff, ko_pair *out_pairs, int cand_cap,
                int pair_cap)
 {
@@ -729,6 +851,15 @@ int ko_candidates_pacbio(const ko_index *ix, int rlen, const ko_seed *seeds, int
 	std::vector<Cand> c;
 	cands_pacbio(*ix, rlen, seeds, n, c);
 	return emit_cands(c, cand_off, score, posdiff, out_pairs, cand_cap, pair_cap);
+}
+
+int ko_normal_pair_alignment(int pacbio, int max_gaps, const char *s1, int m, const char *s2, int n, char *out1, char *out2)
+{
+	std::string a(s1, (size_t)m), b(s2, (size_t)n);
+	normal_pair_alignment(pacbio != 0, max_gaps, a, b);
+	memcpy(out1, a.c_str(), a.size() + 1);
+	memcpy(out2, b.c_str(), b.size() + 1);
+	return (int)a.size();
 }
 
 int ko_identify_normal_pairs(int rlen, int glen, ko_pair *pairs, int n, int cap)

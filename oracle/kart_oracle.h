@@ -79,6 +79,11 @@ void ko_counters_reset(void);
  * Returns aligned length. */
 int ko_nw(const char *s1, int m, const char *s2, int n, char *out1, char *out2);
 
+/* GenerateNormalPairAlignment (src/tools.cpp:142-223): 8-mer partition within the shift limit (pacbio: min(50, 20 % of the longer
+ * side), else max_gaps), IdentifyNormalPairs on the fragment, nw_alignment of the pieces, itself again for pacbio pieces above 300.
+ * out1 / out2 need m + n + 1 bytes.  Returns the aligned length. */
+int ko_normal_pair_alignment(int pacbio, int max_gaps, const char *s1, int m, const char *s2, int n, char *out1, char *out2);
+
 /* chaining */
 int64_t ko_alignment_boundary(const ko_index *ix, int64_t gPos);
 /* Illumina: cand_off[ncand+1] index into out_pairs; score[ncand]; posdiff[ncand].  Returns ncand. */

@@ -69,6 +69,7 @@ class Oracle:
         L.ko_seed_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.ko_nw.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p]
+        L.ko_normal_pair_alignment.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p]
         L.ko_alignment_boundary.argtypes = [C.c_void_p, C.c_int64]
         L.ko_candidates_illumina.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int]
         L.ko_candidates_pacbio.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int]
@@ -147,6 +148,13 @@ class Oracle:
         self.lib.ko_nw(s1, len(s1), s2, len(s2), o1, o2)
         return o1.value, o2.value
 
+    def normal_pair_alignment(self, s1: bytes, s2: bytes, pacbio=True, max_gaps=5):
+        """GenerateNormalPairAlignment(rLen, frag1, gLen, frag2): the two aligned strings"""
+        o1 = C.create_string_buffer(len(s1) + len(s2) + 2)
+        o2 = C.create_string_buffer(len(s1) + len(s2) + 2)
+        self.lib.ko_normal_pair_alignment(int(pacbio), max_gaps, s1, len(s1), s2, len(s2), o1, o2)
+        return o1.value, o2.value
+
     def boundary(self, g):
         return int(self.lib.ko_alignment_boundary(self.h, g))
 
@@ -197,6 +205,8 @@ class RefShim:
         L.shim_bwt_search.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.shim_seed_read.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.shim_nw.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p]
+        if hasattr(L, "shim_normal_pair_alignment"):
+            L.shim_normal_pair_alignment.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p]
         if hasattr(L, "shim_seed_batch"):
             L.shim_seed_batch.restype = C.c_int64
             L.shim_seed_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
@@ -255,6 +265,12 @@ class RefShim:
         o1 = C.create_string_buffer(len(s1) + len(s2) + 2)
         o2 = C.create_string_buffer(len(s1) + len(s2) + 2)
         self.lib.shim_nw(s1, len(s1), s2, len(s2), o1, o2)
+        return o1.value, o2.value
+
+    def normal_pair_alignment(self, s1: bytes, s2: bytes):
+        o1 = C.create_string_buffer(len(s1) + len(s2) + 2)
+        o2 = C.create_string_buffer(len(s1) + len(s2) + 2)
+        self.lib.shim_normal_pair_alignment(s1, len(s1), s2, len(s2), o1, o2)
         return o1.value, o2.value
 
     def candidates(self, rlen, seeds, pacbio=False):

@@ -17,6 +17,7 @@ extern bwtint_t bwt_occ(const bwt_t *bwt, bwtint_t k, ubyte_t c);
 extern void bwt_occ4(const bwt_t *bwt, bwtint_t k, bwtint_t cnt[4]);
 extern bwtint_t bwt_sa(bwtint_t k);
 extern void RemoveRedundantCandidates(vector<AlignmentCandidate_t> &AlignmentVec);  // src/Mapping.cpp:317
+extern void GenerateNormalPairAlignment(int rLen, string &frag1, int gLen, string &frag2);   // src/tools.cpp:142 (exported, not in structure.h)
 
 extern "C" {
 
@@ -90,6 +91,16 @@ int shim_nw(const char *s1, int m, const char *s2, int n, char *out1, char *out2
 {
 	string a(s1, m), b(s2, n);
 	nw_alignment(m, a, n, b);
+	memcpy(out1, a.c_str(), a.size() + 1);
+	memcpy(out2, b.c_str(), b.size() + 1);
+	return (int)a.size();
+}
+
+// GenerateNormalPairAlignment, src/tools.cpp:142 (under the mode shim_set_mode selected)
+int shim_normal_pair_alignment(const char *s1, int m, const char *s2, int n, char *out1, char *out2)
+{
+	string a(s1, m), b(s2, n);
+	GenerateNormalPairAlignment(m, a, n, b);
 	memcpy(out1, a.c_str(), a.size() + 1);
 	memcpy(out2, b.c_str(), b.size() + 1);
 	return (int)a.size();

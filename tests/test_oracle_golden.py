@@ -88,3 +88,21 @@ def test_chaining_and_normal_pairs(golden, oracle_small):
                     assert (got_np[f] == want_np[f]).all()
                 gi += 1
     assert gi == len(rows)
+
+
+def test_normal_pair_alignment_golden():
+    """GenerateNormalPairAlignment (8-mer partition, IdentifyNormalPairs on the fragment, NW, the -pacbio recursion): the oracle against
+    the reference's aligned strings for 267 fragment pairs in both modes (oracle/pin_fragments_against_ref.py)"""
+    import os
+    import numpy as np
+    from conftest import ROOT, SMALL_PREFIX
+    from oracle import oracle as O
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fragments_small.npz"), allow_pickle=True)
+    orc = O.Oracle(SMALL_PREFIX)
+    text = orc.ref_sequence()
+    for mode, pacbio in (("pacbio", True), ("illumina", False)):
+        for i in range(len(g["frag1"])):
+            gp, gl = int(g["gpos"][i]), int(g["glen"][i])
+            got = orc.normal_pair_alignment(bytes(g["frag1"][i]), text[gp:gp + gl].tobytes(), pacbio, 5)
+            assert got == (bytes(g["aln1_" + mode][i]), bytes(g["aln2_" + mode][i])), (mode, i)
+    orc.close()
