@@ -37,6 +37,7 @@ struct NwScratch {
 	hipEvent_t done = nullptr;
 	bool busy = false;
 	bool pending = false;     // acquired, but the event behind its kernels is not recorded yet: `done` still reports the PREVIOUS use
+	hipStream_t last_stream = nullptr;   // where its last kernels were enqueued: the next use on the SAME stream needs no wait (stream order)
 	// staging of the host-buffer entry (kg_nw_batch): inputs, offsets and outputs, grown on demand
 	char *io = nullptr;
 	size_t io_bytes = 0;

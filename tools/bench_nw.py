@@ -22,8 +22,9 @@ for name, n, lo, hi in (("tiny_1-8", 8_000_000, 1, 9), ("small_9-32", 2_000_000,
     ops = torch.empty(int(o1[-1] + o2[-1]) + 16, dtype=torch.uint8, device=dev)
     ln = torch.empty(n, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    max_len = int(max(m.max(), k.max()))      # (outside the timed calls: a numpy reduction over millions of lengths costs more than the kernels)
     def call():
-        rc = L.kg_nw_batch_device(ix.h, f1.data_ptr(), d1.data_ptr(), f2.data_ptr(), d2.data_ptr(), n, int(max(m.max(), k.max())), ops.data_ptr(), ln.data_ptr(), stream)
+        rc = L.kg_nw_batch_device(ix.h, f1.data_ptr(), d1.data_ptr(), f2.data_ptr(), d2.data_ptr(), n, max_len, ops.data_ptr(), ln.data_ptr(), stream)
         assert rc == 0, L.kg_last_error()
     call(); torch.cuda.synchronize()
     t = time.perf_counter()
