@@ -353,6 +353,7 @@ void kg_index_destroy(kg_index *ix)
 {
 	if (!ix) return;
 	(void)hipSetDevice(ix->device);
+	kgi_frag_release(ix);
 	if (ix->d_occ) (void)hipFree(ix->d_occ);
 	if (ix->d_planes) (void)hipFree(ix->d_planes);
 	if (ix->d_planes2) (void)hipFree(ix->d_planes2);

@@ -26,6 +26,23 @@ std::mutex g_frag_mu;
 std::vector<FragScratch *> g_frag_pool;
 }  // namespace
 
+// the index is going away: its scratches (device memory, stream, event) go with it -- called from kg_index_destroy, which the caller
+// must not run while calls on that index are in flight
+extern "C" void kgi_frag_release(kg_index *ix)
+{
+	std::lock_guard<std::mutex> lk(g_frag_mu);
+	for (size_t i = 0; i < g_frag_pool.size();) {
+		FragScratch *s = g_frag_pool[i];
+		if (s->ix != ix) { ++i; continue; }
+		if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+		if (s->done) (void)hipEventDestroy(s->done);
+		if (s->in) (void)hipFree(s->in);
+		if (s->work) (void)hipFree(s->work);
+		delete s;
+		g_frag_pool.erase(g_frag_pool.begin() + (long)i);
+	}
+}
+
 extern "C" int kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t *off1, const int64_t *gpos, const int32_t *glen, int64_t n, int pacbio,
                                   int max_gaps, uint8_t *ops, const int64_t *ops_off, int32_t *aln_len, uint8_t *status)
 {

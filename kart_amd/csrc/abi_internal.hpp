@@ -152,6 +152,7 @@ KG_INTERNAL hipError_t kgi_sync(kg_workspace *ws);
 KG_INTERNAL int kgi_seed_resident(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, int64_t n_reads, int64_t n_bases, int64_t *total_out);
 KG_INTERNAL int kgi_chain_resident(kg_workspace *ws, int pacbio, int max_gaps, int64_t totals[2]);
 KG_INTERNAL int kgi_nw_launch(kg_index *ix, NwArgs &a, int64_t max_len, hipStream_t st);
+KG_INTERNAL void kgi_frag_release(kg_index *ix);      // abi_frag.hip: the fragment service's scratches of this index
 KG_INTERNAL int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks, int est_distance, int max_insert,
                        int max_gaps, int multi_hit, int unset_flag, int64_t host_record_capacity, AlnArgs &a);
 }
