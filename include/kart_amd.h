@@ -277,7 +277,7 @@ int  kg_nw_batch_device(kg_index *ix, const char *d_frag1, const int64_t *d_off1
 
 /* GenerateNormalPairAlignment (src/tools.cpp:142-223) for n fragment pairs: the read fragment i is frag1[off1[i], off1[i+1])
  * (raw characters, host buffer), the genome fragment the glen[i] bases of the indexed text at coordinate gpos[i].  Fragments with
- * both sides above 30 are partitioned at their common 8-mers (shift limit: min(50, 20 %% of the longer side) with pacbio != 0,
+ * both sides above 30 are partitioned at their common 8-mers (shift limit: min(50, 20 % of the longer side) with pacbio != 0,
  * else max_gaps), IdentifyNormalPairs(rLen, gLen, ...) runs on the matches, the pieces between them are aligned by
  * nw_alignment, and with pacbio != 0 a piece with a side above 300 goes through the same procedure again (:197).  The result
  * is the alignment as kg_nw_batch reports one: aln_len[i] op codes at ops[ops_off[i] ...], where ops_off[i] must be the
