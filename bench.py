@@ -190,7 +190,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=None, help="read pairs of the whole job (split over the ranks); default 50 M = the 100 M reads of configs[2] "
                                                              "when the work directory holds them and their SAM, else 10 M")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] sub-lines")
-    ap.add_argument("--parts", action="store_true", help="N > 1: one output file per rank (kart-amd -parts; their concatenation is the single-process SAM) instead of one shared file")
+    ap.add_argument("--parts", action="store_true", help="N > 1: one output file per rank (kart-amd -parts; their concatenation is the single-process SAM) -- the default for N > 1")
+    ap.add_argument("--one-file", action="store_true", help="N > 1: all ranks write into ONE shared SAM file by offset (the ranks then meet at that file's page-cache locks: ~20 GB/s from one L3 domain, less from several)")
     ap.add_argument("--leg", choices=["all", "seeding"], default="all", help="seeding: only the GPU seeding step on resident reads (what the rocprofv3 passes profile)")
     ap.add_argument("--seed-steps", type=int, default=5, help="timed launches of the seeding-stage leg")
     ap.add_argument("--sa", choices=["sampled", "full", "compact", "dense4", "dense8"], default="full", help="suffix array placement (seeding-stage leg and, via KART_AMD_SA, the mapping runs): dense4 / dense8 = the smaller index")
@@ -204,6 +205,7 @@ def main():
                          "falling back to configs[1] (4,639,675) if the large index cannot be built on this machine (single rank only)")
     ap.add_argument("--threads", type=int, default=None, help="worker threads per rank (default: the host CPU quota / ranks)")
     args = ap.parse_args()
+    args.parts = not args.one_file          # (N > 1) a part per rank unless asked otherwise; `kart-amd -gpu a,b,..` itself defaults to one file
 
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:

@@ -66,3 +66,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert two["mapped_reads_per_step"] == one["mapped_reads_per_step"]
     assert two["config"]["sam_bytes_per_step"] == one["config"]["sam_bytes_per_step"]
     assert "cpu_baseline" not in two             # rank 0 at N = 1 only
+    assert two["config"]["output"].startswith("one file per rank")          # the default layout for N > 1 ...
+    shared = _bench(["--gpus", "2", "--one-file", "--genome-len", "500000", "--pairs", "60000", "--steps", "1", "--warmup", "1"], env=env, tmp=tmp_path)
+    assert shared["config"]["output"] == "one SAM file"                       # ... and all ranks writing one file by offset
+    assert shared["mapped_reads_per_step"] == one["mapped_reads_per_step"] and shared["config"]["sam_bytes_per_step"] == one["config"]["sam_bytes_per_step"]
