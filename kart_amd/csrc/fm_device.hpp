@@ -49,7 +49,8 @@ struct FmView {
 	// so that the jump lands on intervals of a few suffixes.  Entry = { k, n | sa << 27 | lf2 << 28 } (u32
 	// index) or k | n << 34 | sa << 59 | lf2 << 60 (u64 index); n == 0 means "no such q-mer / not
 	// representable": the search then starts step by step, so results never depend on the table.  sa = 1
-	// (n == 1 and the full SA resident): k is SA[k] already, the search continues against the text.
+	// (n == 1 and the full SA resident): k is SA[k] already, the search continues against the text.  sa = 1 with n == 0: the q-mer
+	// does not occur in the text at all (SensitiveMode then knows the search has no hit without making it).
 	const uint2 *qtab32;
 	const uint64_t *qtab64;
 	int qmer;
