@@ -116,6 +116,8 @@ extern "C" int kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t
 	a.text = ix->d_text; a.two_genome_size = 2 * ix->l_pac;
 	a.pacbio = pacbio ? 1 : 0; a.max_gaps = max_gaps;
 	a.prof = prof ? 1 : 0;
+	static const bool no_fast_pairs = getenv("KG_FRAG_NO_FAST_PAIRS") != nullptr;
+	a.no_fast_pairs = no_fast_pairs ? 1 : 0;
 	a.tasks = (FragTask *)(sc->work + w_tasks); a.task_capacity = task_cap;
 	a.pieces = (FragPiece *)(sc->work + w_pieces); a.piece_capacity = piece_cap;
 	a.jobs = (NwJobDesc *)(sc->work + w_jobs); a.job_capacity = job_cap; a.ops_capacity = jops_cap;

@@ -43,6 +43,11 @@ __device__ __forceinline__ uint64_t codes32(const uint64_t *w, int n_words, int 
 	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 
+__device__ __forceinline__ unsigned long long shfl_u64_frag(unsigned long long v, int src)
+{
+	return ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src);
+}
+
 __device__ __forceinline__ bool key_less(int g1, int r1, int g2, int r2) { return g1 == g2 ? r1 < r2 : g1 < g2; }   // CompByGenomePos
 
 // vector<SeedPair_t> of one fragment in the LDS (fragment-relative coordinates)
@@ -216,6 +221,62 @@ __device__ bool identify_normal_pairs(int rlen, int glen, FragPairs &v, uint16_t
 	return true;
 }
 
+// IdentifyNormalPairs for the common case, by the whole wave: the matches are already in read order as well (so the tandem and
+// translocation filters, :235-321, find nothing) and no two neighbours overlap in either sequence (so CheckOverlappingSeeds, :375-418,
+// changes nothing).  Then the result is the matches with the gap pairs between neighbours interleaved -- a gap pair sorts right behind
+// the match it follows: its genome position is the match's end, at most the next match's start, and at a tie its read position is
+// smaller -- plus the head and tail pairs (:437-488).  Returns the new count, or -1 without touching anything when the case is not that.
+__device__ int identify_normal_pairs_wave(int rlen, int glen, int n, int lane, int16_t *, int32_t *gPos, int32_t *rPos, int32_t *rLen, int32_t *gLen, uint8_t *simple)
+{
+	bool ok = true;
+	for (int i = lane; i + 1 < n; i += 64)
+		ok = ok && rPos[i] < rPos[i + 1] && rPos[i] + rLen[i] - 1 < rPos[i + 1] && gPos[i] + gLen[i] - 1 < gPos[i + 1];
+	if (__ballot(!ok)) return -1;
+	const bool head = rPos[0] > 0 || gPos[0] > 0;             // (:457-470; glen > 0 here: the genome side's gap is gPos[0])
+	// every lane takes its matches (up to four: n <= 255) and the gap pair behind each into registers, then all write
+	int mg[4], mr[4], ml_r[4], ml_g[4], dst[4], gr[4], gg[4];
+	bool has[4];
+	int before = head ? 1 : 0;                                  // output slots in front of this chunk
+	for (int c = 0; c < 4; ++c) {
+		const int i = c * 64 + lane;
+		has[c] = false; dst[c] = -1; gr[c] = gg[c] = 0; mg[c] = mr[c] = ml_r[c] = ml_g[c] = 0;
+		bool gap = false;
+		if (i < n) {
+			mg[c] = gPos[i]; mr[c] = rPos[i]; ml_r[c] = rLen[i]; ml_g[c] = gLen[i];
+			if (i + 1 < n) {
+				gr[c] = rPos[i + 1] - (mr[c] + ml_r[c]);
+				gg[c] = gPos[i + 1] - (mg[c] + ml_g[c]);
+				gap = gr[c] > 0 || gg[c] > 0;
+			}
+		}
+		const uint64_t mgap = __ballot(gap);
+		const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+		if (i < n) dst[c] = before + (i - c * 64) + __popcll(mgap & below);
+		has[c] = gap;
+		const int in_chunk = n - c * 64 < 64 ? (n - c * 64 > 0 ? n - c * 64 : 0) : 64;
+		before += in_chunk + __popcll(mgap);
+	}
+	const int last = n - 1;
+	const int t_r = rlen - (rPos[last] + rLen[last]), t_g = glen - (gPos[last] + gLen[last]);
+	const int t_rp = rPos[last] + rLen[last], t_gp = gPos[last] + gLen[last];
+	const int h_r = rPos[0] > 0 ? rPos[0] : 0, h_g = gPos[0];
+	__syncthreads();
+	for (int c = 0; c < 4; ++c) {
+		if (dst[c] < 0) continue;
+		const int d = dst[c];
+		gPos[d] = mg[c]; rPos[d] = mr[c]; rLen[d] = ml_r[c]; gLen[d] = ml_g[c]; simple[d] = 1;
+		if (has[c]) { gPos[d + 1] = mg[c] + ml_g[c]; rPos[d + 1] = mr[c] + ml_r[c]; rLen[d + 1] = gr[c]; gLen[d + 1] = gg[c]; simple[d + 1] = 0; }
+	}
+	int total = before;
+	if (lane == 0) {
+		if (head) { gPos[0] = 0; rPos[0] = 0; rLen[0] = h_r; gLen[0] = h_g; simple[0] = 0; }
+		if (t_r > 0 || t_g > 0) { gPos[total] = t_gp; rPos[total] = t_rp; rLen[total] = t_r; gLen[total] = t_g; simple[total] = 0; }
+	}
+	if (t_r > 0 || t_g > 0) total++;
+	__syncthreads();
+	return total;
+}
+
 }  // namespace
 
 // One wave per task of the level [level_begin[level], level_begin[level + 1]).
@@ -351,78 +412,111 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 			__syncthreads();
 			if (a.prof) c3 = clock64();
 		}
-		if (lane == 0) {
+		// IdentifyNormalPairs on the LDS arrays: by the whole wave where the seed filters have nothing to do, else by lane 0 (they are
+		// sequential by nature)
+		int fast_num = -1;
+		if (!host && !whole_job && n_runs > 0 && !a.no_fast_pairs) fast_num = identify_normal_pairs_wave(rL, gL, n_runs, lane, nullptr, s_gPos, s_rPos, s_rLen, s_gLen, s_simple);
+		if (lane == 0 && fast_num >= 0) s_n = fast_num;
+		if (lane == 0 && fast_num < 0) {
 			FragPairs v;
 			v.gPos = s_gPos; v.rPos = s_rPos; v.rLen = s_rLen; v.gLen = s_gLen; v.simple = s_simple; v.num = n_runs;
 			if (!host && !whole_job && n_runs > 0 && !identify_normal_pairs(rL, gL, v, s_byr, kFragMaxPairs)) host = true;
 			if (!host && !whole_job && v.num == 0) whole_job = true;            // no common 8-mer survived: the whole fragment is one alignment (:214-221)
-			if (a.prof) c4 = clock64();
-			int first = 0, count = 0;
-			if (!host) {
-				int n_pieces = 0;
-				if (whole_job) n_pieces = 1;
-				else
-					for (int i = 0; i < v.num; ++i)
-						if (!(v.rLen[i] <= 0 && v.gLen[i] <= 0)) n_pieces++;
-				const unsigned long long at = atomicAdd(&a.ctl[FC_PIECES], (unsigned long long)n_pieces);
-				if (at + (unsigned long long)n_pieces > (unsigned long long)a.piece_capacity) host = true;
-				else {
-					first = (int)at;
-					// the task's NW jobs and their op bytes in ONE reservation each (a same-address atomic per job from every wave was
-					// the kernel: 2 M jobs per batch against ~90 M atomics/s on one word)
-					int n_jobs = 0;
-					long long n_ops = 0;
-					if (whole_job) { n_jobs = 1; n_ops = rL + gL; }
-					else
-						for (int i = 0; i < v.num; ++i) {
-							const int prl = v.rLen[i], pgl = v.gLen[i];
-							if (prl <= 0 || pgl <= 0 || (prl == 1 && pgl == 1) || v.simple[i]) continue;
-							if (a.pacbio && (prl > 300 || pgl > 300)) continue;
-							n_jobs++; n_ops += prl + pgl;
-						}
-					unsigned long long job_at = n_jobs ? atomicAdd(&a.ctl[FC_JOBS], (unsigned long long)n_jobs) : 0;
-					const unsigned long long job_end = job_at + (unsigned long long)n_jobs;
-					unsigned long long ops_next = n_jobs ? atomicAdd(&a.ctl[FC_OPS], (unsigned long long)n_ops) : 0;
-					const bool room = job_at + (unsigned long long)n_jobs <= (unsigned long long)a.job_capacity && ops_next + (unsigned long long)n_ops <= (unsigned long long)a.ops_capacity;
-					auto nw_job = [&](int64_t o1, int64_t o2, int m, int n, FragPiece &pc) {
-						if (!room) return false;
-						NwJobDesc jd;
-						jd.o1 = o1; jd.o2 = o2; jd.ops = (int64_t)ops_next; jd.m = m; jd.n = n;
-						ops_next += (unsigned long long)(m + n);
-						a.jobs[job_at] = jd;
-						pc.kind = FP_JOB; pc.v = (int32_t)job_at;
-						job_at++;
-						return true;
-					};
-					if (whole_job) {
-						FragPiece pc;
-						if (!nw_job(task.f1_off, g, rL, gL, pc)) host = true;
-						else a.pieces[first + count++] = pc;
-					} else {
-						for (int i = 0; i < v.num && !host; ++i) {
-							const int prl = v.rLen[i], pgl = v.gLen[i];
-							if (prl <= 0 && pgl <= 0) continue;
-							FragPiece pc;
-							if (pgl == 0) { pc.kind = KG_OP_GAP2; pc.v = prl; }                         // read characters against '-' (:172-176)
-							else if (prl == 0) { pc.kind = KG_OP_GAP1; pc.v = pgl; }                    // '-' against genome characters (:177-181)
-							else if ((prl == 1 && pgl == 1) || v.simple[i]) { pc.kind = KG_OP_DIAG; pc.v = prl; }
-							else if (a.pacbio && (prl > 300 || pgl > 300)) {                          // the recursion, :197
-								const unsigned long long nt = atomicAdd(&a.ctl[FC_TASKS], 1ull);
-								if (nt >= (unsigned long long)a.task_capacity || level + 1 >= kFragMaxDepth) { host = true; break; }
-								FragTask sub;
-								sub.f1_off = task.f1_off + v.rPos[i]; sub.g = g + v.gPos[i]; sub.rL = prl; sub.gL = pgl;
-								sub.first = 0; sub.count = 0; sub.status = 0; sub.root = task.root;
-								a.tasks[nt] = sub;
-								pc.kind = FP_TASK; pc.v = (int32_t)nt;
-							} else if (!nw_job(task.f1_off + v.rPos[i], g + v.gPos[i], prl, pgl, pc)) { host = true; break; }
-							a.pieces[first + count++] = pc;
-						}
+			s_n = host ? -1 : whole_job ? 0 : v.num;
+		}
+		__syncthreads();
+		if (a.prof) c4 = clock64();
+		// ... and the whole wave turns the pairs into the task's pieces: literal runs, NW jobs, sub-tasks -- counted first, reserved with ONE
+		// atomic per list, then written, every lane its own pair (a lane-0 loop over ~27 pairs with a global store each was 95 k of a task's 320 k cycles)
+		const int num = s_n;                                // -1: outside the envelope; 0: one alignment for the whole fragment
+		host = num < 0;
+		int first = 0, count = 0;
+		if (!host) {
+			// what pair i becomes: 0 nothing, 1 literal, 2 NW job, 3 sub-task
+			auto kind_of = [&](int i, int &prl, int &pgl) {
+				if (num == 0) { prl = rL; pgl = gL; return i == 0 ? 2 : 0; }
+				if (i >= num) { prl = pgl = 0; return 0; }
+				prl = s_rLen[i]; pgl = s_gLen[i];
+				if (prl <= 0 && pgl <= 0) return 0;
+				if (pgl == 0 || prl == 0 || (prl == 1 && pgl == 1) || s_simple[i]) return 1;
+				if (a.pacbio && (prl > 300 || pgl > 300)) return 3;                   // the recursion, :197
+				return 2;
+			};
+			const int n_items = num == 0 ? 1 : num;
+			int n_pieces = 0, n_jobs = 0, n_sub = 0;
+			long long n_ops = 0;
+			for (int base = 0; base < n_items; base += 64) {
+				int prl, pgl;
+				const int kd = kind_of(base + lane, prl, pgl);
+				n_pieces += __popcll(__ballot(kd != 0)); n_jobs += __popcll(__ballot(kd == 2)); n_sub += __popcll(__ballot(kd == 3));
+				long long o = kd == 2 ? prl + pgl : 0;
+				for (int off = 32; off > 0; off >>= 1) o += __shfl_xor(o, off);
+				n_ops += o;
+			}
+			unsigned long long piece_at = 0, job_at = 0, ops_at = 0, task_at = 0;
+			if (lane == 0) {
+				piece_at = atomicAdd(&a.ctl[FC_PIECES], (unsigned long long)n_pieces);
+				if (n_jobs) { job_at = atomicAdd(&a.ctl[FC_JOBS], (unsigned long long)n_jobs); ops_at = atomicAdd(&a.ctl[FC_OPS], (unsigned long long)n_ops); }
+				if (n_sub) task_at = atomicAdd(&a.ctl[FC_TASKS], (unsigned long long)n_sub);
+			}
+			piece_at = shfl_u64_frag(piece_at, 0); job_at = shfl_u64_frag(job_at, 0); ops_at = shfl_u64_frag(ops_at, 0); task_at = shfl_u64_frag(task_at, 0);
+			const bool jobs_fit = job_at + (unsigned long long)n_jobs <= (unsigned long long)a.job_capacity;
+			const bool room = piece_at + (unsigned long long)n_pieces <= (unsigned long long)a.piece_capacity && jobs_fit &&
+			                  ops_at + (unsigned long long)n_ops <= (unsigned long long)a.ops_capacity &&
+			                  (n_sub == 0 || (task_at + (unsigned long long)n_sub <= (unsigned long long)a.task_capacity && level + 1 < kFragMaxDepth));
+			if (!room) {
+				host = true;
+				// (the job slots reserved above stay behind: empty jobs, so that the NW kernels find nothing in them; sub-task slots beyond the
+				//  capacity were never written, the ones inside it become tasks of nothing)
+				if (jobs_fit)
+					for (int j = lane; j < n_jobs; j += 64) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[job_at + (unsigned long long)j] = jd; }
+				for (int j = lane; j < n_sub; j += 64)
+					if (task_at + (unsigned long long)j < (unsigned long long)a.task_capacity) {
+						FragTask sub;
+						sub.f1_off = task.f1_off; sub.g = g; sub.rL = 0; sub.gL = 0; sub.first = 0; sub.count = 0; sub.status = 0; sub.root = task.root;
+						a.tasks[task_at + (unsigned long long)j] = sub;
 					}
-					// (a task that gave up half way leaves reserved job slots behind: empty jobs, so that the NW kernels find nothing in them)
-					if (room)
-						for (; job_at < job_end; ++job_at) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[job_at] = jd; }
+			} else {
+				first = (int)piece_at;
+				count = n_pieces;
+				unsigned long long p_run = piece_at, j_run = job_at, o_run = ops_at, t_run = task_at;
+				for (int base = 0; base < n_items; base += 64) {
+					const int i = base + lane;
+					int prl, pgl;
+					const int kd = kind_of(i, prl, pgl);
+					const uint64_t mp = __ballot(kd != 0), mj = __ballot(kd == 2), ms = __ballot(kd == 3);
+					const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+					long long o = kd == 2 ? prl + pgl : 0, incl = o;                    // exclusive prefix of the op bytes of the jobs before this lane
+					for (int off = 1; off < 64; off <<= 1) { long long t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+					const int64_t rp = num == 0 ? 0 : s_rPos[i < num ? i : 0], gp = num == 0 ? 0 : s_gPos[i < num ? i : 0];
+					if (kd != 0) {
+						FragPiece pc;
+						if (kd == 1) {
+							if (pgl == 0) { pc.kind = KG_OP_GAP2; pc.v = prl; }                 // read characters against '-' (:172-176)
+							else if (prl == 0) { pc.kind = KG_OP_GAP1; pc.v = pgl; }            // '-' against genome characters (:177-181)
+							else { pc.kind = KG_OP_DIAG; pc.v = prl; }                          // one base each, or an exact match
+						} else if (kd == 2) {
+							const unsigned long long jx = j_run + (unsigned long long)__popcll(mj & below);
+							NwJobDesc jd;
+							jd.o1 = task.f1_off + rp; jd.o2 = g + gp; jd.ops = (int64_t)(o_run + (unsigned long long)(incl - o)); jd.m = prl; jd.n = pgl;
+							a.jobs[jx] = jd;
+							pc.kind = FP_JOB; pc.v = (int32_t)jx;
+						} else {
+							const unsigned long long tx = t_run + (unsigned long long)__popcll(ms & below);
+							FragTask sub;
+							sub.f1_off = task.f1_off + rp; sub.g = g + gp; sub.rL = prl; sub.gL = pgl;
+							sub.first = 0; sub.count = 0; sub.status = 0; sub.root = task.root;
+							a.tasks[tx] = sub;
+							pc.kind = FP_TASK; pc.v = (int32_t)tx;
+						}
+						a.pieces[p_run + (unsigned long long)__popcll(mp & below)] = pc;
+					}
+					p_run += (unsigned long long)__popcll(mp); j_run += (unsigned long long)__popcll(mj); t_run += (unsigned long long)__popcll(ms);
+					o_run += (unsigned long long)__shfl(incl, 63);
 				}
 			}
+		}
+		if (lane == 0) {
 			task.first = first; task.count = host ? 0 : count; task.status = host ? 1 : 0;
 			if (host) a.status[task.root] = 1;                                              // the whole request goes back to the caller
 			if (a.prof) {

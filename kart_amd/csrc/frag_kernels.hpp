@@ -35,6 +35,7 @@ struct FragArgs {
 	const uint8_t *text;            // 2-bit text of the index
 	int64_t two_genome_size;
 	int pacbio, max_gaps;
+	int no_fast_pairs;              // KG_FRAG_NO_FAST_PAIRS (A/B aid): IdentifyNormalPairs always by lane 0
 	int prof;                       // KG_FRAG_PROF: wave cycles per phase of the partition kernel into ctl[FC_PROF ..]
 	// work lists
 	FragTask *tasks;
