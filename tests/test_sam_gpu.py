@@ -71,6 +71,17 @@ def test_live_reference_pacbio_7kb(product_binary, tmp_path):
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1]
+    # the long-read pipeline under small batches and slices (several batches, several fragment calls per batch, 1 .. 3 of them in
+    # flight, batches doubling), with the fragment pairs planned by the host, and with IdentifyNormalPairs on lane 0 only: same bytes
+    for env in ({"KART_AMD_PACBIO_CHUNKS": "8", "KART_AMD_FRAG_SLICE": "4", "KART_AMD_FRAG_DEPTH": "1"},
+                {"KART_AMD_PACBIO_CHUNKS": "8", "KART_AMD_FRAG_SLICE": "4", "KART_AMD_FRAG_DEPTH": "2"},
+                {"KART_AMD_PACBIO_CHUNKS": "4", "KART_AMD_PACBIO_MAX_CHUNKS": "16", "KART_AMD_FRAG_SLICE": "6", "KART_AMD_FRAG_DEPTH": "3"},
+                {"KART_AMD_HOST_FRAGMENTS": "1"}, {"KG_FRAG_NO_FAST_PAIRS": "1"}):
+        out = str(tmp_path / "variant.sam")
+        r = subprocess.run([product_binary, "-silent", "-i", SMALL_PREFIX, "-f", fq, "-pacbio", "-o", out, "-t", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, (env, r.stdout.decode()[-400:])
+        assert open(out, "rb").read() == outs[0], env
 
 
 def test_live_reference_pacbio_unseeded_stretch_over_7000(product_binary, tmp_path):
