@@ -1201,7 +1201,9 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 	unsigned long long n_tasks = a.ctl[4];
 	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
 	const int64_t n_all = a.n_cands + (int64_t)n_tasks;                          // chained candidates, then the slots of the rescue windows
-	for (; cand < n_all; cand += stride) {
+	for (int64_t slot = cand; slot < n_all; slot += stride) {
+		// (binned: lanes of a wave then hold candidates with the same number of seeds -- the loops below run equally long)
+		cand = a.plan_order ? (int64_t)a.plan_order[slot] : slot;
 		a.rep_score[cand] = 0; a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
 		const int64_t r = a.c_read[cand];
 		if (a.r_host[r]) continue;
@@ -1662,6 +1664,63 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 	}
 }
 
+// The order in which aln_plan_kernel takes the candidates: four bins by the number of seeds (none or one / two / three / more), each
+// block a contiguous range of candidates -- pass 0 counts the bins (ctl[24..27]), pass 1 places the indices (ctl[28..31] run along).
+__device__ __forceinline__ int plan_bin(const AlnArgs &a, int64_t cand)
+{
+	const int64_t r = a.c_read[cand];
+	if (a.r_host[r] || a.c_score[cand] == 0) return 0;
+	const int n = cand < a.n_cands ? a.cands[cand].count : a.resc_count[cand - a.n_cands];
+	return n <= 1 ? 0 : n == 2 ? 1 : n == 3 ? 2 : 3;
+}
+
+__global__ __launch_bounds__(256) void aln_bin_kernel(AlnArgs a, int pass)
+{
+	__shared__ unsigned int s_cnt[4];
+	__shared__ unsigned long long s_next[4];
+	unsigned long long n_tasks = a.ctl[4];
+	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
+	const int64_t n_all = a.n_cands + (int64_t)n_tasks;
+	const int64_t per = (n_all + gridDim.x - 1) / gridDim.x;
+	const int64_t b0 = (int64_t)blockIdx.x * per, b1 = b0 + per < n_all ? b0 + per : n_all;
+	if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	unsigned int mine[4] = {0, 0, 0, 0};
+	for (int64_t c = b0 + threadIdx.x; c < b1; c += blockDim.x) mine[plan_bin(a, c)]++;
+#pragma unroll
+	for (int b = 0; b < 4; ++b) {
+		unsigned int v = mine[b];
+		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+		if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt[b], v);
+	}
+	__syncthreads();
+	if (pass == 0) {
+		if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&a.ctl[24 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+		return;
+	}
+	if (threadIdx.x < 4) {
+		unsigned long long base = 0;
+		for (int b = 0; b < (int)threadIdx.x; ++b) base += a.ctl[24 + b];
+		s_next[threadIdx.x] = base + (s_cnt[threadIdx.x] ? atomicAdd(&a.ctl[28 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]) : 0ull);
+	}
+	__syncthreads();
+	for (int64_t base = b0; base < b1; base += blockDim.x) {
+		const int64_t c = base + threadIdx.x;
+		const int bin = c < b1 ? plan_bin(a, c) : -1;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const uint64_t mask = __ballot(bin == b);
+			if (mask == 0) continue;
+			const int leader = __ffsll((unsigned long long)mask) - 1;
+			unsigned long long at = 0;
+			if ((int)(threadIdx.x & 63) == leader) at = atomicAdd(&s_next[b], (unsigned long long)__popcll(mask));
+			at = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(at >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)at, leader);
+			const uint64_t below = (threadIdx.x & 63) == 0 ? 0ull : (~0ull >> (64 - (threadIdx.x & 63)));
+			if (bin == b) a.plan_order[at + (unsigned long long)__popcll(mask & below)] = (int32_t)c;
+		}
+	}
+}
+
 __global__ void aln_reset_kernel(AlnArgs a)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1670,6 +1729,7 @@ __global__ void aln_reset_kernel(AlnArgs a)
 	if (i == 0) { a.ctl[21] += a.ctl[0]; a.ctl[22] += a.ctl[1]; a.ctl[23] += a.ctl[5]; }
 	__syncthreads();
 	if (i < 8) a.ctl[i] = 0;
+	if (i >= 24 && i < 32) a.ctl[i] = 0;
 	for (int c = i; c < a.n_chunks; c += gridDim.x * blockDim.x) {
 		kg_chunk_stats z;
 		z.paired = 0; z.distance = 0; z.lo = -1; z.hi = 0x7fffffffffffffffll; z.unmapped = 0; z.unique = 0; z.host_pairs = 0; z.rescue_wanted = 0;
@@ -1693,6 +1753,10 @@ hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 	hipLaunchKernelGGL(aln_rescue_kernel, dim3(grid_for_aln(a.task_capacity, 1, n_cu * 32)), dim3(64), 0, stream, a);
 	hipLaunchKernelGGL(aln_post_rescue_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
 	if (a.n_cands > 0) {
+		if (a.plan_order) {
+			hipLaunchKernelGGL(aln_bin_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 8)), dim3(256), 0, stream, a, 0);
+			hipLaunchKernelGGL(aln_bin_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 8)), dim3(256), 0, stream, a, 1);
+		}
 		hipLaunchKernelGGL(aln_plan_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
 		hipLaunchKernelGGL(aln_partition_kernel, dim3(grid_for_aln(a.n_cands / 8 + 1, 256, n_cu * 8)), dim3(256), 0, stream, a);
 	}
