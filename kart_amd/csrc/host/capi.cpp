@@ -78,7 +78,7 @@ int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
 	if (opt.shard_rank == 0 || opt.parts) {
 		out = kart::open_output(opt.parts && opt.shard_count > 1 ? opt.out_name + "." + std::to_string(opt.shard_rank) : opt.out_name);
 		if (!out) {
-			if (opt.shard_count > 1) kart::shard_mark_failed(opt.rendezvous);
+			if (opt.shard_count > 1) kart::shard_mark_failed(opt.rendezvous, opt.shard_rank);
 			return fail("kh_map: cannot open [%s]", opt.out_name.c_str());
 		}
 	}
@@ -86,7 +86,7 @@ int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
 	auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
 	double t0 = now();
 	rc = kart::run_mapping(opt, s->ref, *s->kern, out, st);
-	if (rc != 0 && opt.shard_count > 1) kart::shard_mark_failed(opt.rendezvous);     // the other shards stop waiting for this one
+	if (rc != 0 && opt.shard_count > 1) kart::shard_mark_failed(opt.rendezvous, opt.shard_rank);     // the other shards stop waiting for this one
 	double t1 = now();
 	if (out) fclose(out);
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "kh_map: run_mapping %.3f s (its own mapping seconds %.3f), closing the output %.3f s\n", t1 - t0, st.map_seconds, now() - t1);
@@ -101,7 +101,9 @@ int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
 		stats->search_useful_bytes = st.device.search_useful_bytes;
 		stats->text_in_bytes = st.device.text_in_bytes; stats->text_out_bytes = st.device.text_out_bytes;
 	}
-	return rc == 0 ? 0 : fail("kh_map: mapping failed");
+	if (rc == 0) return 0;
+	const std::string why = kart::run_error_message();
+	return why.empty() ? fail("kh_map: mapping failed") : fail("kh_map: %s", why.c_str());
 }
 
 void kh_close(kh_session *s) { delete s; }

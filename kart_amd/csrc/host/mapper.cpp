@@ -16,12 +16,14 @@
 #include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/statvfs.h>
+#include <sys/vfs.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstdarg>
 #include <cstdlib>
 #include <atomic>
 #include <climits>
@@ -146,13 +148,14 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	struct rusage ru0;
 	getrusage(RUSAGE_SELF, &ru0);
 	g_sections = getenv("KART_AMD_VERBOSE") != nullptr;
-	if (const char *uf = getenv("KART_AMD_UNSET_FLAG")) g_unset_flag = atoi(uf);
+	{ const char *uf = getenv("KART_AMD_UNSET_FLAG"); g_unset_flag = uf ? atoi(uf) : 0; }      // (per run: a session maps several)
+	run_error_reset();
 	g_check_align = getenv("KART_AMD_CHECK_ALIGN") != nullptr;
 	// (a sharded run: every process takes L3 domains of its own)
-	g_io_cpus = detect_io_cpus(std::max(0, opt.shard_rank));
+	g_io_cpus = detect_io_cpus(opt.shard_count > 1 ? opt.shard_rank : -1);
 	g_lane_cpus = IoCpus();
 	if (const char *e = getenv("KART_AMD_LANE_CPUS"))
-		if (!strcmp(e, "next") && g_io_cpus.valid && opt.shard_count <= 1) g_lane_cpus = detect_io_cpus(1);
+		if (!strcmp(e, "next") && g_io_cpus.valid && opt.shard_count <= 1) g_lane_cpus = detect_io_cpus(-2);
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	cx.frag_service = opt.pacbio && kern.has_fragments();
 	Options &o = const_cast<Options &>(opt);
@@ -274,7 +277,13 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		fprintf(stdout, "worker thread-seconds:");
 		for (int i = 0; i < 6; ++i) fprintf(stdout, " %s %.2f%s", g_sec_name[i], 1e-9 * (double)g_sec_ns[i].load(), i < 5 ? " |" : "\n");
 	}
-	return 0;
+	return run_failed() ? 1 : 0;
+}
+
+std::string run_error_message()
+{
+	std::lock_guard<std::mutex> lk(g_run_err_mu);
+	return g_run_err;
 }
 
 FILE *open_output(const std::string &path)
@@ -302,9 +311,16 @@ bool shard_totals(const std::string &rendezvous, int shard_count, Stats &sum)
 	return ok;
 }
 
-void shard_mark_failed(const std::string &rendezvous)
+void shard_mark_failed(const std::string &rendezvous, int rank)
 {
-	if (Rendezvous *rv = rendezvous_open(rendezvous)) { rv->failed.store(1); munmap(rv, sizeof(Rendezvous)); }
+	if (Rendezvous *rv = rendezvous_open(rendezvous)) {
+		rv->failed.store(1);
+		// (a process that fails while it holds the output file's turn must not keep the others out of it)
+		int32_t mine = rank + 1;
+		if (rank >= 0) rv->file_turn.compare_exchange_strong(mine, 0);
+		else rv->file_turn.store(0);
+		munmap(rv, sizeof(Rendezvous));
+	}
 }
 
 }  // namespace kart

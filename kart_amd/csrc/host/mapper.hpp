@@ -174,7 +174,8 @@ struct Stats {
 
 // the run-wide totals of a sharded run, summed from the rendezvous block once every shard has finished
 bool shard_totals(const std::string &rendezvous, int shard_count, Stats &sum);
-void shard_mark_failed(const std::string &rendezvous);
+void shard_mark_failed(const std::string &rendezvous, int rank = -1);   // rank >= 0: gives up that process's turn at the output file; -1: whoever holds it
+std::string run_error_message();       // why the last run_mapping() returned non-zero (empty: no recorded reason)
 
 // Mapping() of the reference: maps every input library and writes SAM to `out`.
 // Returns 0 on success; `summary` receives the reference's end-of-run statistics.

@@ -26,8 +26,11 @@ def allreduce_counters(counters, device=None):
     return [int(x) for x in t.tolist()]
 
 
-def max_over_ranks(value: float, device=None) -> float:
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+def max_over_ranks(value, device=None):
+    """Element-wise maximum over all ranks of a float or a list of floats (the per-step wall times of a run: a step lasts as
+    long as its slowest rank)."""
+    scalar = not isinstance(value, (list, tuple))
+    t = torch.tensor([value] if scalar else list(value), dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return float(t[0].item()) if scalar else [float(x) for x in t.tolist()]

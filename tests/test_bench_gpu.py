@@ -21,9 +21,17 @@ def _bench(args, env=None, tmp=None):
     e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
-    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout.decode()[-2000:]
-    return json.loads(lines[0])
+    lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    # the headline line (value + roofline + cpu_baseline, flushed before the side legs run) and the final, enriched one; a run
+    # without side legs prints the final line only
+    assert 1 <= len(lines) <= 2 and lines[-1]["line"] == "final", r.stdout.decode()[-2000:]
+    if len(lines) == 2:
+        head, last = lines
+        assert head["line"].startswith("headline")
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline"):
+            assert head[k] == last[k] or k == "config", k
+        assert ("cpu_baseline" in head) == ("cpu_baseline" in last)
+    return lines[-1]
 
 
 def test_bench_line_contract(tmp_path):
@@ -31,7 +39,9 @@ def test_bench_line_contract(tmp_path):
     assert KEYS <= set(d), sorted(KEYS - set(d))
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["higher_is_better"] is True
     assert d["unit"] == "reads/s" and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert abs(d["value"] - 120000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # value = whole-job reads / step time
+    assert abs(d["value"] - d["mapped_reads_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]          # value = whole-job mapped reads / step time
+    assert d["config"]["bracket_seconds"] >= d["ms_per_step"] * 1e-3 * d["steps"] * 0.999     # the K steps lie inside the barrier-to-barrier bracket
+    assert d["config"]["peak_shmem_GB"] >= 0 and d["config"]["host_memory_GB"]["usable"] > 0 and "TWO step outputs" in d["config"]["sizing"]
     assert "FASTQ -> SAM" in d["config"]["workload"] and "model" not in d["config"] and d["config"]["fallback"] is None
     assert 0.5 < d["mapped_fraction"] <= 1.0
     r = d["roofline"]

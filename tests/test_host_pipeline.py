@@ -252,6 +252,26 @@ def test_cli_error_behaviour(host_oracle_binary, tmp_path):
     assert "Cannot open file [/nonexistent_dir/x.sam]" in err
 
 
+def test_output_errors_are_a_status_not_an_exit_inside_the_library(host_oracle_binary, tmp_path):
+    """a write error (ENOSPC from /dev/full) and an output in tmpfs that the host's memory cannot hold end the run with a message
+    and a non-zero status through run_mapping()'s return value (the free-space check used to call exit(), and it
+    tripped on file systems that report no size)"""
+    args = [materialise(str(tmp_path), a) if a.endswith((".fq", ".fa", ".gz")) else a for a in CASES["pe"]]
+    r = subprocess.run([host_oracle_binary, "-silent", "-t", "4", "-i", SMALL_PREFIX] + args + ["-o", "/dev/full"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 1 and b"Error! write to the output" in r.stderr, (r.returncode, r.stderr[-300:])
+    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
+        out = "/dev/shm/kart_test_nomem_%d.sam" % os.getpid()
+        try:
+            env = dict(os.environ, KART_AMD_MEM_RESERVE_MB=str(1 << 40))       # nobody has that much: the gate must trip, politely
+            r = subprocess.run([host_oracle_binary, "-silent", "-t", "4", "-i", SMALL_PREFIX] + args + ["-o", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+            assert r.returncode == 1 and b"the host cannot hold it" in r.stderr, (r.returncode, r.stderr[-300:])
+            r = subprocess.run([host_oracle_binary, "-silent", "-t", "4", "-i", SMALL_PREFIX] + args + ["-o", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            assert r.returncode == 0 and open(out, "rb").read() == gzip.open(os.path.join(SAM, "pe.sam.gz")).read()
+        finally:
+            if os.path.exists(out):
+                os.remove(out)
+
+
 def test_output_to_a_pipe(host_oracle_binary, tmp_path):
     """a FIFO cannot be seeked: the writer must fall back from parallel pwrite to one sequential stream"""
     import threading
