@@ -8,25 +8,38 @@
 Metric (BASELINE.json): mapped reads/sec of the whole job, 150 bp paired-end on hg38 (configs[2]).  There is no network for
 the real FASTA, so a seeded hg38-SIZED synthetic genome stands in (3.1 Gbp in 24 contigs behind a 2 kb decoy, 45 % of it
 mutated copies of a 300 bp and a 6 kb repeat family, generated on the device); its FM-index (2L = 6.2 G symbols) is built by
-kart_amd.index_build on the GPU and loaded with the full suffix array, the 2-bit text, the 4^16-entry q-mer table and the two- / three-step rank planes (168 GB
-of HBM per GPU).  10 M read pairs (20 M reads, 1 % substitution errors + 0.1 % haplotype substitutions) are written as two
-FASTQ files.  `KART_REF_FASTA=<fa>` benchmarks a real reference instead; `--genome-len` selects another synthetic size; if the
-large index cannot be built on the machine a single-rank run falls back to configs[1] and says so in config.fallback.
+kart_amd.index_build on the GPU and loaded with the full suffix array, the 2-bit text, the 4^16-entry q-mer table and the two- /
+three-step rank planes (168 GB of HBM per GPU; --sa compact: 67 GB).  configs[2] names 100 M reads: 50 M read pairs (1 % substitution
+errors + 0.1 % haplotype substitutions) are written as two FASTQ files (32 GB) when the HOST can hold them and two outputs
+(see "Footprint"), otherwise fewer; `--pairs` fixes the number.  `KART_REF_FASTA=<fa>` benchmarks a real reference instead;
+`--genome-len` selects another synthetic size; if the large index cannot be built on the machine a single-rank run falls back
+to configs[1] and says so in config.fallback.
 
 One "step" = one complete mapping run over those files -- the reference's Mapping() (src/Mapping.cpp:639-742): FASTQ parsed,
-seeds found (FM-index search + SA locate + sort), chained, paired / rescued, gaps closed (NW), SAM text written to the output
+seeds found (FM-index search + SA locate + sort), chained, paired / rescued, gaps closed (NW), SAM text written to a FRESH output
 file -- through the host library (include/kart_host.h: index resident across runs, as the metric excludes the index load).
-`value` = reads of the whole job / wall time, max over ranks, first read in to last SAM byte written.  With N ranks the SAME
-20 M reads are split into N contiguous chunk ranges, one process + one GPU + one index replica each (strong scaling), the
+`value` = mapped reads of the K timed steps / the sum of their wall times (every step bracketed by torch.cuda.synchronize, max
+over ranks per step); the whole loop is bracketed by a barrier + synchronize on both sides (config.bracket_seconds).  With N ranks
+the SAME reads are split into N contiguous chunk ranges, one process + one GPU + one index replica each (strong scaling), the
 output byte-identical to one process mapping everything; RCCL carries only the final counter all-reduce.
 
-The line also carries: `roofline` for the dominant GPU kernel, taken FROM THE TIMED REGION (search_kernel: bytes the IMPLEMENTED
-search needs -- exported by the kernel itself, kg_workspace_traffic -- summed over the launches of the timed steps, over the sum
-of their HIP-event durations on the lanes' streams, against the 8 TB/s HBM peak; `traffic` from the committed PMC pass of this
-command when there is one), `seeding_stage` (the GPU seeding step alone on HBM-resident reads in ONE launch of 20 M reads -- a
-sub-field with its own roofline), `other_configs` (configs[4] -m and configs[3] -pacbio through the same session), `cpu_baseline` (the unmodified reference binary at -t <host quota> on a bounded prefix of
-the same files, same box, same run) and `parity` (SAM byte identity with the reference's -t 1 on a 0.5 M-read prefix, and
-GPU seeds == CPU oracle on a random 200 k-read sample).  Rank 0 at N = 1 only for everything but `value`.
+Footprint (round 3 lost its GPU box here): the files live in /dev/shm, i.e. in RAM charged to this process group.  The job is sized
+from min(MemAvailable, cgroup memory.max - memory.current) -- not from the tmpfs's nominal size -- so that FASTQ + TWO step
+outputs stay within 40 % of it; at most two step outputs ever exist (all but the newest are removed between the steps, outside the
+per-step timers), they are gone before the side legs write their own files, and the observed Shmem high-water mark is reported
+(config.peak_shmem_GB).  With N ranks the figure is the same (the FASTQ is written once, the N parts add up to one output); each
+rank adds its host copy of the reference (2 B per base: 6.2 GB) and ~4 GB of page-locked lane buffers.
+
+The JSON line is printed TWICE: the headline (value, roofline from the timed region, cpu_baseline) as soon as those exist, flushed,
+and the same line enriched by the side legs at the very end ("line": "final") -- a leg that dies late cannot cost the measurement.
+It carries: `roofline` for the dominant GPU kernel, taken FROM THE TIMED REGION (search_kernel: bytes the IMPLEMENTED search needs --
+exported by the kernel itself, kg_workspace_traffic -- summed over the launches of the timed steps, over the sum of their HIP-event
+durations on the lanes' streams, against the 8 TB/s HBM peak; `traffic` from the committed PMC pass of this command when there is
+one), `cpu_baseline` (the unmodified reference binary at -t <host quota> on a bounded prefix of the same files, same box, same run),
+then `parity` (SAM byte identity with the reference's -t 1 on a 0.3 M-read prefix, and GPU seeds == CPU oracle on a random 200 k-read
+sample; the 0.5 M-read / -m / -pacbio identities on this index are tests/test_hg38_gpu.py), `other_configs` (configs[4] -m and
+configs[3] -pacbio through the same session), `seeding_stage` (the GPU seeding step alone on HBM-resident reads in ONE launch of 20 M
+reads -- a sub-field with its own roofline) and `nw_kernels`.  Rank 0 at N = 1 only for everything but `value`.
 """
 import argparse
 import json

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -137,6 +138,17 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise KartAmdError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+    # ONE HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's); if
+    # this library is loaded first it pulls in /opt/rocm's copies, a later `import torch` adds its own, and whichever of the two
+    # runtimes touches the device second finds none (measured on the GPU box: kg_device_count() == 0 while torch computes,
+    # tools/probe_fork_hip.py).  Loaded after torch, the library resolves to torch's copies and both share the device.  A process
+    # that has PyTorch installed and may use it (index_build, bench.py, the tests) therefore imports it before this library;
+    # KART_AMD_NO_TORCH=1 skips that for a torch-free embedding.
+    if "torch" not in sys.modules and not os.environ.get("KART_AMD_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     L.kg_last_error.restype = C.c_char_p
     L.kg_index_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]

@@ -38,6 +38,7 @@ def hg38(built_lib):
     if torch.cuda.get_device_properties(0).total_memory < (100 << 30):
         pytest.skip("the hg38-sized index needs 67 GB of device memory")
     dev = torch.device("cuda", 0)
+    assert api.device_count() > 0
     args = argparse.Namespace(genome_len=bench.HG38_LEN, bucketed=None, repeat_frac=0.45)
     workdir = bench.pick_workdir(12 << 30)
     os.makedirs(workdir, exist_ok=True)
@@ -51,6 +52,7 @@ def hg38(built_lib):
     bench.write_long_reads(codes, 1000, 7000, 31, files["long"][0], dev)                            # ... of its configs[3] file
     del codes
     torch.cuda.empty_cache()
+    assert api.device_count() > 0, "the library lost the device after the read generators"
 
     # the reference, four runs at once (-t 1 each: with more threads it prints the chunks in completion order)
     def ref(name, flags, inputs, env=None):
@@ -63,6 +65,7 @@ def hg38(built_lib):
     procs = {"pe": ref("pe", [], files["pe"]), "mh85": ref("mh85", ["-m"], files["mh"], perturb(85)), "mh170": ref("mh170", ["-m"], files["mh"], perturb(170)),
              "long": ref("long", ["-pacbio"], files["long"])}
 
+    assert api.device_count() > 0, "the library lost the device after starting the reference processes"
     # the product meanwhile: one session, the three runs through the host library (kh_map)
     os.environ["KART_AMD_SA"] = "compact"
     try:
