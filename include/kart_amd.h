@@ -303,6 +303,11 @@ typedef struct {
 	int64_t max_reads;       /* reads per batch the lanes are sized for */
 	int64_t max_window;      /* bytes of FASTQ text per file and batch (the staging buffers' size) */
 	int32_t lanes;           /* batches in flight */
+	int32_t seed_group;      /* > 1: ONE seeding launch (FM-index search, locate, sort) over the parsed batches of this many lanes -- lanes
+	                            [g * seed_group, (g + 1) * seed_group) form group g; must divide `lanes`, at most 8.  A search launch costs
+	                            ~0.65 ms + 0.52 ms per M reads, so four lanes' 1 M-read batches in one launch take what 1.6 of them take
+	                            alone; chaining, the report and the text keep the lanes' granularity (the reference's N workers on N
+	                            chunks, src/Mapping.cpp:716-717).  0 / 1: every lane seeds its own batch */
 } kg_stream_config;
 int   kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out);
 void  kg_stream_close(kg_stream *s);
@@ -353,6 +358,12 @@ typedef struct {
 /* seeding (FastMode), chaining, the per-read report (kg_align_batch) and the SAM text for the batch kg_stream_parse left in the
  * lane.  The result's arrays belong to the lane: valid until its next kg_stream_parse. */
 int   kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream_result *out);
+/* Seeding groups (seed_group > 1) work in ROUNDS: in every round each lane of a group either calls kg_stream_map with a parsed batch --
+ * the call returns when the round's one seeding launch is done -- or is absent.  rounds > 0: lane `lane` has no batch for that many
+ * rounds; < 0: until further notice (its input has ended); 0: it takes part again (call it for every lane before a run; also clears an
+ * abort).  kg_stream_group_abort wakes every lane that waits for its group with an error (a caller's failure path). */
+int   kg_stream_group_absent(kg_stream *s, int lane, int rounds);
+int   kg_stream_group_abort(kg_stream *s);
 /* test aid: the reads of the parsed batch as the seeding stage sees them (characters, offsets[n_reads + 1]); enc may be NULL */
 int   kg_stream_fetch_reads(kg_stream *s, int lane, uint8_t *enc, int64_t *read_off);
 

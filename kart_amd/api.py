@@ -42,6 +42,7 @@ ABI_SYMBOLS = (
     "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_set_single_steps", "kg_index_selfcheck", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_align_batch", "kg_align_reasons", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
     "kg_fragments_batch",
     "kg_stream_open", "kg_stream_close", "kg_stream_staging", "kg_stream_upload", "kg_stream_parse", "kg_stream_map", "kg_stream_fetch_reads", "kg_stream_timing",
+    "kg_stream_group_absent", "kg_stream_group_abort",
 )
 
 
@@ -97,7 +98,7 @@ class Traffic(C.Structure):
 
 
 class StreamConfig(C.Structure):
-    _fields_ = [("max_reads", C.c_int64), ("max_window", C.c_int64), ("lanes", C.c_int32)]
+    _fields_ = [("max_reads", C.c_int64), ("max_window", C.c_int64), ("lanes", C.c_int32), ("seed_group", C.c_int32)]
 
 
 class StreamWindow(C.Structure):
@@ -187,6 +188,8 @@ def load_library() -> C.CDLL:
     L.kg_stream_parse.argtypes = [C.c_void_p, C.c_int, C.POINTER(StreamWindow), C.POINTER(StreamParsed)]
     L.kg_stream_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(StreamParams), C.POINTER(StreamResult)]
     L.kg_stream_fetch_reads.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.kg_stream_group_absent.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.kg_stream_group_abort.argtypes = [C.c_void_p]
     L.kg_stream_timing.argtypes = [C.c_void_p, C.POINTER(StreamTiming), C.c_int]
     _lib = L
     return L
@@ -424,10 +427,10 @@ class Index:
 class Stream:
     """kg_stream_*: FASTQ text in, SAM text out (GetNextChunk ... Output*Alignments of the reference on the device)."""
 
-    def __init__(self, index: "Index", max_reads: int = 16000, max_window: int = 8 << 20, lanes: int = 1):
+    def __init__(self, index: "Index", max_reads: int = 16000, max_window: int = 8 << 20, lanes: int = 1, seed_group: int = 0):
         self.lib = load_library()
         self.index = index
-        cfg = StreamConfig(max_reads, max_window, lanes)
+        cfg = StreamConfig(max_reads, max_window, lanes, seed_group)
         h = C.c_void_p()
         _check(self.lib.kg_stream_open(index.h, C.byref(cfg), C.byref(h)), "kg_stream_open")
         self.h = h
@@ -437,6 +440,10 @@ class Stream:
         if self.h:
             self.lib.kg_stream_close(self.h)
             self.h = None
+
+    def group_absent(self, lane: int, rounds: int):
+        """seeding groups: lane `lane` has no batch for `rounds` rounds (< 0: until further notice, 0: it takes part again)"""
+        _check(self.lib.kg_stream_group_absent(self.h, lane, rounds), "kg_stream_group_absent")
 
     def parse(self, text1: bytes, text2: bytes | None = None, paired: bool = True, chunk_reads: int = 4000, want_reads: int | None = None,
               eof=(True, True), begin=(0, 0), lane: int = 0) -> StreamParsed:

@@ -622,6 +622,14 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.seed_off = d_seed_offsets;
 	a.seeds = d_seeds;
 	a.seed_capacity = seed_capacity;
+	a.read_len = nullptr; a.n_seg = 0; a.seg_stride = 0;
+	for (int64_t &x : a.seg_prefix) x = 0;
+	if (ws->group_segments > 0) {          // (kgi_seed_group: one launch over several lanes' batches)
+		a.read_len = ws->group_read_len;
+		a.n_seg = ws->group_segments;
+		a.seg_stride = ws->group_stride;
+		for (int i = 0; i <= a.n_seg; ++i) a.seg_prefix[i] = ws->group_prefix[i];
+	}
 	HIP_TRY(launch_seed_batch(a, ws->d_scan_temp, ws->scan_bytes, ws->ix->n_cu, st, ws->profiling ? ws->ev : nullptr));
 	return KG_OK;
 }
@@ -675,6 +683,34 @@ int kgi_seed_resident(kg_workspace *ws, int mode, int min_seed_len, int occ_thr,
 	ws->last_cands = -1;
 	ws->last_ascii = (mode & KG_INPUT_ASCII) != 0;
 	*total_out = total;
+	return KG_OK;
+}
+
+// ONE seeding launch over the parsed batches of several stream lanes (abi_stream.hip): `ws` is the group's workspace, sized for
+// n_seg * stride read slots; ws->d_enc holds segment s's characters in its own part (the lanes materialise straight into it),
+// ws->d_read_off / group_read_len every slot's offset and length (stream_kernels.hip: group_publish_kernel), counts[s] the reads
+// segment s holds this round (0: the lane is absent).  The seeds of the whole group stay in ws->d_seeds / ws->d_seed_off;
+// seed_base[s] (s = 0 .. n_seg) = first seed of segment s, seed_base[n_seg] the total -- the lanes cut their slices out of that.
+int kgi_seed_group(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, int n_seg, int64_t stride, const int64_t *counts, int64_t *seed_base)
+{
+	if (n_seg < 1 || n_seg > kMaxSeedSegments || stride < 1 || (int64_t)n_seg * stride > ws->max_reads) return fail(KG_ERR_ARG, "kgi_seed_group: %d segments of %lld slots do not fit the group's workspace", n_seg, (long long)stride);
+	ws->group_segments = n_seg;
+	ws->group_stride = stride;
+	ws->group_prefix[0] = 0;
+	for (int i = 0; i < n_seg; ++i) {
+		if (counts[i] < 0 || counts[i] > stride) return fail(KG_ERR_ARG, "kgi_seed_group: segment %d holds %lld reads, its slots are %lld", i, (long long)counts[i], (long long)stride);
+		ws->group_prefix[i + 1] = ws->group_prefix[i] + counts[i];
+	}
+	const int64_t n_slots = (int64_t)n_seg * stride;
+	int64_t total = 0;
+	int rc = kgi_seed_resident(ws, mode, min_seed_len, occ_thr, n_slots, ws->max_bases, &total);
+	if (rc != KG_OK) return rc;
+	// the segments' first seeds: seed_off at every segment's first slot (page-locked words 2 .. 2 + n_seg)
+	unsigned long long *h = ws->h_small;
+	for (int i = 0; i < n_seg; ++i) HIP_TRY(hipMemcpyAsync(&h[2 + i], ws->d_seed_off + (int64_t)i * stride, 8, hipMemcpyDeviceToHost, ws->stream));
+	HIP_TRY(kgi_sync(ws));
+	for (int i = 0; i < n_seg; ++i) seed_base[i] = (int64_t)h[2 + i];
+	seed_base[n_seg] = total;
 	return KG_OK;
 }
 

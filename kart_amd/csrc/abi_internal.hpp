@@ -95,6 +95,11 @@ struct kg_workspace {
 	kg_seed *d_seeds = nullptr;
 	int64_t seed_capacity = 0;
 	int64_t last_reads = 0, last_seeds = 0;   // batch the staging buffers currently hold (kg_seed_batch)
+	// a group's workspace (kgi_seed_group): the batch is n segments of `group_stride` read slots, group_prefix = reads before each
+	int group_segments = 0;
+	int64_t group_stride = 0, group_prefix[kMaxSeedSegments + 1] = {0};
+	int32_t *group_read_len = nullptr;        // [max_reads] length of the read in every slot (0: empty)
+	bool enc_borrowed = false;                // d_enc is a part of a group's array (a stream lane): not this workspace's to free
 	kg_candidate *d_cands = nullptr;
 	kg_seed *d_cand_seeds = nullptr;
 	int32_t *d_n_cands = nullptr;
@@ -150,6 +155,7 @@ struct kg_workspace {
 extern "C" {
 KG_INTERNAL hipError_t kgi_sync(kg_workspace *ws);
 KG_INTERNAL int kgi_seed_resident(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, int64_t n_reads, int64_t n_bases, int64_t *total_out);
+KG_INTERNAL int kgi_seed_group(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, int n_seg, int64_t stride, const int64_t *counts, int64_t *seed_base);
 KG_INTERNAL int kgi_chain_resident(kg_workspace *ws, int pacbio, int max_gaps, int64_t totals[2]);
 KG_INTERNAL int kgi_nw_launch(kg_index *ix, NwArgs &a, int64_t max_len, hipStream_t st);
 KG_INTERNAL void kgi_frag_release(kg_index *ix);      // abi_frag.hip: the fragment service's scratches of this index

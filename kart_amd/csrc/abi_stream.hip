@@ -9,6 +9,8 @@
 #include "stream_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -54,6 +56,35 @@ struct Lane {
 	kg_stream_parsed parsed{};
 	bool have_batch = false;
 	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev_parsed = nullptr;                    // the batch is materialised and published to its group (recorded on the lane's stream)
+};
+
+// ONE seeding launch over the parsed batches of `size` lanes (kg_stream_config::seed_group).  The reference's analogue is simply N
+// workers on N chunks (src/Mapping.cpp:716-717); on the device a search launch costs ~0.65 ms + 0.52 ms per M reads -- at 2.5 reads
+// per persistent lane a launch lasts as long as its slowest lanes -- so four lanes' 1 M-read batches in one launch cost what 1.6 of
+// them cost alone, while chaining, the report and the text keep the lanes' granularity.
+// Lanes [first, first + size) share the group: its workspace holds `size` segments of `stride` read slots; lane j materialises its
+// reads straight into segment j of the group's character array and publishes offsets / lengths of its slots (group_publish_kernel).
+// A ROUND: every lane of the group either arrives with a parsed batch (kg_stream_map) or is absent (kg_stream_group_absent); the
+// thread that completes the round launches the seeding of all segments on the group's stream, waits for it and wakes the others;
+// each lane then cuts its seeds out of the group's arrays on its own stream.  A lane can only arrive again after it has finished
+// with the group's arrays, so the next round never overwrites what a slow lane still reads.
+struct SeedGroup {
+	int first = 0, size = 0;
+	int64_t stride = 0, seg_bases = 0;
+	kg_workspace *ws = nullptr;                        // the group's workspace (hits, packed reads, seeds of all segments)
+	unsigned long long *h_ctl = nullptr;               // page-locked: the search kernel's counters of the round
+	std::mutex mu;
+	std::condition_variable cv;
+	int64_t round = 0;
+	int arrived = 0;
+	bool present[kMaxSeedSegments] = {false};
+	int absent_rounds[kMaxSeedSegments] = {0};         // 0: the lane takes part; > 0: absent for that many rounds; < 0: until further notice
+	int64_t n_reads[kMaxSeedSegments] = {0};
+	// results of the last round
+	int rc = KG_OK;
+	int64_t seed_base[kMaxSeedSegments + 1] = {0};
+	bool aborted = false;
 };
 
 }  // namespace
@@ -63,6 +94,7 @@ struct kg_stream {
 	kg_stream_config cfg{};
 	int64_t text_capacity = 0, line_capacity = 0, rec_capacity = 0;
 	std::vector<Lane> lanes;
+	std::vector<std::unique_ptr<SeedGroup>> groups;    // empty: every lane seeds its own batch
 	uint8_t *d_chr_names = nullptr;
 	int32_t *d_chr_name_off = nullptr;
 	int min_seed_len = 13;
@@ -74,6 +106,8 @@ namespace {
 
 void free_lane(Lane &l)
 {
+	if (l.ws && l.ws->enc_borrowed) l.ws->d_enc = nullptr;        // (a part of its group's array)
+	if (l.ev_parsed) (void)hipEventDestroy(l.ev_parsed);
 	if (l.ws) kg_workspace_destroy(l.ws);
 	for (int f = 0; f < 2; ++f) {
 		if (l.d_text[f]) (void)hipFree(l.d_text[f]);
@@ -125,6 +159,9 @@ int kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out)
 	*out = nullptr;
 	if (cfg->lanes < 1 || cfg->lanes > 16 || cfg->max_reads < 2 || cfg->max_window < 4096 || cfg->max_window > 0xF0000000ll)
 		return fail(KG_ERR_ARG, "kg_stream_open: bad configuration (%d lanes, %lld reads, %lld bytes per window)", cfg->lanes, (long long)cfg->max_reads, (long long)cfg->max_window);
+	const int group = cfg->seed_group > 1 ? cfg->seed_group : 0;
+	if (group && (group > kMaxSeedSegments || cfg->lanes % group != 0))
+		return fail(KG_ERR_ARG, "kg_stream_open: seed_group %d must divide the %d lanes and be at most %d", group, cfg->lanes, kMaxSeedSegments);
 	if (!ix->d_text) return fail(KG_ERR_ARG, "kg_stream_open: the index holds no text");
 	HIP_TRY(hipSetDevice(ix->device));
 	std::unique_ptr<kg_stream, void (*)(kg_stream *)> s(new kg_stream(), kg_stream_close);
@@ -149,11 +186,37 @@ int kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out)
 	}
 	s->lanes.resize((size_t)cfg->lanes);
 	const int64_t n = cfg->max_reads;
-	for (Lane &l : s->lanes) {
+	const int64_t seg_bases = (cfg->max_window + 4096 + 64 + 255) & ~255ll;      // a lane's part of its group's character array
+	for (int g = 0; group && g < cfg->lanes / group; ++g) {
+		std::unique_ptr<SeedGroup> sg(new SeedGroup());
+		sg->first = g * group; sg->size = group;
+		sg->stride = n + 8; sg->seg_bases = seg_bases;
+		int rc = kg_workspace_create(ix, sg->stride * group, seg_bases * group, &sg->ws);
+		if (rc != KG_OK) return rc;
+		kg_workspace *gw = sg->ws;
+		HIP_TRY(hipMalloc((void **)&gw->d_enc, (size_t)gw->max_bases + 64));
+		HIP_TRY(hipMalloc((void **)&gw->d_read_off, 8 * (size_t)(gw->max_reads + 1)));
+		HIP_TRY(hipMalloc((void **)&gw->d_seed_off, 8 * (size_t)(gw->max_reads + 1)));
+		HIP_TRY(hipMalloc((void **)&gw->group_read_len, 4 * (size_t)(gw->max_reads + 1)));
+		HIP_TRY(hipMemset(gw->d_enc, 'N', (size_t)gw->max_bases + 64));
+		HIP_TRY(hipMemset(gw->d_read_off, 0, 8 * (size_t)(gw->max_reads + 1)));
+		HIP_TRY(hipMemset(gw->group_read_len, 0, 4 * (size_t)(gw->max_reads + 1)));
+		HIP_TRY(hipHostMalloc((void **)&sg->h_ctl, 8 * kCtlWords, hipHostMallocDefault));
+		(void)kg_workspace_set_profiling(gw, 1);
+		s->groups.push_back(std::move(sg));
+	}
+	for (size_t li = 0; li < s->lanes.size(); ++li) {
+		Lane &l = s->lanes[li];
 		// bases of a batch: what two windows can hold (every read costs its characters twice plus a header)
 		int rc = kg_workspace_create(ix, n + 8, cfg->max_window + 4096, &l.ws);
 		if (rc != KG_OK) return rc;
 		kg_workspace *ws = l.ws;
+		if (group) {
+			SeedGroup &sg = *s->groups[li / (size_t)group];
+			ws->d_enc = sg.ws->d_enc + (int64_t)(li % (size_t)group) * sg.seg_bases;
+			ws->enc_borrowed = true;
+			HIP_TRY(hipEventCreateWithFlags(&l.ev_parsed, hipEventDisableTiming));
+		} else
 		HIP_TRY(hipMalloc((void **)&ws->d_enc, (size_t)ws->max_bases + 64));
 		HIP_TRY(hipMalloc((void **)&ws->d_read_off, 8 * (size_t)(ws->max_reads + 1)));
 		HIP_TRY(hipMalloc((void **)&ws->d_seed_off, 8 * (size_t)(ws->max_reads + 1)));
@@ -198,6 +261,11 @@ void kg_stream_close(kg_stream *s)
 	if (!s) return;
 	(void)hipSetDevice(s->ix->device);
 	for (Lane &l : s->lanes) free_lane(l);
+	for (std::unique_ptr<SeedGroup> &sg : s->groups) {
+		if (sg->ws && sg->ws->group_read_len) { (void)hipFree(sg->ws->group_read_len); sg->ws->group_read_len = nullptr; }
+		if (sg->ws) kg_workspace_destroy(sg->ws);
+		if (sg->h_ctl) (void)hipHostFree(sg->h_ctl);
+	}
 	if (s->d_chr_names) (void)hipFree(s->d_chr_names);
 	if (s->d_chr_name_off) (void)hipFree(s->d_chr_name_off);
 	delete s;
@@ -266,9 +334,107 @@ int kg_stream_parse(kg_stream *s, int lane, const kg_stream_window *w, kg_stream
 		HIP_TRY(hipMemcpyAsync(l.h_rec_hdr[0], a.w[0].rec_hdr, 4 * (size_t)r0, hipMemcpyDeviceToHost, st));
 		if (w->two_files) HIP_TRY(hipMemcpyAsync(l.h_rec_hdr[1], a.w[1].rec_hdr, 4 * (size_t)r0, hipMemcpyDeviceToHost, st));
 	}
+	if (!s->groups.empty() && p.n_reads > 0) {
+		// the batch as a segment of its group's batch: every slot's offset in the group's character array and its length
+		SeedGroup &sg = *s->groups[(size_t)lane / (size_t)s->cfg.seed_group];
+		const int j = lane - sg.first;
+		HIP_TRY(launch_group_publish(ws->d_read_off, p.n_reads, sg.stride, (int64_t)j * sg.seg_bases, sg.ws->d_read_off + (int64_t)j * sg.stride,
+		                             sg.ws->group_read_len + (int64_t)j * sg.stride, s->ix->n_cu, st));
+		HIP_TRY(hipEventRecord(l.ev_parsed, st));
+	}
 	HIP_TRY(hipEventRecord(l.ev[1], st));
 	l.have_batch = p.n_reads > 0;
 	*out = p;
+	return KG_OK;
+}
+
+// the lane's part in a round of its group (see SeedGroup): returns when the round's seeding is done and the lane's seeds lie in its
+// own workspace; *was_leader: this call launched the round (its search kernel counts once in the statistics)
+static int group_seed(kg_stream *s, int lane, int64_t n, int64_t n_bases, int64_t *n_seeds, bool *was_leader, float *search_ms, double *useful_bytes)
+{
+	SeedGroup &sg = *s->groups[(size_t)lane / (size_t)s->cfg.seed_group];
+	Lane &l = s->lanes[(size_t)lane];
+	const int j = lane - sg.first;
+	*was_leader = false;
+	std::unique_lock<std::mutex> lk(sg.mu);
+	if (sg.aborted) return fail(KG_ERR_ARG, "kg_stream_map: the stream's seeding groups were aborted");
+	if (sg.absent_rounds[j] < 0) return fail(KG_ERR_ARG, "kg_stream_map: lane %d was declared absent until further notice (kg_stream_group_absent) and arrives with a batch", lane);
+	// (a lane that sits out a round and is back with a batch before that round has run waits for it)
+	sg.cv.wait(lk, [&]() { return sg.absent_rounds[j] == 0 || sg.aborted; });
+	if (sg.aborted) return fail(KG_ERR_ARG, "kg_stream_map: the stream's seeding groups were aborted");
+	const int64_t my_round = sg.round;
+	sg.present[j] = true;
+	sg.n_reads[j] = n;
+	sg.arrived++;
+	auto complete = [&]() {
+		int accounted = sg.arrived;
+		for (int i = 0; i < sg.size; ++i) accounted += (!sg.present[i] && sg.absent_rounds[i] != 0) ? 1 : 0;
+		return accounted >= sg.size;
+	};
+	auto run_round = [&]() {           // (sg.mu held by the caller; every other lane of the group waits or is absent)
+		kg_workspace *gw = sg.ws;
+		int64_t counts[kMaxSeedSegments];
+		int rc = KG_OK;
+		for (int i = 0; i < sg.size && rc == KG_OK; ++i) {
+			counts[i] = sg.present[i] ? sg.n_reads[i] : 0;
+			if (sg.present[i]) { if (hipStreamWaitEvent(gw->stream, s->lanes[(size_t)(sg.first + i)].ev_parsed, 0) != hipSuccess) rc = fail(KG_ERR_NO_DEVICE, "kg_stream_map: hipStreamWaitEvent"); }
+			else if (hipMemsetAsync(gw->group_read_len + (int64_t)i * sg.stride, 0, 4 * (size_t)sg.stride, gw->stream) != hipSuccess) rc = fail(KG_ERR_NO_DEVICE, "kg_stream_map: hipMemsetAsync");
+		}
+		if (rc == KG_OK) rc = kgi_seed_group(gw, KG_MODE_FAST | KG_INPUT_ASCII, s->min_seed_len, KG_OCC_THR_DEFAULT, sg.size, sg.stride, counts, sg.seed_base);
+		if (rc == KG_OK && (hipMemcpyAsync(sg.h_ctl, gw->d_ctl, 8 * kCtlWords, hipMemcpyDeviceToHost, gw->stream) != hipSuccess || kgi_sync(gw) != hipSuccess))
+			rc = fail(KG_ERR_NO_DEVICE, "kg_stream_map: reading the group's counters back");
+		sg.rc = rc;
+		for (int i = 0; i < sg.size; ++i) {
+			sg.present[i] = false;
+			if (sg.absent_rounds[i] > 0) sg.absent_rounds[i]--;
+		}
+		sg.arrived = 0;
+		sg.round++;
+		sg.cv.notify_all();
+	};
+	// whoever finds the round complete runs it: the lane that arrives last, or -- when an absence completed it -- the first waiting
+	// lane to look (kg_stream_group_absent wakes them).  The wait is bounded: a caller that lets a lane neither arrive nor declare
+	// itself absent would hang the others for ever.
+	const std::chrono::steady_clock::time_point give_up = std::chrono::steady_clock::now() + std::chrono::seconds(600);
+	for (;;) {
+		if (sg.aborted) return fail(KG_ERR_ARG, "kg_stream_map: the stream's seeding groups were aborted");
+		if (sg.round != my_round) break;
+		if (complete()) {
+			run_round();
+			*was_leader = true;
+			if (sg.rc == KG_OK) {
+				kg_workspace *gw = sg.ws;
+				*search_ms = gw->profiling && gw->ev[0] ? elapsed(gw->ev[0], gw->ev[1]) : 0;
+				const unsigned long long *c = sg.h_ctl;
+				const double sa_bytes = s->ix->view.fsa32 ? 4.0 : 8.0;
+				const int64_t reads = gw->group_prefix[sg.size];
+				*useful_bytes = 8.0 * (double)c[17] + 32.0 * (double)c[18] + (double)c[25] + sa_bytes * (double)c[8] + 48.0 * (double)c[20] + 8.0 * (double)c[21] + 20.0 * (double)reads + 32.0 * (double)c[1];
+			}
+			break;
+		}
+		if (sg.cv.wait_until(lk, give_up) == std::cv_status::timeout) {
+			sg.aborted = true;
+			sg.cv.notify_all();
+			return fail(KG_ERR_ARG, "kg_stream_map: lane %d waited 600 s for the other lanes of its seeding group (a lane without a batch must call kg_stream_group_absent)", lane);
+		}
+	}
+	if (sg.rc != KG_OK) return sg.rc;
+	const int64_t first = sg.seed_base[j], count = (j + 1 < sg.size ? sg.seed_base[j + 1] : sg.seed_base[sg.size]) - first;
+	lk.unlock();
+	// ---- the lane's slice: offsets rebased, seeds copied into its own workspace (the group's arrays belong to the next round) ----
+	kg_workspace *ws = l.ws, *gw = sg.ws;
+	if (count > ws->seed_capacity) {
+		if (ws->d_seeds) HIP_TRY(hipFree(ws->d_seeds));
+		ws->d_seeds = nullptr;
+		const int64_t want = std::max<int64_t>(count + count / 4, 8 * ws->max_reads + 1024);
+		HIP_TRY(hipMalloc((void **)&ws->d_seeds, sizeof(kg_seed) * (size_t)want));
+		ws->seed_capacity = want;
+	}
+	HIP_TRY(launch_group_rebase(gw->d_seed_off + (int64_t)j * sg.stride, n, first, ws->d_seed_off, s->ix->n_cu, ws->stream));
+	if (count > 0) HIP_TRY(hipMemcpyAsync(ws->d_seeds, gw->d_seeds + first, sizeof(kg_seed) * (size_t)count, hipMemcpyDeviceToDevice, ws->stream));
+	ws->last_reads = n; ws->last_seeds = count; ws->last_cands = -1; ws->last_ascii = true;
+	(void)n_bases;
+	*n_seeds = count;
 	return KG_OK;
 }
 
@@ -286,9 +452,15 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 	const int n_chunks = (int)l.parsed.n_chunks;
 	// ---- seeding (IdentifySeedPairs_FastMode) and chaining on the resident characters ---------------------------------------
 	int64_t n_seeds = 0, totals[2] = {0, 0};
-	int rc = kgi_seed_resident(ws, KG_MODE_FAST | KG_INPUT_ASCII, s->min_seed_len, KG_OCC_THR_DEFAULT, n, l.parsed.n_bases, &n_seeds);
+	const bool grouped = !s->groups.empty();
+	bool group_leader = false;
+	float group_search_ms = 0;
+	double group_useful = 0;
+	int rc;
+	if (grouped) rc = group_seed(s, lane, n, l.parsed.n_bases, &n_seeds, &group_leader, &group_search_ms, &group_useful);
+	else rc = kgi_seed_resident(ws, KG_MODE_FAST | KG_INPUT_ASCII, s->min_seed_len, KG_OCC_THR_DEFAULT, n, l.parsed.n_bases, &n_seeds);
 	if (rc != KG_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(l.h_ctl, ws->d_ctl, 8 * kCtlWords, hipMemcpyDeviceToHost, st));
+	if (!grouped) HIP_TRY(hipMemcpyAsync(l.h_ctl, ws->d_ctl, 8 * kCtlWords, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipEventRecord(l.ev[2], st));
 	rc = kgi_chain_resident(ws, 0, prm->max_gaps, totals);
 	if (rc != KG_OK) return rc;
@@ -374,18 +546,48 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 	{
 		// what the batch cost on the device, stage by stage, and what its search kernel fetched (kg_workspace_traffic's formula)
 		float sk = 0;
-		if (ws->profiling && ws->ev[0]) sk = elapsed(ws->ev[0], ws->ev[1]);
+		if (!grouped && ws->profiling && ws->ev[0]) sk = elapsed(ws->ev[0], ws->ev[1]);
 		const unsigned long long *c = l.h_ctl;
 		const double sa_bytes = ix->view.fsa32 ? 4.0 : 8.0;
-		const double useful = 8.0 * (double)c[17] + 32.0 * (double)c[18] + (double)c[25] + sa_bytes * (double)c[8] + 48.0 * (double)c[20] + 8.0 * (double)c[21] + 20.0 * (double)n + 32.0 * (double)c[1];
+		double useful = grouped ? 0.0 : 8.0 * (double)c[17] + 32.0 * (double)c[18] + (double)c[25] + sa_bytes * (double)c[8] + 48.0 * (double)c[20] + 8.0 * (double)c[21] + 20.0 * (double)n + 32.0 * (double)c[1];
+		// (a group's launch counts once, with the lane that launched it)
+		if (grouped && group_leader) { sk = group_search_ms; useful = group_useful; }
 		std::lock_guard<std::mutex> lk(s->mu);
 		kg_stream_timing_t &t = s->total;
 		t.batches += 1; t.reads += n;
 		t.parse_ms += elapsed(l.ev[0], l.ev[1]); t.seed_ms += elapsed(l.ev[1], l.ev[2]); t.chain_ms += elapsed(l.ev[2], l.ev[3]);
 		t.align_ms += elapsed(l.ev[3], l.ev[4]); t.format_ms += elapsed(l.ev[4], l.ev[5]); t.copy_ms += elapsed(l.ev[5], l.ev[6]);
-		t.search_kernel_ms += sk; t.search_kernel_launches += 1; t.search_useful_bytes += useful;
+		t.search_kernel_ms += sk; t.search_kernel_launches += (!grouped || group_leader) ? 1 : 0; t.search_useful_bytes += useful;
 		t.text_in_bytes += (double)((l.parsed.used[0] - l.win.begin[0]) + (l.win.two_files ? l.parsed.used[1] - l.win.begin[1] : 0));
 		t.text_out_bytes += (double)sam_bytes;
+	}
+	return KG_OK;
+}
+
+int kg_stream_group_absent(kg_stream *s, int lane, int rounds)
+{
+	if (!s || lane < 0 || lane >= (int)s->lanes.size()) return fail(KG_ERR_ARG, "kg_stream_group_absent: bad argument");
+	if (s->groups.empty()) return KG_OK;
+	SeedGroup &sg = *s->groups[(size_t)lane / (size_t)s->cfg.seed_group];
+	const int j = lane - sg.first;
+	std::unique_lock<std::mutex> lk(sg.mu);
+	if (sg.present[j]) return fail(KG_ERR_ARG, "kg_stream_group_absent: lane %d is inside a round", lane);
+	sg.absent_rounds[j] = rounds;
+	if (rounds == 0) sg.aborted = false;               // (a new run: the lanes take part again; an aborted run's half-finished round is forgotten)
+	// the round may be complete now: everybody else has arrived and waits
+	int accounted = sg.arrived;
+	for (int i = 0; i < sg.size; ++i) accounted += (!sg.present[i] && sg.absent_rounds[i] != 0) ? 1 : 0;
+	if (rounds != 0 && sg.arrived > 0 && accounted >= sg.size) sg.cv.notify_all();     // a waiting lane runs the round (group_seed's loop)
+	return KG_OK;
+}
+
+int kg_stream_group_abort(kg_stream *s)
+{
+	if (!s) return fail(KG_ERR_ARG, "kg_stream_group_abort: null stream");
+	for (std::unique_ptr<SeedGroup> &sg : s->groups) {
+		std::lock_guard<std::mutex> lk(sg->mu);
+		sg->aborted = true;
+		sg->cv.notify_all();
 	}
 	return KG_OK;
 }

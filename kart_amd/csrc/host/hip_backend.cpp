@@ -57,6 +57,11 @@ public:
 		if (kg_stream_map(s_, lane, &p, &out) != KG_OK) die("kg_stream_map");
 	}
 	bool timing(kg_stream_timing_t &t, bool reset) override { return kg_stream_timing(s_, &t, reset ? 1 : 0) == KG_OK; }
+	int seed_group() const override { return cfg_.seed_group > 1 ? cfg_.seed_group : 0; }
+	void group_absent(int lane, int rounds) override
+	{
+		if (kg_stream_group_absent(s_, lane, rounds) != KG_OK) die("kg_stream_group_absent");
+	}
 	kg_stream *handle() const { return s_; }
 
 private:
@@ -102,14 +107,16 @@ public:
 		kg_workspace_destroy(ws_);
 		kg_index_destroy(ix_);
 	}
-	StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes) override
+	StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes, int seed_group) override
 	{
 		static const bool off = getenv("KART_AMD_NO_STREAM") != nullptr || getenv("KART_AMD_HOST_ALIGN") != nullptr;      // A/B aids: the host parses and prints, as before
 		if (off) return nullptr;
-		if (stream_ && stream_->max_reads() >= max_reads && stream_->max_window() >= max_window && stream_->lanes() >= lanes) return stream_.get();
+		if (seed_group < 2 || lanes % seed_group != 0) seed_group = 0;
+		if (stream_ && stream_->max_reads() >= max_reads && stream_->max_window() >= max_window &&
+		    (seed_group ? stream_->lanes() == lanes : stream_->lanes() >= lanes) && stream_->seed_group() == seed_group) return stream_.get();
 		stream_.reset();
 		kg_stream_config cfg;
-		cfg.max_reads = max_reads; cfg.max_window = max_window; cfg.lanes = lanes;
+		cfg.max_reads = max_reads; cfg.max_window = max_window; cfg.lanes = lanes; cfg.seed_group = seed_group;
 		kg_stream *s = nullptr;
 		if (kg_stream_open(ix_, &cfg, &s) != KG_OK) {
 			fprintf(stderr, "Warning! no device stream (%s): the host parses and prints\n", kg_last_error());

@@ -84,6 +84,10 @@ struct StreamBackend {
 	virtual bool parse(int lane, const kg_stream_window &w, kg_stream_parsed &out) = 0;   // false: the window does not fit the lane (the caller's own reader takes over)
 	virtual void map(int lane, const kg_stream_params &p, kg_stream_result &out) = 0;
 	virtual bool timing(kg_stream_timing_t &t, bool reset) { (void)t; (void)reset; return false; }   // device time per stage since the last reset
+	// seeding groups (kg_stream_group_absent): lanes [g * seed_group(), (g + 1) * seed_group()) seed their batches in ONE launch per round;
+	// a lane without a batch for `rounds` rounds says so (< 0: until further notice, 0: it takes part again)
+	virtual int seed_group() const { return 0; }
+	virtual void group_absent(int lane, int rounds) { (void)lane; (void)rounds; }
 };
 
 // The fragment pairs of one chunk whose alignment GenerateNormalPairAlignment (src/tools.cpp:142-223) is to produce -- 8-mer partition,
@@ -119,7 +123,8 @@ struct KernelBackend {
 	virtual bool fragments_batch(std::vector<FragJobs *> &parts, bool pacbio, int max_gaps) { (void)parts; (void)pacbio; (void)max_gaps; return false; }
 	virtual bool has_fragments() const { return false; }
 	// a stream with at least this capacity (kept by the backend across runs), or null: the backend has no such path
-	virtual StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes) { (void)max_reads; (void)max_window; (void)lanes; return nullptr; }
+	// seed_group > 1: one seeding launch over the batches of that many lanes (kg_stream_config::seed_group)
+	virtual StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes, int seed_group = 0) { (void)max_reads; (void)max_window; (void)lanes; (void)seed_group; return nullptr; }
 	// index constants the host needs
 	virtual int min_seed_len() const = 0;
 	// IdentifySeedPairs_{Fast,Sensitive}Mode + GenerateAlignmentCandidateFor{Illumina,PacBio}Seq for a batch: enc = the concatenated

@@ -25,6 +25,7 @@ struct Hit {
 //   [17..21] what the search kernel itself fetched: q-mer table lookups, rank steps executed, those touching two 128-byte
 //            lines, text-comparison rounds, packed window words, two-line rank steps on intervals below 960, double steps, those with two lines, bytes their ranks read (kg_workspace_traffic)
 constexpr int kCtlWords = 27;
+constexpr int kMaxSeedSegments = 8;
 
 struct SeedArgs {
 	FmView ix;
@@ -34,6 +35,15 @@ struct SeedArgs {
 	int64_t n_bases;
 	int mode, min_seed_len, occ_thr;
 	int ascii;           // the read bytes are characters, not codes (KG_INPUT_ASCII)
+	// A GROUPED batch (abi_stream.hip: ONE seeding launch over the parsed batches of several stream lanes -- the MI355X form of the
+	// reference's N workers on N chunks, src/Mapping.cpp:716-717): n_seg segments of seg_stride read slots each, segment s holding
+	// seg_prefix[s+1] - seg_prefix[s] reads in its first slots; the rest of a segment's slots are empty (read_len 0).  read_off
+	// then jumps from one segment's part of `enc` to the next, so the lengths come from read_len, and the search kernel's lanes
+	// draw tickets 0 .. seg_prefix[n_seg]-1 that skip the empty slots.  n_seg == 0: an ordinary batch (read_len null).
+	const int32_t *read_len;
+	int n_seg;
+	int64_t seg_stride;
+	int64_t seg_prefix[kMaxSeedSegments + 1];
 	// scratch
 	uint64_t *packed;    // 4-bit read codes, 16 per word, read r at word (read_off[r] >> 4) + 3 r
 	// EXPERIMENT (KG_SORT_READS): the order in which the search kernel's lanes draw the reads -- sorted by the first 16 bases, so

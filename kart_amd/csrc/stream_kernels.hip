@@ -541,6 +541,39 @@ hipError_t launch_fq_materialise(const FqArgs &a, int n_cu, hipStream_t stream)
 	return hipGetLastError();
 }
 
+// ---- grouped seeding (abi_stream.hip): a lane's batch as one segment of its group's batch ------------------------------------------
+// slot i of the segment: offset of the read in the GROUP's character array (the lane's part starts at enc_base) and its length;
+// the slots behind the n reads are empty
+__global__ __launch_bounds__(256) void group_publish_kernel(const int64_t *local_off, int64_t n, int64_t slots, int64_t enc_base, int64_t *g_off, int32_t *g_len)
+{
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += stride) {
+		const int64_t at = local_off[i < n ? i : n];
+		g_off[i] = enc_base + at;
+		g_len[i] = i < n ? (int32_t)(local_off[i + 1] - at) : 0;
+	}
+}
+
+// the lane's seed offsets out of the group's: seed_off[i] = g_seed_off[i] - first, i = 0 .. n (the slot behind a segment's last read
+// holds the segment's end: empty slots have no seeds)
+__global__ __launch_bounds__(256) void group_rebase_kernel(const int64_t *g_seed_off, int64_t n, int64_t first, int64_t *seed_off)
+{
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) seed_off[i] = g_seed_off[i] - first;
+}
+
+hipError_t launch_group_publish(const int64_t *local_off, int64_t n, int64_t slots, int64_t enc_base, int64_t *g_off, int32_t *g_len, int n_cu, hipStream_t stream)
+{
+	hipLaunchKernelGGL(group_publish_kernel, dim3(grid_of(slots, 256, n_cu * 8)), dim3(256), 0, stream, local_off, n, slots, enc_base, g_off, g_len);
+	return hipGetLastError();
+}
+
+hipError_t launch_group_rebase(const int64_t *g_seed_off, int64_t n, int64_t first, int64_t *seed_off, int n_cu, hipStream_t stream)
+{
+	hipLaunchKernelGGL(group_rebase_kernel, dim3(grid_of(n + 1, 256, n_cu * 8)), dim3(256), 0, stream, g_seed_off, n, first, seed_off);
+	return hipGetLastError();
+}
+
 hipError_t launch_sam_size(const SamArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream)
 {
 	hipLaunchKernelGGL(sam_reset_kernel, dim3(1), dim3(64), 0, stream, a);

@@ -79,5 +79,8 @@ hipError_t launch_fq_parse(const FqArgs &a, void *scan_temp, size_t scan_temp_by
 hipError_t launch_fq_materialise(const FqArgs &a, int n_cu, hipStream_t stream);
 hipError_t launch_sam_size(const SamArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream);
 hipError_t launch_sam_format(const SamArgs &a, int n_cu, hipStream_t stream);
+// grouped seeding: a lane's parsed batch published as a segment of its group's batch; the lane's seed offsets cut out of the group's
+hipError_t launch_group_publish(const int64_t *local_off, int64_t n, int64_t slots, int64_t enc_base, int64_t *g_off, int32_t *g_len, int n_cu, hipStream_t stream);
+hipError_t launch_group_rebase(const int64_t *g_seed_off, int64_t n, int64_t first, int64_t *seed_off, int n_cu, hipStream_t stream);
 
 }  // namespace kg

@@ -172,15 +172,82 @@ def test_product_runs_through_the_stream(case, extra, built_lib, tmp_path):
     assert open(out2, "rb").read() == got
 
 
-@pytest.mark.parametrize("lanes,reads", [(1, 4000), (2, 8000), (4, 4000)])
-def test_stream_with_small_batches_and_many_lanes(lanes, reads, built_lib, tmp_path):
-    """batches of one or two chunks through 1..4 lanes: every carry / ordering path of the feeder, byte-identical output"""
+def test_grouped_seeding_one_launch_for_several_lanes(gpu_index_full):
+    """seed_group: the lanes of a group seed their batches in ONE launch per round (kg_stream_map returns when the round is done).
+    Every lane's text must be what the lane prints on its own -- with all lanes present, with a lane absent for a round, with
+    different batches in the lanes, and round after round."""
+    import threading
+    from kart_amd import api
+    t1, t2 = _golden_text("pe_1.fq"), _golden_text("pe_2.fq")
+
+    def cut(text, r0, r1):            # records [r0, r1) of a 4-line FASTQ text
+        lines = text.split(b"\n")
+        return b"\n".join(lines[4 * r0:4 * r1]) + b"\n"
+
+    batches = [(cut(t1, 0, 2000), cut(t2, 0, 2000)), (cut(t1, 2000, 4000), cut(t2, 2000, 4000)), (cut(t1, 4000, 4500), cut(t2, 4000, 4500))]
+    solo = api.Stream(gpu_index_full, max_reads=8000, max_window=4 << 20, lanes=1)
+    want = []
+    for a, b in batches:
+        p = solo.parse(a, b, paired=True, want_reads=4000)
+        want.append(solo.map())
+    single_launches = solo.timing()["search_kernel_launches"]
+    solo.close()
+    assert single_launches == 3
+    s = api.Stream(gpu_index_full, max_reads=8000, max_window=4 << 20, lanes=4, seed_group=2)
+    try:
+        def round_of(assign):         # {lane: batch index}: parse in the calling thread, map from one thread per lane
+            got, errs = {}, []
+            for lane, bi in assign.items():
+                p = s.parse(batches[bi][0], batches[bi][1], paired=True, want_reads=4000, lane=lane)
+                assert p.n_reads == 2 * (batches[bi][0].count(b"\n") // 4)
+
+            def work(lane):
+                try:
+                    got[lane] = s.map(lane=lane)
+                except Exception as exc:      # noqa: BLE001
+                    errs.append((lane, exc))
+            th = [threading.Thread(target=work, args=(lane,)) for lane in assign]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join(120)
+            assert not errs, errs
+            assert all(not t.is_alive() for t in th), "a lane never came back from its group's round"
+            for lane, bi in assign.items():
+                assert got[lane] == want[bi], (lane, bi)
+        for lane in range(4):
+            s.group_absent(lane, 0)
+        s.timing(reset=True)
+        round_of({0: 0, 1: 1})                      # group 0 complete: one launch for two batches
+        assert s.timing()["search_kernel_launches"] == 1
+        round_of({0: 2, 1: 0, 2: 1, 3: 1})          # both groups, different batch sizes in the lanes
+        assert s.timing()["search_kernel_launches"] == 3
+        s.group_absent(1, 1)                        # lane 1 sits this round out: lane 0's round completes without it
+        round_of({0: 1})
+        round_of({0: 0, 1: 2})                      # ... and it is back in the next
+        s.group_absent(3, -1)                       # lane 3's input has ended: lane 2 goes on alone, round after round
+        round_of({2: 0})
+        round_of({2: 2})
+        # a lane that is absent until further notice may not arrive with a batch
+        s.parse(batches[0][0], batches[0][1], paired=True, want_reads=4000, lane=3)
+        with pytest.raises(api.KartAmdError):
+            s.map(lane=3)
+        s.group_absent(3, 0)
+        round_of({2: 1, 3: 0})
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("lanes,reads,group", [(1, 4000, 0), (2, 8000, 0), (4, 4000, 0), (4, 4000, 4), (8, 4000, 4), (4, 4000, 2), (6, 8000, 3), (8, 1 << 20, 4)])
+def test_stream_with_small_batches_and_many_lanes(lanes, reads, group, built_lib, tmp_path):
+    """batches of one or two chunks through 1..8 lanes, every lane seeding for itself or in groups of 2..4 (partial groups where the
+    input ends): every carry / ordering path of the feeder, byte-identical output"""
     paths = []
     for f in ("pe_1.fq", "pe_2.fq"):
         dst = str(tmp_path / f)
         open(dst, "wb").write(_golden_text(f))
         paths.append(dst)
     out = str(tmp_path / "o.sam")
-    log = _run(["-f", paths[0], "-f2", paths[1]], out, {"KART_AMD_STREAM_LANES": str(lanes), "KART_AMD_STREAM_READS": str(reads)})
+    log = _run(["-f", paths[0], "-f2", paths[1]], out, {"KART_AMD_STREAM_LANES": str(lanes), "KART_AMD_STREAM_READS": str(reads), "KART_AMD_SEED_GROUP": str(group)})
     assert "device stream:" in log
     assert open(out, "rb").read() == _golden_text("pe.sam")
