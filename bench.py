@@ -588,6 +588,9 @@ def run(args, fallback_note):
                    "reads_per_step": n_reads, "reads_per_gpu_per_step": n_reads // world, "threads_per_rank": threads, "host_cpu_quota": cores,
                    "parallelism": "%d process(es), one GPU + index replica each, contiguous chunk ranges of the same input, SAM merged by file offset" % world,
                    "files": "page-cache resident (%s)" % workdir,
+                   "seed_group": seed_group_setting()[0], "stream_lanes": seed_group_setting()[1],
+                   "seeding": ("ONE search launch per round over the parsed batches of %d stream lanes (%d lanes in flight, 1 M-read batches)" % seed_group_setting()) if seed_group_setting()[0]
+                              else "every stream lane seeds its own 1 M-read batch (%d lanes)" % seed_group_setting()[1],
                    "sam_bytes_per_step": sum(os.path.getsize(f) for f in out_files(outs[-1])),
                    "host_memory_GB": {k: (round(v / 1e9, 1) if isinstance(v, (int, float)) else v) for k, v in mem0.items()},
                    "sizing": "reads per step chosen so that FASTQ + TWO step outputs (%.1f GB) stay within %d %% of min(MemAvailable, cgroup headroom) = %s GB; every step writes a "
@@ -616,7 +619,8 @@ def run(args, fallback_note):
                             "launches": sk_n, "avg_launch_ms": sk_ms / sk_n, "algorithmic_bytes_per_launch": sk_bytes / sk_n,
                             "algorithmic_bytes_per_read": sk_bytes / max(1, reads_here), "search_kernel_ms_per_step": sk_ms / args.steps,
                             "note": "achieved = bytes the IMPLEMENTED search needs (kg_workspace_traffic's formula, summed over the launches) / the sum of the launches' HIP-event "
-                                    "durations.  The lanes' kernels share the device, so a launch's duration includes what other lanes' kernels took from it."}
+                                    "durations (the ramp-up launches of a step -- batches of 4 k .. 256 k reads while EstDistance settles -- included).  Other lanes' kernels "
+                                    "share the device, so a launch's duration includes what they took from it."}
 
     # the step outputs go first: the side legs below write their own files and must never add to them
     while outs:
@@ -951,6 +955,18 @@ def effective_cores():
     return n
 
 
+def seed_group_setting():
+    """(lanes per seeding group, stream lanes) as host/detail/pipeline.inc chooses them: KART_AMD_SEED_GROUP (default 4: ONE search launch over four
+    lanes' batches), KART_AMD_STREAM_LANES (default two groups, or four independent lanes)"""
+    g = int(os.environ.get("KART_AMD_SEED_GROUP", "4"))
+    g = min(g, 8) if g > 1 else 0
+    lanes = int(os.environ.get("KART_AMD_STREAM_LANES", "0"))
+    lanes = min(lanes, 16) if lanes > 0 else (2 * g if g else 4)
+    if g and lanes % g:
+        lanes = (lanes + g - 1) // g * g
+    return g, lanes
+
+
 def measured_traffic(n_reads, args, tag=None):
     """HBM/fabric bytes per search_kernel launch from the committed PMC passes of this exact command
     (rocprofv3 --pmc, separate passes; profiles/*_pmc_summary.json, corrected for gfx950 as
@@ -965,8 +981,16 @@ def measured_traffic(n_reads, args, tag=None):
                 t = json.load(open(os.path.join(ROOT, "profiles", f))).get("_search_traffic")
             except Exception:
                 t = None
-            if t and t.get("tag") == tag and (tag is not None or t.get("reads_per_launch") == n_reads) and t.get("genome_len", GENOME_LEN) == args.genome_len:
-                best = (t["traffic_bytes_per_launch"], "profiles/" + f)
+            if not t or t.get("tag") != tag or t.get("genome_len", GENOME_LEN) != args.genome_len:
+                continue
+            if tag is None and t.get("reads_per_launch") != n_reads:
+                continue
+            # the timed region: the same reads per step and the same seeding configuration as the profiled run (a launch of a run with
+            # other batch sizes fetches other bytes -- round 3 quoted the 20 M-read run's figure for the 100 M-read run)
+            if tag is not None and (t.get("pairs_per_step") != getattr(args, "pairs", None) or t.get("seed_group") != seed_group_setting()[0]
+                                    or t.get("stream_lanes") != seed_group_setting()[1]):
+                continue
+            best = (t["traffic_bytes_per_launch"], "profiles/" + f)
     return best if best else (None, None)
 
 
