@@ -955,7 +955,7 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 		if (ws->d_aln_cand) HIP_TRY(hipFree(ws->d_aln_cand));
 		ws->d_aln_cand = nullptr;
 		int64_t cap = std::max<int64_t>(nc + nc / 4, 3 * ws->max_reads) + task_cap + task_cap / 4 + ws->max_reads / 4 + 4096;
-		HIP_TRY(hipMalloc(&ws->d_aln_cand, up(4 * (size_t)cap) * 6 + up(8 * (size_t)cap) + up((size_t)cap) * 2 + up((size_t)cap * KG_ALN_CIGAR_MAX)));
+		HIP_TRY(hipMalloc(&ws->d_aln_cand, up(4 * (size_t)cap) * 7 + up(8 * (size_t)cap) + up((size_t)cap) * 2 + up((size_t)cap * KG_ALN_CIGAR_MAX)));
 		ws->aln_cand_capacity = cap;
 	}
 	if (n + 2 > ws->aln_read_capacity) {
@@ -989,7 +989,7 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 		HIP_TRY(hipMalloc((void **)&ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)cap));
 		ws->chunk_capacity = cap;
 	}
-	if (!ws->d_aln_ctl) { HIP_TRY(hipMalloc((void **)&ws->d_aln_ctl, 8 * 32)); HIP_TRY(hipMemset(ws->d_aln_ctl, 0, 8 * 32)); }
+	if (!ws->d_aln_ctl) { HIP_TRY(hipMalloc((void **)&ws->d_aln_ctl, 8 * 40)); HIP_TRY(hipMemset(ws->d_aln_ctl, 0, 8 * 40)); }
 	HIP_TRY(hipMemcpyAsync(ws->d_chunk_off, chunk_off, 8 * (size_t)(n_chunks + 1), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(ws->d_chunk_paired, chunk_paired, (size_t)n_chunks, hipMemcpyHostToDevice, st));
 	// ---- arguments ------------------------------------------------------------------------------------------------------------
@@ -1021,6 +1021,9 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 		a.rep_cigar = p; p += up(cap * KG_ALN_CIGAR_MAX);
 		static const bool no_bins = getenv("KG_ALN_NO_BINS") != nullptr;      // A/B aid: aln_plan_kernel takes the candidates in their own order
 		a.plan_order = no_bins ? nullptr : (int32_t *)p;
+		p += up(4 * cap);
+		static const bool no_fast = getenv("KG_ALN_NO_FAST") != nullptr;      // A/B aid: every candidate takes the general plan kernel
+		a.plan_slow = no_fast ? nullptr : (int32_t *)p;
 		char *q = (char *)ws->d_aln_read;
 		size_t rcap = (size_t)ws->aln_read_capacity;
 		a.r_host = (uint8_t *)q; q += up(rcap);

@@ -40,6 +40,13 @@ __device__ __forceinline__ char text_char(const AlnArgs &a, int64_t g)      // R
 
 __device__ __forceinline__ int chunk_of(const AlnArgs &a, int64_t r)
 {
+	// (the chunks of a batch are equally long but for the last: the proportional guess is right, two independent loads confirm it;
+	//  the search below -- ~8 dependent loads for the 250 chunks of a 1 M-read batch -- is only the fallback)
+	if (a.n_chunks > 1 && a.n_reads > 0) {
+		int c = (int)((r * (int64_t)a.n_chunks) / a.n_reads);
+		c = c < 0 ? 0 : c > a.n_chunks - 1 ? a.n_chunks - 1 : c;
+		if (a.chunk_off[c] <= r && r < a.chunk_off[c + 1]) return c;
+	}
 	int lo = 0, hi = a.n_chunks - 1;
 	while (lo < hi) {
 		int mid = (lo + hi + 1) >> 1;
@@ -1193,6 +1200,182 @@ __device__ int plan_partition(const AlnArgs &a, int64_t enc_off, const uint8_t *
 	return 1;
 }
 
+// ---- pass 1a: the candidates whose report needs no alignment and no private arrays -------------------------------------------------
+// Most candidates of 150 bp reads at 1 % error are a few seeds ON ONE DIAGONAL, in order, without overlap, separated by single
+// substituted bases: IdentifyNormalPairs (src/AlignmentCandidates.cpp:420-490) then removes nothing and only inserts the gap pairs
+// between them (equal read and genome length), every gap pair is decided without nw_alignment -- the <= 2-mismatch shortcut or the
+// 1 x 1 case of Process{Head,Normal,Tail}SequencePair (src/tools.cpp:240, 301, 352) -- every CIGAR element is an M, and
+// GenMappingReport's result is: AlnScore = seed bases + matching gap bases, CIGAR "<rlen>M", the coordinate of the first pair
+// (of the second when the head pair scored nothing, :674-686; likewise the tail).  This kernel decides exactly those candidates in
+// registers -- 87 % of aln_plan_kernel's wave cycles were waits on its per-lane arrays in scratch memory (profiles/r03w) -- and
+// lists every other candidate, untouched, for aln_plan_kernel (dense: its lanes all walk the general path).  KG_ALN_NO_FAST: off.
+constexpr int kFastSeeds = 6;        // seeds of a candidate this kernel takes
+constexpr int kFastGap = 32;         // longest gap between them (one text word)
+
+// mismatches of the read characters rd[0 .. L) against the text at g (raw characters as CalFragPairMismatchBases compares them,
+// src/tools.cpp:40-47); dash: a literal '-' among them (the 1 x 1 case then goes to nw_alignment, src/tools.cpp:229-233)
+__device__ __forceinline__ int fast_gap_mismatches(const AlnArgs &a, const uint8_t *rd, int64_t g, int L, bool &dash)
+{
+	int n = 0;
+	const uint64_t tw = text_word32(a, g);
+	for (int i0 = 0; i0 < L; i0 += 8) {
+		const uint64_t w = reinterpret_cast<const AlnU64u *>(rd + i0)->v;          // (the character array has 64 bytes of slack)
+		const int m = L - i0 < 8 ? L - i0 : 8;
+		for (int i = 0; i < m; ++i) {
+			const int c = (int)((w >> (8 * i)) & 255);
+			const int code = (int)((tw >> (2 * (i0 + i))) & 3);
+			const int t = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T';
+			n += c != t ? 1 : 0;
+			dash = dash || c == '-';
+		}
+	}
+	return n;
+}
+
+// a gap pair of L = L bases on the diagonal: its score when it needs no alignment (W_IMMEDIATE with op 'M'), -1 when it does
+__device__ __forceinline__ int fast_gap_value(const AlnArgs &a, const uint8_t *rd, int64_t g, int L)
+{
+	bool dash = false;
+	const int n = fast_gap_mismatches(a, rd, g, L, dash);
+	if (n <= 2 && n <= (int)(L * 0.2)) return L - n;           // :240 / :301 / :352
+	if (L == 1 && !dash) return 0;                               // one base against one other base: 1M, nothing identical
+	return -1;
+}
+
+__global__ __launch_bounds__(256) void aln_plan_fast_kernel(AlnArgs a)
+{
+	__shared__ int64_t s_end[128];
+	const bool ends_in_lds = a.n_ends <= 128;
+	if (ends_in_lds)
+		for (int i = threadIdx.x; i < a.n_ends; i += blockDim.x) s_end[i] = a.contig_end[i];
+	__syncthreads();
+	auto lower_bound = [&](int64_t g) {
+		int lo = 0, hi = a.n_ends;
+		while (lo < hi) {
+			int mid = (lo + hi) >> 1;
+			if ((ends_in_lds ? s_end[mid] : a.contig_end[mid]) < g) lo = mid + 1; else hi = mid;
+		}
+		return lo;
+	};
+	unsigned long long n_tasks = a.ctl[4];
+	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
+	const int64_t n_all = a.n_cands + (int64_t)n_tasks;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t slot0 = (int64_t)blockIdx.x * blockDim.x; slot0 < n_all; slot0 += stride) {
+		const int64_t slot = slot0 + threadIdx.x;
+		bool slow = false;
+		int64_t cand = 0;
+		if (slot < n_all) {
+			cand = a.plan_order ? (int64_t)a.plan_order[slot] : slot;
+			a.rep_score[cand] = 0; a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
+			const int64_t r = a.c_read[cand];
+			if (!a.r_host[r] && a.c_score[cand] != 0) {
+				const bool rescued = cand >= a.n_cands;
+				int count;
+				const kg_seed *seeds;
+				if (!rescued) { const kg_candidate cd = a.cands[cand]; count = cd.count; seeds = a.cand_seeds + cd.first; }
+				else { const int64_t t = cand - a.n_cands; count = a.resc_count[t]; seeds = a.resc_seeds + t * kAlnMaxSeeds; }
+				const int64_t rbase = a.read_off[r];
+				const int rlen = (int)(a.read_off[r + 1] - rbase);
+				slow = count < 1 || count > kFastSeeds || rlen > 4000;
+				// ---- the seeds: one diagonal, in order, no overlap; gaps of at most a text word ----
+				int64_t d = 0;
+				int prev_end = 0, first_r = 0, seed_bases = 0;
+				int gap_at[kFastSeeds + 1], gap_len[kFastSeeds + 1];      // (indexed by unrolled constants: registers)
+#pragma unroll
+				for (int i = 0; i < kFastSeeds; ++i) {
+					gap_at[i] = 0; gap_len[i] = 0;
+					if (!slow && i < count) {
+						const kg_seed sd = seeds[i];
+						const int64_t di = sd.gPos - (int64_t)sd.rPos;
+						if (i == 0) { d = di; first_r = sd.rPos; if (di < 0 || sd.rPos > kFastGap) slow = true; }
+						else {
+							if (di != d || sd.rPos < prev_end || sd.rPos - prev_end > kFastGap) slow = true;
+							gap_at[i] = prev_end; gap_len[i] = sd.rPos - prev_end;
+						}
+						prev_end = sd.rPos + sd.len;
+						seed_bases += sd.len;
+					}
+				}
+				const int tail_len = rlen - prev_end;
+				if (tail_len < 0 || tail_len > kFastGap) slow = true;
+				if (!slow) {
+					// ---- CheckCoordinateValidity (:582-610) on [d, d + rlen - 1]: one strand copy, one contig ----
+					const int64_t g1 = d, g2 = d + rlen - 1, L = a.genome_size;
+					const int i1 = lower_bound(g1);
+					bool valid = !((g1 < L && g2 >= L) || (g1 >= L && g2 < L)) && i1 < a.n_ends;
+					if (valid && g2 > (ends_in_lds ? s_end[i1] : a.contig_end[i1])) {
+						const int i2 = lower_bound(g2);
+						valid = i2 < a.n_ends && a.end_chr[i1] == a.end_chr[i2];
+						slow = valid;          // (two keys of one contig cannot lie in one strand copy: never taken; the general path decides)
+					}
+					if (!valid) a.c_score[cand] = -1;          // no report, and no best/second-best step (:647)
+					else if (!slow) {
+						// ---- the gap pairs ----
+						const uint8_t *rd = a.enc + rbase;
+						int score = seed_bases;
+						int head_val = 1, tail_val = 1;
+						if (first_r > 0) { head_val = fast_gap_value(a, rd, d, first_r); slow = head_val < 0; score += head_val > 0 ? head_val : 0; }
+#pragma unroll
+						for (int i = 1; i < kFastSeeds; ++i)
+							if (!slow && i < count && gap_len[i] > 0) {
+								const int v = fast_gap_value(a, rd + gap_at[i], d + gap_at[i], gap_len[i]);
+								slow = v < 0;
+								score += v > 0 ? v : 0;
+							}
+						if (!slow && tail_len > 0) { tail_val = fast_gap_value(a, rd + prev_end, d + prev_end, tail_len); slow = tail_val < 0; score += tail_val > 0 ? tail_val : 0; }
+						if (!slow) {
+							// ---- GenMappingReport's tail: GenCoordinateInfo (:515-562), GenerateCIGAR (:492-513) ----
+							const int ck = chunk_of(a, r);
+							const bool first = a.chunk_paired[ck] ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
+							const int64_t gPos = head_val > 0 ? d : d + first_r;                     // a head pair that scored nothing gives its place up (:674-686)
+							const int64_t end_gPos = (tail_val > 0 ? d + rlen : d + prev_end) - 1;   // ... and so does the tail pair
+							bool fwd;
+							int chr;
+							int64_t pos;
+							if (gPos < L) {
+								fwd = first;
+								if (a.n_chr == 1) { chr = 0; pos = gPos + 1; }
+								else { chr = a.end_chr[i1]; pos = gPos + 1 - a.chr_fwd_start[chr]; }
+							} else {
+								fwd = !first;
+								if (a.n_chr == 1) { chr = 0; pos = a.two_genome_size - end_gPos; }
+								else { pos = (ends_in_lds ? s_end[i1] : a.contig_end[i1]) - end_gPos + 1; chr = a.end_chr[i1]; }
+							}
+							// "<rlen>M": at most four digits
+							uint64_t text = 0;
+							int at = 0;
+							{
+								char buf[4];
+								int k = 0, nn = rlen;
+								do { buf[k++] = (char)('0' + nn % 10); nn /= 10; } while (nn);
+								while (k) text |= (uint64_t)(uint8_t)buf[--k] << (8 * at++);
+								text |= (uint64_t)'M' << (8 * at++);
+							}
+							*reinterpret_cast<uint64_t *>(a.rep_cigar + cand * KG_ALN_CIGAR_MAX) = text;
+							a.rep_cigar_len[cand] = (uint8_t)at;
+							a.rep_chr[cand] = chr;
+							a.rep_pos[cand] = pos;
+							a.rep_fwd[cand] = fwd ? 1 : 0;
+							a.rep_score[cand] = pos <= 0 ? 0 : score;
+						}
+					}
+				}
+			}
+		}
+		// ---- everything else: listed for the general kernel, densely ----
+		const uint64_t mask = __ballot(slow);
+		if (mask) {
+			const int leader = __ffsll((unsigned long long)mask) - 1;
+			unsigned long long at = 0;
+			if ((int)(threadIdx.x & 63) == leader) at = atomicAdd(&a.ctl[32], (unsigned long long)__popcll(mask));
+			at = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(at >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)at, leader);
+			const uint64_t below = (threadIdx.x & 63) == 0 ? 0ull : (~0ull >> (64 - (threadIdx.x & 63)));
+			if (slow) a.plan_slow[at + (unsigned long long)__popcll(mask & below)] = (int32_t)cand;
+		}
+	}
+}
+
 // ---- pass 1: one candidate per lane -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 {
@@ -1200,10 +1383,11 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	unsigned long long n_tasks = a.ctl[4];
 	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
-	const int64_t n_all = a.n_cands + (int64_t)n_tasks;                          // chained candidates, then the slots of the rescue windows
+	int64_t n_all = a.n_cands + (int64_t)n_tasks;                                // chained candidates, then the slots of the rescue windows
+	if (a.plan_slow) n_all = (int64_t)a.ctl[32];                                 // ... or what aln_plan_fast_kernel left
 	for (int64_t slot = cand; slot < n_all; slot += stride) {
 		// (binned: lanes of a wave then hold candidates with the same number of seeds -- the loops below run equally long)
-		cand = a.plan_order ? (int64_t)a.plan_order[slot] : slot;
+		cand = a.plan_slow ? (int64_t)a.plan_slow[slot] : a.plan_order ? (int64_t)a.plan_order[slot] : slot;
 		a.rep_score[cand] = 0; a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
 		const int64_t r = a.c_read[cand];
 		if (a.r_host[r]) continue;
@@ -1728,8 +1912,9 @@ __global__ void aln_reset_kernel(AlnArgs a)
 	// partition plans of the batches before this one)
 	if (i == 0) { a.ctl[21] += a.ctl[0]; a.ctl[22] += a.ctl[1]; a.ctl[23] += a.ctl[5]; }
 	__syncthreads();
+	if (i == 0) a.ctl[33] += a.ctl[32];                  // (running tally: candidates the fast plan kernel left to the general one)
 	if (i < 8) a.ctl[i] = 0;
-	if (i >= 24 && i < 32) a.ctl[i] = 0;
+	if (i >= 24 && i < 33) a.ctl[i] = 0;
 	for (int c = i; c < a.n_chunks; c += gridDim.x * blockDim.x) {
 		kg_chunk_stats z;
 		z.paired = 0; z.distance = 0; z.lo = -1; z.hi = 0x7fffffffffffffffll; z.unmapped = 0; z.unique = 0; z.host_pairs = 0; z.rescue_wanted = 0;
@@ -1757,6 +1942,7 @@ hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 			hipLaunchKernelGGL(aln_bin_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 8)), dim3(256), 0, stream, a, 0);
 			hipLaunchKernelGGL(aln_bin_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 8)), dim3(256), 0, stream, a, 1);
 		}
+		if (a.plan_slow) hipLaunchKernelGGL(aln_plan_fast_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
 		hipLaunchKernelGGL(aln_plan_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
 		hipLaunchKernelGGL(aln_partition_kernel, dim3(grid_for_aln(a.n_cands / 8 + 1, 256, n_cu * 8)), dim3(256), 0, stream, a);
 	}
