@@ -846,10 +846,15 @@ static int nw_acquire(kg_index *ix, size_t list_words, size_t dir_words, hipStre
 	std::lock_guard<std::mutex> lock(ix->nw_mu);
 	NwScratch *pick = nullptr;
 	for (NwScratch *s : ix->nw_pool) {
-		// free again: its kernels are through -- or they were enqueued on this very stream, whose order keeps the next ones behind them
-		// (back-to-back calls on one stream used to take a fresh 100 MB scratch each: 2.3 ms of hipMalloc per call of 0.5 ms of kernels)
-		if (s->busy && !s->pending && (s->last_stream == st || hipEventQuery(s->done) == hipSuccess)) s->busy = false;
-		if (!s->busy && (!pick || (s->list_words >= list_words && s->dir_words >= dir_words && !(pick->list_words >= list_words && pick->dir_words >= dir_words)))) pick = s;
+		// free again for everybody: its kernels are through
+		if (s->busy && !s->pending && hipEventQuery(s->done) == hipSuccess) s->busy = false;
+		// ... or usable by THIS caller alone: its kernels were enqueued on this very stream, whose order keeps the next ones behind them
+		// (back-to-back calls on one stream used to take a fresh 100 MB scratch each: 2.3 ms of hipMalloc per call of 0.5 ms of kernels).
+		// It stays busy for everybody else -- rounds 2 and 3 cleared the flag here, and when this caller then picked ANOTHER scratch, a
+		// lane on a different stream could take this one while its kernels still ran (seen as a read reported with another read's
+		// alignment once eight lanes were in flight; tools/stress_groups.py).
+		const bool usable = !s->busy || (!s->pending && s->last_stream == st);
+		if (usable && (!pick || (s->list_words >= list_words && s->dir_words >= dir_words && !(pick->list_words >= list_words && pick->dir_words >= dir_words)))) pick = s;
 	}
 	if (!pick) {
 		pick = new NwScratch();
