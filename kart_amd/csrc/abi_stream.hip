@@ -17,6 +17,22 @@
 
 #define fail kg_fail
 
+// One hardware queue per HIP stream.  The runtime maps its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); on this
+// ROCm, once two streams shared a queue, a kernel was seen to start before an asynchronous host-to-device copy enqueued in front
+// of it on its own stream had landed (eight lanes: the first reads of a batch seeded from the text of the batch before;
+// tools/stress_groups.py -- 4-8 of 16 runs wrong with 6 or 8 lanes, none with GPU_MAX_HW_QUEUES=8, none with <= 5 lanes).  The
+// variable is read when the runtime initialises, i.e. at the first HIP call of the process: a process that loads this library
+// before it touches HIP (kart-amd) gets it from here; Python processes from kart_amd/__init__.py; anybody else sets it himself --
+// kg_stream_open counts its streams against it and refuses more.
+__attribute__((constructor)) static void kg_ask_for_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
+static int kg_hardware_queues()
+{
+	const char *e = getenv("GPU_MAX_HW_QUEUES");
+	const int v = e ? atoi(e) : 4;
+	return v > 0 ? v : 4;
+}
+
 namespace {
 
 struct Lane {
@@ -191,6 +207,11 @@ int kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out)
 	const int group = cfg->seed_group > 1 ? cfg->seed_group : 0;
 	if (group && (group > kMaxSeedSegments || cfg->lanes % group != 0))
 		return fail(KG_ERR_ARG, "kg_stream_open: seed_group %d must divide the %d lanes and be at most %d", group, cfg->lanes, kMaxSeedSegments);
+	const int n_streams = cfg->lanes + (group ? cfg->lanes / group : 0);
+	if (n_streams > kg_hardware_queues())
+		return fail(KG_ERR_ARG, "kg_stream_open: %d lanes%s need %d HIP streams, GPU_MAX_HW_QUEUES allows %d hardware queues: set it to at least %d before the "
+		                        "first HIP call of the process (streams that share a queue were seen to run a kernel before its own stream's upload had landed)",
+		            cfg->lanes, group ? " in seeding groups" : "", n_streams, kg_hardware_queues(), n_streams);
 	if (!ix->d_text) return fail(KG_ERR_ARG, "kg_stream_open: the index holds no text");
 	HIP_TRY(hipSetDevice(ix->device));
 	std::unique_ptr<kg_stream, void (*)(kg_stream *)> s(new kg_stream(), kg_stream_close);

@@ -27,7 +27,9 @@ want, _ = run({"KART_AMD_SEED_GROUP": "0"}, "base")
 configs = [("8 lanes g4 turns (default)", {}), ("8 lanes g4 no turns", {"KG_GROUP_NO_TURNS": "1"}), ("4 lanes g4 turns", {"KART_AMD_STREAM_LANES": "4"}),
            ("8 lanes independent", {"KART_AMD_SEED_GROUP": "0", "KART_AMD_STREAM_LANES": "8"}), ("8 lanes g2", {"KART_AMD_SEED_GROUP": "2", "KART_AMD_STREAM_LANES": "8"}),
            ("8 lanes g4 turns 4 k batches", {"KART_AMD_STREAM_READS": "4000"}), ("8 lanes independent 4 k batches", {"KART_AMD_SEED_GROUP": "0", "KART_AMD_STREAM_LANES": "8", "KART_AMD_STREAM_READS": "4000"})]
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and "=" in sys.argv[2]:          # explicit environments: "K=V,K=V" ...
+    configs = [(spec, dict(kv.split("=", 1) for kv in spec.split(","))) for spec in sys.argv[2:]]
+elif len(sys.argv) > 2:
     configs = [c for c in configs if any(k in c[0] for k in sys.argv[2:])]
 for name, env in configs:
     bad = 0
@@ -43,5 +45,7 @@ for name, env in configs:
                     if x != y:
                         print("   ", j, x[:150].decode()); print("   ", j, y[:150].decode()); k += 1
                         if k >= 4: break
-                print("   ", [l for l in log.splitlines() if "re-mapped" in l or "device stream" in l][-2:])
+                diff = [j for j, (x, y) in enumerate(zip(a, b)) if x != y]
+                print("    differing lines (header = 6 lines, 4000 reads per chunk):", diff[:60], "chunks", sorted(set((j - 6) // 4000 for j in diff)))
+                print("   ", [l for l in log.splitlines() if "re-mapped" in l or "device stream" in l or "device report" in l][-3:])
     print("%-18s %d of %d runs differ" % (name, bad, runs))
