@@ -51,8 +51,6 @@ import sys
 import tempfile
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # before the first HIP call of this process: see kart_amd/__init__.py (one hardware queue per stream)
-
 import numpy as np
 import torch
 

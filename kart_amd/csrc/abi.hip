@@ -7,6 +7,7 @@
 #include <cmath>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -457,7 +458,6 @@ int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_w
 	HIP_TRY(hipMalloc((void **)&ws->d_packed, 8 * (size_t)(max_bases / 16 + 3 * max_reads + 64)));
 	HIP_TRY(hipMalloc((void **)&ws->d_seeds_per_read, 4 * (size_t)max_reads));
 	HIP_TRY(hipMalloc((void **)&ws->d_ctl, 8 * kCtlWords));
-	HIP_TRY(hipMemset(ws->d_ctl, 0, 8 * kCtlWords));
 	ws->scan_bytes = scan_temp_bytes(max_reads + 1);
 	HIP_TRY(hipMalloc(&ws->d_scan_temp, ws->scan_bytes ? ws->scan_bytes : 256));
 	if (getenv("KG_SORT_READS")) {
@@ -466,6 +466,9 @@ int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_w
 		HIP_TRY(hipMalloc(&ws->d_sort_temp, ws->sort_bytes ? ws->sort_bytes : 256));
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+	// (zeroed ON THE WORKSPACE'S STREAM: a hipMemset of device memory runs on the null stream, asynchronously, and nothing orders
+	//  it against later work on a non-blocking stream -- it can land in the middle of the first batch)
+	HIP_TRY(hipMemsetAsync(ws->d_ctl, 0, 8 * kCtlWords, ws->stream));
 	HIP_TRY(hipHostMalloc((void **)&ws->h_small, 8 * 16, hipHostMallocDefault));
 	*out = ws.release();
 	return KG_OK;
@@ -535,6 +538,7 @@ int kg_index_selfcheck(kg_index *ix, int64_t samples, uint64_t seed, uint64_t *d
 	unsigned long long *bad = nullptr;
 	HIP_TRY(hipMalloc((void **)&bad, 8));
 	HIP_TRY(hipMemset(bad, 0, 8));
+	HIP_TRY(hipDeviceSynchronize());
 	hipError_t e = launch_planes2_check(ix->view, (uint64_t)samples, seed, bad, nullptr);
 	unsigned long long h = 0;
 	hipError_t e2 = hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
@@ -994,7 +998,11 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 		HIP_TRY(hipMalloc((void **)&ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)cap));
 		ws->chunk_capacity = cap;
 	}
-	if (!ws->d_aln_ctl) { HIP_TRY(hipMalloc((void **)&ws->d_aln_ctl, 8 * 40)); HIP_TRY(hipMemset(ws->d_aln_ctl, 0, 8 * 40)); }
+	// (zeroed on THIS stream: a plain hipMemset runs on the null stream, asynchronously, unordered against the kernels below -- behind a
+	//  long null-stream operation (the seeding groups' buffers are filled at kg_stream_open) it landed in the middle of the lane's first
+	//  batch and took the counters of the rescue tasks / spills / NW jobs with it: pairs that needed mate rescue came out unpaired in
+	//  4-11 of 16 runs, tools/stress_groups.py; latent since round 2)
+	if (!ws->d_aln_ctl) { HIP_TRY(hipMalloc((void **)&ws->d_aln_ctl, 8 * 40)); HIP_TRY(hipMemsetAsync(ws->d_aln_ctl, 0, 8 * 40, st)); }
 	HIP_TRY(hipMemcpyAsync(ws->d_chunk_off, chunk_off, 8 * (size_t)(n_chunks + 1), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(ws->d_chunk_paired, chunk_paired, (size_t)n_chunks, hipMemcpyHostToDevice, st));
 	// ---- arguments ------------------------------------------------------------------------------------------------------------

@@ -17,22 +17,6 @@
 
 #define fail kg_fail
 
-// One hardware queue per HIP stream.  The runtime maps its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); on this
-// ROCm, once two streams shared a queue, a kernel was seen to start before an asynchronous host-to-device copy enqueued in front
-// of it on its own stream had landed (eight lanes: the first reads of a batch seeded from the text of the batch before;
-// tools/stress_groups.py -- 4-8 of 16 runs wrong with 6 or 8 lanes, none with GPU_MAX_HW_QUEUES=8, none with <= 5 lanes).  The
-// variable is read when the runtime initialises, i.e. at the first HIP call of the process: a process that loads this library
-// before it touches HIP (kart-amd) gets it from here; Python processes from kart_amd/__init__.py; anybody else sets it himself --
-// kg_stream_open counts its streams against it and refuses more.
-__attribute__((constructor)) static void kg_ask_for_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
-
-static int kg_hardware_queues()
-{
-	const char *e = getenv("GPU_MAX_HW_QUEUES");
-	const int v = e ? atoi(e) : 4;
-	return v > 0 ? v : 4;
-}
-
 namespace {
 
 struct Lane {
@@ -207,11 +191,6 @@ int kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out)
 	const int group = cfg->seed_group > 1 ? cfg->seed_group : 0;
 	if (group && (group > kMaxSeedSegments || cfg->lanes % group != 0))
 		return fail(KG_ERR_ARG, "kg_stream_open: seed_group %d must divide the %d lanes and be at most %d", group, cfg->lanes, kMaxSeedSegments);
-	const int n_streams = cfg->lanes + (group ? cfg->lanes / group : 0);
-	if (n_streams > kg_hardware_queues())
-		return fail(KG_ERR_ARG, "kg_stream_open: %d lanes%s need %d HIP streams, GPU_MAX_HW_QUEUES allows %d hardware queues: set it to at least %d before the "
-		                        "first HIP call of the process (streams that share a queue were seen to run a kernel before its own stream's upload had landed)",
-		            cfg->lanes, group ? " in seeding groups" : "", n_streams, kg_hardware_queues(), n_streams);
 	if (!ix->d_text) return fail(KG_ERR_ARG, "kg_stream_open: the index holds no text");
 	HIP_TRY(hipSetDevice(ix->device));
 	std::unique_ptr<kg_stream, void (*)(kg_stream *)> s(new kg_stream(), kg_stream_close);
@@ -248,9 +227,10 @@ int kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out)
 		HIP_TRY(hipMalloc((void **)&gw->d_read_off, 8 * (size_t)(gw->max_reads + 1)));
 		HIP_TRY(hipMalloc((void **)&gw->d_seed_off, 8 * (size_t)(gw->max_reads + 1)));
 		HIP_TRY(hipMalloc((void **)&gw->group_read_len, 4 * (size_t)(gw->max_reads + 1)));
-		HIP_TRY(hipMemset(gw->d_enc, 'N', (size_t)gw->max_bases + 64));
-		HIP_TRY(hipMemset(gw->d_read_off, 0, 8 * (size_t)(gw->max_reads + 1)));
-		HIP_TRY(hipMemset(gw->group_read_len, 0, 4 * (size_t)(gw->max_reads + 1)));
+		HIP_TRY(hipMemsetAsync(gw->d_enc, 'N', (size_t)gw->max_bases + 64, gw->stream));
+		HIP_TRY(hipMemsetAsync(gw->d_read_off, 0, 8 * (size_t)(gw->max_reads + 1), gw->stream));
+		HIP_TRY(hipMemsetAsync(gw->group_read_len, 0, 4 * (size_t)(gw->max_reads + 1), gw->stream));
+		HIP_TRY(hipStreamSynchronize(gw->stream));          // (the lanes write these arrays from their own streams)
 		HIP_TRY(hipHostMalloc((void **)&sg->h_ctl, 8 * kCtlWords, hipHostMallocDefault));
 		(void)kg_workspace_set_profiling(gw, 1);
 		s->groups.push_back(std::move(sg));
@@ -302,6 +282,7 @@ int kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out)
 		HIP_TRY(hipHostMalloc((void **)&l.h_records, sizeof(kg_aln_record) * (size_t)l.record_capacity, hipHostMallocDefault));
 		for (hipEvent_t &e : l.ev) HIP_TRY(hipEventCreate(&e));
 	}
+	HIP_TRY(hipDeviceSynchronize());                     // everything above has landed before a lane's first batch
 	*out = s.release();
 	return KG_OK;
 }
@@ -583,7 +564,8 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 	}
 	HIP_TRY(launch_sam_format(q, ix->n_cu, st));
 	HIP_TRY(hipEventRecord(l.ev[5], st));
-	turn.release();                    // (grouped seeding: the next lane of the group starts its stages; this one's copies overlap them)
+	static const bool turn_late = getenv("KG_GROUP_TURN_LATE") != nullptr;          // A/B aid: the turn is kept until the batch is back on the host
+	if (!turn_late) turn.release();    // (grouped seeding: the next lane of the group starts its stages; this one's copies overlap them)
 	if (sam_bytes > 0) HIP_TRY(hipMemcpyAsync(l.h_sam, l.d_sam, (size_t)sam_bytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(l.h_sam_off, l.d_sam_off, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(l.h_records, a.records, sizeof(kg_aln_record) * (size_t)(n + extra), hipMemcpyDeviceToHost, st));

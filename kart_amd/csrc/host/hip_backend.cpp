@@ -119,11 +119,6 @@ public:
 		cfg.max_reads = max_reads; cfg.max_window = max_window; cfg.lanes = lanes; cfg.seed_group = seed_group;
 		kg_stream *s = nullptr;
 		if (kg_stream_open(ix_, &cfg, &s) != KG_OK) {
-			// (more streams than hardware queues: round 3's shape -- four independent lanes -- needs four)
-			if (lanes > 4 || seed_group) {
-				fprintf(stderr, "Warning! %s -- using 4 independent lanes\n", kg_last_error());
-				return stream(max_reads, max_window, 4, 0);
-			}
 			fprintf(stderr, "Warning! no device stream (%s): the host parses and prints\n", kg_last_error());
 			return nullptr;
 		}

@@ -1,8 +1,6 @@
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # before the first HIP call of the test process: see kart_amd/__init__.py
-
 import numpy as np
 import pytest
 

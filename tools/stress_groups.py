@@ -24,6 +24,8 @@ def run(env, tag):
 
 
 want, _ = run({"KART_AMD_SEED_GROUP": "0"}, "base")
+# (round 4: 224 runs of this matrix clean once the two null-stream memsets of the alignment control block / the workspace's control
+#  block were moved onto the workspace's stream; before, 4-11 of 16 runs of the grouped configurations lost the mate rescue of a few pairs)
 configs = [("8 lanes g4 turns (default)", {}), ("8 lanes g4 no turns", {"KG_GROUP_NO_TURNS": "1"}), ("4 lanes g4 turns", {"KART_AMD_STREAM_LANES": "4"}),
            ("8 lanes independent", {"KART_AMD_SEED_GROUP": "0", "KART_AMD_STREAM_LANES": "8"}), ("8 lanes g2", {"KART_AMD_SEED_GROUP": "2", "KART_AMD_STREAM_LANES": "8"}),
            ("8 lanes g4 turns 4 k batches", {"KART_AMD_STREAM_READS": "4000"}), ("8 lanes independent 4 k batches", {"KART_AMD_SEED_GROUP": "0", "KART_AMD_STREAM_LANES": "8", "KART_AMD_STREAM_READS": "4000"})]
@@ -47,5 +49,5 @@ for name, env in configs:
                         if k >= 4: break
                 diff = [j for j, (x, y) in enumerate(zip(a, b)) if x != y]
                 print("    differing lines (header = 6 lines, 4000 reads per chunk):", diff[:60], "chunks", sorted(set((j - 6) // 4000 for j in diff)))
-                print("   ", [l for l in log.splitlines() if "re-mapped" in l or "device stream" in l or "device report" in l][-3:])
+                print("   ", [l for l in log.splitlines() if "re-mapped" in l or "device report" in l][-2:])
     print("%-18s %d of %d runs differ" % (name, bad, runs))
