@@ -627,10 +627,10 @@ def run(args, fallback_note):
         drop(outs.pop(0))
     emitted = [False]
 
-    def emit():
+    def emit(final=True):
         """the JSON line, flushed; called as soon as value + roofline + cpu_baseline exist and again, enriched, at the very end
         (a side leg that dies late must not cost the line; a reader that wants ONE line takes the last)"""
-        line["line"] = "final" if emitted[0] else "headline (an enriched copy follows when the side legs have run)"
+        line["line"] = "final" if final else "headline (an enriched copy follows when the side legs have run)"
         sys.stdout.write(json.dumps(line) + "\n")
         sys.stdout.flush()
         emitted[0] = True
@@ -643,7 +643,7 @@ def run(args, fallback_note):
             except Exception as exc:      # a side measurement must never cost the line
                 line["cpu_baseline_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
         if not (args.no_seeding_leg and args.no_parity and (args.no_other_configs or not large)):
-            emit()
+            emit(final=False)
         if not args.no_parity:
             try:
                 line["parity"] = reference_legs(args, sess, prefix, workdir, f1, f2, n_pairs, threads, cores, want="identity")
