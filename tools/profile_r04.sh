@@ -40,3 +40,5 @@ json.dump(out, open("gpurun_out/${TAG}_bench_pmc_summary.json", "w"), indent=1, 
 print("kernels with counters:", len(out), out.get("_search_traffic"))
 PY
 head -30 gpurun_out/${TAG}_bench_kernel_stats.csv | cut -c1-170
+# the raw traces and counter files are far beyond what travels back (64 MiB): keep the condensed files only
+rm -rf gpurun_out/${TAG}_bench_trace gpurun_out/${TAG}_bench_pmc_TCC_EA0_RDREQ_128B_sum gpurun_out/${TAG}_bench_pmc_WRITE_SIZE gpurun_out/${TAG}_bench_pmc_TCC_HIT_sum gpurun_out/${TAG}_bench_pmc_SQ_WAVE_CYCLES
