@@ -264,8 +264,8 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		fprintf(stdout, "cpu seconds of the mapping phase: user %.2f, system %.2f (wall %.2f)\n", secs(ru1.ru_utime, ru0.ru_utime), secs(ru1.ru_stime, ru0.ru_stime), stats.map_seconds);
 	}
 	if (getenv("KART_AMD_VERBOSE") && shard.active())
-		fprintf(stdout, "shard %d/%d: %lld reads in %.3f s | waited %.3f s for the totals of the shard before | settled in %.3f s (%lld chunks mapped again) | writer drain %.3f s\n", shard.rank, shard.count,
-		        (long long)stats.total_reads, stats.map_seconds, tot.t_shard_wait, tot.t_shard_settle, (long long)stats.respeculated, tot.t_drain);
+		fprintf(stdout, "shard %d/%d: %lld reads in %.3f s | waited %.3f s for the totals of the shard before | settled in %.3f s (%lld chunks mapped again, %lld chunks of text written again) | writer drain %.3f s\n", shard.rank, shard.count,
+		        (long long)stats.total_reads, stats.map_seconds, tot.t_shard_wait, tot.t_shard_settle, (long long)stats.respeculated, (long long)stats.rewritten_chunks, tot.t_drain);
 	if (getenv("KART_AMD_VERBOSE") && g_frag_total.load() > 0)
 		fprintf(stdout, "fragment pairs (GenerateNormalPairAlignment) aligned by the device: %lld, of them handed back and planned here: %lld\n", (long long)g_frag_total.load(), (long long)g_frag_back.load());
 	if (getenv("KART_AMD_VERBOSE")) fprintf(stdout, "i/o threads: %s (%d CPUs)\n", g_io_cpus.valid ? "kept on the CPUs of one last-level cache" : "not pinned", g_io_cpus.count);

@@ -172,6 +172,7 @@ struct Stats {
 	int64_t total_reads = 0, unmapped = 0, unique = 0, paired = 0, distance = 0;
 	double map_seconds = 0;     // first read in -> last SAM byte handed to the writer (index load excluded)
 	int64_t respeculated = 0;   // chunks re-mapped because their speculated EstDistance did not hold
+	int64_t rewritten_chunks = 0;   // (-parts, a later shard) chunks whose text was written a second time because settling changed a chunk in front of them
 	int64_t stream_reads = 0;   // reads that went through the device's FASTQ-in / SAM-out stream
 	kg_stream_timing_t device{};   // ... and what their batches cost on the device (HIP events on the lanes' streams, summed)
 	bool sharded = false;       // the totals above are this process's shard only (kart::shard_totals() gives the run's)

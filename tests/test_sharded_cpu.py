@@ -82,3 +82,24 @@ def test_sharded_parts_concatenate_to_the_golden_file(case, devices, host_oracle
     got = b"".join(open("%s.%d" % (out, q), "rb").read() for q in range(n))
     from test_host_pipeline import GOLD_OF, SAM
     assert got == gzip.open(os.path.join(SAM, GOLD_OF.get(case, case) + ".sam.gz")).read()
+
+
+@pytest.mark.parametrize("devices", ["0,1", "0,1,2,3", "0,1,2,3,4,5,6,7"])
+def test_sharded_parts_written_while_mapping_match_live_reference(devices, moving_estimate_input, host_oracle_binary, tmp_path):
+    """-parts: a later shard writes its text while it maps (speculating EstDistance from rank 0's running totals plus its own) and
+    writes the tail of its part again when settling changed a chunk -- the drifting insert size forces exactly that.  The parts'
+    concatenation is the reference's -t 1 file either way, and the same with the text held back until the end."""
+    f1, f2, ref = moving_estimate_input
+    n = len(devices.split(","))
+    rewritten = 0
+    for env in ({}, {"KART_AMD_NO_EAGER_PARTS": "1"}):
+        out = str(tmp_path / ("o%d.sam" % len(env)))
+        r = subprocess.run([host_oracle_binary, "-silent", "-i", SMALL_PREFIX, "-f", f1, "-f2", f2, "-o", out, "-gpu", devices, "-parts", "-t", "8"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, KART_AMD_VERBOSE="1", **env))
+        assert r.returncode == 0, r.stdout.decode()[-600:]
+        assert b"".join(open("%s.%d" % (out, q), "rb").read() for q in range(n)) == ref, env
+        if not env:
+            for l in r.stdout.decode().splitlines():
+                if l.startswith("shard ") and "chunks of text written again" in l:
+                    rewritten += int(l.split("chunks mapped again, ")[1].split()[0])
+    assert rewritten > 0, "the drifting estimate should have changed at least one chunk of a later shard"
