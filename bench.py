@@ -651,7 +651,8 @@ def run(args, fallback_note):
                 line["parity"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     for f in (f1, f2):
         try:
-            os.remove(f)
+            if not os.environ.get("KART_BENCH_KEEP_FASTQ"):          # (debug aid: the two input files stay for a run of kart-amd by hand)
+                os.remove(f)
         except OSError:
             pass
     if world == 1 and large and not args.no_other_configs:
