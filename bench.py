@@ -635,6 +635,22 @@ def run(args, fallback_note):
         sys.stdout.flush()
         emitted[0] = True
 
+    # the alignment stage (pairing / rescue / plan / NW / finish / records: everything kg_align_batch does) has a roofline entry of its own:
+    # HIP-event time of the stage per step against the bytes it must touch -- read characters, candidates and their seeds in, the
+    # per-candidate report (78 B) and one record per read (112 B) out; the 2-bit text it compares with is ~1/4 B per read base.
+    n_cand = sum(float(st.candidates) for st in stats) / args.steps
+    n_cseed = sum(float(st.candidate_seeds) for st in stats) / args.steps
+    if stage_ms["align"] > 0 and n_cand > 0:
+        aln_bytes = n_reads * (READ_LEN + READ_LEN / 4 + 112) + n_cand * (32 + 78) + n_cseed * 16
+        aln_gbs = aln_bytes / (stage_ms["align"] * 1e-3) / 1e9
+        line["alignment_stage"] = {"bound": "hbm", "kernels": "aln_pair, aln_rescue, aln_bin, aln_plan_fast, aln_plan, aln_partition, nw_*, aln_finish, aln_final",
+                                   "ms_per_step": stage_ms["align"], "candidates_per_read": n_cand / n_reads, "candidate_seeds_per_read": n_cseed / n_reads,
+                                   "algorithmic_bytes_per_step": aln_bytes, "algorithmic_bytes_per_read": aln_bytes / n_reads,
+                                   "achieved": aln_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": aln_gbs / HBM_PEAK_GBS,
+                                   "note": "HIP-event time of the stage on the lanes' streams (a group's lanes take turns at it, so it is mostly the stage alone on the device) "
+                                           "against the bytes it has to move: dependent small gathers per candidate, not streaming -- the wait share per kernel "
+                                           "(SQ_WAIT_ANY / SQ_WAVE_CYCLES) is in the round's PMC summary under profiles/"}
+
     if world == 1:
         # ---- CPU baseline + parity on a prefix of the very files that were timed -------------------------------------------
         if not args.no_cpu_baseline:

@@ -376,6 +376,7 @@ typedef struct {
 	int64_t search_kernel_launches;
 	double search_useful_bytes;
 	double text_in_bytes, text_out_bytes;
+	double candidates, candidate_seeds;     /* chained candidates and their seeds of the batches (what the alignment stage reads per candidate) */
 } kg_stream_timing_t;
 int   kg_stream_timing(kg_stream *s, kg_stream_timing_t *out, int reset);
 

@@ -45,6 +45,7 @@ typedef struct {
 	int64_t search_kernel_launches;
 	double  search_useful_bytes;     /* bytes the implemented search fetched in them (kg_traffic_t's formula) */
 	double  text_in_bytes, text_out_bytes;
+	double  candidates, candidate_seeds;     /* of the batches that went through the device stream (kg_stream_timing_t) */
 } kh_stats_t;
 
 const char *kh_last_error(void);

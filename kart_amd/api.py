@@ -122,7 +122,7 @@ class StreamResult(C.Structure):
 
 class StreamTiming(C.Structure):
     _fields_ = [("batches", C.c_int64), ("reads", C.c_int64)] + [(n, C.c_double) for n in ("parse_ms", "seed_ms", "chain_ms", "align_ms", "format_ms", "copy_ms", "search_kernel_ms")] + \
-               [("search_kernel_launches", C.c_int64)] + [(n, C.c_double) for n in ("search_useful_bytes", "text_in_bytes", "text_out_bytes")]
+               [("search_kernel_launches", C.c_int64)] + [(n, C.c_double) for n in ("search_useful_bytes", "text_in_bytes", "text_out_bytes", "candidates", "candidate_seeds")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -510,7 +510,8 @@ class HostStats(C.Structure):
     _fields_ = [("total_reads", C.c_int64), ("unmapped", C.c_int64), ("unique", C.c_int64), ("paired", C.c_int64), ("distance", C.c_int64),
                 ("respeculated", C.c_int64), ("map_seconds", C.c_double), ("sharded", C.c_int32), ("pad", C.c_int32),
                 ("stream_reads", C.c_int64), ("stream_batches", C.c_int64), ("stage_ms", C.c_double * 6), ("search_kernel_ms", C.c_double),
-                ("search_kernel_launches", C.c_int64), ("search_useful_bytes", C.c_double), ("text_in_bytes", C.c_double), ("text_out_bytes", C.c_double)]
+                ("search_kernel_launches", C.c_int64), ("search_useful_bytes", C.c_double), ("text_in_bytes", C.c_double), ("text_out_bytes", C.c_double),
+                ("candidates", C.c_double), ("candidate_seeds", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

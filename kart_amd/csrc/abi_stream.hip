@@ -606,6 +606,7 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 		t.search_kernel_ms += sk; t.search_kernel_launches += (!grouped || group_leader) ? 1 : 0; t.search_useful_bytes += useful;
 		t.text_in_bytes += (double)((l.parsed.used[0] - l.win.begin[0]) + (l.win.two_files ? l.parsed.used[1] - l.win.begin[1] : 0));
 		t.text_out_bytes += (double)sam_bytes;
+		t.candidates += (double)totals[0]; t.candidate_seeds += (double)totals[1];
 	}
 	return KG_OK;
 }
