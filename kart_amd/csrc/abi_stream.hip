@@ -88,7 +88,7 @@ struct SeedGroup {
 	// After the round the lanes run their own stages (chaining .. text) ONE AFTER THE OTHER, in lane order: started all at once they
 	// share the device, all finish late and together, and the caller's writer -- which takes the batches in order -- first starves and
 	// is then handed four batches at once (measured, 100 M reads: 27.6-28.4 M reads/s against 29.0-29.9 M with independent lanes).
-	// A lane passes the turn on once its text kernels are enqueued: its copies to the host overlap the next lane's kernels.
+	// A lane keeps the turn until its batch is back on the host (kg_stream_map's last sync).
 	int order[kMaxSeedSegments] = {0};
 	int n_order = 0, turn = 0;
 };
@@ -564,8 +564,12 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 	}
 	HIP_TRY(launch_sam_format(q, ix->n_cu, st));
 	HIP_TRY(hipEventRecord(l.ev[5], st));
-	static const bool turn_late = getenv("KG_GROUP_TURN_LATE") != nullptr;          // A/B aid: the turn is kept until the batch is back on the host
-	if (!turn_late) turn.release();    // (grouped seeding: the next lane of the group starts its stages; this one's copies overlap them)
+	// (grouped seeding) the turn is kept until the batch is back on the host.  Passing it on here -- so that this lane's copies overlap the
+	// next lane's kernels, KG_GROUP_TURN_EARLY=1 -- gives the same FASTQ -> SAM rate at 100 M reads (29.4-29.9 M against 29.8-30.4 M
+	// mapped reads/s) while the next lane's first kernel then waits behind this one's copies: chain_kernel 5.0 ms per launch instead of 0.35,
+	// the stage sums twice as long (profiles/r04u_trace_chain.log, r04v_ab_turn_late.log); the other group's lanes overlap either way.
+	static const bool turn_early = getenv("KG_GROUP_TURN_EARLY") != nullptr;
+	if (turn_early) turn.release();
 	if (sam_bytes > 0) HIP_TRY(hipMemcpyAsync(l.h_sam, l.d_sam, (size_t)sam_bytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(l.h_sam_off, l.d_sam_off, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(l.h_records, a.records, sizeof(kg_aln_record) * (size_t)(n + extra), hipMemcpyDeviceToHost, st));
