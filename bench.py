@@ -263,14 +263,24 @@ def job_bytes(n_pairs):
     return 2 * n_pairs * REC_BYTES + 2 * (2 * n_pairs) * SAM_BYTES_PER_READ
 
 
-def pick_pairs(mem, large):
+PROCESS_SHARE = 0.80             # files + what the N rank processes themselves hold (below) may take this much of it
+
+
+def rank_bytes(lanes, large):
+    """host memory of one rank process besides the files: the host copy of the reference (2 B per base: forward + reverse strand), the
+    stream lanes' page-locked buffers (~1.8 GB each at 1 M-read batches: two text windows, the SAM text, records, candidates), and
+    python + torch + the HIP runtime"""
+    return (2 * HG38_LEN if large else 2 * GENOME_LEN) + lanes * (1800 << 20) + (4 << 30)
+
+
+def pick_pairs(mem, large, world=1, lanes=8):
     """read pairs per step: configs[2]'s 50 M (100 M reads) if FASTQ + two outputs stay within MEM_SHARE of what the host can
-    hold, else the largest multiple of 5 M that does (at least 1 M)"""
+    hold AND files + the rank processes' own memory within PROCESS_SHARE, else the largest multiple of 5 M that does (at least 1 M)"""
     full = 50_000_000 if large else 10_000_000
     usable = mem.get("usable")
     if usable is None:
         return min(full, 10_000_000)
-    budget = usable * MEM_SHARE
+    budget = min(usable * MEM_SHARE, usable * PROCESS_SHARE - world * rank_bytes(lanes, large))
     if mem.get("shm_free") is not None:
         budget = min(budget, mem["shm_free"] * 0.8)
     n = full
@@ -445,10 +455,15 @@ def run(args, fallback_note):
     from kart_amd import api, shard
 
     mem0 = host_memory()
+    if world >= 4 and "KART_AMD_STREAM_LANES" not in os.environ and "KART_AMD_SEED_GROUP" not in os.environ:
+        # N >= 4 ranks share one host: one seeding group of four lanes per rank instead of two (every rank maps 1/N of the reads, and
+        # eight ranks' 64 lanes would pin ~115 GB of host memory beside the files)
+        os.environ["KART_AMD_STREAM_LANES"] = "4"
+        os.environ["KART_AMD_SEED_GROUP"] = "4"
     if args.pairs is None:
         # configs[2] names 100 M reads: 32 GB of FASTQ and 38 GB of SAM per step, page-cache resident -- when the HOST can hold
         # FASTQ + two outputs within MEM_SHARE of min(MemAvailable, cgroup headroom); otherwise fewer
-        pick = [pick_pairs(mem0, args.genome_len >= 300_000_000)]
+        pick = [pick_pairs(mem0, args.genome_len >= 300_000_000, world, seed_group_setting()[1])]
         if world > 1:
             from kart_amd import shard as _sh
             pick = [-_sh.max_over_ranks(-float(pick[0]), device=None if share else dev)]      # the smallest pick of any rank, for all
@@ -595,6 +610,7 @@ def run(args, fallback_note):
                    "host_memory_GB": {k: (round(v / 1e9, 1) if isinstance(v, (int, float)) else v) for k, v in mem0.items()},
                    "sizing": "reads per step chosen so that FASTQ + TWO step outputs (%.1f GB) stay within %d %% of min(MemAvailable, cgroup headroom) = %s GB; every step writes a "
                              "fresh output, all but the newest are removed between the steps (outside the per-step timers)" % (job_bytes(n_pairs) / 1e9, int(MEM_SHARE * 100), "%.1f" % (mem0["usable"] / 1e9) if mem0.get("usable") else "?"),
+                   "rank_processes_GB": round(world * rank_bytes(seed_group_setting()[1], large) / 1e9, 1),
                    "peak_shmem_GB": round(peak_shmem[0] / 1e9, 1), "shmem_before_GB": round((mem0.get("Shmem") or 0) / 1e9, 1),
                    "timing": "value = mapped reads of the K timed steps / the sum of their wall times (each step bracketed by torch.cuda.synchronize, max over ranks per step); "
                              "bracket_seconds = barrier-to-barrier wall of the same K steps including the removal of old outputs between them",
