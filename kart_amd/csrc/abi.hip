@@ -1018,6 +1018,7 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 	a.est_distance = est_distance; a.max_insert = max_insert; a.max_gaps = max_gaps;
 	a.multi_hit = multi_hit ? 1 : 0; a.unset_flag = unset_flag;
 	{ static const bool nopart = getenv("KG_DBG_NO_PARTITION") != nullptr; a.dbg_no_partition = nopart ? 1 : 0; }
+	{ static const bool scan = getenv("KG_RESCUE_SCAN") != nullptr; a.dbg_rescue_scan = scan ? 1 : 0; }
 	a.extra_capacity = 0;                                  // (set below, once the pinned array of this call is known)
 	a.mapq_tab = ix->d_mapq_tab;
 	{

@@ -312,6 +312,8 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 	__shared__ int raw_key[kRescueMaxRuns], raw_len[kRescueMaxRuns];      // runs as the lanes find them: (diagonal index << 8 | read position), length
 	__shared__ int run_d[kRescueMaxRuns], run_t[kRescueMaxRuns], run_l[kRescueMaxRuns];   // ... sorted by (diagonal, read position)
 	__shared__ int n_raw;
+	__shared__ int kh_head[512], kh_next[kRescueMaxRead];           // the read's 10-mers: hash slot -> chain of read positions
+	__shared__ uint32_t kh_key[kRescueMaxRead];
 	const int lane = threadIdx.x;
 	unsigned long long n_tasks = a.ctl[4];
 	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
@@ -367,6 +369,43 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 		__syncthreads();
 		// diagonals d = gpos - rpos of k-mer pairs: -(rlen - 8) .. slen - 8
 		const int d_lo = -(rlen - 8), nd = slen + rlen - 15;
+		if (!a.dbg_rescue_scan) {
+			// Round 4: the runs through the read's 10-mers.  Every maximal exact match of >= 10 bases starts with a common 10-mer whose
+			// predecessor pair differs (or does not exist): the read's <= 247 10-mers go into a 512-slot LDS hash, every lane looks the
+			// window's 10-mers up (26 positions per lane for a 1650-base window), and a hit that starts a run is extended 32 bases per
+			// step.  The scan below walked all ~1800 diagonals of the window, 8 words each (87 G VALU wave-instructions per 80 M
+			// reads, 54 % of the kernel's cycles waiting on its own issue, profiles/r03w); the same runs come out (rank-sorted afterwards).
+			auto bits_at = [](const uint64_t *v, int pos) -> uint64_t {        // 32 bases from base `pos` (2 bits each)
+				const int w = pos >> 5, sh = (pos & 31) << 1;
+				return sh ? (v[w] >> sh) | (v[w + 1] << (64 - sh)) : v[w];
+			};
+			for (int i = lane; i < 512; i += 64) kh_head[i] = -1;
+			__syncthreads();
+			for (int q = lane; q + 10 <= rlen; q += 64) {
+				const uint32_t key = (uint32_t)(bits_at(rd2, q) & 0xFFFFFull);
+				kh_key[q] = key;
+				kh_next[q] = atomicExch(&kh_head[(key * 0x9E3779B1u) >> 23], q);
+			}
+			__syncthreads();
+			for (int w = lane; w + 10 <= slen; w += 64) {
+				const uint32_t key = (uint32_t)(bits_at(win2, w) & 0xFFFFFull);
+				for (int q = kh_head[(key * 0x9E3779B1u) >> 23]; q >= 0; q = kh_next[q]) {
+					if (kh_key[q] != key) continue;
+					if (q > 0 && w > 0 && ((((rd2[(q - 1) >> 5] >> (((q - 1) & 31) << 1)) ^ (win2[(w - 1) >> 5] >> (((w - 1) & 31) << 1))) & 3) == 0)) continue;   // not where the run starts
+					const int room = rlen - q < slen - w ? rlen - q : slen - w;
+					int e = 0;
+					while (e < room) {
+						const uint64_t diff = bits_at(rd2, q + e) ^ bits_at(win2, w + e);
+						const uint64_t ne = (diff | (diff >> 1)) & 0x5555555555555555ull;
+						if (ne) { e += (__ffsll((unsigned long long)ne) - 1) >> 1; break; }
+						e += 32;
+					}
+					if (e > room) e = room;
+					const int at_ = atomicAdd(&n_raw, 1);
+					if (at_ < kRescueMaxRuns) { raw_key[at_] = ((w - q - d_lo) << 8) | q; raw_len[at_] = e; }
+				}
+			}
+		} else {
 		const int per = (nd + 63) >> 6;
 		// per diagonal: the equality bit of every read position (one bit per base, up to 256), then the positions where ten
 		// consecutive bits are set by shift-and doubling; almost every diagonal ends there with nothing set
@@ -425,6 +464,7 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 				if (at_ < kRescueMaxRuns) { raw_key[at_] = (di << 8) | p; raw_len[at_] = e - p; }
 				for (int c = p; c < e; ++c) R[c >> 6] &= ~(1ull << (c & 63));   // (positions of this run cannot start another)
 			}
+		}
 		}
 		// the runs in (diagonal, read position) order -- the order IdentifyCommonKmers' sort leaves the k-mer hits in: rank sort
 		__syncthreads();
