@@ -1010,6 +1010,8 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 	a.ix.text = ix->d_text;
 	a.enc = ws->d_enc; a.read_off = ws->d_read_off; a.n_reads = n;
 	a.chunk_off = ws->d_chunk_off; a.chunk_paired = ws->d_chunk_paired; a.n_chunks = n_chunks;
+	a.all_paired = 1;
+	for (int c = 0; c < n_chunks; ++c) a.all_paired = a.all_paired && chunk_paired[c] ? 1 : 0;
 	a.cand_off = ws->d_cand_off; a.cands = ws->d_dense_cands; a.cand_seeds = ws->d_dense_seeds; a.n_cands = nc;
 	a.contig_end = ix->d_contig_end; a.end_chr = ix->d_end_chr; a.n_ends = ix->n_ends;
 	a.n_chr = (int)ix->contigs.size();

@@ -134,15 +134,14 @@ __device__ void remove_unmated(const AlnArgs &a, const CandList &l1, const CandL
 }  // namespace
 
 // ---- pairing ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
+// one pair (or one single-end read): CheckPairedAlignmentCandidates and what follows it.  out_ck / out_lo / out_hi: the pair's
+// contribution to its chunk's EstDistance validity interval (out_ck < 0: none) -- merged per wave by the kernel
+__device__ __forceinline__ void pair_one(const AlnArgs &a, const int64_t r, int &out_ck, long long &out_lo, long long &out_hi)
 {
-	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	for (; r < a.n_reads; r += stride) {
 		const int ck = chunk_of(a, r);
 		const bool paired = a.chunk_paired[ck] != 0;
 		const int64_t in_chunk = r - a.chunk_off[ck];
-		if (paired && (in_chunk & 1)) continue;                      // the first mate's lane does the pair
+		if (paired && (in_chunk & 1)) return;                        // the first mate's lane does the pair
 		const CandList l1 = cand_list(a, r);                         // (no rescue slots yet: resc_n is zero)
 		const int64_t a0 = l1.c0;
 		const int n1 = l1.nd;
@@ -150,14 +149,14 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 		a.records[r].est_lo = -1; a.records[r].est_hi = 0x7fffffff; a.records[r].rescue = 0;
 		if (!paired) {
 			remove_redundant(a, l1);                                 // src/Mapping.cpp:589
-			continue;
+			return;
 		}
 		a.records[r + 1].est_lo = -1; a.records[r + 1].est_hi = 0x7fffffff; a.records[r + 1].rescue = 0;
 		const CandList l2 = cand_list(a, r + 1);
 		const int64_t a1 = l2.c0;
 		const int n2 = l2.nd;
 		for (int j = 0; j < n2; ++j) { a.c_score[a1 + j] = a.cands[a1 + j].score; a.c_mate[a1 + j] = -1; a.c_read[a1 + j] = (int32_t)(r + 1); }
-		if ((int64_t)n1 * n2 > kAlnPairProduct) { flag_host(a, r, WHY_PAIR_PRODUCT); continue; }
+		if ((int64_t)n1 * n2 > kAlnPairProduct) { flag_host(a, r, WHY_PAIR_PRODUCT); return; }
 		// CheckPairedAlignmentCandidates, src/Mapping.cpp:348-400
 		if (n1 * n2 > 1000) { remove_redundant(a, l1); remove_redundant(a, l2); }
 		bool pairing = false;
@@ -192,8 +191,7 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 				}
 			}
 		}
-		if (lo > -1) atomicMax((long long *)&a.chunk_stats[ck].lo, lo);
-		if (hi != 0x7fffffffffffffffll) atomicMin((long long *)&a.chunk_stats[ck].hi, hi);
+		out_ck = ck; out_lo = lo; out_hi = hi;                       // (into the chunk's interval by the caller: one atomic pair per wave)
 		{
 			// the pair's own interval (every distance that matters is far below 2^31: EstDistance never exceeds 1.5 x 10000)
 			int32_t plo = (int32_t)lo, phi = hi > 0x7fffffffll ? 0x7fffffff : (int32_t)hi;
@@ -290,11 +288,43 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 					}
 				}
 			}
-			if (host) { a.resc_n[r] = 0; flag_host(a, r, why); continue; }
-			if (nt > 0) { a.r_pending[r] = 1; continue; }           // filters follow once the windows are scanned (aln_post_rescue_kernel)
+			if (host) { a.resc_n[r] = 0; flag_host(a, r, why); return; }
+			if (nt > 0) { a.r_pending[r] = 1; return; }           // filters follow once the windows are scanned (aln_post_rescue_kernel)
 		}
 		remove_redundant(a, l1);                                     // src/Mapping.cpp:563
 		remove_redundant(a, l2);
+}
+
+// One PAIR per lane (one read per lane where a chunk is not paired).  Rounds 2-3 ran one READ per lane and let the second mate's lane
+// leave at once -- half of every wave idle -- and sent two same-address atomics per pair at the chunk's interval (2000 pairs per
+// chunk: a wave's 64 lanes hit one address); now a wave whose pairs lie in one chunk sends one pair of atomics.
+__global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
+{
+	const int64_t n_units = a.all_paired ? a.n_reads >> 1 : a.n_reads;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t u0 = (int64_t)blockIdx.x * blockDim.x; u0 < n_units; u0 += stride) {
+		const int64_t u = u0 + threadIdx.x;
+		int ck = -1;
+		long long lo = -1, hi = 0x7fffffffffffffffll;
+		if (u < n_units) pair_one(a, a.all_paired ? u << 1 : u, ck, lo, hi);
+		// ---- the chunk's interval: lo = max over the pairs, hi = min ----
+		const uint64_t have = __ballot(ck >= 0);
+		if (have == 0) continue;
+		const int ck0 = __shfl(ck, __ffsll((unsigned long long)have) - 1);
+		if (__ballot(ck >= 0 && ck != ck0) == 0) {
+			for (int off = 32; off > 0; off >>= 1) {
+				const long long l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+				lo = l2 > lo ? l2 : lo;
+				hi = h2 < hi ? h2 : hi;
+			}
+			if ((threadIdx.x & 63) == 0) {
+				if (lo > -1) atomicMax((long long *)&a.chunk_stats[ck0].lo, lo);
+				if (hi != 0x7fffffffffffffffll) atomicMin((long long *)&a.chunk_stats[ck0].hi, hi);
+			}
+		} else if (ck >= 0) {
+			if (lo > -1) atomicMax((long long *)&a.chunk_stats[ck].lo, lo);
+			if (hi != 0x7fffffffffffffffll) atomicMin((long long *)&a.chunk_stats[ck].hi, hi);
+		}
 	}
 }
 
@@ -1974,7 +2004,7 @@ static inline int grid_for_aln(int64_t items, int block, int max_blocks)
 hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 {
 	hipLaunchKernelGGL(aln_reset_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 8)), dim3(256), 0, stream, a);
-	hipLaunchKernelGGL(aln_pair_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(aln_pair_kernel, dim3(grid_for_aln(a.all_paired ? a.n_reads / 2 + 1 : a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
 	hipLaunchKernelGGL(aln_rescue_kernel, dim3(grid_for_aln(a.task_capacity, 1, n_cu * 32)), dim3(64), 0, stream, a);
 	hipLaunchKernelGGL(aln_post_rescue_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
 	if (a.n_cands > 0) {

@@ -84,6 +84,7 @@ struct AlnArgs {
 	const int64_t *chunk_off;       // [n_chunks + 1]
 	const uint8_t *chunk_paired;    // [n_chunks]
 	int n_chunks;
+	int all_paired;                 // every chunk is paired (the usual case): aln_pair_kernel then takes pair u = reads 2u, 2u + 1 per lane
 	// candidates (dense, read order)
 	const int64_t *cand_off;        // [n_reads + 1]
 	const kg_candidate *cands;
