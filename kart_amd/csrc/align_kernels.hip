@@ -1280,36 +1280,47 @@ __device__ int plan_partition(const AlnArgs &a, int64_t enc_off, const uint8_t *
 // registers -- 87 % of aln_plan_kernel's wave cycles were waits on its per-lane arrays in scratch memory (profiles/r03w) -- and
 // lists every other candidate, untouched, for aln_plan_kernel (dense: its lanes all walk the general path).  KG_ALN_NO_FAST: off.
 constexpr int kFastSeeds = 6;        // seeds of a candidate this kernel takes
-constexpr int kFastGap = 32;         // longest gap between them (one text word)
+constexpr int kFastGap = 2048;       // longest gap it looks at (head / tail gaps of candidates at repeat copies run to most of the read)
 
 // mismatches of the read characters rd[0 .. L) against the text at g (raw characters as CalFragPairMismatchBases compares them,
-// src/tools.cpp:40-47); dash: a literal '-' among them (the 1 x 1 case then goes to nw_alignment, src/tools.cpp:229-233)
-__device__ __forceinline__ int fast_gap_mismatches(const AlnArgs &a, const uint8_t *rd, int64_t g, int L, bool &dash)
+// src/tools.cpp:40-47), counted up to `stop` (the decisions below only ask "at most 2?"); dash: a literal '-' in the first character
+// (the 1 x 1 case then goes to nw_alignment, src/tools.cpp:229-233)
+__device__ __forceinline__ int fast_gap_mismatches(const AlnArgs &a, const uint8_t *rd, int64_t g, int L, int stop, bool &dash)
 {
 	int n = 0;
-	const uint64_t tw = text_word32(a, g);
-	for (int i0 = 0; i0 < L; i0 += 8) {
-		const uint64_t w = reinterpret_cast<const AlnU64u *>(rd + i0)->v;          // (the character array has 64 bytes of slack)
-		const int m = L - i0 < 8 ? L - i0 : 8;
-		for (int i = 0; i < m; ++i) {
-			const int c = (int)((w >> (8 * i)) & 255);
-			const int code = (int)((tw >> (2 * (i0 + i))) & 3);
-			const int t = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T';
-			n += c != t ? 1 : 0;
-			dash = dash || c == '-';
+	dash = rd[0] == '-';
+	for (int b0 = 0; b0 < L && n < stop; b0 += 32) {
+		const uint64_t tw = text_word32(a, g + b0);
+		const int lim = L - b0 < 32 ? L - b0 : 32;
+		for (int i0 = 0; i0 < lim && n < stop; i0 += 8) {
+			const uint64_t w = reinterpret_cast<const AlnU64u *>(rd + b0 + i0)->v;          // (the character array has 64 bytes of slack)
+			const int m = lim - i0 < 8 ? lim - i0 : 8;
+			for (int i = 0; i < m; ++i) {
+				const int c = (int)((w >> (8 * i)) & 255);
+				const int code = (int)((tw >> (2 * (i0 + i))) & 3);
+				const int t = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T';
+				n += c != t ? 1 : 0;
+			}
 		}
 	}
 	return n;
 }
 
-// a gap pair of L = L bases on the diagonal: its score when it needs no alignment (W_IMMEDIATE with op 'M'), -1 when it does
-__device__ __forceinline__ int fast_gap_value(const AlnArgs &a, const uint8_t *rd, int64_t g, int L)
+// A gap pair of L bases on the diagonal (read and genome side alike), role 0 = head, 1 = between seeds, 2 = tail: what
+// Process{Head,Normal,Tail}SequencePair decide WITHOUT an alignment (src/tools.cpp:225-397), as aln_plan_kernel's pair loop does:
+//   >= 0        : an 'M' element of L bases scoring that many identical ones (the <= 2-mismatch shortcut :240 / :301 / :352, or 1 x 1)
+//   kFastClip   : the whole gap soft-clipped, score 0 (a head beyond 50 bases :307-311, a tail beyond 100 :358-362)
+//   kFastSlow   : nw_alignment / the 8-mer partition / the > 3000 clip are due: the general kernel's
+constexpr int kFastClip = -1, kFastSlow = -2;
+__device__ __forceinline__ int fast_gap_value(const AlnArgs &a, const uint8_t *rd, int64_t g, int L, int role)
 {
+	if (role != 1 && L > 3000) return kFastSlow;
 	bool dash = false;
-	const int n = fast_gap_mismatches(a, rd, g, L, dash);
-	if (n <= 2 && n <= (int)(L * 0.2)) return L - n;           // :240 / :301 / :352
+	const int n = fast_gap_mismatches(a, rd, g, L, 3, dash);
+	if (n <= 2 && n <= (int)(L * 0.2)) return L - n;
+	if ((role == 0 && L > 50) || (role == 2 && L > 100)) return kFastClip;
 	if (L == 1 && !dash) return 0;                               // one base against one other base: 1M, nothing identical
-	return -1;
+	return kFastSlow;
 }
 
 __global__ __launch_bounds__(256) void aln_plan_fast_kernel(AlnArgs a)
@@ -1384,16 +1395,16 @@ __global__ __launch_bounds__(256) void aln_plan_fast_kernel(AlnArgs a)
 						// ---- the gap pairs ----
 						const uint8_t *rd = a.enc + rbase;
 						int score = seed_bases;
-						int head_val = 1, tail_val = 1;
-						if (first_r > 0) { head_val = fast_gap_value(a, rd, d, first_r); slow = head_val < 0; score += head_val > 0 ? head_val : 0; }
+						int head_val = 1, tail_val = 1;          // (> 0: scored; 0: an M element without identical bases; kFastClip: soft-clipped)
+						if (first_r > 0) { head_val = fast_gap_value(a, rd, d, first_r, 0); slow = head_val == kFastSlow; score += head_val > 0 ? head_val : 0; }
 #pragma unroll
 						for (int i = 1; i < kFastSeeds; ++i)
 							if (!slow && i < count && gap_len[i] > 0) {
-								const int v = fast_gap_value(a, rd + gap_at[i], d + gap_at[i], gap_len[i]);
-								slow = v < 0;
+								const int v = fast_gap_value(a, rd + gap_at[i], d + gap_at[i], gap_len[i], 1);
+								slow = v == kFastSlow;
 								score += v > 0 ? v : 0;
 							}
-						if (!slow && tail_len > 0) { tail_val = fast_gap_value(a, rd + prev_end, d + prev_end, tail_len); slow = tail_val < 0; score += tail_val > 0 ? tail_val : 0; }
+						if (!slow && tail_len > 0) { tail_val = fast_gap_value(a, rd + prev_end, d + prev_end, tail_len, 2); slow = tail_val == kFastSlow; score += tail_val > 0 ? tail_val : 0; }
 						if (!slow) {
 							// ---- GenMappingReport's tail: GenCoordinateInfo (:515-562), GenerateCIGAR (:492-513) ----
 							const int ck = chunk_of(a, r);
@@ -1403,7 +1414,8 @@ __global__ __launch_bounds__(256) void aln_plan_fast_kernel(AlnArgs a)
 							bool fwd;
 							int chr;
 							int64_t pos;
-							if (gPos < L) {
+							const bool rev = gPos >= L;
+							if (!rev) {
 								fwd = first;
 								if (a.n_chr == 1) { chr = 0; pos = gPos + 1; }
 								else { chr = a.end_chr[i1]; pos = gPos + 1 - a.chr_fwd_start[chr]; }
@@ -1412,17 +1424,30 @@ __global__ __launch_bounds__(256) void aln_plan_fast_kernel(AlnArgs a)
 								if (a.n_chr == 1) { chr = 0; pos = a.two_genome_size - end_gPos; }
 								else { pos = (ends_in_lds ? s_end[i1] : a.contig_end[i1]) - end_gPos + 1; chr = a.end_chr[i1]; }
 							}
-							// "<rlen>M": at most four digits
-							uint64_t text = 0;
+							// the elements: [head S] M [tail S] -- every M element merges into one; the reverse strand shows them in reverse order
+							const int clip_h = head_val == kFastClip ? first_r : 0, clip_t = tail_val == kFastClip ? tail_len : 0;
+							const int e_len[3] = {rev ? clip_t : clip_h, rlen - clip_h - clip_t, rev ? clip_h : clip_t};
+							char out[16];
 							int at = 0;
-							{
+#pragma unroll
+							for (int q = 0; q < 3; ++q) {
+								int nn = e_len[q];
+								if (nn <= 0) continue;
 								char buf[4];
-								int k = 0, nn = rlen;
+								int k = 0;
 								do { buf[k++] = (char)('0' + nn % 10); nn /= 10; } while (nn);
-								while (k) text |= (uint64_t)(uint8_t)buf[--k] << (8 * at++);
-								text |= (uint64_t)'M' << (8 * at++);
+								while (k) out[at++] = buf[--k];
+								out[at++] = q == 1 ? 'M' : 'S';
 							}
-							*reinterpret_cast<uint64_t *>(a.rep_cigar + cand * KG_ALN_CIGAR_MAX) = text;
+							uint64_t t0 = 0, t1 = 0;
+#pragma unroll
+							for (int q = 0; q < 16; ++q) {
+								const uint64_t ch = q < at ? (uint64_t)(uint8_t)out[q] : 0ull;
+								if (q < 8) t0 |= ch << (8 * q); else t1 |= ch << (8 * (q - 8));
+							}
+							uint64_t *dst = reinterpret_cast<uint64_t *>(a.rep_cigar + cand * KG_ALN_CIGAR_MAX);
+							dst[0] = t0;
+							if (at > 8) dst[1] = t1;
 							a.rep_cigar_len[cand] = (uint8_t)at;
 							a.rep_chr[cand] = chr;
 							a.rep_pos[cand] = pos;
