@@ -366,6 +366,7 @@ void kg_index_destroy(kg_index *ix)
 		if (sc->queue) (void)hipFree(sc->queue);
 		if (sc->dir) (void)hipFree(sc->dir);
 		if (sc->io) (void)hipFree(sc->io);
+		if (sc->io_stream) (void)hipStreamDestroy(sc->io_stream);
 		delete sc;
 	}
 	if (ix->d_sa) (void)hipFree(ix->d_sa);
@@ -1200,20 +1201,24 @@ int kg_nw_batch(kg_index *ix, const char *frag1, const int64_t *off1, const char
 		io->io_busy = true;   // holds the staging block; the kernels' own scratch comes from nw_acquire below
 	}
 	char *base = io->io;
-	hipStream_t st = nullptr;
-	hipError_t e = hipMemcpy(base + p_f1, frag1, (size_t)b1, hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(base + p_f2, frag2, (size_t)b2, hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(base + p_o1, off1, 8 * (size_t)(n + 1), hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(base + p_o2, off2, 8 * (size_t)(n + 1), hipMemcpyHostToDevice);
+	// a stream of the staging block's own: the call used to run on the null stream and end in hipDeviceSynchronize(), i.e. every one of
+	// the ~1300 small calls a 100 M-read run makes for the reads handed back waited for whatever ALL the lanes had in flight
+	hipError_t e = hipSuccess;
+	if (!io->io_stream) e = hipStreamCreateWithFlags(&io->io_stream, hipStreamNonBlocking);
+	hipStream_t st = io->io_stream;
+	if (e == hipSuccess) e = hipMemcpyAsync(base + p_f1, frag1, (size_t)b1, hipMemcpyHostToDevice, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(base + p_f2, frag2, (size_t)b2, hipMemcpyHostToDevice, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(base + p_o1, off1, 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(base + p_o2, off2, 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st);
 	int rc = KG_OK;
 	if (e != hipSuccess) rc = fail(KG_ERR_NO_DEVICE, "kg_nw_batch: %s", hipGetErrorString(e));
 	if (rc == KG_OK)
 		rc = nw_run(ix, base + p_f1, (const int64_t *)(base + p_o1), base + p_f2, (const int64_t *)(base + p_o2), n, max_len,
 		            (uint8_t *)(base + p_ops), (int32_t *)(base + p_len), st);
 	if (rc == KG_OK) {
-		e = hipDeviceSynchronize();
-		if (e == hipSuccess) e = hipMemcpy(ops, base + p_ops, (size_t)(b1 + b2), hipMemcpyDeviceToHost);
-		if (e == hipSuccess) e = hipMemcpy(aln_len, base + p_len, 4 * (size_t)n, hipMemcpyDeviceToHost);
+		e = hipMemcpyAsync(ops, base + p_ops, (size_t)(b1 + b2), hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipMemcpyAsync(aln_len, base + p_len, 4 * (size_t)n, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipStreamSynchronize(st);
 		if (e != hipSuccess) rc = fail(KG_ERR_NO_DEVICE, "kg_nw_batch: %s", hipGetErrorString(e));
 	}
 	{

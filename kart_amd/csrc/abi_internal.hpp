@@ -42,6 +42,7 @@ struct NwScratch {
 	char *io = nullptr;
 	size_t io_bytes = 0;
 	bool io_busy = false;
+	hipStream_t io_stream = nullptr;   // kg_nw_batch's copies and kernels (created with the staging block)
 };
 
 struct kg_index {
