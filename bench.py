@@ -604,8 +604,8 @@ def run(args, fallback_note):
                    "parallelism": "%d process(es), one GPU + index replica each, contiguous chunk ranges of the same input, SAM merged by file offset" % world,
                    "files": "page-cache resident (%s)" % workdir,
                    "seed_group": seed_group_setting()[0], "stream_lanes": seed_group_setting()[1],
-                   "seeding": ("ONE search launch per round over the parsed batches of %d stream lanes (%d lanes in flight, 1 M-read batches)" % seed_group_setting()) if seed_group_setting()[0]
-                              else "every stream lane seeds its own 1 M-read batch (%d lanes)" % seed_group_setting()[1],
+                   "seeding": ("ONE search launch per round over the parsed batches of %d stream lanes (%d lanes in flight, 1.12 M-read batches)" % seed_group_setting()) if seed_group_setting()[0]
+                              else "every stream lane seeds its own 1.12 M-read batch (%d lanes)" % seed_group_setting()[1],
                    "sam_bytes_per_step": sum(os.path.getsize(f) for f in out_files(outs[-1])),
                    "host_memory_GB": {k: (round(v / 1e9, 1) if isinstance(v, (int, float)) else v) for k, v in mem0.items()},
                    "sizing": "reads per step chosen so that FASTQ + TWO step outputs (%.1f GB) stay within %d %% of min(MemAvailable, cgroup headroom) = %s GB; every step writes a "
