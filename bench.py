@@ -603,7 +603,7 @@ def run(args, fallback_note):
                    "reads_per_step": n_reads, "reads_per_gpu_per_step": n_reads // world, "threads_per_rank": threads, "host_cpu_quota": cores,
                    "parallelism": "%d process(es), one GPU + index replica each, contiguous chunk ranges of the same input, SAM merged by file offset" % world,
                    "files": "page-cache resident (%s)" % workdir,
-                   "seed_group": seed_group_setting()[0], "stream_lanes": seed_group_setting()[1],
+                   "seed_group": seed_group_setting()[0], "stream_lanes": seed_group_setting()[1], "stream_reads": stream_reads_setting(),
                    "seeding": ("ONE search launch per round over the parsed batches of %d stream lanes (%d lanes in flight, 1.12 M-read batches)" % seed_group_setting()) if seed_group_setting()[0]
                               else "every stream lane seeds its own 1.12 M-read batch (%d lanes)" % seed_group_setting()[1],
                    "sam_bytes_per_step": sum(os.path.getsize(f) for f in out_files(outs[-1])),
@@ -988,6 +988,12 @@ def effective_cores():
     return n
 
 
+def stream_reads_setting():
+    """reads per stream batch as host/mapper.hpp chooses them (KART_AMD_STREAM_READS, default 1.12 M)"""
+    v = int(os.environ.get("KART_AMD_STREAM_READS", "0") or 0)
+    return v if v >= 4000 else 1120000
+
+
 def seed_group_setting():
     """(lanes per seeding group, stream lanes) as host/detail/pipeline.inc chooses them: KART_AMD_SEED_GROUP (default 4: ONE search launch over four
     lanes' batches), KART_AMD_STREAM_LANES (default two groups, or four independent lanes)"""
@@ -1021,7 +1027,7 @@ def measured_traffic(n_reads, args, tag=None):
             # the timed region: the same reads per step and the same seeding configuration as the profiled run (a launch of a run with
             # other batch sizes fetches other bytes -- round 3 quoted the 20 M-read run's figure for the 100 M-read run)
             if tag is not None and (t.get("pairs_per_step") != getattr(args, "pairs", None) or t.get("seed_group") != seed_group_setting()[0]
-                                    or t.get("stream_lanes") != seed_group_setting()[1]):
+                                    or t.get("stream_lanes") != seed_group_setting()[1] or t.get("stream_reads") != stream_reads_setting()):
                 continue
             best = (t["traffic_bytes_per_launch"], "profiles/" + f)
     return best if best else (None, None)

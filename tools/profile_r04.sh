@@ -31,7 +31,7 @@ for k, cs in list(out.items()):
         wr_b = wr["sum"] * 1024 * (n / max(1, wr["dispatches"]))
         hit, miss = cs.get("TCC_HIT_sum", {"sum": 0})["sum"], cs.get("TCC_MISS_sum", {"sum": 0})["sum"]
         out["_search_traffic"] = {"tag": "timed", "kernel": k.replace("kg::", ""), "genome_len": 3100000000, "launches": n, "pairs_per_step": $PAIRS,
-                                  "seed_group": cfg.get("seed_group"), "stream_lanes": cfg.get("stream_lanes"),
+                                  "seed_group": cfg.get("seed_group"), "stream_lanes": cfg.get("stream_lanes"), "stream_reads": cfg.get("stream_reads"),
                                   "read_bytes_corrected": rd, "WRITE_SIZE_bytes": wr_b, "traffic_bytes_per_launch": (rd + wr_b) / n,
                                   "l2_hit_rate": hit / (hit + miss) if hit + miss else None, "TCC_HIT": hit, "TCC_MISS": miss,
                                   "note": "gfx950: read traffic = RDREQ_128B x 128 + RDREQ_64B x 64 (FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); "
