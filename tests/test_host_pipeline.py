@@ -55,6 +55,14 @@ def run_case(binary, case, tmp, extra=()):
     return got, want, r.stdout.decode()
 
 
+def run_case_env(binary, case, tmp, extra, env):
+    args = [materialise(tmp, a) if (a.endswith((".fq", ".fa", ".gz"))) else a for a in CASES[case]]
+    out = os.path.join(tmp, case + ".sam")
+    r = subprocess.run([binary, "-silent", "-i", SMALL_PREFIX] + args + list(extra) + ["-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout.decode()[-500:]
+    return open(out, "rb").read(), gzip.open(os.path.join(SAM, GOLD_OF.get(case, case) + ".sam.gz")).read(), r.stdout.decode()
+
+
 UNSET_FLAG = 1 << 20     # not a SAM flag: no assigned value can collide with it
 
 
@@ -270,6 +278,15 @@ def test_output_errors_are_a_status_not_an_exit_inside_the_library(host_oracle_b
         finally:
             if os.path.exists(out):
                 os.remove(out)
+
+
+@pytest.mark.parametrize("writers,pwriters", [(1, 1), (2, 2), (4, 1), (1, 0)])
+def test_writer_thread_mix_gives_the_same_file(writers, pwriters, host_oracle_binary, tmp_path):
+    """the output through any mix of mapping threads and pwrite() threads (round 4: seven + one by default from -t 16 on) is the
+    same file -- chunks of 4000 reads land at their offsets whoever copies them"""
+    for case in ("pe", "se_m"):
+        got, want, _ = run_case_env(host_oracle_binary, case, str(tmp_path), ["-t", "8"], {"KART_AMD_WRITER_THREADS": str(writers), "KART_AMD_PWRITE_THREADS": str(pwriters)})
+        assert got == want, (case, writers, pwriters)
 
 
 def test_output_to_a_pipe(host_oracle_binary, tmp_path):
