@@ -445,6 +445,10 @@ class Stream:
         """seeding groups: lane `lane` has no batch for `rounds` rounds (< 0: until further notice, 0: it takes part again)"""
         _check(self.lib.kg_stream_group_absent(self.h, lane, rounds), "kg_stream_group_absent")
 
+    def group_abort(self):
+        """every lane that waits for its seeding group returns with an error (a caller's failure path)"""
+        _check(self.lib.kg_stream_group_abort(self.h), "kg_stream_group_abort")
+
     def parse(self, text1: bytes, text2: bytes | None = None, paired: bool = True, chunk_reads: int = 4000, want_reads: int | None = None,
               eof=(True, True), begin=(0, 0), lane: int = 0) -> StreamParsed:
         """uploads the window(s) (placed at staging offset begin[f]) and runs GetNextChunk's arithmetic on the device"""

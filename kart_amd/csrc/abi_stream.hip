@@ -430,8 +430,11 @@ static int group_seed(kg_stream *s, int lane, int64_t n, int64_t n_bases, int64_
 	// lane to look (kg_stream_group_absent wakes them).  The wait is bounded: a caller that lets a lane neither arrive nor declare
 	// itself absent would hang the others for ever.
 	const std::chrono::steady_clock::time_point give_up = std::chrono::steady_clock::now() + std::chrono::seconds(600);
+	auto leave = [&]() {                // (an aborted round: this lane is no longer part of it)
+		if (sg.round == my_round && sg.present[j]) { sg.present[j] = false; sg.arrived--; }
+	};
 	for (;;) {
-		if (sg.aborted) return fail(KG_ERR_ARG, "kg_stream_map: the stream's seeding groups were aborted");
+		if (sg.aborted) { leave(); return fail(KG_ERR_ARG, "kg_stream_map: the stream's seeding groups were aborted"); }
 		if (sg.round != my_round) break;
 		if (complete()) {
 			run_round();
@@ -449,6 +452,7 @@ static int group_seed(kg_stream *s, int lane, int64_t n, int64_t n_bases, int64_
 		if (sg.cv.wait_until(lk, give_up) == std::cv_status::timeout) {
 			sg.aborted = true;
 			sg.cv.notify_all();
+			leave();
 			return fail(KG_ERR_ARG, "kg_stream_map: lane %d waited 600 s for the other lanes of its seeding group (a lane without a batch must call kg_stream_group_absent)", lane);
 		}
 	}

@@ -234,6 +234,27 @@ def test_grouped_seeding_one_launch_for_several_lanes(gpu_index_full):
             s.map(lane=3)
         s.group_absent(3, 0)
         round_of({2: 1, 3: 0})
+        # a caller's failure path: a lane that waits for its group comes back with an error once the groups are aborted ...
+        s.parse(batches[0][0], batches[0][1], paired=True, want_reads=4000, lane=0)
+        errs = []
+
+        def waits():
+            try:
+                s.map(lane=0)
+            except api.KartAmdError as exc:
+                errs.append(str(exc))
+        t = threading.Thread(target=waits)
+        t.start()
+        import time
+        time.sleep(0.3)
+        assert t.is_alive()                          # (lane 1 has neither arrived nor said that it has no batch)
+        s.group_abort()
+        t.join(30)
+        assert not t.is_alive() and errs and "aborted" in errs[0]
+        # ... and the next run starts clean
+        for lane in range(4):
+            s.group_absent(lane, 0)
+        round_of({0: 1, 1: 0})
     finally:
         s.close()
 
