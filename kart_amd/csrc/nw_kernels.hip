@@ -372,11 +372,10 @@ __device__ __forceinline__ void nw_sweep(const NwArgs &a, int lane, int m, int n
 // was computed by lane ((j-1) mod 64 K) / K at step i + lane: the masks of the 64 steps below the current one are loaded by the 64
 // lanes at once and read lane by lane (v_readlane on scalar lane / bit indices); every move lowers the step by one or two (or keeps
 // it, between columns of one lane).  Returns the number of ops written (in reverse order).
-template <int K, int kLanes = 64>
-__device__ __forceinline__ int nw_walk(int lane, int m, int n, const uint64_t *dir64, uint8_t *ops, int lane_base = 0)
+template <int K>
+__device__ __forceinline__ int nw_walk(int lane, int m, int n, const uint64_t *dir64, uint8_t *ops)
 {
-	// (kLanes = 32, lane_base = 0 / 32: one of the two pairs a wave swept side by side -- its bits are one half of every mask)
-	constexpr int W = kLanes * K;
+	constexpr int W = 64 * K;
 	const int steps = m + 63;
 	int len = 0, i = m, jj = n;
 	while (i > 0 || jj > 0) {
@@ -405,7 +404,7 @@ __device__ __forceinline__ int nw_walk(int lane, int m, int n, const uint64_t *d
 			const int col = (jj - 1) % W, cl = col / K, d = i + cl;
 			const int src = d_hi - d;
 			if (src > 63) break;
-			const int us = __builtin_amdgcn_readfirstlane(src), ub = __builtin_amdgcn_readfirstlane(cl + lane_base), kk = __builtin_amdgcn_readfirstlane(col % K);
+			const int us = __builtin_amdgcn_readfirstlane(src), ub = __builtin_amdgcn_readfirstlane(cl), kk = __builtin_amdgcn_readfirstlane(col % K);
 			uint64_t wr = cr[0], wt = ct[0];
 #pragma unroll
 			for (int k = 1; k < K; ++k) { if (kk == k) { wr = cr[k]; wt = ct[k]; } }
@@ -421,59 +420,6 @@ __device__ __forceinline__ int nw_walk(int lane, int m, int n, const uint64_t *d
 	return len;
 }
 
-// Two pairs per wave (round 4): pairs of up to 128 x 128 -- the 33-128 class -- used 42 % of a wave's lane-steps when a wave swept one
-// of them (an 80 x 80 matrix: 40 of 64 lanes, 119 steps).  Here the two halves of a wave sweep one pair each, side by side: lane l of half h
-// owns columns 4 l + 1 .. 4 l + 4 of pair h (K = 4: a single stripe, so the boundary column is the analytic column 0), the anti-diagonal
-// steps run in lockstep, and every ballot carries both pairs' bits -- pair h's in bits 32 h .. 32 h + 31 -- so the per-step work
-// that does not depend on the cell count (shifts, mask stores, loop) is paid once for two pairs.  s1c: the pairs' sequence-1 codes,
-// pair h at s1c + 128 h.
-__device__ __forceinline__ void nw_sweep_dual(const NwArgs &a, int lane, int m, int n, int64_t o2, int steps_max, const unsigned char *s1c, uint64_t *dir64)
-{
-	constexpr int K = 4;
-	const int l = lane & 31;
-	const unsigned char *codes = s1c + ((lane >> 5) << 7);
-	const int j0 = K * l + 1;
-	int c2[K], up_s[K], up_t[K];
-#pragma unroll
-	for (int k = 0; k < K; ++k) {
-		c2[k] = j0 + k <= n ? nw_code2(a, o2 + j0 + k - 1) : 9 + k;
-		up_s[k] = -2 - (j0 + k); up_t[k] = NEG;         // row 0
-	}
-	int res_s = 0, res_r = 0, prev_left_s = 0, c1 = 15;
-	int code_in = m >= 1 ? codes[0] : 15;
-	for (int d = 1; d <= steps_max; ++d) {
-		const int i = d - l;
-		int left_s = wave_shr1(res_s, 0), left_r = wave_shr1(res_r, 0);
-		c1 = wave_shr1(c1, 0);
-		if (l == 0) { left_s = -2 - d; left_r = NEG; c1 = code_in; }          // column 0 of the pair's own matrix, the code of row d
-		code_in = codes[d < m ? d : (m > 0 ? m - 1 : 0)];
-		const bool valid = (unsigned)(i - 1) < (unsigned)m;
-		int sv[K], rv[K], tv[K];
-		uint64_t mr[K], mt[K];
-#pragma unroll
-		for (int k = 0; k < K; ++k) {
-			const int ls = k == 0 ? left_s : sv[k - 1], lr = k == 0 ? left_r : rv[k - 1];
-			const int diag = k == 0 ? (i == 1 ? (j0 == 1 ? 0 : -2 - (j0 - 1)) : prev_left_s) : up_s[k - 1];
-			rv[k] = max(lr - 1, ls - 3);
-			tv[k] = max(up_t[k] - 1, up_s[k] - 3);
-			sv[k] = max(diag + (c1 == c2[k] ? 3 : -3), max(rv[k], tv[k]));
-			mr[k] = __builtin_amdgcn_ballot_w64(sv[k] == rv[k]);
-			mt[k] = __builtin_amdgcn_ballot_w64(sv[k] == tv[k]);
-		}
-		if (lane == 0) {
-			uint64_t *o = dir64 + (2 * K) * (d - 1);
-#pragma unroll
-			for (int k = 0; k < K; ++k) { o[2 * k] = mr[k]; o[2 * k + 1] = mt[k]; }
-		}
-		prev_left_s = left_s;
-		if (valid) {
-#pragma unroll
-			for (int k = 0; k < K; ++k) { up_s[k] = sv[k]; up_t[k] = tv[k]; }
-		}
-		res_s = sv[K - 1]; res_r = rv[K - 1];
-	}
-}
-
 // kGlobal: fragments longer than kNwMaxLen -- the boundary column and the sequence-1 codes no longer fit the LDS and
 // live in a per-wave HBM slab behind the direction words instead (same sweep; the reference's nw_alignment has no length
 // limit, src/nw_alignment.cpp:24-33, so neither has this path).
@@ -487,44 +433,10 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 	uint32_t *dir = a.dir_scratch + (int64_t)blockIdx.x * a.dir_words_per_wave;
 	for (;;) {
 		unsigned long long t = 0;
-		if (lane == 0) t = atomicAdd(a.queue + 3, kGlobal ? 1ull : 2ull);
+		if (lane == 0) t = atomicAdd(a.queue + 3, 1ull);
 		t = __shfl(t, 0);
 		if (t >= count) break;
-		if (!kGlobal) {
-			// two list entries at a time: both of at most 128 x 128 -> side by side in the two halves of the wave; else one after the other below
-			const bool two = t + 1 < count;
-			const int64_t pa = list[t], pb = two ? list[t + 1] : pa;
-			const NwPair qa = nw_pair(a, pa), qb = nw_pair(a, pb);
-			const int sa = qa.m + (qa.n + 3) / 4 - 1, sb = qb.m + (qb.n + 3) / 4 - 1;          // anti-diagonal steps of either pair (K = 4)
-			if (two && qa.m <= 128 && qa.n <= 128 && qb.m <= 128 && qb.n <= 128 && 16ll * (sa > sb ? sa : sb) <= a.dir_words_per_wave) {
-				const int h = lane >> 5;
-				const NwPair &qh = h ? qb : qa;
-				unsigned char *s1c = reinterpret_cast<unsigned char *>(lds_dyn);
-				for (int i = lane & 31; i < qh.m; i += 32) s1c[(h << 7) + i] = (unsigned char)nt4_code((unsigned char)a.f1[qh.o1 + i]);
-				__syncthreads();
-				uint64_t *dir64 = reinterpret_cast<uint64_t *>(dir);
-				nw_sweep_dual(a, lane, qh.m, qh.n, qh.o2, sa > sb ? sa : sb, s1c, dir64);
-				__threadfence_block();
-				__syncthreads();
-				for (int hh = 0; hh < 2; ++hh) {
-					const NwPair &q2 = hh ? qb : qa;
-					uint8_t *ops = a.ops + q2.oo;
-					const int len = nw_walk<4, 32>(lane, q2.m, q2.n, dir64, ops, hh << 5);
-					if (lane == 0) a.aln_len[hh ? pb : pa] = len;
-					__threadfence_block();
-					__syncthreads();
-					for (int x = lane; x < len / 2; x += 64) {
-						uint8_t t0 = ops[x], t1 = ops[len - 1 - x];
-						ops[x] = t1; ops[len - 1 - x] = t0;
-					}
-					__syncthreads();
-				}
-				continue;
-			}
-		}
-		for (int rep = 0; rep < (kGlobal ? 1 : 2); ++rep) {
-		if (t + (unsigned long long)rep >= count) break;
-		int64_t p = list[t + (unsigned long long)rep];
+		int64_t p = list[t];
 		const NwPair q = nw_pair(a, p);
 		const int64_t o1 = q.o1, o2 = q.o2;
 		const int m = q.m, n = q.n;
@@ -548,7 +460,6 @@ __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
 			ops[x] = t1; ops[len - 1 - x] = t0;
 		}
 		__syncthreads();
-		}
 	}
 }
 

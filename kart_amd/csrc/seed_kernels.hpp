@@ -130,7 +130,7 @@ struct NwArgs {
 
 constexpr int kNwMaxLen = 7000;  // longest fragment the wave-per-pair kernel's 64 KB LDS holds
 inline int nw_big_lds_bytes(int max_len) { return 8 * (max_len + 1) + ((max_len + 15) & ~15) + 16; }
-inline int64_t nw_dir_words(int max_len) { return max_len > 128 ? 16ll * (((int64_t)max_len + 255) / 256) * ((int64_t)max_len + 64) : 16ll * ((int64_t)max_len + 64); }   // per stripe (64 K columns, K = 2 up to 128 columns, else 4) and anti-diagonal step 2 K 64-bit lane masks; up to 128 columns also room for the two-pairs-per-wave sweep (K = 4 on 32 lanes each)
+inline int64_t nw_dir_words(int max_len) { return max_len > 128 ? 16ll * (((int64_t)max_len + 255) / 256) * ((int64_t)max_len + 64) : 8ll * ((int64_t)max_len + 64); }   // per stripe (64 K columns, K = 2 up to 128 columns, else 4) and anti-diagonal step 2 K 64-bit lane masks
 
 hipError_t launch_nw_batch(const NwArgs &a, int n_cu, hipStream_t stream);
 
