@@ -153,9 +153,19 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	g_check_align = getenv("KART_AMD_CHECK_ALIGN") != nullptr;
 	// (a sharded run: every process takes L3 domains of its own)
 	g_io_cpus = detect_io_cpus(opt.shard_count > 1 ? opt.shard_rank : -1);
+	// The stream's lane threads (they pread the input into the staging buffers and drive the device) take the NEXT L3 domain, the
+	// writers keep theirs: 34.2 / 34.4 -> 41.3 / 41.7 M mapped reads/s at 100 M reads (profiles/r04zi_ab_lane_cpus.log).  Round 3 saw
+	// no gain from it -- four lanes then, reading the input through its mapping: their page faults met the writers' at the address space's
+	// lock wherever they ran; with pread and eight lanes what is left to share is the cores.  A sharded run keeps a process on one domain
+	// (the next one is the next process's).  KART_AMD_LANE_CPUS=same: with the writers.
 	g_lane_cpus = IoCpus();
-	if (const char *e = getenv("KART_AMD_LANE_CPUS"))
-		if (!strcmp(e, "next") && g_io_cpus.valid && opt.shard_count <= 1) g_lane_cpus = detect_io_cpus(-2);
+	{
+		const char *e = getenv("KART_AMD_LANE_CPUS");
+		if ((!e || !strcmp(e, "next")) && g_io_cpus.valid && opt.shard_count <= 1) {
+			g_lane_cpus = detect_io_cpus(-2);
+			// (one domain only: "next" is the same one -- nothing gained, nothing lost)
+		}
+	}
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
 	cx.frag_service = opt.pacbio && kern.has_fragments();
 	Options &o = const_cast<Options &>(opt);
