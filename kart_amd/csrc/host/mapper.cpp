@@ -164,6 +164,10 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		if ((!e || !strcmp(e, "next")) && g_io_cpus.valid && opt.shard_count <= 1) {
 			g_lane_cpus = detect_io_cpus(-2);
 			// (one domain only: "next" is the same one -- nothing gained, nothing lost)
+		} else if ((!e || !strcmp(e, "next")) && g_io_cpus.valid && opt.shard_count > 1 && count_l3_domains() >= 2 * opt.shard_count) {
+			// a sharded run on a machine with domains to spare: process r's writers on domain r, its lanes on domain r + N (by analogy
+			// with the measurement above; not measured itself -- the pool has no multi-GPU node)
+			g_lane_cpus = detect_io_cpus(opt.shard_rank + opt.shard_count);
 		}
 	}
 	Ctx cx{opt, ref, kern, kern.min_seed_len()};
