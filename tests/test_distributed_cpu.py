@@ -28,8 +28,10 @@ def _worker(rank, world, port, n_units, out):
     counters = [len(mine), sum(u % 7 == 0 for u in mine), 2 * sum(u % 3 == 0 for u in mine), sum(mine)]
     total = shard.allreduce_counters(counters)
     tmax = shard.max_over_ranks(1.0 + rank)
+    # per-step wall times of K timed steps: a step lasts as long as its slowest rank (bench.py sums these maxima)
+    steps = shard.max_over_ranks([1.0 + rank, 3.0 - rank, 2.0])
     dist.barrier()
-    out.put((rank, lo, hi, total, tmax))
+    out.put((rank, lo, hi, total, tmax, steps))
     dist.destroy_process_group()
 
 
@@ -48,9 +50,10 @@ def test_two_rank_sharding_and_counter_allreduce():
     # shards tile the input exactly, in order
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n_units
     want = [n_units, sum(u % 7 == 0 for u in range(n_units)), 2 * sum(u % 3 == 0 for u in range(n_units)), sum(range(n_units))]
-    for _, _, _, total, tmax in res:
+    for _, _, _, total, tmax, steps in res:
         assert total == want          # every rank sees the whole-job counters
         assert tmax == 2.0            # max over ranks
+        assert steps == [2.0, 3.0, 2.0]   # element-wise: the per-step maxima
 
 
 def test_shard_range_properties():
