@@ -7,6 +7,10 @@
 // kart_amd/bin/kart-amd links hip_backend.cpp and nothing else.
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "../../kart_amd/csrc/host/mapper.hpp"
 #include "../../oracle/kart_oracle.h"
@@ -73,6 +77,51 @@ public:
 		cands_out = cands.data();
 		seeds_out = cand_seeds.data();
 	}
+	// The fragment service (kg_fragments_batch in the product) restated through the oracle's GenerateNormalPairAlignment, so that the
+	// host's -pacbio path WITH the service (plan -> one batched call -> stitch) is covered without a GPU.  KART_ORACLE_FRAGMENTS=1
+	// turns it on; KART_ORACLE_FRAGMENTS=<k> (k > 1) also hands every k-th job back (status 1), as the kernels do outside their envelope.
+	bool has_fragments() const override { return getenv("KART_ORACLE_FRAGMENTS") != nullptr; }
+	bool fragments_batch(std::vector<FragJobs *> &parts, bool pacbio, int max_gaps) override
+	{
+		if (!has_fragments()) return false;
+		const int back_every = atoi(getenv("KART_ORACLE_FRAGMENTS"));
+		const char *text = ko_ref_sequence(ix_);
+		// result sets in rotation like the product's page-locked ones (valid for the next few calls)
+		FragSet &io = sets_[(size_t)(next_set_.fetch_add(1) % kSets)];
+		std::lock_guard<std::mutex> lk(io.mu);
+		int64_t n = 0, cols = 0;
+		std::vector<int64_t> p_at(parts.size() + 1, 0), p_ac(parts.size() + 1, 0);
+		for (size_t k = 0; k < parts.size(); ++k) { p_at[k + 1] = p_at[k] + (int64_t)parts[k]->size(); p_ac[k + 1] = p_ac[k] + parts[k]->cols; }
+		n = p_at[parts.size()]; cols = p_ac[parts.size()];
+		if (n == 0) return true;
+		io.ops.assign((size_t)cols + 64, 0); io.len.assign((size_t)n, 0); io.status.assign((size_t)n, 0);
+		std::atomic<size_t> next{0};
+		auto work = [&]() {
+			std::vector<char> g1, g2;
+			for (size_t k; (k = next.fetch_add(1)) < parts.size();) {
+				const FragJobs *p = parts[k];
+				for (size_t j = 0; j < p->size(); ++j) {
+					const int64_t at = p_at[k] + (int64_t)j;
+					if (back_every > 1 && at % back_every == back_every - 1) { io.status[(size_t)at] = 1; continue; }
+					const int m = (int)(p->o1[j + 1] - p->o1[j]), g_n = p->gl[j];
+					g1.resize((size_t)(m + g_n + 2)); g2.resize((size_t)(m + g_n + 2));
+					int L = ko_normal_pair_alignment(pacbio ? 1 : 0, max_gaps, p->f1.data() + p->o1[j], m, text + p->g[j], g_n, g1.data(), g2.data());
+					uint8_t *op = io.ops.data() + p_ac[k] + p->oo[j];
+					for (int t = 0; t < L; ++t) op[t] = g1[(size_t)t] == '-' ? KG_OP_GAP1 : g2[(size_t)t] == '-' ? KG_OP_GAP2 : KG_OP_DIAG;
+					io.len[(size_t)at] = L;
+				}
+			}
+		};
+		std::vector<std::thread> th;
+		for (int t = 1; t < 8; ++t) th.emplace_back(work);
+		work();
+		for (std::thread &x : th) x.join();
+		for (size_t k = 0; k < parts.size(); ++k) {
+			FragJobs *p = parts[k];
+			p->ops = io.ops.data() + p_ac[k]; p->len = io.len.data() + p_at[k]; p->status = io.status.data() + p_at[k];
+		}
+		return true;
+	}
 	void nw_batch(std::vector<NwJobs *> &parts) override
 	{
 		for (NwJobs *p : parts) {
@@ -91,6 +140,14 @@ public:
 
 private:
 	ko_index *ix_;
+	static constexpr int kSets = 5;
+	struct FragSet {
+		std::mutex mu;
+		std::vector<uint8_t> ops, status;
+		std::vector<int32_t> len;
+	};
+	FragSet sets_[kSets];
+	std::atomic<uint64_t> next_set_{0};
 };
 
 static KernelBackend *make_oracle_backend(const Options &opt, std::string &err)

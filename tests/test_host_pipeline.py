@@ -135,6 +135,20 @@ def test_host_pipeline_matches_reference_sam(case, host_oracle_binary, tmp_path)
     assert got == want
 
 
+@pytest.mark.parametrize("back_every", [1, 3])
+def test_pacbio_with_the_fragment_service(back_every, host_oracle_binary, tmp_path):
+    """-pacbio as the product runs it: the workers plan a batch's reads, every fragment pair goes through ONE batched
+    GenerateNormalPairAlignment call (kg_fragments_batch there; here the oracle's restatement behind the same backend interface),
+    the workers stitch the results.  back_every 3: a third of the jobs come back with status != 0 (outside the kernels'
+    envelope) and are planned by the host."""
+    got, want, log = run_case_env(host_oracle_binary, "pacbio", str(tmp_path), ["-t", "4"],
+                                  {"KART_ORACLE_FRAGMENTS": str(back_every), "KART_AMD_VERBOSE": "1"})
+    assert got == want
+    line = [ln for ln in log.splitlines() if ln.startswith("fragment pairs")][0]
+    sent, back = (int(x) for x in __import__("re").findall(r": (\d+)", line))
+    assert sent > 0 and (back == 0 if back_every == 1 else 0 < back < sent)
+
+
 def test_summary_statistics(host_oracle_binary, tmp_path):
     _, _, log = run_case(host_oracle_binary, "pe", str(tmp_path))
     assert "All the 9000 paired-end reads have been processed" in log
