@@ -18,6 +18,32 @@
 namespace kart {
 int cli_main(int argc, char **argv, KernelBackend *(*make_backend)(const Options &, std::string &));
 
+// The op string of an alignment the oracle returns as two gapped strings.  A '-' in the gapped read string is a gap the
+// alignment inserted -- or a literal '-' of the read itself (the reference takes whatever the file holds).  Within a run of
+// dashes of the gapped read string the read's own characters say how many are literal; the columns where the text string has
+// a gap must be among those (two gaps never face each other); which of the others are is immaterial to either string.
+static void ops_from_strings(const char *read, int m, const char *g1, const char *g2, int L, uint8_t *op)
+{
+	int i = 0;
+	for (int t = 0; t < L;) {
+		if (g1[t] != '-') { op[t] = g2[t] == '-' ? KG_OP_GAP2 : KG_OP_DIAG; ++i; ++t; continue; }
+		int e = t;
+		while (e < L && g1[e] == '-') ++e;               // the run [t, e)
+		int literal = 0;
+		while (i + literal < m && literal < e - t && read[i + literal] == '-') ++literal;
+		if (e == L) literal = m - i;                    // (at the end every remaining read character is one)
+		int forced = 0;
+		for (int c = t; c < e; ++c) forced += g2[c] == '-';
+		int spare = literal - forced;                   // literal dashes that face a text character
+		for (int c = t; c < e; ++c) {
+			if (g2[c] == '-') { op[c] = KG_OP_GAP2; ++i; }
+			else if (spare > 0) { op[c] = KG_OP_DIAG; ++i; --spare; }
+			else op[c] = KG_OP_GAP1;
+		}
+		t = e;
+	}
+}
+
 class OracleBackend : public KernelBackend {
 public:
 	explicit OracleBackend(ko_index *ix) : ix_(ix) {}
@@ -106,8 +132,7 @@ public:
 					const int m = (int)(p->o1[j + 1] - p->o1[j]), g_n = p->gl[j];
 					g1.resize((size_t)(m + g_n + 2)); g2.resize((size_t)(m + g_n + 2));
 					int L = ko_normal_pair_alignment(pacbio ? 1 : 0, max_gaps, p->f1.data() + p->o1[j], m, text + p->g[j], g_n, g1.data(), g2.data());
-					uint8_t *op = io.ops.data() + p_ac[k] + p->oo[j];
-					for (int t = 0; t < L; ++t) op[t] = g1[(size_t)t] == '-' ? KG_OP_GAP1 : g2[(size_t)t] == '-' ? KG_OP_GAP2 : KG_OP_DIAG;
+					ops_from_strings(p->f1.data() + p->o1[j], m, g1.data(), g2.data(), L, io.ops.data() + p_ac[k] + p->oo[j]);
 					io.len[(size_t)at] = L;
 				}
 			}
@@ -131,8 +156,7 @@ public:
 				int m = (int)(p->o1[j + 1] - p->o1[j]), n = (int)(p->o2[j + 1] - p->o2[j]);
 				std::vector<char> g1((size_t)(m + n + 2)), g2((size_t)(m + n + 2));
 				int L = ko_nw(p->f1.data() + p->o1[j], m, p->f2.data() + p->o2[j], n, g1.data(), g2.data());
-				uint8_t *op = p->ops.data() + p->o1[j] + p->o2[j];
-				for (int t = 0; t < L; ++t) op[t] = g1[(size_t)t] == '-' ? KG_OP_GAP1 : g2[(size_t)t] == '-' ? KG_OP_GAP2 : KG_OP_DIAG;
+				ops_from_strings(p->f1.data() + p->o1[j], m, g1.data(), g2.data(), L, p->ops.data() + p->o1[j] + p->o2[j]);
 				p->len[j] = L;
 			}
 		}

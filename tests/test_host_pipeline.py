@@ -180,6 +180,57 @@ def test_speculative_chunks_match_live_reference(ins_mean, threads, host_oracle_
     assert outs[0] == outs[1]
 
 
+def test_reads_with_dashes_and_ns_match_live_reference(host_oracle_binary, tmp_path):
+    """Characters the reference does not reject: a literal '-' in a read is a base like any other non-ACGT one for seeding and
+    nw_alignment, but AddNewCigarElements / the head and tail trimming (src/tools.cpp:49-104,314-394) scan the gapped strings for
+    '-' and take it for a gap column; N runs break the 8-mers.  Short pairs and long reads (-pacbio: host planning, the fragment
+    service with and without handed-back jobs, pass 2 from the op strings and from the gapped strings) against kart -t 1."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "kart")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/kart not present")
+    import numpy as np
+    from kart_amd import synth
+    from kart_amd.index_build import read_fasta
+    genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
+    rng = np.random.default_rng(12)
+
+    def spoil(reads):
+        out = []
+        for i, r in enumerate(reads):
+            r = np.array(r, copy=True)
+            ch = ord("-") if i % 3 else ord("N")
+            if i % 2 == 0:
+                r[rng.integers(0, len(r), size=int(rng.integers(1, 6)))] = ch
+            if i % 5 == 0:
+                p0 = int(rng.integers(0, len(r) - 12)); r[p0:p0 + int(rng.integers(2, 9))] = ch
+            if i % 11 == 0:
+                r[:3] = ord("-"); r[-2:] = ord("-")          # at the ends: the head / tail pairs
+            out.append(r)
+        return out
+
+    names, r1, r2 = synth.simulate_pairs(genome, 1500, seed=21, err=0.02, mut=0.002, indel_frac=0.3)
+    f1, f2 = str(tmp_path / "d_1.fq"), str(tmp_path / "d_2.fq")
+    synth.write_fastq(f1, names, spoil(r1), mate=1)
+    synth.write_fastq(f2, names, spoil(r2), mate=2)
+    lnames, lreads = synth.simulate_long_reads(genome, 150, seed=22, read_len=2500, err=0.15, indel_err_frac=0.3)
+    fl = str(tmp_path / "d_long.fq")
+    synth.write_fastq(fl, lnames, spoil(lreads))
+
+    def run(binary, args, env=None):
+        out = str(tmp_path / "o.sam")
+        subprocess.run([binary, "-silent", "-i", SMALL_PREFIX] + args + ["-o", out], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, env=dict(os.environ, **(env or {})))
+        return open(out, "rb").read()
+
+    short = ["-f", f1, "-f2", f2]
+    assert run(host_oracle_binary, short + ["-t", "3"]) == run(ref_bin, short + ["-t", "1"])
+    long_ = ["-f", fl, "-pacbio"]
+    want = run(ref_bin, long_ + ["-t", "1"])
+    assert want.count(b"\n") > 150
+    for env in ({}, {"KART_ORACLE_FRAGMENTS": "1"}, {"KART_ORACLE_FRAGMENTS": "3"}, {"KART_ORACLE_FRAGMENTS": "1", "KART_AMD_FINISH_STRINGS": "1"}):
+        assert run(host_oracle_binary, long_ + ["-t", "3"], env) == want, env
+
+
 def test_odd_input_files_match_live_reference(host_oracle_binary, tmp_path):
     """inputs the readers must treat exactly like the reference's getline()/gzgets() loops: a second file shorter than the
     first, CRLF line ends, no newline at the end of the file, empty files, an interleaved file with an odd number of records,
