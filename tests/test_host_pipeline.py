@@ -149,6 +149,17 @@ def test_pacbio_with_the_fragment_service(back_every, host_oracle_binary, tmp_pa
     assert sent > 0 and (back == 0 if back_every == 1 else 0 < back < sent)
 
 
+def test_pass2_from_op_strings_equals_pass2_from_gapped_strings():
+    """add_cigar_ops / local_quality_ok_ops / finish_head_ops / finish_tail_ops (pass 2 of the long-read report since round 4) against
+    add_cigar / local_quality_ok / finish_head / finish_tail (src/tools.cpp:49-104,255-290,314-394 restated on the gapped strings) on
+    300 000 random alignments: CIGAR elements, score and the trimmed pair must agree (tests/cpu_backend/ops_selftest.cpp)."""
+    target = os.path.join("..", "..", "tests", "_build", "ops_selftest")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpu_backend"), target], stdout=subprocess.DEVNULL)
+    for seed in ("1", "2"):
+        r = subprocess.run([os.path.join(ROOT, "tests", "_build", "ops_selftest"), "150000", seed], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0 and b"cases identical" in r.stdout, r.stdout.decode()[-400:]
+
+
 def test_summary_statistics(host_oracle_binary, tmp_path):
     _, _, log = run_case(host_oracle_binary, "pe", str(tmp_path))
     assert "All the 9000 paired-end reads have been processed" in log
