@@ -509,7 +509,7 @@ def run(args, fallback_note):
     peak_shmem = [shmem_now()]
 
     def out_files(out):
-        return [out + ".%d" % q for q in range(world)] if (args.parts and world > 1) else [out]
+        return shard.part_files(out, world, args.parts)
 
     def drop(out):
         if rank == 0:
@@ -522,12 +522,8 @@ def run(args, fallback_note):
     def step(tag):
         out = os.path.join(workdir, "bench_out_%s.sam" % tag)
         outs.append(out)
-        a = ["-silent", "-f", f1, "-f2", f2, "-o", out]
-        if world > 1:
-            a += ["-shard", "%d/%d" % (rank, world), "-rendezvous", os.path.join(workdir, "rdv_%s" % tag)]
-            if args.parts:
-                a += ["-parts"]
-        return sess.map(a)
+        # this rank's share of the run: -shard r/N -rendezvous <file> [-parts] behind the run's own options (kart_amd/shard.py)
+        return shard.map_shard(sess.map, ["-silent", "-f", f1, "-f2", f2], out, rank, world, os.path.join(workdir, "rdv_%s" % tag), args.parts)
 
     def between_steps():
         """not timed: note the shmem high-water mark, remove all but the newest output, line the ranks up for the next step"""

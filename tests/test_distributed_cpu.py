@@ -1,7 +1,9 @@
 """CPU, world_size 2 over gloo: the N>1 path of bench.py -- read sharding with no data-path collective,
 counter all-reduce, max-over-ranks timing -- exercised with real processes."""
+import gzip
 import os
 import socket
+import subprocess
 
 import torch
 import torch.distributed as dist
@@ -54,6 +56,76 @@ def test_two_rank_sharding_and_counter_allreduce():
         assert total == want          # every rank sees the whole-job counters
         assert tmax == 2.0            # max over ranks
         assert steps == [2.0, 3.0, 2.0]   # element-wise: the per-step maxima
+
+
+def _map_worker(rank, world, port, binary, prefix, f1, f2, out, rdv, parts, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def run(arguments):            # what Session.map is on the GPU box: one mapping run of this rank (here the CPU backend's CLI)
+        r = subprocess.run([binary] + arguments, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode == 0, r.stdout.decode()[-400:]
+        return r.stdout.decode()
+
+    dist.barrier()
+    log = shard.map_shard(run, ["-silent", "-t", "3", "-i", prefix, "-f", f1, "-f2", f2], out, rank, world, rdv, parts)
+    mine = 0
+    for f in shard.part_files(out, world, parts) if parts else []:
+        if f.endswith(".%d" % rank):
+            mine = sum(1 for ln in open(f, "rb") if not ln.startswith(b"@"))
+    total = shard.allreduce_counters([mine])
+    dist.barrier()
+    q.put((rank, total[0], log[-200:]))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_map_one_library_like_bench(tmp_path):
+    """bench.py --gpus 2 on CPU: two torch.distributed ranks (gloo), each ONE mapping run with `-shard r/2 -rendezvous <file>`
+    (shard.map_shard; the CPU backend's CLI stands in for Session.map), no data-path collective, the record counts all-reduced;
+    the parts in rank order -- and the one shared file -- are the golden SAM of the unmodified reference."""
+    from conftest import GOLDEN, ROOT, SMALL_PREFIX
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpu_backend")], stdout=subprocess.DEVNULL)
+    binary = os.path.join(ROOT, "tests", "_build", "kart-host-oracle")
+    files = []
+    for name in ("pe_1.fq", "pe_2.fq"):
+        dst = str(tmp_path / name)
+        with gzip.open(os.path.join(GOLDEN, "sam", name + ".gz")) as fi, open(dst, "wb") as fo:
+            fo.write(fi.read())
+        files.append(dst)
+    want = gzip.open(os.path.join(GOLDEN, "sam", "pe.sam.gz")).read()
+    n_records = sum(1 for ln in want.split(b"\n") if ln and not ln.startswith(b"@"))
+    world = 2
+    ctx = mp.get_context("spawn")
+    for parts in (True, False):
+        out, rdv = str(tmp_path / ("out_%d.sam" % parts)), str(tmp_path / ("rdv_%d" % parts))
+        shard.remove_rendezvous(rdv)
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_map_worker, args=(r, world, port, binary, SMALL_PREFIX, files[0], files[1], out, rdv, parts, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=240) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        if parts:
+            assert [os.path.exists(f) for f in shard.part_files(out, world)] == [True, True]
+            assert all(total == n_records for _, total, _ in res)      # every rank sees the whole job's record count
+            shard.concatenate_parts(out, world)
+            assert not os.path.exists(out + ".0")
+        assert open(out, "rb").read() == want
+
+
+def test_shard_arguments():
+    assert shard.shard_arguments(0, 1, "/x/rdv") == []
+    assert shard.shard_arguments(1, 4, "/x/rdv") == ["-shard", "1/4", "-rendezvous", "/x/rdv", "-parts"]
+    assert shard.shard_arguments(3, 4, "/x/rdv", parts=False) == ["-shard", "3/4", "-rendezvous", "/x/rdv"]
+    assert shard.part_files("/o.sam", 3) == ["/o.sam.0", "/o.sam.1", "/o.sam.2"]
+    assert shard.part_files("/o.sam", 3, parts=False) == ["/o.sam"] and shard.part_files("/o.sam", 1) == ["/o.sam"]
+    import pytest
+    with pytest.raises(ValueError):
+        shard.shard_arguments(4, 4, "/x/rdv")
 
 
 def test_shard_range_properties():
