@@ -220,7 +220,14 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 		src.sep = sep;
 		src.fast = want_fast && src.m1.open(f1) && (!sep || src.m2.open(opt.files2[lib]));
 		src.gzfast = gz && cx.fastq && !getenv("KART_AMD_NO_MMAP");
-		if (src.gzfast) { src.g1.f = in1.gz; src.g2.f = in2.gz; gzbuffer(in1.gz, 1 << 20); if (in2.gz) gzbuffer(in2.gz, 1 << 20); }
+		if (src.gzfast) {
+			src.g1.f = in1.gz; src.g2.f = in2.gz; gzbuffer(in1.gz, 1 << 20); if (in2.gz) gzbuffer(in2.gz, 1 << 20);
+			src.g1.path = f1; if (sep) src.g2.path = opt.files2[lib];
+			// bgzip-ped files are inflated member by member on several threads (both mate files are filled side by side: half each)
+			const int per_file = std::max(1, opt.threads / (sep ? 2 : 1));
+			src.g1.try_bgzf(f1.c_str(), per_file);
+			if (sep) src.g2.try_bgzf(opt.files2[lib].c_str(), per_file);
+		}
 		if (shard.active()) {
 			// only a single library of plain 4-line FASTQ is split; anything else is mapped by shard 0 alone
 			bool splittable = src.fast && opt.files1.size() == 1;
