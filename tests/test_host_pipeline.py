@@ -242,6 +242,53 @@ def test_reads_with_dashes_and_ns_match_live_reference(host_oracle_binary, tmp_p
         assert run(host_oracle_binary, long_ + ["-t", "3"], env) == want, env
 
 
+def test_records_cut_short_match_live_reference(host_oracle_binary, tmp_path):
+    """A FASTQ file that ends inside a record (an interrupted copy): the reference reads the record's remaining lines into one buffer
+    without looking at the results (src/GetData.cpp:73, :168-175), so a line that never came is whatever the buffer still held --
+    the '+' line (the "qualities" are then "+" and a line break), the bases themselves, or, behind gzgets(), the header line taken
+    for the bases.  Every cut position, either mate file, plain and gz, paired and single-end, the mapped-file / inflated-text
+    reader and the line reader (KART_AMD_NO_MMAP): byte-identical to kart -t 1.  Not compared: a gz mate-1 file cut inside or right
+    after a header in paired mode -- the header text becomes a 24-base mate 1, and the reference encodes mate 2 with mate 1's
+    length (src/Mapping.cpp:550, SURVEY App. B-5: uninitialised bytes)."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "kart")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/kart not present")
+    raw = [gzip.open(os.path.join(SAM, "pe_%d.fq.gz" % m)).read().split(b"\n")[:2400] for m in (1, 2)]     # 600 records each
+    at = 2000                                                                                              # record 500 starts here
+
+    def variants(lines):
+        def upto(n, extra=b""):
+            return b"\n".join(lines[:n]) + b"\n" + extra
+        return {"after_header": upto(at + 1), "mid_seq": upto(at + 1, lines[at + 1][:70]), "after_seq": upto(at + 2), "mid_plus": upto(at + 2, b"+"),
+                "after_plus": upto(at + 3), "mid_qual": upto(at + 3, lines[at + 3][:70]), "mid_header": upto(at, lines[at][:5])}
+
+    def run(binary, args, env=None):
+        out = str(tmp_path / "o.sam")
+        r = subprocess.run([binary, "-silent", "-i", SMALL_PREFIX] + args + ["-o", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           env=dict(os.environ, **(env or {})))
+        return open(out, "rb").read() if r.returncode == 0 else None
+
+    whole = [b"\n".join(x) + b"\n" for x in raw]
+    compared = 0
+    for gz in (False, True):
+        ext = ".fq.gz" if gz else ".fq"
+        f1, f2 = str(tmp_path / ("t1" + ext)), str(tmp_path / ("t2" + ext))
+        for which in (0, 1):
+            for name, data in variants(raw[which]).items():
+                for f, d in ((f1, data if which == 0 else whole[0]), (f2, data if which == 1 else whole[1])):
+                    open(f, "wb").write(gzip.compress(d) if gz else d)
+                modes = [["-f", f1, "-f2", f2]] + ([["-f", f1]] if which == 0 else [])
+                for args in modes:
+                    if gz and which == 0 and len(args) == 4 and name in ("after_header", "mid_header"):
+                        continue                                                                           # App. B-5, see above
+                    want = run(ref_bin, args + ["-t", "1"])
+                    assert want is not None
+                    for env in ({}, {"KART_AMD_NO_MMAP": "1"}):
+                        assert run(host_oracle_binary, args + ["-t", "3"], env) == want, (gz, which, name, args[:1], env)
+                        compared += 1
+    assert compared == 80
+
+
 def test_bgzf_inputs_are_inflated_member_by_member(host_oracle_binary, tmp_path):
     """bgzip-ped FASTQ: the members are inflated side by side (GzText::fill_bgzf) instead of through one gzread() stream; the text --
     and so the SAM -- is what gzgets() reads in the reference.  Full-size and ragged members (records cut anywhere), no EOF member,
