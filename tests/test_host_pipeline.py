@@ -289,6 +289,51 @@ def test_records_cut_short_match_live_reference(host_oracle_binary, tmp_path):
     assert compared == 80
 
 
+def test_gz_text_that_gzgets_reads_differently_matches_live_reference(host_oracle_binary, tmp_path):
+    """The reference reads a gz library through gzgets() with a 1000-byte buffer (src/GetData.cpp:152-159): a longer line -- a 1200-base
+    read without -pacbio, a 1500-character header -- comes back in pieces that are taken for the record's next lines, and an entry
+    whose first line does not start with '@' / '>' ends after that line (:162).  The inflated-text parser hands such a window, and
+    the rest of the library, to the line reader (gz_text_regular): first batch or late in a paired library, plain gzip or BGZF."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "kart")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/kart not present")
+    from bgzf_util import bgzf
+    from kart_amd import synth
+    from kart_amd.index_build import read_fasta
+    genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
+
+    def put(name, data):
+        path = str(tmp_path / name)
+        open(path, "wb").write(data)
+        return path
+
+    def same(args):
+        outs = []
+        for binary, t in ((ref_bin, "1"), (host_oracle_binary, "4")):
+            out = str(tmp_path / "o.sam")
+            subprocess.run([binary, "-silent", "-i", SMALL_PREFIX] + args + ["-t", t, "-o", out], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            outs.append(open(out, "rb").read())
+        return outs[0] == outs[1]
+
+    names, reads = synth.simulate_long_reads(genome, 40, seed=3, read_len=1200, err=0.02)
+    plain = str(tmp_path / "l12.fq")
+    synth.write_fastq(plain, names, reads)
+    assert same(["-f", put("l12.fq.gz", gzip.compress(open(plain, "rb").read()))])
+    synth.write_fastq(plain, [n + " " + "x" * 1500 for n in names], reads)
+    assert same(["-f", put("lh.fq.gz", gzip.compress(open(plain, "rb").read()))])
+    r1 = gzip.open(os.path.join(SAM, "pe_1.fq.gz")).read()
+    l2 = gzip.open(os.path.join(SAM, "pe_2.fq.gz")).read().split(b"\n")
+    l2[4 * 3000] += b" " + b"y" * 1500                                  # record 3000 of mate file 2: several batches in
+    r2 = b"\n".join(l2)
+    assert same(["-f", put("p1.fq.gz", gzip.compress(r1)), "-f2", put("p2.fq.gz", gzip.compress(r2))])
+    assert same(["-f", put("b1.fq.gz", bgzf(r1)), "-f2", put("b2.fq.gz", bgzf(r2, 7000))])
+    l1 = r1.split(b"\n")
+    l1[4 * 1000] = b"X" + l1[4 * 1000][1:]
+    nh = put("nh.fq.gz", gzip.compress(b"\n".join(l1)))
+    assert same(["-f", nh])
+    assert same(["-f", nh, "-f2", put("q2.fq.gz", gzip.compress(gzip.open(os.path.join(SAM, "pe_2.fq.gz")).read()))])
+
+
 def test_bgzf_inputs_are_inflated_member_by_member(host_oracle_binary, tmp_path):
     """bgzip-ped FASTQ: the members are inflated side by side (GzText::fill_bgzf) instead of through one gzread() stream; the text --
     and so the SAM -- is what gzgets() reads in the reference.  Full-size and ragged members (records cut anywhere), no EOF member,
