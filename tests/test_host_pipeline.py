@@ -334,6 +334,42 @@ def test_gz_text_that_gzgets_reads_differently_matches_live_reference(host_oracl
     assert same(["-f", nh, "-f2", put("q2.fq.gz", gzip.compress(gzip.open(os.path.join(SAM, "pe_2.fq.gz")).read()))])
 
 
+def test_pacbio_with_mate_files_matches_live_reference(host_oracle_binary, tmp_path):
+    """-pacbio with -f / -f2 (or -p): the reference maps the reads one by one (src/Mapping.cpp:514-529) but prints an even-sized
+    chunk through OutputPairedAlignments (:598) -- mate 2 is held reverse-complemented and shown flipped back by a forward report.
+    Mate files of 61 reads (the last chunk is odd: printed singly), an unmappable read in either file, gz, -p, -m."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "kart")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/kart not present")
+    import numpy as np
+    from kart_amd import synth
+    from kart_amd.index_build import read_fasta
+    genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
+    names, l1 = synth.simulate_long_reads(genome, 61, seed=51, read_len=1500, err=0.12, indel_err_frac=0.3)
+    _, l2 = synth.simulate_long_reads(genome, 61, seed=52, read_len=1800, err=0.12, indel_err_frac=0.3)
+    rng = np.random.default_rng(1)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    l2[5], l1[7] = rng.choice(acgt, 1800), rng.choice(acgt, 1500)
+    f1, f2, fi = (str(tmp_path / n) for n in ("x1.fq", "x2.fq", "xi.fq"))
+    synth.write_fastq(f1, names, l1)
+    synth.write_fastq(f2, names, l2)
+    synth.write_fastq(fi, [n for n in names[:60] for _ in (0, 1)], [x for p in zip(l1[:60], l2[:60]) for x in p])
+    g1, g2 = f1 + ".gz", f2 + ".gz"
+    for src, dst in ((f1, g1), (f2, g2)):
+        open(dst, "wb").write(gzip.compress(open(src, "rb").read()))
+
+    def run(binary, args, env=None):
+        out = str(tmp_path / "o.sam")
+        subprocess.run([binary, "-silent", "-i", SMALL_PREFIX] + args + ["-o", out], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, **(env or {})))
+        return open(out, "rb").read()
+
+    for args in (["-f", f1, "-f2", f2, "-pacbio"], ["-f", g1, "-f2", g2, "-pacbio"], ["-f", fi, "-p", "-pacbio"], ["-f", f1, "-f2", f2, "-pacbio", "-m"]):
+        want = run(ref_bin, args + ["-t", "1"])
+        for env in ({}, {"KART_ORACLE_FRAGMENTS": "1"}):
+            assert run(host_oracle_binary, args + ["-t", "4"], env) == want, (args, env)
+
+
 def test_bgzf_inputs_are_inflated_member_by_member(host_oracle_binary, tmp_path):
     """bgzip-ped FASTQ: the members are inflated side by side (GzText::fill_bgzf) instead of through one gzread() stream; the text --
     and so the SAM -- is what gzgets() reads in the reference.  Full-size and ragged members (records cut anywhere), no EOF member,
