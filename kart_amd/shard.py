@@ -67,13 +67,28 @@ def part_files(out: str, world: int, parts: bool = True):
 
 def concatenate_parts(out: str, world: int, remove: bool = True):
     """`cat <out>.0 ... > <out>`: the parts of a `-parts` run in rank order ARE the single-process file (rank 0's part starts with
-    the header).  Returns `out`."""
-    with open(out, "wb") as dst:
-        for f in part_files(out, world, True):
-            with open(f, "rb") as src:
-                shutil.copyfileobj(src, dst, 1 << 24)
-            if remove:
-                os.remove(f)
+    the header).  A single process wrote `out` itself (shard_arguments adds no `-parts` then): nothing to do.  The text goes to a
+    temporary file next to `out` and takes its name at the end, so `out` is never one of the sources and a failure leaves the
+    parts where they are.  Returns `out`."""
+    if world <= 1:
+        return out
+    parts = [out + ".%d" % q for q in range(world)]
+    tmp = out + ".cat.%d" % os.getpid()
+    try:
+        with open(tmp, "wb") as dst:
+            for f in parts:
+                with open(f, "rb") as src:
+                    shutil.copyfileobj(src, dst, 1 << 24)
+        os.replace(tmp, out)
+    except BaseException:
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+        raise
+    if remove:
+        for f in parts:
+            os.remove(f)
     return out
 
 

@@ -136,3 +136,25 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_concatenate_parts_leaves_a_single_process_file_alone(tmp_path):
+    """with one process the run wrote `out` itself; concatenate_parts(out, 1) used to truncate it, copy the empty file
+    onto itself and remove it.  With several parts the text is assembled beside `out` and renamed, and `out` is never a source."""
+    out = str(tmp_path / "a.sam")
+    open(out, "wb").write(b"@PG\tone process\nr1\t4\n")
+    assert shard.concatenate_parts(out, 1) == out
+    assert open(out, "rb").read() == b"@PG\tone process\nr1\t4\n"
+    assert shard.part_files(out, 1) == [out] and shard.shard_arguments(0, 1, "rv") == []
+    for q, text in enumerate((b"@PG\thead\nr1\t4\n", b"r2\t4\n", b"r3\t4\n")):
+        open(out + ".%d" % q, "wb").write(text)
+    assert shard.concatenate_parts(out, 3) == out               # an older `out` is replaced, not appended to
+    assert open(out, "rb").read() == b"@PG\thead\nr1\t4\nr2\t4\nr3\t4\n"
+    assert sorted(os.listdir(tmp_path)) == ["a.sam"]
+    open(out + ".0", "wb").write(b"x\n")                        # a missing part: an error, `out` untouched, no temporary left
+    try:
+        shard.concatenate_parts(out, 2)
+        raise AssertionError("a missing part must raise")
+    except FileNotFoundError:
+        pass
+    assert open(out, "rb").read() == b"@PG\thead\nr1\t4\nr2\t4\nr3\t4\n" and sorted(os.listdir(tmp_path)) == ["a.sam", "a.sam.0"]
