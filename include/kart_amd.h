@@ -252,6 +252,27 @@ int  kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *c
                     int est_distance, int max_insert, int max_gaps, int multi_hit, int unset_flag,
                     const kg_aln_record **records, kg_chunk_stats *chunk_stats);
 
+/* ---- the per-read report of long reads (-pacbio) on the device ------------------------------------------------------- */
+/* What ReadMapping()'s bPacBioData branch does per read between chaining and the SAM text (src/Mapping.cpp:513-530), for the reads
+ * of the batch the last kg_seed_batch (KG_MODE_SENSITIVE | KG_INPUT_ASCII) + kg_candidates_batch (pacbio != 0) calls on this
+ * workspace left on the device:
+ *   RemoveRedundantCandidates (src/Mapping.cpp:317-346), GenMappingReport (src/AlignmentCandidates.cpp:624-745: IdentifyNormalPairs
+ *   of the read :420-490, CheckCoordinateValidity :582-610, Process{Head,Normal,Tail}SequencePair src/tools.cpp:225-397 with
+ *   GenerateNormalPairAlignment :142-223 and nw_alignment on the device, GenCoordinateInfo / GenerateCIGAR :492-562),
+ *   SetSingleAlignmentFlag and EvaluateMAPQ (src/Mapping.cpp:49-70, 160-175).
+ * One record per read, what OutputSingledAlignments prints for it (:272-315).  A mapped record's CIGAR does not fit the record:
+ * cigar_len is KG_ALN_CIGAR_POOLED and the first 12 bytes of `cigar` hold {int64_t offset; int32_t bytes} into *cigar_pool.
+ * A read the kernels do not take (a literal '-' among its characters, a fragment pair outside the fragment kernels' envelope, seeds
+ * that CheckOverlappingSeeds leaves out of order) comes back with kind KG_ALN_HOST: the caller maps it with its own implementation of
+ * the same reference code (the candidates kg_candidates_batch returned are unmodified).  *records and *cigar_pool are library-owned
+ * page-locked arrays; four sets rotate: valid while the next three batches go through the workspace. */
+#define KG_ALN_CIGAR_POOLED 255
+int  kg_longread_batch(kg_workspace *ws, const kg_aln_record **records, const char **cigar_pool, int64_t *cigar_bytes, int64_t *n_host_reads);
+/* Running tallies since the workspace was created: [0] reads through kg_longread_batch, [1] of them handed back (KG_ALN_HOST), and why
+ * (candidates): [2] a literal '-' in the read, [3] a fragment pair outside the fragment kernels' envelope, [4] seeds out of order after
+ * CheckOverlappingSeeds, [5] element pool full; [6] candidates that went through CheckOverlappingSeeds' sequential form.  Diagnostics only. */
+int  kg_longread_reasons(kg_workspace *ws, uint64_t out[8]);
+
 /* Running tallies (since the workspace was created) of why read pairs came back as KG_ALN_HOST: [0] candidate product too large,
  * [1] a mate-2 rescue window would be scanned, [2] rescue window too long, [3] mate not plain A/C/G/T or too long for the rescue
  * kernel, [4] too many exact-match runs in a window, [5] rescued candidate with too many pairs, [6] candidate with too many
@@ -377,6 +398,11 @@ typedef struct {
 	double search_useful_bytes;
 	double text_in_bytes, text_out_bytes;
 	double candidates, candidate_seeds;     /* chained candidates and their seeds of the batches (what the alignment stage reads per candidate) */
+	/* the batches' kernels one by one (HIP events around each launch on the lane's stream; other lanes' kernels share the device):
+	 * [0] chain, [1] aln_pair, [2] aln_rescue + post_rescue, [3] aln_plan_fast, [4] aln_plan, [5] aln_partition, [6] the NW kernels,
+	 * [7] aln_finish, [8] aln_final, [9] sam_size + scan, [10] sam_format, [11] fq_count / index / record / plan, [12] fq_materialise */
+	double kernel_ms[16];
+	int64_t kernel_launches[16];
 } kg_stream_timing_t;
 int   kg_stream_timing(kg_stream *s, kg_stream_timing_t *out, int reset);
 

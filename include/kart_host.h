@@ -46,6 +46,8 @@ typedef struct {
 	double  search_useful_bytes;     /* bytes the implemented search fetched in them (kg_traffic_t's formula) */
 	double  text_in_bytes, text_out_bytes;
 	double  candidates, candidate_seeds;     /* of the batches that went through the device stream (kg_stream_timing_t) */
+	double  kernel_ms[16];           /* the batches' kernels one by one (kg_stream_timing_t::kernel_ms: chain, aln_pair, aln_rescue, aln_plan_fast, ...) */
+	int64_t kernel_launches[16];
 } kh_stats_t;
 
 const char *kh_last_error(void);

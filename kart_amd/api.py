@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "kg_last_error", "kg_device_count", "kg_index_load", "kg_index_destroy", "kg_index_info",
     "kg_index_contig", "kg_host_alloc", "kg_host_free", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters", "kg_workspace_traffic",
     "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_set_single_steps", "kg_index_selfcheck", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_align_batch", "kg_align_reasons", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
-    "kg_fragments_batch",
+    "kg_fragments_batch", "kg_longread_batch", "kg_longread_reasons",
     "kg_stream_open", "kg_stream_close", "kg_stream_staging", "kg_stream_upload", "kg_stream_parse", "kg_stream_map", "kg_stream_fetch_reads", "kg_stream_timing",
     "kg_stream_group_absent", "kg_stream_group_abort",
 )
@@ -122,10 +122,11 @@ class StreamResult(C.Structure):
 
 class StreamTiming(C.Structure):
     _fields_ = [("batches", C.c_int64), ("reads", C.c_int64)] + [(n, C.c_double) for n in ("parse_ms", "seed_ms", "chain_ms", "align_ms", "format_ms", "copy_ms", "search_kernel_ms")] + \
-               [("search_kernel_launches", C.c_int64)] + [(n, C.c_double) for n in ("search_useful_bytes", "text_in_bytes", "text_out_bytes", "candidates", "candidate_seeds")]
+               [("search_kernel_launches", C.c_int64)] + [(n, C.c_double) for n in ("search_useful_bytes", "text_in_bytes", "text_out_bytes", "candidates", "candidate_seeds")] + \
+               [("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_int64 * 16)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n.startswith("kernel_") else getattr(self, n)) for n, _ in self._fields_}
 
 
 _lib = None
@@ -515,10 +516,10 @@ class HostStats(C.Structure):
                 ("respeculated", C.c_int64), ("map_seconds", C.c_double), ("sharded", C.c_int32), ("pad", C.c_int32),
                 ("stream_reads", C.c_int64), ("stream_batches", C.c_int64), ("stage_ms", C.c_double * 6), ("search_kernel_ms", C.c_double),
                 ("search_kernel_launches", C.c_int64), ("search_useful_bytes", C.c_double), ("text_in_bytes", C.c_double), ("text_out_bytes", C.c_double),
-                ("candidates", C.c_double), ("candidate_seeds", C.c_double)]
+                ("candidates", C.c_double), ("candidate_seeds", C.c_double), ("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_int64 * 16)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n.startswith(("kernel_", "stage_")) else getattr(self, n)) for n, _ in self._fields_}
 
 
 _host_lib = None

@@ -18,6 +18,8 @@
 #include <thread>
 #include <vector>
 
+namespace kg { KG_INTERNAL thread_local KernelTimer *kt_current = nullptr; }      // seed_kernels.hpp: the calling thread's kernel timer
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -480,6 +482,7 @@ void kg_workspace_destroy(kg_workspace *ws)
 	if (!ws) return;
 	(void)hipSetDevice(ws->ix->device);
 	if (ws->stream) { (void)hipStreamSynchronize(ws->stream); (void)hipStreamDestroy(ws->stream); }
+	kgi_long_release(ws);
 	for (int i = 0; i < kg_workspace::kRing; ++i) {
 		if (ws->ring_cands[i]) (void)hipHostFree(ws->ring_cands[i]);
 		if (ws->ring_seeds[i]) (void)hipHostFree(ws->ring_seeds[i]);
@@ -493,6 +496,10 @@ void kg_workspace_destroy(kg_workspace *ws)
 	if (ws->sync_ev) (void)hipEventDestroy(ws->sync_ev);
 	for (hipEvent_t e : ws->ev)
 		if (e) (void)hipEventDestroy(e);
+	for (int i = 0; i < KT_SLOTS; ++i) {
+		if (ws->kt.b[i]) (void)hipEventDestroy(ws->kt.b[i]);
+		if (ws->kt.e[i]) (void)hipEventDestroy(ws->kt.e[i]);
+	}
 	delete ws;
 }
 
@@ -555,6 +562,8 @@ int kg_workspace_set_profiling(kg_workspace *ws, int enabled)
 	HIP_TRY(hipSetDevice(ws->ix->device));
 	if (enabled && !ws->ev[0])
 		for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&ws->ev[i]));
+	if (enabled && !ws->kt.b[0])
+		for (int i = 0; i < KT_SLOTS; ++i) { HIP_TRY(hipEventCreate(&ws->kt.b[i])); HIP_TRY(hipEventCreate(&ws->kt.e[i])); }
 	ws->profiling = enabled != 0;
 	return KG_OK;
 }
@@ -803,6 +812,8 @@ int kgi_chain_resident(kg_workspace *ws, int pacbio, int max_gaps, int64_t total
 	HIP_TRY(kgi_sync(ws));
 	totals[0] = (int64_t)h[0]; totals[1] = (int64_t)h[1];
 	ws->last_cands = totals[0];
+	ws->last_cand_seeds = totals[1];
+	ws->last_pacbio = pacbio != 0;
 	return KG_OK;
 }
 
@@ -1080,7 +1091,9 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 		int rc = nw_acquire(ix, 3 * (size_t)ws->job_capacity, (size_t)w.big_waves * (size_t)w.dir_words_per_wave, st, &sc);
 		if (rc != KG_OK) return rc;
 		w.big_list = sc->lists; w.queue = sc->queue; w.dir_scratch = sc->dir;
+		kt_begin(KT_NW, st);
 		hipError_t e = launch_nw_batch(w, ix->n_cu, st);
+		kt_end(KT_NW, st);
 		hipError_t e2 = nw_submitted(ix, sc, st);
 		if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_align_batch: %s", hipGetErrorString(e != hipSuccess ? e : e2));
 	}

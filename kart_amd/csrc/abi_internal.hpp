@@ -125,6 +125,9 @@ struct kg_workspace {
 	int64_t h_seed_capacity = 0;
 	// alignment stage (kg_align_batch)
 	int64_t last_cands = -1;            // candidates the last kg_candidates_batch left on the device
+	int64_t last_cand_seeds = 0;        // ... and their seeds
+	bool last_pacbio = false;           // ... chained for long reads (GenerateAlignmentCandidateForPacBioSeq)
+	void *lr = nullptr;                 // scratch of the long-read report (abi_long.hip: kg_longread_batch)
 	bool last_ascii = false;            // the resident reads are characters (KG_INPUT_ASCII)
 	void *d_aln_cand = nullptr;         // per-candidate state, one block
 	int64_t aln_cand_capacity = 0;
@@ -149,6 +152,7 @@ struct kg_workspace {
 	unsigned long long *h_small = nullptr;   // pinned, 16 words: totals and flags read back between stages
 	bool profiling = false;
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	KernelTimer kt;                     // per-kernel events of the launches made for this workspace (created with profiling; seed_kernels.hpp)
 };
 
 
@@ -159,6 +163,7 @@ KG_INTERNAL int kgi_seed_resident(kg_workspace *ws, int mode, int min_seed_len, 
 KG_INTERNAL int kgi_seed_group(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, int n_seg, int64_t stride, const int64_t *counts, int64_t *seed_base);
 KG_INTERNAL int kgi_chain_resident(kg_workspace *ws, int pacbio, int max_gaps, int64_t totals[2]);
 KG_INTERNAL int kgi_nw_launch(kg_index *ix, NwArgs &a, int64_t max_len, hipStream_t st);
+KG_INTERNAL void kgi_long_release(kg_workspace *ws);  // abi_long.hip: the long-read report's scratch of this workspace
 KG_INTERNAL void kgi_frag_release(kg_index *ix);      // abi_frag.hip: the fragment service's scratches of this index
 KG_INTERNAL int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *chunk_paired, int n_chunks, int est_distance, int max_insert,
                        int max_gaps, int multi_hit, int unset_flag, int64_t host_record_capacity, AlnArgs &a);

@@ -348,6 +348,7 @@ int kg_stream_parse(kg_stream *s, int lane, const kg_stream_window *w, kg_stream
 	a.enc = ws->d_enc;
 	a.n_reads = 0;
 	hipStream_t st = ws->stream;
+	KtUse kt_use(ws->profiling ? &ws->kt : nullptr);
 	HIP_TRY(hipEventRecord(l.ev[0], st));
 	HIP_TRY(launch_fq_parse(a, l.d_scan, l.scan_bytes, s->ix->n_cu, st));
 	HIP_TRY(hipMemcpyAsync(l.h_meta, l.d_meta, 8 * FQM_WORDS, hipMemcpyDeviceToHost, st));
@@ -486,6 +487,7 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 	kg_workspace *ws = l.ws;
 	hipStream_t st = ws->stream;
 	HIP_TRY(hipSetDevice(ix->device));
+	KtUse kt_use(ws->profiling ? &ws->kt : nullptr);
 	const int64_t n = l.parsed.n_reads;
 	const int n_chunks = (int)l.parsed.n_chunks;
 	// ---- seeding (IdentifySeedPairs_FastMode) and chaining on the resident characters ---------------------------------------
@@ -615,6 +617,13 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 		t.text_in_bytes += (double)((l.parsed.used[0] - l.win.begin[0]) + (l.win.two_files ? l.parsed.used[1] - l.win.begin[1] : 0));
 		t.text_out_bytes += (double)sam_bytes;
 		t.candidates += (double)totals[0]; t.candidate_seeds += (double)totals[1];
+		// the kernels' own launches of this batch (events around each, the lane's stream is synchronised)
+		for (int i = 0; i < KT_SLOTS; ++i) {
+			if (!ws->kt.armed[i]) continue;
+			ws->kt.armed[i] = false;
+			t.kernel_ms[i] += elapsed(ws->kt.b[i], ws->kt.e[i]);
+			t.kernel_launches[i] += 1;
+		}
 	}
 	return KG_OK;
 }

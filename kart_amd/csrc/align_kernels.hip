@@ -2029,25 +2029,39 @@ static inline int grid_for_aln(int64_t items, int block, int max_blocks)
 hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 {
 	hipLaunchKernelGGL(aln_reset_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	kt_begin(KT_ALN_PAIR, stream);
 	hipLaunchKernelGGL(aln_pair_kernel, dim3(grid_for_aln(a.all_paired ? a.n_reads / 2 + 1 : a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	kt_end(KT_ALN_PAIR, stream);
+	kt_begin(KT_ALN_RESCUE, stream);
 	hipLaunchKernelGGL(aln_rescue_kernel, dim3(grid_for_aln(a.task_capacity, 1, n_cu * 32)), dim3(64), 0, stream, a);
 	hipLaunchKernelGGL(aln_post_rescue_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	kt_end(KT_ALN_RESCUE, stream);
 	if (a.n_cands > 0) {
 		if (a.plan_order) {
 			hipLaunchKernelGGL(aln_bin_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 8)), dim3(256), 0, stream, a, 0);
 			hipLaunchKernelGGL(aln_bin_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 8)), dim3(256), 0, stream, a, 1);
 		}
+		kt_begin(KT_ALN_PLAN_FAST, stream);
 		if (a.plan_slow) hipLaunchKernelGGL(aln_plan_fast_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
+		kt_end(KT_ALN_PLAN_FAST, stream);
+		kt_begin(KT_ALN_PLAN, stream);
 		hipLaunchKernelGGL(aln_plan_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
+		kt_end(KT_ALN_PLAN, stream);
+		kt_begin(KT_ALN_PARTITION, stream);
 		hipLaunchKernelGGL(aln_partition_kernel, dim3(grid_for_aln(a.n_cands / 8 + 1, 256, n_cu * 8)), dim3(256), 0, stream, a);
+		kt_end(KT_ALN_PARTITION, stream);
 	}
 	return hipGetLastError();
 }
 
 hipError_t launch_align_back(const AlnArgs &a, int n_cu, hipStream_t stream)
 {
+	kt_begin(KT_ALN_FINISH, stream);
 	hipLaunchKernelGGL(aln_finish_kernel, dim3(grid_for_aln(a.spill_capacity, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	kt_end(KT_ALN_FINISH, stream);
+	kt_begin(KT_ALN_FINAL, stream);
 	hipLaunchKernelGGL(aln_final_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	kt_end(KT_ALN_FINAL, stream);
 	return hipGetLastError();
 }
 

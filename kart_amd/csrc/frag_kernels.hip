@@ -552,7 +552,7 @@ __global__ void frag_reset_kernel(FragArgs a)
 	}
 	for (int64_t r = i; r < a.n; r += (int64_t)gridDim.x * blockDim.x) {
 		FragTask t;
-		t.f1_off = a.off1[r]; t.g = a.gpos[r]; t.rL = (int32_t)(a.off1[r + 1] - a.off1[r]); t.gL = a.glen[r];
+		t.f1_off = a.off1[r]; t.g = a.gpos[r]; t.rL = a.rlen ? a.rlen[r] : (int32_t)(a.off1[r + 1] - a.off1[r]); t.gL = a.glen[r];
 		t.first = 0; t.count = 0; t.status = 0; t.root = (int32_t)r;
 		a.tasks[r] = t;
 		a.status[r] = 0;

@@ -28,7 +28,8 @@ struct FragPiece {
 struct FragArgs {
 	// requests
 	const char *f1;                 // read fragments, concatenated
-	const int64_t *off1;            // [n + 1]
+	const int64_t *off1;            // [n + 1]; with rlen: [n] offsets of fragments that lie anywhere in f1
+	const int32_t *rlen = nullptr;  // [n] or null (the fragments are consecutive: rLen = off1[r + 1] - off1[r])
 	const int64_t *gpos;            // [n] text coordinate of the genome fragment
 	const int32_t *glen;            // [n]
 	int64_t n;

@@ -169,15 +169,50 @@ public:
 		t_align += t1 - t0; t_reccopy += now_sec() - t1;
 		return true;
 	}
+	bool align_long(const std::vector<int64_t> &chunk_off, const kg_aln_record *&records, const char *&cigar_pool, std::vector<kg_chunk_stats> &chunk_stats) override
+	{
+		static const bool off = getenv("KART_AMD_HOST_ALIGN") != nullptr || getenv("KART_AMD_HOST_LONG") != nullptr;      // A/B aids: the whole report on the host, as before
+		if (off) return false;
+		const kg_aln_record *rec = nullptr;
+		const char *pool = nullptr;
+		int64_t bytes = 0, n_host = 0;
+		double t0 = now_sec();
+		if (kg_longread_batch(ws_, &rec, &pool, &bytes, &n_host) != KG_OK) die("kg_longread_batch");
+		double t1 = now_sec();
+		const size_t n_chunks = chunk_off.size() - 1;
+		chunk_stats.assign(n_chunks, kg_chunk_stats());
+		for (size_t c = 0; c < n_chunks; ++c) {
+			kg_chunk_stats &cs = chunk_stats[c];
+			cs.paired = 0; cs.distance = 0; cs.lo = -1; cs.hi = INT64_MAX; cs.unmapped = 0; cs.unique = 0; cs.host_pairs = 0; cs.rescue_wanted = 0;
+			for (int64_t r = chunk_off[c]; r < chunk_off[c + 1]; ++r) {
+				if (rec[r].kind == KG_ALN_HOST) cs.host_pairs++;
+				else if (rec[r].kind == KG_ALN_UNMAPPED) cs.unmapped++;          // what OutputSingledAlignments counts (src/Mapping.cpp:278,288)
+				else if (rec[r].mapq == 60) cs.unique++;
+			}
+		}
+		records = rec;
+		cigar_pool = pool;
+		t_align += t1 - t0; t_reccopy += now_sec() - t1;
+		long_used_ = true;
+		return true;
+	}
 	std::string align_diagnostics() override
 	{
 		uint64_t w[16];
 		if (kg_align_reasons(ws_, w) != KG_OK) return std::string();
 		static const char *const name[13] = {"candidate product", "mate-2 window", "window length", "mate characters/length", "runs per window", "rescued pairs", "seeds",
 		                                     "gap pairs", "8-mer partition", "list capacity", "CIGAR length", "score", "read length"};
-		char tb[256];
+		char tb[512];
 		snprintf(tb, sizeof(tb), "device stage seconds: seed (H2D + kernels) %.3f | chain + D2H %.3f | candidate copies %.3f | align (kernels + D2H) %.3f | record copy %.3f || ", t_seed, t_cands, t_copy, t_align, t_reccopy);
 		std::string s(tb);
+		if (long_used_) {
+			uint64_t lw[8];
+			if (kg_longread_reasons(ws_, lw) == KG_OK) {
+				snprintf(tb, sizeof(tb), "long-read report on the device: %llu reads, %llu handed back (candidates: literal '-' %llu, fragment envelope %llu, seed order %llu, element pool %llu; sequential overlap check %llu) || ",
+				         (unsigned long long)lw[0], (unsigned long long)lw[1], (unsigned long long)lw[2], (unsigned long long)lw[3], (unsigned long long)lw[4], (unsigned long long)lw[5], (unsigned long long)lw[6]);
+				s += tb;
+			}
+		}
 		if (n_frag_calls) {
 			snprintf(tb, sizeof(tb), "fragment service: %lld calls, copying the parts together %.3f s, kg_fragments_batch %.3f s || ", (long long)n_frag_calls, t_frag_in, t_frag_call);
 			s += tb;
@@ -286,6 +321,7 @@ private:
 		if (kg_workspace_create(ix_, cap_reads_, cap_bases_, &ws_) != KG_OK) die("kg_workspace_create");
 	}
 	int64_t cap_reads_ = 0, cap_bases_ = 0;
+	bool long_used_ = false;
 	kg_index *ix_;
 	int threads_;
 	std::mutex nw_mu_, frag_mu_;

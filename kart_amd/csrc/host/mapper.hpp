@@ -150,6 +150,15 @@ struct KernelBackend {
 		(void)chunk_off; (void)chunk_paired; (void)est; (void)max_insert; (void)max_gaps; (void)multi_hit; (void)unset_flag; (void)records; (void)chunk_stats;
 		return false;
 	}
+	// The same for long reads (-pacbio, kg_longread_batch; src/Mapping.cpp:513-530): one record per read of the batch the last
+	// seed_and_chain(pacbio) call left on the device, the CIGAR strings in `cigar_pool` (records with cigar_len == KG_ALN_CIGAR_POOLED
+	// hold {int64 offset, int32 bytes} in their first 12 CIGAR bytes); chunk_stats[c].unmapped / unique / host_pairs are counted from the
+	// records.  false: the host maps every read itself.
+	virtual bool align_long(const std::vector<int64_t> &chunk_off, const kg_aln_record *&records, const char *&cigar_pool, std::vector<kg_chunk_stats> &chunk_stats)
+	{
+		(void)chunk_off; (void)records; (void)cigar_pool; (void)chunk_stats;
+		return false;
+	}
 	// diagnostics of the stage above (why pairs came back for the host), empty when there is none
 	virtual std::string align_diagnostics() { return std::string(); }
 };

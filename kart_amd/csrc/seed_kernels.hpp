@@ -76,6 +76,24 @@ hipError_t launch_rank_sa(const FmView &ix, const uint64_t *ks, int64_t n, uint6
 hipError_t launch_expand_sa(const FmView &ix, uint64_t n_sa, uint32_t *fsa32, uint64_t *fsa64, uint8_t *fsa40, hipStream_t stream);
 hipError_t launch_sample_sa(const uint32_t *fsa32, const uint64_t *fsa64, uint64_t n_out, int shift, uint32_t *d32, uint64_t *d64, hipStream_t stream);
 
+// Optional per-kernel timing of one workspace's launches (bench.py's per-kernel roofline entries): the entry points set the calling
+// thread's current timer, the launchers bracket their kernels with its events on the launch stream, and the entry point reads the
+// durations once the stream has been synchronised.
+enum { KT_CHAIN = 0, KT_ALN_PAIR, KT_ALN_RESCUE, KT_ALN_PLAN_FAST, KT_ALN_PLAN, KT_ALN_PARTITION, KT_NW, KT_ALN_FINISH, KT_ALN_FINAL,
+       KT_SAM_SIZE, KT_SAM_FORMAT, KT_FQ_PARSE, KT_FQ_MATERIALISE, KT_LOCATE_SORT, KT_SLOTS = 16 };
+struct KernelTimer {
+	hipEvent_t b[KT_SLOTS] = {}, e[KT_SLOTS] = {};
+	bool armed[KT_SLOTS] = {};
+};
+extern thread_local KernelTimer *kt_current;
+inline void kt_begin(int slot, hipStream_t st) { KernelTimer *k = kt_current; if (k && k->b[slot]) (void)hipEventRecord(k->b[slot], st); }
+inline void kt_end(int slot, hipStream_t st) { KernelTimer *k = kt_current; if (k && k->e[slot]) { (void)hipEventRecord(k->e[slot], st); k->armed[slot] = true; } }
+struct KtUse {                     // the calling thread's launches are timed by `k` (null: not at all) while this object lives
+	KernelTimer *prev;
+	explicit KtUse(KernelTimer *k) : prev(kt_current) { kt_current = k; }
+	~KtUse() { kt_current = prev; }
+};
+
 struct ChainArgs {
 	const int64_t *read_off;     // for rlen
 	int64_t n_reads;

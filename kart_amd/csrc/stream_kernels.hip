@@ -516,6 +516,7 @@ size_t fq_scan_temp_bytes(int64_t max_items)
 hipError_t launch_fq_parse(const FqArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream)
 {
 	hipError_t e;
+	kt_begin(KT_FQ_PARSE, stream);
 	hipLaunchKernelGGL(fq_reset_kernel, dim3(grid_of(a.max_reads + 1, 256, n_cu * 8)), dim3(256), 0, stream, a);
 	for (int f = 0; f < (a.two_files ? 2 : 1); ++f) {
 		const FqWindow &w = a.w[f];
@@ -531,13 +532,16 @@ hipError_t launch_fq_parse(const FqArgs &a, void *scan_temp, size_t scan_temp_by
 	Wide32Iter it(a.read_len, Widen32());
 	if ((e = hipcub::DeviceScan::ExclusiveSum(scan_temp, tb, it, a.read_off, (int)(a.max_reads + 1), stream)) != hipSuccess) return e;
 	hipLaunchKernelGGL(fq_plan_kernel, dim3(1), dim3(64), 0, stream, a);
+	kt_end(KT_FQ_PARSE, stream);
 	return hipGetLastError();
 }
 
 hipError_t launch_fq_materialise(const FqArgs &a, int n_cu, hipStream_t stream)
 {
 	if (a.n_reads <= 0) return hipSuccess;
+	kt_begin(KT_FQ_MATERIALISE, stream);
 	hipLaunchKernelGGL(fq_materialise_kernel, dim3(grid_of(a.n_reads, 4, n_cu * 32)), dim3(256), 0, stream, a);
+	kt_end(KT_FQ_MATERIALISE, stream);
 	return hipGetLastError();
 }
 
@@ -576,19 +580,23 @@ hipError_t launch_group_rebase(const int64_t *g_seed_off, int64_t n, int64_t fir
 
 hipError_t launch_sam_size(const SamArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream)
 {
+	kt_begin(KT_SAM_SIZE, stream);
 	hipLaunchKernelGGL(sam_reset_kernel, dim3(1), dim3(64), 0, stream, a);
 	hipLaunchKernelGGL(sam_size_kernel, dim3(grid_of(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
 	size_t tb = scan_temp_bytes;
 	Wide32Iter it(a.sam_len, Widen32());
 	hipError_t e = hipcub::DeviceScan::ExclusiveSum(scan_temp, tb, it, a.sam_off, (int)(a.n_reads + 1), stream);
 	if (e != hipSuccess) return e;
+	kt_end(KT_SAM_SIZE, stream);
 	return hipGetLastError();
 }
 
 hipError_t launch_sam_format(const SamArgs &a, int n_cu, hipStream_t stream)
 {
 	if (a.n_reads <= 0) return hipSuccess;
+	kt_begin(KT_SAM_FORMAT, stream);
 	hipLaunchKernelGGL(sam_format_kernel, dim3(grid_of((a.n_reads + 63) / 64, 1, n_cu * 64)), dim3(64), 0, stream, a);
+	kt_end(KT_SAM_FORMAT, stream);
 	return hipGetLastError();
 }
 

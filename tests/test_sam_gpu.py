@@ -4,6 +4,7 @@ unmodified reference binary travelled with the snapshot (oracle/_ref/kart) -- ag
 `kart -t 1` run on a larger seeded input."""
 import gzip
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -113,6 +114,47 @@ def test_live_reference_pacbio_unseeded_stretch_over_7000(product_binary, tmp_pa
     assert b"7599I7599D" in cigars[0] and b"7099I7099D" in cigars[1] and b"8199I8199D" in cigars[2], cigars   # the stretch went through nw_alignment, not a clip
 
 
+def test_long_read_report_is_the_devices(product_binary, tmp_path):
+    """kg_longread_batch (src/Mapping.cpp:513-530 on the device: IdentifyNormalPairs of the read, pass 1, the fragment kernels on
+    device-resident requests, pass 2 off the op strings, CIGAR pool, flag, MAPQ): 400 x 7 kb reads at 15 % error plus reads that must
+    go back to the host (a literal '-', which the reference's scans take for a gap column) and reads with N runs -- identical to the
+    live reference, nearly every read decided on the device, every device record equal to the host's text (KART_AMD_CHECK_ALIGN),
+    the same bytes with the report forced onto the host, under small batches, and with mate files (printed by the paired function:
+    the host's report)"""
+    assert os.path.exists(KART_REF), "oracle/_ref/kart did not travel to the GPU box: __graft_entry__.build() makes it where /root/reference exists"
+    from kart_amd import synth
+    from kart_amd.index_build import read_fasta
+    genome = {n: s for n, _, s in read_fasta(os.path.join(GOLDEN, "small.fa"))}
+    names, reads = synth.simulate_long_reads(genome, 400, seed=77, read_len=7000, err=0.15, indel_err_frac=0.1)
+    names2, reads2 = synth.simulate_long_reads(genome, 60, seed=78, read_len=3000, err=0.02, indel_err_frac=0.3)      # accurate reads: long exact matches, the <= 2-mismatch shortcut
+    names, reads = list(names) + ["acc_" + n for n in names2], [np.array(r, dtype=np.uint8) for r in reads] + [np.array(r, dtype=np.uint8) for r in reads2]
+    for i in (3, 50, 120):                                  # literal dashes -> KG_ALN_HOST
+        reads[i][1000 + i] = ord("-"); reads[i][2000] = ord("-")
+    for i in (7, 90):                                       # N runs inside the read (fragment kernels hand such fragments back)
+        reads[i][3000:3040] = ord("N")
+    reads[200][10] = ord("n"); reads[200][4000] = ord("a") if reads[200][4000] != ord("A") else ord("c")     # lower case: raw-character comparisons
+    fq = str(tmp_path / "long.fq")
+    synth.write_fastq(fq, names, reads)
+    ref_out = str(tmp_path / "ref.sam")
+    subprocess.run([KART_REF, "-silent", "-i", SMALL_PREFIX, "-f", fq, "-pacbio", "-o", ref_out, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    want = open(ref_out, "rb").read()
+    out = str(tmp_path / "amd.sam")
+    log, err = _run_verbose(product_binary, ["-f", fq, "-pacbio"], out, {})
+    assert open(out, "rb").read() == want
+    m = re.search(r"device report: (\d+) reads decided on the device, (\d+) mapped by the host stages", log)
+    assert m and int(m.group(1)) + int(m.group(2)) == len(reads), log[-600:]
+    assert int(m.group(1)) >= 0.9 * len(reads) and int(m.group(2)) >= 3, log[-600:]
+    log, err = _run_verbose(product_binary, ["-f", fq, "-pacbio"], out, {"KART_AMD_CHECK_ALIGN": "1"})
+    line = [l for l in log.splitlines() if l.startswith("CHECK_ALIGN")]
+    assert line and line[0].endswith(" 0 differ") and not line[0].startswith("CHECK_ALIGN: 0 device"), (line, err[:800])
+    assert open(out, "rb").read() == want
+    for env in ({"KART_AMD_HOST_LONG": "1"}, {"KART_AMD_PACBIO_CHUNKS": "4", "KART_AMD_FRAG_SLICE": "4"}, {"KART_AMD_PACBIO_CHUNKS": "8", "KART_AMD_PACBIO_MAX_CHUNKS": "32", "KG_FRAG_NO_FAST_PAIRS": "1"}):
+        log, err = _run_verbose(product_binary, ["-f", fq, "-pacbio"], out, env)
+        assert open(out, "rb").read() == want, env
+        if "KART_AMD_HOST_LONG" in env:
+            assert "device report: 0 reads decided on the device" in log
+
+
 @pytest.mark.parametrize("threads", [1, 3, 16, 64])
 def test_output_does_not_depend_on_the_thread_count(threads, product_binary, tmp_path):
     for case in ("pe", "pe_m", "pacbio"):
@@ -196,7 +238,7 @@ def _run_verbose(binary, args, out, env=None):
     return r.stdout.decode(), r.stderr.decode()
 
 
-@pytest.mark.parametrize("case", ["pe", "pe_g2", "se", "edge_pe", "edge_se", "pe_m", "se_m", "edge_se_m"])
+@pytest.mark.parametrize("case", ["pe", "pe_g2", "se", "edge_pe", "edge_se", "pe_m", "se_m", "edge_se_m", "pacbio"])
 def test_device_report_equals_the_host_report_record_by_record(case, product_binary, tmp_path):
     """kg_align_batch (pairing, mate rescue, normal pairs, 8-mer partition, NW, CIGAR, flags, MAPQ on the device) against the host
     implementation of the same reference code: KART_AMD_CHECK_ALIGN maps every read on the host as well and compares the SAM text
