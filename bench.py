@@ -634,6 +634,9 @@ def run(args, fallback_note):
                                     "durations (the ramp-up launches of a step -- batches of 4 k .. 256 k reads while EstDistance settles -- included).  Other lanes' kernels "
                                     "share the device, so a launch's duration includes what they took from it."}
 
+    # ---- every kernel of the timed region with a share of the step: HIP events around each launch on the lanes' streams (kg_stream_timing_t::
+    # kernel_ms), against the bytes the kernel has to touch (its inputs and outputs as laid out in HBM) ----------------
+    line["kernels"] = kernel_entries(stats, args.steps, n_reads, sk_ms / args.steps if sk_n else 0.0, args)
     # the step outputs go first: the side legs below write their own files and must never add to them
     while outs:
         drop(outs.pop(0))
@@ -663,6 +666,11 @@ def run(args, fallback_note):
                                            "against the bytes it has to move: dependent small gathers per candidate, not streaming -- the wait share per kernel "
                                            "(SQ_WAIT_ANY / SQ_WAVE_CYCLES) is in the round's PMC summary under profiles/"}
 
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            line["host_output"] = host_output_entry(workdir, line["config"]["sam_bytes_per_step"], elapsed / args.steps, threads)
+        except Exception as exc:      # a side measurement must never cost the line
+            line["host_output"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
     if world == 1:
         # ---- CPU baseline + parity on a prefix of the very files that were timed -------------------------------------------
         if not args.no_cpu_baseline:
@@ -696,6 +704,8 @@ def run(args, fallback_note):
             line["seeding_stage"] = seed
             if "roofline" in line:
                 seed["roofline_single_launch"] = seed.pop("roofline")
+                survey_and_traffic_fractions(line["roofline"], seed.get("reference_algorithm_bytes_per_read"), reads_here / max(1, sk_n))
+                survey_and_traffic_fractions(seed["roofline_single_launch"], seed.get("reference_algorithm_bytes_per_read"), seed.get("reads_per_launch", 0))
             else:
                 line["roofline"] = seed.pop("roofline")
             if "oracle_sample" in seed:
@@ -1002,6 +1012,156 @@ def seed_group_setting():
     return g, lanes
 
 
+KERNEL_SLOTS = ("chain", "aln_pair", "aln_rescue", "aln_plan_fast", "aln_plan", "aln_partition", "nw", "aln_finish", "aln_final", "sam_size", "sam_format",
+                "fq_parse", "fq_materialise")
+VALU_INT32_PEAK_TOPS = 78.0       # int32 VALU lane-operations per second of the device, in 1e12 (VERDICT r4 #6's figure; ~12 of them per DP cell)
+NW_OPS_PER_CELL = 12.0
+
+
+def survey_and_traffic_fractions(roof, ref_bytes_per_read, reads_per_launch):
+    """SURVEY.md 8(d) defines the algorithmic bytes of seeding on the REFERENCE's algorithm (64-byte Occ blocks per LF step, 8 B per SA
+    entry, 16 B per seed).  The implemented search skips ~90 % of those steps (q-mer table, pair / triple planes, text comparison), so that
+    figure over the kernel's time exceeds the HBM peak: it is an algorithmic speed-up, not a fraction -- printed beside `frac`, which
+    prices the bytes the implemented search needs, and `traffic_frac`, the counter traffic over the same time."""
+    if not roof or not roof.get("avg_launch_ms"):
+        return
+    sec = roof["avg_launch_ms"] * 1e-3
+    if ref_bytes_per_read and reads_per_launch:
+        gbs = ref_bytes_per_read * reads_per_launch / sec / 1e9
+        roof["survey_8d"] = {"bytes_per_read": ref_bytes_per_read, "bytes_per_launch": ref_bytes_per_read * reads_per_launch, "GBps": gbs, "over_peak": gbs / HBM_PEAK_GBS,
+                             "label": ("algorithmic speed-up over the reference's block-per-step search, not a roofline fraction" if gbs > HBM_PEAK_GBS
+                                       else "SURVEY 8(d) bytes / launch time / peak")}
+        roof["frac_survey_8d"] = gbs / HBM_PEAK_GBS
+    if roof.get("traffic"):
+        roof["traffic_frac"] = roof["traffic"] / sec / 1e9 / HBM_PEAK_GBS
+        roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"] if roof.get("algorithmic_bytes_per_launch") else None
+
+
+def kernel_traffic(args):
+    """per-kernel HBM bytes per step from the committed PMC passes of this very command (profiles/*_pmc_summary.json, `_kernel_traffic`:
+    {kernel: bytes per step}, made by tools/profile_to_profiles.py from rocprofv3 --pmc passes with the guide's gfx950 corrections);
+    only when the profiled run had this run's shape"""
+    best = ({}, None)
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not f.endswith("_pmc_summary.json"):
+            continue
+        try:
+            t = json.load(open(os.path.join(pdir, f))).get("_kernel_traffic")
+        except Exception:
+            t = None
+        if not t or t.get("pairs_per_step") != getattr(args, "pairs", None) or t.get("genome_len", GENOME_LEN) != args.genome_len:
+            continue
+        if t.get("seed_group") != seed_group_setting()[0] or t.get("stream_lanes") != seed_group_setting()[1] or t.get("stream_reads") != stream_reads_setting():
+            continue
+        best = (t.get("bytes_per_step", {}), "profiles/" + f)
+    return best
+
+
+def kernel_entries(stats, steps, n_reads, search_ms_per_step, args):
+    """achieved / peak / frac for every kernel of the timed region (rank 0): ms = HIP events around each launch of the timed steps."""
+    ms = [sum(float(st.kernel_ms[i]) for st in stats) / steps for i in range(len(KERNEL_SLOTS))]
+    launches = [sum(int(st.kernel_launches[i]) for st in stats) / steps for i in range(len(KERNEL_SLOTS))]
+    cnt = [sum(float(st.aln_counts[i]) for st in stats) / steps for i in range(8)]
+    C = sum(float(st.candidates) for st in stats) / steps
+    S = sum(float(st.candidate_seeds) for st in stats) / steps
+    t_in = sum(float(st.text_in_bytes) for st in stats) / steps
+    t_out = sum(float(st.text_out_bytes) for st in stats) / steps
+    R = float(n_reads)
+    spills, jobs, op_bytes, part_tasks, resc_tasks, slow = cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[7]
+    per_cand = 32 + 78 + READ_LEN + READ_LEN / 4          # candidate, its report, the read's characters, the text under it
+    # bytes every kernel has to move (inputs read once + outputs written once, HBM layout of DESIGN.md section 3)
+    alg = {
+        "chain": 32 * S + 32 * C + 24 * R,                                           # seeds in (16 B), candidate seeds out (16 B), candidates (32 B), per-read counts / offsets
+        "aln_pair": 32 * C + 12 * C + 16 * R,                                        # candidates in, score / mate / read per candidate out, per-read flags
+        "aln_rescue": resc_tasks * (40 + 1650 / 4 + READ_LEN + 12 * 16),             # task, window text (2 bit/base), the mate's characters, the rescued seeds
+        "aln_plan_fast": C * per_cand + 16 * S + 4 * C,                              # every candidate + its seeds; the list of the ones it leaves
+        "aln_plan": slow * (per_cand + 536) + 16 * S * (slow / C if C else 0) + 24 * jobs,   # the candidates left to it, their spill slots (536 B), job descriptors
+        "aln_partition": part_tasks * (32 + 2 * 255 / 2 + 64),                       # task, both fragments (characters / 2-bit text), plan + pieces
+        "nw": None,
+        "aln_finish": spills * (536 + 78) + 2 * op_bytes + spills * READ_LEN,        # spill slot in, report out, op strings, the read's characters
+        "aln_final": 112 * R + 78 * C + 12 * C,                                      # record out, reports + scores / mates in
+        "sam_size": (112 + 24 + 4) * R,                                              # record + record table in, length out
+        "sam_format": t_in * 0.75 + t_out + (112 + 24 + 8) * R,                      # name + bases + qualities of the FASTQ text (the '+' line and newlines are not read), SAM text out, records
+        "fq_parse": 2 * t_in + 16 * R + 24 * R,                                      # the text twice (line count, line index), line ends (4 x 4 B), record table
+        "fq_materialise": (READ_LEN + READ_LEN + 8) * R,                             # bases in, characters out, offsets
+    }
+    traffic, traffic_src = kernel_traffic(args)
+    total = sum(ms) + search_ms_per_step
+    out = {"what": "rank 0, per step: HIP events around each launch on the lanes' streams (other lanes' kernels share the device, so a launch's time includes what "
+                   "they took from it); achieved = algorithmic bytes / that time; peak = %.0f GB/s (HBM); traffic = counter bytes of the same command "
+                   "(profiles/, null when no pass of this run's shape is committed)" % HBM_PEAK_GBS,
+           "timed_kernel_ms_per_step": total, "counts_per_step": {"candidates": C, "candidate_seeds": S, "parked_candidates": spills, "nw_jobs": jobs, "nw_op_bytes": op_bytes,
+                                                                 "partition_tasks": part_tasks, "rescue_windows": resc_tasks, "candidates_left_to_aln_plan": slow},
+           "traffic_source": traffic_src}
+    for i, name in enumerate(KERNEL_SLOTS):
+        if ms[i] <= 0:
+            continue
+        e = {"ms_per_step": ms[i], "launches_per_step": launches[i], "share_of_timed_kernels": ms[i] / total if total else None}
+        if name == "nw":
+            e.update({"bound": "valu", "note": "integer max-plus DP: priced in cells per second by the nw_kernels leg of this line (GCUPS per size class against %.0f T int32 "
+                                               "VALU operations/s at ~%.0f per cell); in the timed region: %.0f jobs, %.0f op bytes per step" % (VALU_INT32_PEAK_TOPS, NW_OPS_PER_CELL, jobs, op_bytes)})
+        elif alg[name]:
+            gbs = alg[name] / (ms[i] * 1e-3) / 1e9
+            e.update({"bound": "hbm", "algorithmic_bytes_per_step": alg[name], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+        t = traffic.get(name)
+        e["traffic"] = t
+        if t:
+            e["traffic_frac"] = t / (ms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out[name] = e
+    return out
+
+
+def host_output_entry(workdir, sam_bytes, step_seconds, threads):
+    """What bounds a step is the host side of the output: fresh page-cache pages of the SAM file.  peak = this box's
+    rate for exactly that, measured here: N threads copying 64 MB blocks into shared mappings of ONE fresh file in the same directory
+    (numpy copies release the GIL; every 4 KB page is a write fault that allocates it), N = the writer threads the pipeline uses."""
+    import mmap
+    import threading
+    n_thr = max(2, min(8, threads * 7 // 16 + 1))
+    total = 6 << 30
+    blk = 64 << 20
+    path = os.path.join(workdir, "kart_bench_hostout_%d.bin" % os.getpid())
+    src = np.full(blk, 65, dtype=np.uint8)
+    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
+    try:
+        os.ftruncate(fd, total)
+        mm = mmap.mmap(fd, total)
+        dst = np.frombuffer(mm, dtype=np.uint8)
+        nxt = [0]
+        lock = threading.Lock()
+
+        def work():
+            while True:
+                with lock:
+                    at = nxt[0]
+                    nxt[0] += blk
+                if at >= total:
+                    return
+                np.copyto(dst[at:at + blk], src)
+        th = [threading.Thread(target=work) for _ in range(n_thr)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        del dst
+        mm.close()
+    finally:
+        os.close(fd)
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    peak = total / dt / 1e9
+    achieved = sam_bytes / step_seconds / 1e9
+    return {"bound": "host page cache", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak, "bytes_per_step": sam_bytes,
+            "peak_source": "%d threads x 64 MB copies into mappings of one fresh %d GB file in %s, measured in this run (%.2f s)" % (n_thr, total >> 30, workdir, dt),
+            "note": "the step's SAM text over the step's wall time against the rate at which this box hands out fresh pages of one tmpfs file: the pipeline's writers "
+                    "(mapped copies + one pwrite thread, kept on one L3 domain) run beside the lanes' input copies on the same cores"}
+
+
 def measured_traffic(n_reads, args, tag=None):
     """HBM/fabric bytes per search_kernel launch from the committed PMC passes of this exact command
     (rocprofv3 --pmc, separate passes; profiles/*_pmc_summary.json, corrected for gfx950 as
@@ -1058,7 +1218,9 @@ def nw_leg(ix, dev):
             call()
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t) / 3
-        out[name] = {"pairs_per_s": round(n / dt), "GCUPS": round(float((m.astype(np.float64) * k).sum()) / dt / 1e9, 1)}
+        gcups = float((m.astype(np.float64) * k).sum()) / dt / 1e9
+        out[name] = {"pairs_per_s": round(n / dt), "GCUPS": round(gcups, 1), "bound": "valu", "peak_GCUPS": round(VALU_INT32_PEAK_TOPS * 1e3 / NW_OPS_PER_CELL, 1),
+                     "frac": gcups / (VALU_INT32_PEAK_TOPS * 1e3 / NW_OPS_PER_CELL)}
         del f1, f2, ops, ln
     return out
 

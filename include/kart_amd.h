@@ -403,6 +403,9 @@ typedef struct {
 	 * [7] aln_finish, [8] aln_final, [9] sam_size + scan, [10] sam_format, [11] fq_count / index / record / plan, [12] fq_materialise */
 	double kernel_ms[16];
 	int64_t kernel_launches[16];
+	/* what the alignment stage's lists held, summed over the batches: [0] candidates parked for NW, [1] NW jobs, [2] bytes of their op strings,
+	 * [3] fragment pairs through the 8-mer partition, [4] rescue windows, [5] partition plans, [6] their pieces, [7] candidates aln_plan_fast left to aln_plan */
+	double aln_counts[8];
 } kg_stream_timing_t;
 int   kg_stream_timing(kg_stream *s, kg_stream_timing_t *out, int reset);
 

@@ -48,6 +48,7 @@ typedef struct {
 	double  candidates, candidate_seeds;     /* of the batches that went through the device stream (kg_stream_timing_t) */
 	double  kernel_ms[16];           /* the batches' kernels one by one (kg_stream_timing_t::kernel_ms: chain, aln_pair, aln_rescue, aln_plan_fast, ...) */
 	int64_t kernel_launches[16];
+	double  aln_counts[8];           /* kg_stream_timing_t::aln_counts */
 } kh_stats_t;
 
 const char *kh_last_error(void);

@@ -123,10 +123,10 @@ class StreamResult(C.Structure):
 class StreamTiming(C.Structure):
     _fields_ = [("batches", C.c_int64), ("reads", C.c_int64)] + [(n, C.c_double) for n in ("parse_ms", "seed_ms", "chain_ms", "align_ms", "format_ms", "copy_ms", "search_kernel_ms")] + \
                [("search_kernel_launches", C.c_int64)] + [(n, C.c_double) for n in ("search_useful_bytes", "text_in_bytes", "text_out_bytes", "candidates", "candidate_seeds")] + \
-               [("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_int64 * 16)]
+               [("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_int64 * 16), ("aln_counts", C.c_double * 8)]
 
     def as_dict(self):
-        return {n: (list(getattr(self, n)) if n.startswith("kernel_") else getattr(self, n)) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n.startswith(("kernel_", "aln_counts")) else getattr(self, n)) for n, _ in self._fields_}
 
 
 _lib = None
@@ -516,10 +516,10 @@ class HostStats(C.Structure):
                 ("respeculated", C.c_int64), ("map_seconds", C.c_double), ("sharded", C.c_int32), ("pad", C.c_int32),
                 ("stream_reads", C.c_int64), ("stream_batches", C.c_int64), ("stage_ms", C.c_double * 6), ("search_kernel_ms", C.c_double),
                 ("search_kernel_launches", C.c_int64), ("search_useful_bytes", C.c_double), ("text_in_bytes", C.c_double), ("text_out_bytes", C.c_double),
-                ("candidates", C.c_double), ("candidate_seeds", C.c_double), ("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_int64 * 16)]
+                ("candidates", C.c_double), ("candidate_seeds", C.c_double), ("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_int64 * 16), ("aln_counts", C.c_double * 8)]
 
     def as_dict(self):
-        return {n: (list(getattr(self, n)) if n.startswith(("kernel_", "stage_")) else getattr(self, n)) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n.startswith(("kernel_", "stage_", "aln_counts")) else getattr(self, n)) for n, _ in self._fields_}
 
 
 _host_lib = None

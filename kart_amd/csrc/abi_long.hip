@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #define fail kg_fail
 
@@ -179,6 +180,45 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 	if (text_bytes > 0) HIP_TRY(hipMemcpyAsync(ls->h_cigar[slot], a.cigar, (size_t)text_bytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(h, a.ctl, 8 * LC_WORDS, hipMemcpyDeviceToHost, st));
 	HIP_TRY(kgi_sync(ws));
+	if (const char *dbg = getenv("KG_LONG_DEBUG")) {
+		// diagnostics: the pairs, the requests' op strings (as runs) and the merged elements of read <KG_LONG_DEBUG> of this batch
+		const int64_t r = atoll(dbg);
+		if (r >= 0 && r < n) {
+			std::vector<int64_t> co(2);
+			(void)hipMemcpy(co.data(), ws->d_cand_off + r, 16, hipMemcpyDeviceToHost);
+			for (int64_t c = co[0]; c < co[1]; ++c) {
+				int32_t lc = -1;
+				(void)hipMemcpy(&lc, a.cand_lc + c, 4, hipMemcpyDeviceToHost);
+				kg_candidate cd;
+				(void)hipMemcpy(&cd, ws->d_dense_cands + c, sizeof(cd), hipMemcpyDeviceToHost);
+				fprintf(stderr, "KG_LONG_DEBUG read %lld candidate %lld: score %d, %d seeds, lc %d\n", (long long)r, (long long)c, cd.score, cd.count, lc);
+				if (lc < 0) continue;
+				LrCand k;
+				(void)hipMemcpy(&k, a.lcs + lc, sizeof(k), hipMemcpyDeviceToHost);
+				fprintf(stderr, "  state %d, %d pairs, score %d, chr %d pos %lld fwd %d, %d elements, %d text bytes\n", k.state, k.n_pairs, k.score, k.chr, (long long)k.pos, k.fwd, k.n_elems, k.text_bytes);
+				std::vector<LrPair> P((size_t)std::max(0, k.n_pairs));
+				if (k.n_pairs > 0) (void)hipMemcpy(P.data(), a.pool + k.pair_off, sizeof(LrPair) * P.size(), hipMemcpyDeviceToHost);
+				for (size_t j = 0; j < P.size(); ++j) {
+					const LrPair &q = P[j];
+					fprintf(stderr, "  pair %zu: kind %d r[%d +%d] g[%lld +%d] v %d op %c", j, q.kind, q.rPos, q.rLen, (long long)q.gPos, q.gLen, q.v, q.op ? q.op : '.');
+					if (q.kind == LP_REQ && q.v >= 0 && q.v < n_req) {
+						int32_t L = 0; int64_t oo = 0; uint8_t stt = 0;
+						(void)hipMemcpy(&L, a.aln_len + q.v, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&oo, a.req_oo + q.v, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&stt, a.status + q.v, 1, hipMemcpyDeviceToHost);
+						std::vector<uint8_t> o((size_t)std::max(0, L));
+						if (L > 0) (void)hipMemcpy(o.data(), a.ops + oo, (size_t)L, hipMemcpyDeviceToHost);
+						fprintf(stderr, " | request %d: status %d, %d columns:", q.v, stt, L);
+						for (int t = 0; t < L;) { int e = t; while (e < L && o[(size_t)e] == o[(size_t)t]) ++e; fprintf(stderr, " %d%c", e - t, "MDI?"[o[(size_t)t] & 3]); t = e; }
+					}
+					fprintf(stderr, "\n");
+				}
+				std::vector<uint32_t> E((size_t)std::max(0, k.n_elems));
+				if (k.n_elems > 0) (void)hipMemcpy(E.data(), a.elems + k.elem_off, 4 * E.size(), hipMemcpyDeviceToHost);
+				fprintf(stderr, "  elements:");
+				for (uint32_t e : E) fprintf(stderr, " %u%c", e >> 2, "MIDS"[e & 3]);
+				fprintf(stderr, "\n");
+			}
+		}
+	}
 	int64_t n_host = 0;
 	for (int64_t r = 0; r < n; ++r) n_host += ws->h_records[r].kind == KG_ALN_HOST;
 	ls->reads += (unsigned long long)n; ls->host_reads += (unsigned long long)n_host;

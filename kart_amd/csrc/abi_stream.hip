@@ -37,7 +37,7 @@ struct Lane {
 	int64_t d_sam_capacity = 0;
 	// page-locked
 	char *h_text[2] = {nullptr, nullptr};
-	int64_t *h_meta = nullptr;                         // [FQM_WORDS] + [8] spare words for totals
+	int64_t *h_meta = nullptr;                         // [FQM_WORDS] + [24] spare words for totals
 	char *h_sam = nullptr;
 	int64_t h_sam_capacity = 0;
 	int64_t *h_sam_off = nullptr, *h_cand_off = nullptr;
@@ -217,7 +217,10 @@ int kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out)
 	const int64_t n = cfg->max_reads;
 	const int64_t seg_bases = (cfg->max_window + 4096 + 64 + 255) & ~255ll;      // a lane's part of its group's character array
 	for (int g = 0; group && g < cfg->lanes / group; ++g) {
-		std::unique_ptr<SeedGroup> sg(new SeedGroup());
+		// (in the stream's list at once: whatever fails below, kg_stream_close frees what the group holds -- ADVICE r4: a group that failed half-way
+		//  used to keep its multi-GB arrays, and the host path the caller falls back to then ran out of device memory)
+		s->groups.push_back(std::unique_ptr<SeedGroup>(new SeedGroup()));
+		SeedGroup *sg = s->groups.back().get();
 		sg->first = g * group; sg->size = group;
 		sg->stride = n + 8; sg->seg_bases = seg_bases;
 		int rc = kg_workspace_create(ix, sg->stride * group, seg_bases * group, &sg->ws);
@@ -233,7 +236,6 @@ int kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out)
 		HIP_TRY(hipStreamSynchronize(gw->stream));          // (the lanes write these arrays from their own streams)
 		HIP_TRY(hipHostMalloc((void **)&sg->h_ctl, 8 * kCtlWords, hipHostMallocDefault));
 		(void)kg_workspace_set_profiling(gw, 1);
-		s->groups.push_back(std::move(sg));
 	}
 	for (size_t li = 0; li < s->lanes.size(); ++li) {
 		Lane &l = s->lanes[li];
@@ -268,7 +270,7 @@ int kg_stream_open(kg_index *ix, const kg_stream_config *cfg, kg_stream **out)
 		HIP_TRY(hipMalloc((void **)&l.d_host_list, 4 * (size_t)(n + 8)));
 		HIP_TRY(hipMalloc((void **)&l.d_sam_off, 8 * (size_t)(n + 8)));
 		HIP_TRY(hipMalloc((void **)&l.d_sam_ctl, 8 * 4));
-		HIP_TRY(hipHostMalloc((void **)&l.h_meta, 8 * (FQM_WORDS + 8), hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void **)&l.h_meta, 8 * (FQM_WORDS + 24), hipHostMallocDefault));
 		HIP_TRY(hipHostMalloc((void **)&l.h_sam_off, 8 * (size_t)(n + 8), hipHostMallocDefault));
 		HIP_TRY(hipHostMalloc((void **)&l.h_cand_off, 8 * (size_t)(n + 8), hipHostMallocDefault));
 		HIP_TRY(hipHostMalloc((void **)&l.h_host_list, 4 * (size_t)(n + 8), hipHostMallocDefault));
@@ -587,6 +589,8 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 	if (totals[0] > 0) HIP_TRY(hipMemcpyAsync(l.h_cands, ws->d_dense_cands, sizeof(kg_candidate) * (size_t)totals[0], hipMemcpyDeviceToHost, st));
 	if (totals[1] > 0) HIP_TRY(hipMemcpyAsync(l.h_cand_seeds, ws->d_dense_seeds, sizeof(kg_seed) * (size_t)totals[1], hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&tot[2], l.d_sam_ctl + 1, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&tot[8], ws->d_aln_ctl, 8 * 7, hipMemcpyDeviceToHost, st));          // the alignment stage's list sizes of this batch ...
+	HIP_TRY(hipMemcpyAsync(&tot[15], ws->d_aln_ctl + 32, 8, hipMemcpyDeviceToHost, st));        // ... and the candidates its fast plan kernel left to the general one
 	HIP_TRY(hipEventRecord(l.ev[6], st));
 	HIP_TRY(kgi_sync(ws));
 	if (tot[2] != 0) return fail(KG_ERR_NO_DEVICE, "kg_stream_map: %lld records were formatted to a size other than the one announced", (long long)tot[2]);
@@ -617,6 +621,7 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 		t.text_in_bytes += (double)((l.parsed.used[0] - l.win.begin[0]) + (l.win.two_files ? l.parsed.used[1] - l.win.begin[1] : 0));
 		t.text_out_bytes += (double)sam_bytes;
 		t.candidates += (double)totals[0]; t.candidate_seeds += (double)totals[1];
+		for (int i = 0; i < 8; ++i) t.aln_counts[i] += (double)tot[8 + i];
 		// the kernels' own launches of this batch (events around each, the lane's stream is synchronised)
 		for (int i = 0; i < KT_SLOTS; ++i) {
 			if (!ws->kt.armed[i]) continue;

@@ -102,6 +102,7 @@ int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
 		stats->text_in_bytes = st.device.text_in_bytes; stats->text_out_bytes = st.device.text_out_bytes;
 		stats->candidates = st.device.candidates; stats->candidate_seeds = st.device.candidate_seeds;
 		for (int i = 0; i < 16; ++i) { stats->kernel_ms[i] = st.device.kernel_ms[i]; stats->kernel_launches[i] = st.device.kernel_launches[i]; }
+		for (int i = 0; i < 8; ++i) stats->aln_counts[i] = st.device.aln_counts[i];
 	}
 	if (rc == 0) return 0;
 	const std::string why = kart::run_error_message();

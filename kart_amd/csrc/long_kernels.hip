@@ -361,7 +361,8 @@ __device__ int scan_columns(const LrArgs &a, const uint8_t *rd, int64_t g, const
 		const int cop = op == KG_OP_DIAG ? 0 : op == KG_OP_GAP2 ? 1 : 2;      // M, I (gap in the text side), D (gap in the read side)
 		if (kStats) {
 			st->n += __popcll(mD);
-			const int prev = lane == 0 ? prev_raw : __shfl(op, (lane - 1) & 63);
+			const int up = __shfl(op, (lane - 1) & 63);                        // (outside the conditional: lane 0 must take part for lane 1 to read it)
+			const int prev = lane == 0 ? prev_raw : up;
 			uint64_t B = __ballot(valid && op != prev);
 			while (B) {
 				const int p = __ffsll((unsigned long long)B) - 1;
@@ -374,7 +375,8 @@ __device__ int scan_columns(const LrArgs &a, const uint8_t *rd, int64_t g, const
 		}
 		if (kEmit) {
 			// the runs that END inside this step are closed by the lane that starts the next one
-			const int prev = lane == 0 ? cg.op : __shfl(cop, (lane - 1) & 63);
+			const int up = __shfl(cop, (lane - 1) & 63);
+			const int prev = lane == 0 ? cg.op : up;
 			const uint64_t B = __ballot(valid && cop != prev);
 			const bool skip0 = cg.len == 0 && (B & 1ull);                 // nothing was in progress at column 0
 			if (valid && cop != prev) {

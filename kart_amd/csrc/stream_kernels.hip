@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) void sam_size_kernel(SamArgs a)
 namespace {
 
 constexpr int kFmtA = 16, kFmtB = 92, kFmtT = 52, kFmtSlot = kFmtA + kFmtB + kFmtT;     // bytes of a lane's strings
+constexpr int kFmtBuf = 16384;                                                          // bytes of consecutive lines assembled in the LDS before a flush
 
 struct FmtDesc {                       // what phase 2 needs for one read
 	const uint8_t *name, *qual, *seq, *chr;
@@ -406,6 +407,7 @@ __device__ __forceinline__ uint8_t *copy_line(uint8_t *__restrict__ p, int lane,
 __global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
 {
 	__shared__ char str[64 * kFmtSlot];
+	__shared__ __attribute__((aligned(16))) uint8_t buf[kFmtBuf + 32];
 	__shared__ FmtDesc desc[64];
 	__shared__ int chain_len[3];
 	const int lane = threadIdx.x;
@@ -443,14 +445,52 @@ __global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
 		}
 		__syncthreads();
 		// ---- phase 2: all lanes per read ------------------------------------------------------------------------------------
-		for (int i = 0; i < 64; ++i) {
+		// The lines of consecutive reads are consecutive in a.sam (sam_off is a prefix sum): runs of them are assembled in the LDS and
+		// flushed with 16-byte stores (1 KB per wave instruction) -- one byte per lane and store, as rounds 3-4 wrote them, made this the
+		// largest kernel of a run at 31 bytes per store instruction (profiles/r04zg).  A line the buffer cannot hold, or one with chained
+		// records (-m), is written straight to a.sam as before.
+		for (int i = 0; i < 64;) {
+			if (!(desc[i].flags & 1)) { ++i; continue; }
+			const bool direct = (desc[i].flags & 8) || desc[i].room_end_lo > kFmtBuf - 16;
+			if (!direct) {
+				uint8_t *const g0 = desc[i].out;
+				uint8_t *const g0a = g0 - ((uintptr_t)g0 & 15);                  // the buffer starts at the 16-byte word that holds the first byte
+				uint8_t *g1 = g0;
+				int j = i;
+				for (; j < 64; ++j) {
+					const FmtDesc &d = desc[j];
+					if (!(d.flags & 1)) continue;                               // (a read handed back: no line)
+					if ((d.flags & 8) || d.out != g1 || (d.out - g0a) + d.room_end_lo > kFmtBuf) break;
+					const char *S = str + j * kFmtSlot;
+					uint8_t *e = copy_line(buf + (d.out - g0a), lane, d.name, d.name_len, S, d.nA, d.chr, d.n_chr, S + kFmtA, d.nB, d.seq, d.rlen, (d.flags & 2) != 0, d.qual, d.qlen,
+					                       (d.flags & 4) != 0, S + kFmtA + kFmtB, d.nT);
+					if (lane == 0 && (int32_t)(e - (buf + (d.out - g0a))) != d.room_end_lo) atomicAdd(&a.ctl[1], 1ull);
+					g1 = d.out + d.room_end_lo;
+				}
+				__syncthreads();
+				// flush [g0, g1): the partial words at either end byte by byte (a neighbouring wave owns the rest of them), whole words in between
+				uint8_t *const w0 = g0a + (g0 == g0a ? 0 : 16), *const w1 = g1 - ((uintptr_t)g1 & 15);
+				if (w0 >= w1 + 16 || w1 < w0) {                                    // (less than one whole word)
+					for (uint8_t *q = g0 + lane; q < g1; q += 64) *q = buf[q - g0a];
+				} else {
+					if (g0 + lane < w0) g0[lane] = buf[(g0 - g0a) + lane];
+					const uint4 *src = reinterpret_cast<const uint4 *>(buf + (w0 - g0a));
+					uint4 *dst = reinterpret_cast<uint4 *>(w0);
+					const int n_words = (int)((w1 - w0) >> 4);
+					for (int k = lane; k < n_words; k += 64) dst[k] = src[k];
+					if (w1 + lane < g1) w1[lane] = buf[(w1 - g0a) + lane];
+				}
+				__syncthreads();
+				i = j;
+				continue;
+			}
 			const FmtDesc &d = desc[i];
-			if (!(d.flags & 1)) continue;
 			if (!(d.flags & 8)) {
 				const char *S = str + i * kFmtSlot;
 				uint8_t *e = copy_line(d.out, lane, d.name, d.name_len, S, d.nA, d.chr, d.n_chr, S + kFmtA, d.nB, d.seq, d.rlen, (d.flags & 2) != 0, d.qual, d.qlen, (d.flags & 4) != 0,
 				                       S + kFmtA + kFmtB, d.nT);
 				if (lane == 0 && (int32_t)(e - d.out) != d.room_end_lo) atomicAdd(&a.ctl[1], 1ull);
+				++i;
 				continue;
 			}
 			// -m: every record chained behind the read's own, one after the other (lane 0 prints the fields of each)
@@ -459,7 +499,7 @@ __global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
 			const uint8_t *const seq = a.enc + a.read_off[r];
 			uint8_t *p = a.sam + a.sam_off[r];
 			const int64_t room = a.sam_off[r + 1];
-			if (room > a.sam_capacity) { if (lane == 0) atomicAdd(&a.ctl[1], 1ull); continue; }
+			if (room > a.sam_capacity) { if (lane == 0) atomicAdd(&a.ctl[1], 1ull); ++i; continue; }
 			char *S = str + i * kFmtSlot;                    // (the read's own slot is free: nothing was printed into it)
 			for (int64_t at = r; at >= 0; at = a.records[at].next) {
 				const kg_aln_record &rec = a.records[at];
@@ -476,6 +516,7 @@ __global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
 				              S + kFmtA + kFmtB, chain_len[2]);
 			}
 			if (lane == 0 && (int64_t)(p - a.sam) != room) atomicAdd(&a.ctl[1], 1ull);
+			++i;
 		}
 		__syncthreads();
 	}
