@@ -553,12 +553,17 @@ def run(args, fallback_note):
     barrier()
     t0 = time.perf_counter()
     stats, step_wall = [], []
+    import resource
+    cpu_steps = 0.0                                   # user + system CPU seconds of this rank's process inside the timed steps (the library's threads are its own)
     for s_ in range(args.steps):
         torch.cuda.synchronize(dev)
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         ts = time.perf_counter()
         stats.append(step("s%d" % s_))
         torch.cuda.synchronize(dev)
         step_wall.append(time.perf_counter() - ts)
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        cpu_steps += (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
         if s_ + 1 < args.steps:
             between_steps()
     torch.cuda.synchronize(dev)
@@ -570,6 +575,7 @@ def run(args, fallback_note):
     reads_here = sum(int(st.total_reads) for st in stats)
     totals = shard.allreduce_counters([reads_here, reads_mapped_here, sum(int(st.respeculated) for st in stats)], device=cdev)   # the path's only collective
     step_max = shard.max_over_ranks(step_wall, device=cdev)       # a step lasts as long as its slowest rank
+    cpu_all = shard.allreduce_counters([int(cpu_steps * 1e6)], device=cdev)[0] / 1e6     # (microseconds: the counters travel as integers)
     elapsed = float(sum(step_max))                                # the K timed steps; what lies between them (removing old outputs) is not a mapping run
     bracket = shard.max_over_ranks(bracket, device=cdev)
     clean_rendezvous()
@@ -634,9 +640,26 @@ def run(args, fallback_note):
                                     "durations (the ramp-up launches of a step -- batches of 4 k .. 256 k reads while EstDistance settles -- included).  Other lanes' kernels "
                                     "share the device, so a launch's duration includes what they took from it."}
 
+    # ---- the host side of the path: what a read costs in CPU time bounds the whole node whatever the number of GPUs (the ranks share the host) ----
+    cpu_per_read = cpu_all / max(1, totals[0])
+    line["host_cpu"] = {"cpu_seconds_per_step_all_ranks": cpu_all / args.steps, "host_cpu_seconds_per_read": cpu_per_read, "host_cpu_quota": cores,
+                        "implied_ceiling_reads_per_s": (cores / cpu_per_read) if cpu_per_read > 0 else None,
+                        "note": "user + system CPU seconds of the rank processes inside the timed steps (reading + uploading the FASTQ text, the handed-back reads, the output copies and "
+                                "their page faults) per read; quota / that = the rate at which this host saturates however many GPUs feed it -- the bound on 1 -> N scaling on this "
+                                "host shape (unmeasured beyond the GPUs this run had)"}
     # ---- every kernel of the timed region with a share of the step: HIP events around each launch on the lanes' streams (kg_stream_timing_t::
     # kernel_ms), against the bytes the kernel has to touch (its inputs and outputs as laid out in HBM) ----------------
     line["kernels"] = kernel_entries(stats, args.steps, n_reads, sk_ms / args.steps if sk_n else 0.0, args)
+    if os.environ.get("KART_BENCH_HASH_OUTPUT") == "1" and outs:
+        # test aid: the last step's SAM as one stream -- the ranks' parts in rank order, or the one shared file -- so that a test can hold an
+        # N-rank run to the single-process bytes
+        import hashlib
+        h = hashlib.sha256()
+        for f in out_files(outs[-1]):
+            with open(f, "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    h.update(blk)
+        line["config"]["sam_sha256_last_step"] = h.hexdigest()
     # the step outputs go first: the side legs below write their own files and must never add to them
     while outs:
         drop(outs.pop(0))
@@ -957,7 +980,7 @@ def other_configs(args, sess, prefix, workdir, codes, dev, threads, cores, mem):
 
     # ---- configs[3]: -pacbio -------------------------------------------------------------------------------------------
     read_len = 7000
-    n_long = int(max(10_000, min(1_000_000, budget // (2 * read_len + 16 + 2 * read_len + 1000))))
+    n_long = int(max(10_000, min(2_000_000, budget // (2 * read_len + 16 + 2 * read_len + 1000))))        # (configs[3]'s literal size: 2 M reads = 28 GB of FASTQ in, ~30 GB of SAM out)
     fq = os.path.join(workdir, "cfg3_long.fq")
     write_long_reads(codes, n_long, read_len, 31, fq, dev)
     sam = os.path.join(workdir, "cfg3.sam")
@@ -978,7 +1001,70 @@ def other_configs(args, sess, prefix, workdir, codes, dev, threads, cores, mem):
             os.remove(f)
     out["configs[3]"] = c3
     os.remove(fq)
+    # ---- configs[1]: E. coli-sized index --------------------------------------------------------------------------------
+    try:
+        out["configs[1]"] = config1(args, workdir, dev, threads, budget, ref)
+    except Exception as exc:      # a side measurement must never cost the line
+        out["configs[1]"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     return out
+
+
+def config1(args, workdir, dev, threads, budget, ref):
+    """BASELINE.json configs[1]: E. coli-sized genome (4 639 675 bp behind the 2 kb decoy), 10 M x 150 bp pairs at 1 % error -- a second
+    session beside the large one (the index takes ~0.3 GB of HBM and lives in the L2 / Infinity Cache: SURVEY 8(d) asks for L2-hit
+    counters here instead of an HBM fraction; they come from the committed PMC pass of `bench.py --genome-len 4639675`)."""
+    from kart_amd import api
+    a1 = argparse.Namespace(genome_len=GENOME_LEN, bucketed=None, repeat_frac=0.45)
+    prefix1, codes1, _ = prepare_index(a1, dev, 0, workdir, lambda: None)
+    n_pairs = int(max(100_000, min(10_000_000, budget // (2 * REC_BYTES + 2 * 450))))
+    f1, f2 = os.path.join(workdir, "cfg1_1.fq"), os.path.join(workdir, "cfg1_2.fq")
+    write_fastq_pairs(codes1, n_pairs, 7, f1, f2, dev)
+    del codes1
+    sess1 = api.HostSession(prefix1, 0, threads)
+    sam = os.path.join(workdir, "cfg1.sam")
+    try:
+        sess1.map(["-silent", "-f", f1, "-f2", f2, "-o", sam])          # (warm-up: the stream's buffers)
+        os.remove(sam)
+        st = sess1.map(["-silent", "-f", f1, "-f2", f2, "-o", sam])
+        c1 = {"workload": "configs[1]: E. coli-sized synthetic genome (4 639 675 bp + 2 kb decoy), %d x 150 bp paired-end reads at 1.1 %% error" % (2 * n_pairs),
+              "value": (st.total_reads - st.unmapped) / st.map_seconds, "unit": "mapped reads/s", "map_seconds": round(st.map_seconds, 3),
+              "reads_through_the_device_stream": int(st.stream_reads), "sam_bytes": os.path.getsize(sam),
+              "device_ms": {nm: float(st.stage_ms[i]) for i, nm in enumerate(("parse", "seed", "chain", "align", "format", "copy_out"))}}
+        if st.search_kernel_launches > 0 and st.search_kernel_ms > 0:
+            gbs = float(st.search_useful_bytes) / (float(st.search_kernel_ms) * 1e-3) / 1e9
+            c1["search_kernel"] = {"ms": float(st.search_kernel_ms), "launches": int(st.search_kernel_launches), "useful_GBps": gbs,
+                                   "note": "the 9 MB rank structure and the 134 MB q-mer table are L2 / Infinity-Cache resident: bytes per second against the HBM peak say nothing "
+                                           "here; the L2 hit rate below is the figure SURVEY 8(d) asks for"}
+        os.remove(sam)
+        pdir = os.path.join(ROOT, "profiles")
+        for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+            if f.endswith("_ecoli_pmc_summary.json"):
+                try:
+                    c1["l2"] = dict(json.load(open(os.path.join(pdir, f))).get("_l2", {}), source="profiles/" + f)
+                except Exception:
+                    pass
+        if os.path.exists(ref) and not args.no_parity:
+            k = min(n_pairs, 200_000)
+            p1, p2 = os.path.join(workdir, "cfg1_p1.fq"), os.path.join(workdir, "cfg1_p2.fq")
+            for src, dst in ((f1, p1), (f2, p2)):
+                with open(src, "rb") as fi, open(dst, "wb") as fo:
+                    fo.write(fi.read(k * REC_BYTES))
+            sa, sr = os.path.join(workdir, "cfg1_p_amd.sam"), os.path.join(workdir, "cfg1_p_ref.sam")
+            sess1.map(["-silent", "-f", p1, "-f2", p2, "-o", sa])
+            t0 = time.perf_counter()
+            rc = subprocess.run([ref, "-silent", "-i", prefix1, "-f", p1, "-f2", p2, "-o", sr, "-t", "1"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+            c1["sam_vs_reference_t1"] = {"reads": 2 * k, "identical": bool(rc == 0 and open(sa, "rb").read() == open(sr, "rb").read()),
+                                         "reference_t1_seconds_whole_process": round(time.perf_counter() - t0, 1)}
+            for f in (p1, p2, sa, sr):
+                os.remove(f)
+    finally:
+        sess1.close()
+        for f in (f1, f2):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    return c1
 
 
 def effective_cores():

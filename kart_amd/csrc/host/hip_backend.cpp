@@ -100,11 +100,16 @@ public:
 		if (getenv("KART_AMD_TINY_WORKSPACE")) reserve(2048, 1 << 16);
 		else reserve(max_reads, max_reads * 256);
 	}
+	// long reads: the batches alternate between two workspaces, so that the report of batch k (kg_longread_batch: the fragment and NW
+	// kernels, instruction-bound) runs beside the seeding of batch k + 1 (the FM-index search, latency-bound) on streams of their own
+	int long_slot() const override { return cur_; }
 	~HipBackend() override
 	{
 		stream_.reset();
-		for (std::pair<kg_workspace *, int> &r : retired_) kg_workspace_destroy(r.first);
-		kg_workspace_destroy(ws_);
+		for (Slot &sl : slots_) {
+			for (std::pair<kg_workspace *, int> &r : sl.retired) kg_workspace_destroy(r.first);
+			if (sl.ws) kg_workspace_destroy(sl.ws);
+		}
 		kg_index_destroy(ix_);
 	}
 	StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes, int seed_group) override
@@ -133,7 +138,10 @@ public:
 	                    const kg_candidate *&cands, const kg_seed *&cand_seeds) override
 	{
 		int64_t n = (int64_t)off.size() - 1;
+		static const bool overlap = !getenv("KART_AMD_LONG_NO_OVERLAP");
+		cur_ = (pacbio && overlap) ? (cur_ ^ 1) : 0;
 		reserve(n, off[(size_t)n]);
+		kg_workspace *const ws_ = slots_[cur_].ws;
 		seed_off_.assign(off.size(), 0);
 		double t0 = now_sec();
 		// the seeds stay on the device (seeds = NULL); only the chained candidates come back, packed
@@ -163,16 +171,22 @@ public:
 		chunk_stats.resize((size_t)n_chunks);
 		const kg_aln_record *rec = nullptr;
 		double t0 = now_sec();
+		kg_workspace *const ws_ = slots_[cur_].ws;
 		if (kg_align_batch(ws_, chunk_off.data(), chunk_paired.data(), n_chunks, est, max_insert, max_gaps, multi_hit ? 1 : 0, unset_flag, &rec, chunk_stats.data()) != KG_OK) die("kg_align_batch");
 		double t1 = now_sec();
 		records = rec;                    // (rotating pinned arrays, as above)
 		t_align += t1 - t0; t_reccopy += now_sec() - t1;
 		return true;
 	}
-	bool align_long(const std::vector<int64_t> &chunk_off, const kg_aln_record *&records, const char *&cigar_pool, std::vector<kg_chunk_stats> &chunk_stats) override
+	bool long_enabled() const override
 	{
 		static const bool off = getenv("KART_AMD_HOST_ALIGN") != nullptr || getenv("KART_AMD_HOST_LONG") != nullptr;      // A/B aids: the whole report on the host, as before
-		if (off) return false;
+		return !off;
+	}
+	bool align_long(int slot, const std::vector<int64_t> &chunk_off, const kg_aln_record *&records, const char *&cigar_pool, std::vector<kg_chunk_stats> &chunk_stats) override
+	{
+		if (!long_enabled()) return false;
+		kg_workspace *const ws_ = slots_[slot & 1].ws;
 		const kg_aln_record *rec = nullptr;
 		const char *pool = nullptr;
 		int64_t bytes = 0, n_host = 0;
@@ -192,13 +206,17 @@ public:
 		}
 		records = rec;
 		cigar_pool = pool;
-		t_align += t1 - t0; t_reccopy += now_sec() - t1;
-		long_used_ = true;
+		{
+			std::lock_guard<std::mutex> tl(frag_mu_);
+			t_align += t1 - t0; t_reccopy += now_sec() - t1;
+			long_used_ = true;
+		}
 		return true;
 	}
 	std::string align_diagnostics() override
 	{
 		uint64_t w[16];
+		kg_workspace *const ws_ = slots_[0].ws;
 		if (kg_align_reasons(ws_, w) != KG_OK) return std::string();
 		static const char *const name[13] = {"candidate product", "mate-2 window", "window length", "mate characters/length", "runs per window", "rescued pairs", "seeds",
 		                                     "gap pairs", "8-mer partition", "list capacity", "CIGAR length", "score", "read length"};
@@ -206,8 +224,11 @@ public:
 		snprintf(tb, sizeof(tb), "device stage seconds: seed (H2D + kernels) %.3f | chain + D2H %.3f | candidate copies %.3f | align (kernels + D2H) %.3f | record copy %.3f || ", t_seed, t_cands, t_copy, t_align, t_reccopy);
 		std::string s(tb);
 		if (long_used_) {
-			uint64_t lw[8];
-			if (kg_longread_reasons(ws_, lw) == KG_OK) {
+			uint64_t lw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l1[8];
+			bool ok = false;
+			for (const Slot &sl : slots_)
+				if (sl.ws && kg_longread_reasons(sl.ws, l1) == KG_OK) { ok = true; for (int i = 0; i < 8; ++i) lw[i] += l1[i]; }
+			if (ok) {
 				snprintf(tb, sizeof(tb), "long-read report on the device: %llu reads, %llu handed back (candidates: literal '-' %llu, fragment envelope %llu, seed order %llu, element pool %llu; sequential overlap check %llu) || ",
 				         (unsigned long long)lw[0], (unsigned long long)lw[1], (unsigned long long)lw[2], (unsigned long long)lw[3], (unsigned long long)lw[4], (unsigned long long)lw[5], (unsigned long long)lw[6]);
 				s += tb;
@@ -307,20 +328,27 @@ private:
 	// the seeding workspace grows with the largest batch seen (long-read batches are far larger in bases)
 	void reserve(int64_t reads, int64_t bases)
 	{
+		Slot &sl = slots_[cur_];
 		// a workspace that was outgrown is retired, not destroyed: its page-locked result arrays (candidates, records) are still
 		// being read by the stages of up to kRing - 1 earlier batches; it is freed once that many further batches have passed
-		for (size_t i = 0; i < retired_.size();) {
-			if (--retired_[i].second <= 0) { kg_workspace_destroy(retired_[i].first); retired_.erase(retired_.begin() + (std::ptrdiff_t)i); }
+		for (size_t i = 0; i < sl.retired.size();) {
+			if (--sl.retired[i].second <= 0) { kg_workspace_destroy(sl.retired[i].first); sl.retired.erase(sl.retired.begin() + (std::ptrdiff_t)i); }
 			else ++i;
 		}
-		if (ws_ && reads <= cap_reads_ && bases <= cap_bases_) return;
-		if (ws_) retired_.emplace_back(ws_, 4);
-		ws_ = nullptr;
-		cap_reads_ = std::max(cap_reads_, reads + reads / 4 + 1024);
-		cap_bases_ = std::max(cap_bases_, bases + bases / 4 + 65536);
-		if (kg_workspace_create(ix_, cap_reads_, cap_bases_, &ws_) != KG_OK) die("kg_workspace_create");
+		if (sl.ws && reads <= sl.cap_reads && bases <= sl.cap_bases) return;
+		if (sl.ws) sl.retired.emplace_back(sl.ws, 4);
+		sl.ws = nullptr;
+		sl.cap_reads = std::max(sl.cap_reads, reads + reads / 4 + 1024);
+		sl.cap_bases = std::max(sl.cap_bases, bases + bases / 4 + 65536);
+		if (kg_workspace_create(ix_, sl.cap_reads, sl.cap_bases, &sl.ws) != KG_OK) die("kg_workspace_create");
 	}
-	int64_t cap_reads_ = 0, cap_bases_ = 0;
+	struct Slot {
+		kg_workspace *ws = nullptr;
+		int64_t cap_reads = 0, cap_bases = 0;
+		std::vector<std::pair<kg_workspace *, int>> retired;   // outgrown workspaces and the batches left until their arrays are unused
+	};
+	Slot slots_[2];
+	int cur_ = 0;                   // the slot of the batch seeded last
 	bool long_used_ = false;
 	kg_index *ix_;
 	int threads_;
@@ -340,8 +368,6 @@ private:
 	std::vector<uint8_t> ops_;
 	std::vector<int32_t> len_;
 	std::vector<int64_t> seed_off_;
-	kg_workspace *ws_ = nullptr;
-	std::vector<std::pair<kg_workspace *, int>> retired_;   // outgrown workspaces and the batches left until their arrays are unused
 	std::unique_ptr<HipStream> stream_;
 	kg_index_info_t info_;
 };

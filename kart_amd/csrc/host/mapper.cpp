@@ -276,8 +276,8 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 	stats.distance = tot.iDistance;
 	stats.map_seconds = now_s() - t_begin;
 	if (getenv("KART_AMD_VERBOSE"))
-		fprintf(stdout, "stage seconds: unhidden read+encode+seed %.2f (seed calls %.2f) | finish+format(k-1) with chain+pair+plan(k) %.2f | nw %.2f | commit %.2f (of it formatting into the output %.2f) | writer drain %.2f | libraries %.2f of %.2f\n",
-		        tot.t_read, tot.t_seed, tot.t_a, tot.t_nw, tot.t_commit, tot.t_format, tot.t_drain, tot.t_lib, stats.map_seconds);
+		fprintf(stdout, "stage seconds: unhidden read+encode+seed %.2f (seed calls %.2f) | finish+format(k-1) with chain+pair+plan(k) %.2f | nw %.2f | commit %.2f (of it formatting into the output %.2f) | writer drain %.2f | waiting for the long-read report %.2f | libraries %.2f of %.2f\n",
+		        tot.t_read, tot.t_seed, tot.t_a, tot.t_nw, tot.t_commit, tot.t_format, tot.t_drain, tot.t_long_wait, tot.t_lib, stats.map_seconds);
 	if (getenv("KART_AMD_VERBOSE")) {
 		struct rusage ru1;
 		getrusage(RUSAGE_SELF, &ru1);

@@ -154,11 +154,15 @@ struct KernelBackend {
 	// seed_and_chain(pacbio) call left on the device, the CIGAR strings in `cigar_pool` (records with cigar_len == KG_ALN_CIGAR_POOLED
 	// hold {int64 offset, int32 bytes} in their first 12 CIGAR bytes); chunk_stats[c].unmapped / unique / host_pairs are counted from the
 	// records.  false: the host maps every read itself.
-	virtual bool align_long(const std::vector<int64_t> &chunk_off, const kg_aln_record *&records, const char *&cigar_pool, std::vector<kg_chunk_stats> &chunk_stats)
+	// `slot`: long_slot() right after the batch's seed_and_chain() call -- long-read batches alternate between two workspaces, and this call
+	// may run on a thread of its own while the next batch is being seeded in the other one.  long_enabled(): the backend has the stage.
+	virtual bool align_long(int slot, const std::vector<int64_t> &chunk_off, const kg_aln_record *&records, const char *&cigar_pool, std::vector<kg_chunk_stats> &chunk_stats)
 	{
-		(void)chunk_off; (void)records; (void)cigar_pool; (void)chunk_stats;
+		(void)slot; (void)chunk_off; (void)records; (void)cigar_pool; (void)chunk_stats;
 		return false;
 	}
+	virtual int long_slot() const { return 0; }
+	virtual bool long_enabled() const { return false; }
 	// diagnostics of the stage above (why pairs came back for the host), empty when there is none
 	virtual std::string align_diagnostics() { return std::string(); }
 };

@@ -80,3 +80,21 @@ def test_bench_starts_its_own_ranks(tmp_path):
     shared = _bench(["--gpus", "2", "--one-file", "--genome-len", "500000", "--pairs", "60000", "--steps", "1", "--warmup", "1"], env=env, tmp=tmp_path)
     assert shared["config"]["output"] == "one SAM file"                       # ... and all ranks writing one file by offset
     assert shared["mapped_reads_per_step"] == one["mapped_reads_per_step"] and shared["config"]["sam_bytes_per_step"] == one["config"]["sam_bytes_per_step"]
+
+
+def test_bench_eight_ranks_on_one_device_write_the_single_process_sam(tmp_path):
+    """the N > 1 path with EIGHT ranks at reduced size (VERDICT r4 #7c): every rank a `-shard r/8` mapping run over its own contiguous chunk
+    range, the final counter all-reduce over all eight, and the parts in rank order byte-identical to the one-process SAM (sha256 of the
+    last step's output, KART_BENCH_HASH_OUTPUT).  On a 1-GPU box the ranks share device 0 over gloo: this says nothing about scaling."""
+    import torch
+    env = {"KART_BENCH_HASH_OUTPUT": "1"}
+    common = ["--genome-len", "500000", "--pairs", "160000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--no-seeding-leg"]
+    one = _bench(common, env=env, tmp=tmp_path)
+    if torch.cuda.device_count() < 8:
+        env = dict(env, KART_BENCH_SHARE_DEVICE="1", KART_AMD_STREAM_LANES="2", KART_AMD_SEED_GROUP="0")     # (eight processes' lanes on one device: two each)
+    eight = _bench(["--gpus", "8"] + common, env=env, tmp=tmp_path)
+    assert eight["n_gpus"] == 8 and eight["config"]["reads_per_step"] == 320000 and eight["config"]["reads_per_gpu_per_step"] == 40000
+    assert eight["mapped_reads_per_step"] == one["mapped_reads_per_step"]                   # totals[1] all-reduced over the eight ranks
+    assert eight["config"]["sam_bytes_per_step"] == one["config"]["sam_bytes_per_step"]
+    assert eight["config"]["sam_sha256_last_step"] == one["config"]["sam_sha256_last_step"]
+    assert eight["host_cpu"]["host_cpu_seconds_per_read"] > 0 and eight["host_cpu"]["implied_ceiling_reads_per_s"] > 0

@@ -1,0 +1,73 @@
+"""GPU: BASELINE.json configs[1] -- the E. coli-SIZED index (one contig of 4 639 675 bp behind the 2 kb decoy, bench.py's
+`--genome-len 4639675` workload, same seed, same generators) with 200 000 x 150 bp pairs at 1.1 % error: SAM identical to the live
+reference (oracle/_ref/kart -t 1), through the device stream and, for a prefix, through the host reader with the device report.
+VERDICT r4: no -m gpu test built an index of this size (the small goldens are 100 kb, the large ones 3.1 Gbp)."""
+import argparse
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+KART_REF = os.path.join(ROOT, "oracle", "_ref", "kart")
+N_PAIRS = 200_000
+
+
+@pytest.fixture(scope="module")
+def ecoli(built_lib, tmp_path_factory):
+    import torch
+    import bench
+    from kart_amd import api
+    assert os.path.exists(KART_REF), "oracle/_ref/kart did not travel to the GPU box: __graft_entry__.build() makes it where /root/reference exists"
+    dev = torch.device("cuda", 0)
+    assert api.device_count() > 0
+    work = str(tmp_path_factory.mktemp("ecoli"))
+    args = argparse.Namespace(genome_len=bench.GENOME_LEN, bucketed=None, repeat_frac=0.45)
+    prefix, codes, _ = bench.prepare_index(args, dev, 0, work, lambda: None)
+    f1, f2 = os.path.join(work, "e_1.fq"), os.path.join(work, "e_2.fq")
+    bench.write_fastq_pairs(codes, N_PAIRS, 7, f1, f2, dev)
+    del codes
+    torch.cuda.empty_cache()
+    ref_out = os.path.join(work, "ref.sam")
+    ref = subprocess.Popen([KART_REF, "-silent", "-t", "1", "-i", prefix, "-f", f1, "-f2", f2, "-o", ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sess = api.HostSession(prefix, 0, 8)
+    out = os.path.join(work, "amd.sam")
+    st = sess.map(["-silent", "-f", f1, "-f2", f2, "-o", out])
+    got = open(out, "rb").read()
+    # the first 40 000 pairs again through the host reader (no device stream): the same records by another path
+    os.environ["KART_AMD_NO_STREAM"] = "1"
+    try:
+        p1, p2 = os.path.join(work, "p_1.fq"), os.path.join(work, "p_2.fq")
+        for src, dst in ((f1, p1), (f2, p2)):
+            with open(src, "rb") as fi, open(dst, "wb") as fo:
+                fo.write(fi.read(40_000 * bench.REC_BYTES))
+        sess2 = api.HostSession(prefix, 0, 8)
+        st2 = sess2.map(["-silent", "-f", p1, "-f2", p2, "-o", out])
+        got_prefix = open(out, "rb").read()
+        sess2.close()
+    finally:
+        del os.environ["KART_AMD_NO_STREAM"]
+    sess.close()
+    assert ref.wait(timeout=1200) == 0, "the reference failed on the E. coli-sized set"
+    want = open(ref_out, "rb").read()
+    return {"got": got, "want": want, "stats": st, "got_prefix": got_prefix, "stats_prefix": st2}
+
+
+def test_configs1_ecoli_sized_200k_pairs_identical(ecoli):
+    assert ecoli["stats"].total_reads == 2 * N_PAIRS and ecoli["stats"].stream_reads > 0
+    got, want = ecoli["got"], ecoli["want"]
+    if got != want:
+        g, w = got.split(b"\n"), want.split(b"\n")
+        bad = [i for i, (x, y) in enumerate(zip(g, w)) if x != y]
+        assert False, "%d / %d lines, %d differ, first: %r vs %r" % (len(g), len(w), len(bad), g[bad[0]][:300] if bad else None, w[bad[0]][:300] if bad else None)
+
+
+def test_configs1_prefix_through_the_host_reader_identical(ecoli):
+    """the first 40 000 pairs alone see the same EstDistance history as inside the whole file (src/Mapping.cpp:533-540 looks only at the
+    chunks before): their records are the first 80 000 of the whole run, by the host reader + device report instead of the device stream"""
+    assert ecoli["stats_prefix"].total_reads == 80_000 and ecoli["stats_prefix"].stream_reads == 0
+    g, w = ecoli["got_prefix"].split(b"\n"), ecoli["want"].split(b"\n")
+    n_hdr = sum(1 for l in w if l.startswith(b"@"))
+    assert g == w[:n_hdr + 80_000] + [b""]
