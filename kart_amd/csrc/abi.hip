@@ -875,7 +875,7 @@ static int nw_acquire(kg_index *ix, size_t list_words, size_t dir_words, hipStre
 	if (!pick) {
 		pick = new NwScratch();
 		HIP_TRY(hipEventCreateWithFlags(&pick->done, hipEventDisableTiming));
-		HIP_TRY(hipMalloc((void **)&pick->queue, 8 * 4));
+		HIP_TRY(hipMalloc((void **)&pick->queue, 8 * 8));
 		ix->nw_pool.push_back(pick);
 	}
 	if (pick->list_words < list_words) {
@@ -945,12 +945,27 @@ int kgi_nw_launch(kg_index *ix, NwArgs &a, int64_t max_len, hipStream_t st)
 		a.big_waves = (int)waves;
 		dir_words = (size_t)(waves * a.dir_words_per_wave);
 	}
+	// Two tiers (long-read batches): one pair of a few thousand bases -- a head or tail fragment, a fragment without a common 8-mer -- sizes the LDS
+	// block and the slab of EVERY wave of the launch, and the hundreds of thousands of 33 .. 256-base pairs beside it then run at 6 waves per CU:
+	// pairs up to 256 bases get a launch of their own with 32 (417 ms of nw_big_kernel per 400 k x 7 kb reads, profiles/r05f_pacbio_kernel_stats.csv).
+	static const bool no_tiers = getenv("KG_NW_NO_TIERS") != nullptr;
+	size_t t1_words = 0;
+	a.tier_len = 0;
+	if (!no_tiers && max_len > 512 && max_len <= kNwMaxLen && a.desc != nullptr) {
+		a.tier_len = 256;
+		a.t1_lds_bytes = nw_big_lds_bytes(a.tier_len);
+		const int per_cu = std::max(1, std::min(32, (160 * 1024) / std::max(a.t1_lds_bytes, 1024)));
+		a.t1_waves = (int)std::min<int64_t>((int64_t)ix->n_cu * per_cu, n);
+		a.t1_dir_words_per_wave = nw_dir_words(a.tier_len);
+		t1_words = (size_t)a.t1_waves * (size_t)a.t1_dir_words_per_wave;
+	}
 	NwScratch *sc = nullptr;
-	int rc = nw_acquire(ix, 3 * (size_t)n, dir_words, st, &sc);
+	int rc = nw_acquire(ix, 3 * (size_t)n, dir_words + t1_words, st, &sc);
 	if (rc != KG_OK) return rc;
 	a.big_list = sc->lists;
 	a.queue = sc->queue;
 	if (dir_words) a.dir_scratch = sc->dir;
+	if (t1_words) a.t1_dir_scratch = sc->dir + dir_words;
 	hipError_t e = launch_nw_batch(a, ix->n_cu, st);
 	hipError_t e2 = nw_submitted(ix, sc, st);
 	if (e != hipSuccess || e2 != hipSuccess) return fail(KG_ERR_NO_DEVICE, "kg_nw_batch: %s", hipGetErrorString(e != hipSuccess ? e : e2));

@@ -86,10 +86,10 @@ __device__ __forceinline__ void append(bool want, unsigned long long *count, int
 // (a hipMemsetAsync of freshly pool-allocated words was observed to land after the classify kernel)
 __global__ void nw_reset_kernel(unsigned long long *queue)
 {
-	if (threadIdx.x < 4) queue[threadIdx.x] = 0;
+	if (threadIdx.x < 8) queue[threadIdx.x] = 0;
 }
 
-// queue words: [0..2] list sizes of the three classes, [3] class-2 work queue head
+// queue words: [0..2] list sizes of the three classes, [3] class-2 work queue head, [4] the same for the launch of the longer pairs (two tiers)
 // Every block takes ONE contiguous range of pairs: it counts its pairs per class, reserves its share of the three lists with three
 // atomics, and fills it -- the waves drawing their places from counters in the LDS.  (One global atomic per wave and class, as
 // before, was the kernel: 125 k same-address atomics for 8 M tiny pairs = 1.5 ms of the call's 3.4 ms.)
@@ -248,15 +248,36 @@ __global__ __launch_bounds__(256) void nw_small32_kernel(NwArgs a)
 		const NwPair q = nw_pair(a, p);
 		const int64_t o1 = q.o1, o2 = q.o2;
 		const int m = q.m, n = q.n;
+		// descriptor mode (the alignment stage's / the fragment kernels' jobs): both sequences lie in buffers with slack behind them (the read
+		// characters, the 2-bit text), so sequence 1 is four unaligned 8-byte loads and sequence 2 one 8-byte load + a byte instead of up to 32 + 32
+		// byte gathers of 64 lanes at 64 different addresses each (round 5: 250 ms per 400 k long reads in product against ~30 ms in tools/bench_nw.py)
+		const bool packed = a.desc != nullptr && a.text2 != nullptr;
+		uint64_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, tw = 0;
+		if (packed) {
+			r0 = reinterpret_cast<const NwU64u *>(a.f1 + o1)->v;
+			if (m > 8) r1 = reinterpret_cast<const NwU64u *>(a.f1 + o1 + 8)->v;
+			if (m > 16) r2 = reinterpret_cast<const NwU64u *>(a.f1 + o1 + 16)->v;
+			if (m > 24) r3 = reinterpret_cast<const NwU64u *>(a.f1 + o1 + 24)->v;
+			const uint8_t *tp = a.text2 + ((uint64_t)o2 >> 2);
+			const uint64_t lo = reinterpret_cast<const NwU64u *>(tp)->v, hi = tp[8];
+			const int sh = ((int)o2 & 3) << 1;
+			tw = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;              // 32 bases from o2
+		}
 		int c2[32];
 #pragma unroll
-		for (int j = 0; j < 32; ++j) c2[j] = j < n ? nw_code2(a, o2 + j) : 8 + j;
+		for (int j = 0; j < 32; ++j) c2[j] = j < n ? (packed ? (int)((tw >> (2 * j)) & 3u) : nw_code2(a, o2 + j)) : 8 + j;
 		int S[33], T[33];
 		S[0] = 0; T[0] = 0;
 #pragma unroll
 		for (int j = 1; j <= 32; ++j) { S[j] = -2 - j; T[j] = NEG; }
+		uint64_t cw = 0;
 		for (int i = 1; i <= m; ++i) {
-			int c1 = nt4_code((unsigned char)a.f1[o1 + i - 1]);
+			int c1;
+			if (packed) {
+				const int k = i - 1;
+				if ((k & 7) == 0) cw = k < 8 ? r0 : k < 16 ? r1 : k < 24 ? r2 : r3;
+				c1 = nt4_code((unsigned char)(cw >> (8 * (k & 7))));
+			} else c1 = nt4_code((unsigned char)a.f1[o1 + i - 1]);
 			int diag = S[0];
 			S[0] = -2 - i;
 			int left_s = S[0], left_r = NEG;
@@ -274,16 +295,30 @@ __global__ __launch_bounds__(256) void nw_small32_kernel(NwArgs a)
 			}
 			dirs[i - 1][threadIdx.x] = make_uint2(fr, ft);
 		}
+		// the traceback yields the columns right to left: one walk counts them, a second writes them where they belong, eight at a time (one
+		// byte store per column and a reversal in place -- byte loads and stores again -- was the rest of the kernel's memory traffic)
 		uint8_t *ops = a.ops + q.oo;
-		int i = m, j = n, len = 0;
-		while (i > 0 || j > 0) {
+		int len = 0;
+		for (int i = m, j = n; i > 0 || j > 0; ++len) {
 			uint2 w = i > 0 ? dirs[i - 1][threadIdx.x] : make_uint2(0, 0);
 			bool g1 = i == 0 || (j > 0 && ((w.x >> (j - 1)) & 1));
 			bool g2 = !g1 && (j == 0 || ((w.y >> (j - 1)) & 1));
-			ops[len++] = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
 			if (g1) j--; else if (g2) i--; else { i--; j--; }
 		}
-		reverse_ops(ops, len);
+		{
+			int i = m, j = n, at = len, na = 0;
+			uint64_t acc = 0;
+			while (i > 0 || j > 0) {
+				uint2 w = i > 0 ? dirs[i - 1][threadIdx.x] : make_uint2(0, 0);
+				bool g1 = i == 0 || (j > 0 && ((w.x >> (j - 1)) & 1));
+				bool g2 = !g1 && (j == 0 || ((w.y >> (j - 1)) & 1));
+				acc = (acc << 8) | (uint64_t)(g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG);
+				--at;
+				if (++na == 8) { reinterpret_cast<NwU64u *>(ops + at)->v = acc; acc = 0; na = 0; }
+				if (g1) j--; else if (g2) i--; else { i--; j--; }
+			}
+			for (int k = 0; k < na; ++k) ops[k] = (uint8_t)(acc >> (8 * k));
+		}
 		a.aln_len[p] = len;
 	}
 }
@@ -423,23 +458,26 @@ __device__ __forceinline__ int nw_walk(int lane, int m, int n, const uint64_t *d
 // kGlobal: fragments longer than kNwMaxLen -- the boundary column and the sequence-1 codes no longer fit the LDS and
 // live in a per-wave HBM slab behind the direction words instead (same sweep; the reference's nw_alignment has no length
 // limit, src/nw_alignment.cpp:24-33, so neither has this path).
+// tier: 0 = every pair of the class; 1 = the pairs up to a.tier_len (slabs a.t1_*); 2 = the longer ones
 template <bool kGlobal>
-__global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a)
+__global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a, int tier)
 {
 	extern __shared__ int lds_dyn[];
 	const int lane = threadIdx.x;
 	const unsigned long long count = a.queue[2];
 	const int32_t *list = a.big_list + 2 * a.n;
-	uint32_t *dir = a.dir_scratch + (int64_t)blockIdx.x * a.dir_words_per_wave;
+	uint32_t *dir = tier == 1 ? a.t1_dir_scratch + (int64_t)blockIdx.x * a.t1_dir_words_per_wave : a.dir_scratch + (int64_t)blockIdx.x * a.dir_words_per_wave;
+	unsigned long long *const ticket = a.queue + (tier == 2 ? 4 : 3);
 	for (;;) {
 		unsigned long long t = 0;
-		if (lane == 0) t = atomicAdd(a.queue + 3, 1ull);
+		if (lane == 0) t = atomicAdd(ticket, 1ull);
 		t = __shfl(t, 0);
 		if (t >= count) break;
 		int64_t p = list[t];
 		const NwPair q = nw_pair(a, p);
 		const int64_t o1 = q.o1, o2 = q.o2;
 		const int m = q.m, n = q.n;
+		if (tier != 0 && ((m > n ? m : n) <= a.tier_len) != (tier == 1)) continue;      // the other launch's pair
 		int *lds = kGlobal ? reinterpret_cast<int *>(dir + a.gb_offset_words) : lds_dyn;
 		int2 *bSR = reinterpret_cast<int2 *>(lds);                                   // boundary column: {S, R} of rows 0..m
 		unsigned char *s1c = reinterpret_cast<unsigned char *>(lds + 2 * (m + 1));  // fits: see nw_big_lds_bytes()
@@ -483,15 +521,21 @@ hipError_t launch_nw_batch(const NwArgs &a, int n_cu, hipStream_t stream)
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	hipLaunchKernelGGL(nw_small32_kernel, dim3(grid_for_nw(a.n, 256, n_cu * 2)), dim3(256), 0, stream, a);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
+	if (a.tier_len > 0 && a.t1_dir_scratch && a.t1_waves > 0) {
+		// the pairs up to tier_len first: a launch sized for them (nw_big_kernel<false>'s dynamic LDS limit stays what the other launch asked for)
+		hipLaunchKernelGGL(nw_big_kernel<false>, dim3(a.t1_waves), dim3(64), a.t1_lds_bytes, stream, a, 1);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+	}
+	const int rest = a.tier_len > 0 ? 2 : 0;
 	if (a.dir_scratch && a.big_waves > 0) {
 		if (a.gb_offset_words > 0) {
-			hipLaunchKernelGGL(nw_big_kernel<true>, dim3(a.big_waves), dim3(64), 0, stream, a);
+			hipLaunchKernelGGL(nw_big_kernel<true>, dim3(a.big_waves), dim3(64), 0, stream, a, rest);
 			return hipGetLastError();
 		}
 		if (a.big_lds_bytes > 48 * 1024 &&
 		    (e = hipFuncSetAttribute(reinterpret_cast<const void *>(nw_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, a.big_lds_bytes)) != hipSuccess)
 			return e;
-		hipLaunchKernelGGL(nw_big_kernel<false>, dim3(a.big_waves), dim3(64), a.big_lds_bytes, stream, a);
+		hipLaunchKernelGGL(nw_big_kernel<false>, dim3(a.big_waves), dim3(64), a.big_lds_bytes, stream, a, rest);
 	}
 	return hipGetLastError();
 }

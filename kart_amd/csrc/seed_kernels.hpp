@@ -144,6 +144,12 @@ struct NwArgs {
 	int big_waves;               // number of slabs = grid of the wave-per-pair kernel
 	int big_lds_bytes;           // boundary column + sequence-1 codes for the longest pair
 	int64_t gb_offset_words;     // > 0: fragments beyond kNwMaxLen -- boundary column and codes at this word offset of the wave's slab instead of the LDS
+	// two tiers of the wave-per-pair kernel (tier_len > 0): pairs up to tier_len take a launch of their own whose LDS and slabs are sized for
+	// tier_len -- many waves per CU -- instead of sharing the few waves a launch sized for the batch's longest pair can hold
+	int tier_len = 0;
+	int t1_waves = 0, t1_lds_bytes = 0;
+	int64_t t1_dir_words_per_wave = 0;
+	uint32_t *t1_dir_scratch = nullptr;
 };
 
 constexpr int kNwMaxLen = 7000;  // longest fragment the wave-per-pair kernel's 64 KB LDS holds
