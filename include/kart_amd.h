@@ -270,8 +270,10 @@ int  kg_align_batch(kg_workspace *ws, const int64_t *chunk_off, const uint8_t *c
 int  kg_longread_batch(kg_workspace *ws, const kg_aln_record **records, const char **cigar_pool, int64_t *cigar_bytes, int64_t *n_host_reads);
 /* Running tallies since the workspace was created: [0] reads through kg_longread_batch, [1] of them handed back (KG_ALN_HOST), and why
  * (candidates): [2] a literal '-' in the read, [3] a fragment pair outside the fragment kernels' envelope, [4] seeds out of order after
- * CheckOverlappingSeeds, [5] element pool full; [6] candidates that went through CheckOverlappingSeeds' sequential form.  Diagnostics only. */
-int  kg_longread_reasons(kg_workspace *ws, uint64_t out[8]);
+ * CheckOverlappingSeeds, [5] element pool full; [6] candidates that went through CheckOverlappingSeeds' sequential form; [8..13] fragment
+ * tasks that sent their request back: a side above 8192 bases, a read character other than A/C/G/T, more than 383 exact matches, more normal pairs than
+ * the kernel holds, a work list full, recursion deeper than 6.  Diagnostics only. */
+int  kg_longread_reasons(kg_workspace *ws, uint64_t out[16]);
 
 /* Running tallies (since the workspace was created) of why read pairs came back as KG_ALN_HOST: [0] candidate product too large,
  * [1] a mate-2 rescue window would be scanned, [2] rescue window too long, [3] mate not plain A/C/G/T or too long for the rescue
@@ -303,7 +305,7 @@ int  kg_nw_batch_device(kg_index *ix, const char *d_frag1, const int64_t *d_off1
  * nw_alignment, and with pacbio != 0 a piece with a side above 300 goes through the same procedure again (:197).  The result
  * is the alignment as kg_nw_batch reports one: aln_len[i] op codes at ops[ops_off[i] ...], where ops_off[i] must be the
  * number of columns (rLen + gLen) of the requests before i.  status[i] != 0: the request lies outside the kernels' envelope (a
- * read character other than A/C/G/T, more than 255 matches, a side above 4096) -- the caller plans it itself. */
+ * read character other than A/C/G/T, more than 383 matches, a side above 8192) -- the caller plans it itself. */
 int  kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t *off1, const int64_t *gpos, const int32_t *glen, int64_t n,
                         int pacbio, int max_gaps, uint8_t *ops, const int64_t *ops_off, int32_t *aln_len, uint8_t *status);
 

@@ -39,7 +39,9 @@ struct LongScratch {
 	DevBuf frag_work, elems, cigar;
 	char *h_cigar[kg_workspace::kRing] = {nullptr, nullptr, nullptr, nullptr};     // page-locked, in rotation with the records
 	size_t h_cigar_cap[kg_workspace::kRing] = {0, 0, 0, 0};
+	unsigned long long *h_why = nullptr;                                             // page-locked, 6 words
 	unsigned long long reasons[8] = {0, 0, 0, 0, 0, 0, 0, 0};                       // running tallies (kg_longread_reasons)
+	unsigned long long frag_why[6] = {0, 0, 0, 0, 0, 0};                            // ... of the fragment kernels' hand-backs (FC_WHY)
 	unsigned long long reads = 0, host_reads = 0;
 };
 
@@ -54,6 +56,7 @@ extern "C" void kgi_long_release(kg_workspace *ws)
 		b->release();
 	for (int i = 0; i < kg_workspace::kRing; ++i)
 		if (ls->h_cigar[i]) (void)hipHostFree(ls->h_cigar[i]);
+	if (ls->h_why) (void)hipHostFree(ls->h_why);
 	delete ls;
 	ws->lr = nullptr;
 }
@@ -72,6 +75,7 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 	hipStream_t st = ws->stream;
 	if (!ws->lr) ws->lr = new LongScratch();
 	LongScratch *ls = static_cast<LongScratch *>(ws->lr);
+	if (!ls->h_why) HIP_TRY(hipHostMalloc((void **)&ls->h_why, 8 * 8, hipHostMallocDefault));
 	const int64_t n = ws->last_reads, n_cands = ws->last_cands, n_cseeds = ws->last_cand_seeds;
 	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	int rc;
@@ -108,7 +112,7 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 	a.req_f1 = (int64_t *)ls->req_f1.p; a.req_g = (int64_t *)ls->req_g.p; a.req_rl = (int32_t *)ls->req_rl.p; a.req_gl = (int32_t *)ls->req_gl.p;
 	a.req_oo = (int64_t *)ls->req_oo.p; a.req_capacity = req_cap;
 	a.ctl = (unsigned long long *)ls->ctl.p;
-	a.ops = nullptr; a.aln_len = nullptr; a.status = nullptr; a.elems = nullptr; a.elem_capacity = 0;
+	a.ops = nullptr; a.aln_len = nullptr; a.runs = nullptr; a.status = nullptr; a.elems = nullptr; a.elem_capacity = 0;
 	a.r_host = (uint8_t *)ls->r_host.p; a.cig_bytes = (int64_t *)ls->cig_bytes.p; a.r_best = (int32_t *)ls->r_best.p;
 	a.records = (kg_aln_record *)ls->records.p; a.cigar = nullptr;
 
@@ -126,13 +130,16 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 	const int64_t task_cap = n_req + n_req / 2 + cols / 300 + 4096, piece_cap = 4 * n_req + cols / 8 + 4096, job_cap = 2 * n_req + cols / 16 + 4096, jops_cap = cols + 4096;
 	const size_t w_tasks = 0, w_pieces = w_tasks + up(sizeof(FragTask) * (size_t)task_cap), w_jobs = w_pieces + up(sizeof(FragPiece) * (size_t)piece_cap),
 	             w_jops = w_jobs + up(sizeof(NwJobDesc) * (size_t)job_cap), w_jlen = w_jops + up((size_t)jops_cap + 64), w_ctl = w_jlen + up(4 * (size_t)job_cap),
-	             w_status = w_ctl + up(8 * FC_WORDS), w_ops = w_status + up((size_t)n_req + 64), w_len = w_ops + up((size_t)cols + 64), work_total = w_len + up(4 * (size_t)n_req + 64);
+	             w_status = w_ctl + up(8 * FC_WORDS), w_ops = w_status + up((size_t)n_req + 64), w_len = w_ops + up((size_t)cols + 64), w_runs = w_len + up(4 * (size_t)n_req + 64), work_total = w_runs + up(4 * (size_t)n_req + 64);
 	ENSURE(ls->frag_work, work_total);
-	const int64_t elem_cap = std::min<int64_t>(pool_used, pool_cap) * 2 + cols + 4096;
+	// merged CIGAR elements: at most two per pair and one per run of a column string -- a run every ~6 columns at 15 % error; a quarter of the columns
+	// is room for a run every second column of every alignment (a candidate that needs more goes back to the host: LC_R_ELEMS)
+	const int64_t elem_cap = std::min<int64_t>(pool_used, pool_cap) * 2 + cols / 4 + 4096;
 	ENSURE(ls->elems, 4 * (size_t)elem_cap);
 	char *fw = (char *)ls->frag_work.p;
-	a.ops = (const uint8_t *)(fw + w_ops); a.aln_len = (const int32_t *)(fw + w_len); a.status = (const uint8_t *)(fw + w_status);
+	a.ops = (const uint8_t *)(fw + w_ops); a.aln_len = (const int32_t *)(fw + w_len); a.runs = (const int32_t *)(fw + w_runs); a.status = (const uint8_t *)(fw + w_status);
 	a.elems = (uint32_t *)ls->elems.p; a.elem_capacity = elem_cap;
+	bool have_why = false;
 	if (n_req > 0) {
 		FragArgs f;
 		f.f1 = (const char *)ws->d_enc; f.off1 = a.req_f1; f.rlen = a.req_rl; f.gpos = a.req_g; f.glen = a.req_gl; f.n = n_req;
@@ -147,7 +154,7 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 		f.job_ops = (uint8_t *)(fw + w_jops); f.job_len = (int32_t *)(fw + w_jlen);
 		f.ctl = (unsigned long long *)(fw + w_ctl);
 		f.status = (uint8_t *)(fw + w_status);
-		f.ops = (uint8_t *)(fw + w_ops); f.ops_off = a.req_oo; f.aln_len = (int32_t *)(fw + w_len);
+		f.ops = (uint8_t *)(fw + w_ops); f.ops_off = a.req_oo; f.aln_len = (int32_t *)(fw + w_len); f.runs = (int32_t *)(fw + w_runs);
 		HIP_TRY(launch_frag_partition(f, ix->n_cu, st));
 		NwArgs w;
 		w.desc = f.jobs; w.text2 = ix->d_text; w.n_dev = f.ctl + FC_JOBS;
@@ -157,6 +164,8 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 		rc = kgi_nw_launch(ix, w, max_len, st);
 		if (rc != KG_OK) return rc;
 		HIP_TRY(launch_frag_stitch(f, ix->n_cu, st));
+		HIP_TRY(hipMemcpyAsync(ls->h_why, f.ctl + FC_WHY, 8 * 6, hipMemcpyDeviceToHost, st));
+		have_why = true;
 	}
 
 	// ---- pass 2, the records, the CIGAR strings ----
@@ -180,6 +189,19 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 	if (text_bytes > 0) HIP_TRY(hipMemcpyAsync(ls->h_cigar[slot], a.cigar, (size_t)text_bytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(h, a.ctl, 8 * LC_WORDS, hipMemcpyDeviceToHost, st));
 	HIP_TRY(kgi_sync(ws));
+	if (getenv("KG_LONG_DEBUG_STATUS") && n_req > 0) {
+		// diagnostics: the requests the fragment kernels sent back, and why
+		std::vector<uint8_t> stv((size_t)n_req);
+		std::vector<int32_t> rl((size_t)n_req), gl((size_t)n_req);
+		(void)hipMemcpy(stv.data(), a.status, (size_t)n_req, hipMemcpyDeviceToHost);
+		(void)hipMemcpy(rl.data(), a.req_rl, 4 * (size_t)n_req, hipMemcpyDeviceToHost);
+		(void)hipMemcpy(gl.data(), a.req_gl, 4 * (size_t)n_req, hipMemcpyDeviceToHost);
+		int64_t bad = 0;
+		for (int64_t i = 0; i < n_req; ++i)
+			if (stv[(size_t)i]) { if (bad++ < 12) fprintf(stderr, "KG_LONG_DEBUG_STATUS request %lld: status %d, read side %d, text side %d\n", (long long)i, stv[(size_t)i], rl[(size_t)i], gl[(size_t)i]); }
+		fprintf(stderr, "KG_LONG_DEBUG_STATUS %lld of %lld requests sent back; why: %llu %llu %llu %llu %llu %llu\n", (long long)bad, (long long)n_req,
+		        ls->h_why[0], ls->h_why[1], ls->h_why[2], ls->h_why[3], ls->h_why[4], ls->h_why[5]);
+	}
 	if (const char *dbg = getenv("KG_LONG_DEBUG")) {
 		// diagnostics: the pairs, the requests' op strings (as runs) and the merged elements of read <KG_LONG_DEBUG> of this batch
 		const int64_t r = atoll(dbg);
@@ -223,6 +245,7 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 	for (int64_t r = 0; r < n; ++r) n_host += ws->h_records[r].kind == KG_ALN_HOST;
 	ls->reads += (unsigned long long)n; ls->host_reads += (unsigned long long)n_host;
 	for (int i = 0; i < 5; ++i) ls->reasons[i] += h[LC_R_DASH + i];
+	if (have_why) for (int i = 0; i < 6; ++i) ls->frag_why[i] += ls->h_why[i];
 	*records = ws->h_records;
 	*cigar_pool = ls->h_cigar[slot];
 	*cigar_bytes = text_bytes;
@@ -231,13 +254,14 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 #undef ENSURE
 }
 
-extern "C" int kg_longread_reasons(kg_workspace *ws, uint64_t out[8])
+extern "C" int kg_longread_reasons(kg_workspace *ws, uint64_t out[16])
 {
 	if (!ws || !out) return fail(KG_ERR_ARG, "kg_longread_reasons: null argument");
-	for (int i = 0; i < 8; ++i) out[i] = 0;
+	for (int i = 0; i < 16; ++i) out[i] = 0;
 	const LongScratch *ls = static_cast<const LongScratch *>(ws->lr);
 	if (!ls) return KG_OK;
 	out[0] = ls->reads; out[1] = ls->host_reads;
 	for (int i = 0; i < 5; ++i) out[2 + i] = ls->reasons[i];
+	for (int i = 0; i < 6; ++i) out[8 + i] = ls->frag_why[i];
 	return KG_OK;
 }

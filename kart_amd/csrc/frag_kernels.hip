@@ -51,8 +51,9 @@ __device__ __forceinline__ unsigned long long shfl_u64_frag(unsigned long long v
 __device__ __forceinline__ bool key_less(int g1, int r1, int g2, int r2) { return g1 == g2 ? r1 < r2 : g1 < g2; }   // CompByGenomePos
 
 // vector<SeedPair_t> of one fragment in the LDS (fragment-relative coordinates)
+typedef int16_t frp_t;               // fragment-relative positions and lengths (a side holds at most kFragMaxLen = 8192 bases)
 struct FragPairs {
-	int32_t *gPos, *rPos, *rLen, *gLen;
+	frp_t *gPos, *rPos, *rLen, *gLen;
 	uint8_t *simple;
 	int num;
 };
@@ -226,18 +227,19 @@ __device__ bool identify_normal_pairs(int rlen, int glen, FragPairs &v, uint16_t
 // changes nothing).  Then the result is the matches with the gap pairs between neighbours interleaved -- a gap pair sorts right behind
 // the match it follows: its genome position is the match's end, at most the next match's start, and at a tie its read position is
 // smaller -- plus the head and tail pairs (:437-488).  Returns the new count, or -1 without touching anything when the case is not that.
-__device__ int identify_normal_pairs_wave(int rlen, int glen, int n, int lane, int16_t *, int32_t *gPos, int32_t *rPos, int32_t *rLen, int32_t *gLen, uint8_t *simple)
+__device__ int identify_normal_pairs_wave(int rlen, int glen, int n, int lane, int16_t *, frp_t *gPos, frp_t *rPos, frp_t *rLen, frp_t *gLen, uint8_t *simple)
 {
 	bool ok = true;
 	for (int i = lane; i + 1 < n; i += 64)
 		ok = ok && rPos[i] < rPos[i + 1] && rPos[i] + rLen[i] - 1 < rPos[i + 1] && gPos[i] + gLen[i] - 1 < gPos[i + 1];
 	if (__ballot(!ok)) return -1;
 	const bool head = rPos[0] > 0 || gPos[0] > 0;             // (:457-470; glen > 0 here: the genome side's gap is gPos[0])
-	// every lane takes its matches (up to four: n <= 255) and the gap pair behind each into registers, then all write
-	int mg[4], mr[4], ml_r[4], ml_g[4], dst[4], gr[4], gg[4];
-	bool has[4];
+	// every lane takes its matches (one per 64: n <= kFragMaxRuns) and the gap pair behind each into registers, then all write
+	constexpr int kC = (kFragMaxRuns + 63) / 64;
+	int mg[kC], mr[kC], ml_r[kC], ml_g[kC], dst[kC], gr[kC], gg[kC];
+	bool has[kC];
 	int before = head ? 1 : 0;                                  // output slots in front of this chunk
-	for (int c = 0; c < 4; ++c) {
+	for (int c = 0; c < kC; ++c) {
 		const int i = c * 64 + lane;
 		has[c] = false; dst[c] = -1; gr[c] = gg[c] = 0; mg[c] = mr[c] = ml_r[c] = ml_g[c] = 0;
 		bool gap = false;
@@ -261,7 +263,7 @@ __device__ int identify_normal_pairs_wave(int rlen, int glen, int n, int lane, i
 	const int t_rp = rPos[last] + rLen[last], t_gp = gPos[last] + gLen[last];
 	const int h_r = rPos[0] > 0 ? rPos[0] : 0, h_g = gPos[0];
 	__syncthreads();
-	for (int c = 0; c < 4; ++c) {
+	for (int c = 0; c < kC; ++c) {
 		if (dst[c] < 0) continue;
 		const int d = dst[c];
 		gPos[d] = mg[c]; rPos[d] = mr[c]; rLen[d] = ml_r[c]; gLen[d] = ml_g[c]; simple[d] = 1;
@@ -283,9 +285,9 @@ __device__ int identify_normal_pairs_wave(int rlen, int glen, int n, int lane, i
 __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int level)
 {
 	__shared__ uint64_t s_rd[kFragMaxLen / 32 + 2], s_tx[kFragMaxLen / 32 + 2];
-	__shared__ int32_t s_gPos[kFragMaxPairs], s_rPos[kFragMaxPairs], s_rLen[kFragMaxPairs], s_gLen[kFragMaxPairs];
+	__shared__ frp_t s_gPos[kFragMaxPairs], s_rPos[kFragMaxPairs], s_rLen[kFragMaxPairs], s_gLen[kFragMaxPairs];
 	__shared__ uint8_t s_simple[kFragMaxPairs];
-	__shared__ int32_t s_run_r[kFragMaxRuns], s_run_d[kFragMaxRuns], s_run_l[kFragMaxRuns];
+	__shared__ frp_t s_run_r[kFragMaxRuns], s_run_d[kFragMaxRuns], s_run_l[kFragMaxRuns];
 	__shared__ uint16_t s_byr[kFragMaxPairs];
 	__shared__ int s_n, s_bad;
 	const int lane = threadIdx.x;
@@ -300,7 +302,8 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		// lane 0 decides the task's pieces; everybody else helps with the runs
 		bool whole_job = !(rL > 30 && gL > 30);            // src/tools.cpp:146
 		bool host = false;
-		if (!whole_job && (rL > kFragMaxLen || gL > kFragMaxLen)) host = true;
+		int why = -1;                                      // (diagnostics: which limit sent the request back, FC_WHY)
+		if (!whole_job && (rL > kFragMaxLen || gL > kFragMaxLen)) { host = true; why = 0; }
 		int n_runs = 0;
 		if (!whole_job && !host) {
 			int max_shift;
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 			for (int w = lane; w < gw; w += 64) s_tx[w] = text_word32_at(a.text, a.two_genome_size, g + ((int64_t)w << 5));
 			__syncthreads();
 			if (a.prof) c1 = clock64();
-			if (s_bad) host = true;
+			if (s_bad) { host = true; why = 1; }
 			else {
 				// ---- runs of >= 8 equal bases along the diagonals |gpos - rpos| < max_shift (= the merged common 8-mers) ----
 				for (int d = -(max_shift - 1) + lane; d <= max_shift - 1; d += 64) {
@@ -371,23 +374,29 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 						e = (e | (e >> 8)) & 0x0000FFFF0000FFFFull;
 						e = (e | (e >> 16)) & 0x00000000FFFFFFFFull;
 						const uint32_t m = (uint32_t)e;
-						int pos = 0;
-						while (pos < 32) {
-							const uint32_t rest = m >> pos;
-							if (rest & 1u) {
-								int ones = __ffs(~rest) - 1;                                    // (rest != all ones once shifted, or pos == 0 and m full)
-								if (ones < 0 || ones > 32 - pos) ones = 32 - pos;
-								run += ones; pos += ones;
-							} else {
-								if (run >= 8) {
-									int k = atomicAdd(&s_n, 1);
-									if (k < kFragMaxRuns) { s_run_r[k] = base + pos - run; s_run_d[k] = d; s_run_l[k] = run; }
-								}
-								run = 0;
-								if (rest == 0) break;
-								pos += __ffs(rest) - 1;
-							}
+						// the runs of equal bases in this word, without walking every run and gap (a 15 %-error diagonal alternates ~10 times per word, and
+						// the whole wave waited for the one lane on the alignment's diagonal: round 5): the run entering the word ends at the first zero; runs
+						// of >= 8 inside the word start where eight ones in a row begin; the run touching the top is carried on
+						if (m == 0xffffffffu) { run += 32; continue; }
+						auto emit = [&](int start, int len) {
+							int k = atomicAdd(&s_n, 1);
+							if (k < kFragMaxRuns) { s_run_r[k] = start; s_run_d[k] = d; s_run_l[k] = len; }
+						};
+						const int t = __ffs((int)~m) - 1;                                   // equal bases from position 0 up
+						if (run + t >= 8) emit(base - run, run + t);
+						const int top = __clz((int)~m);                                     // equal bases from position 31 down (m != all ones)
+						uint32_t in = m & ~((2u << t) - 1u);                                // what lies strictly inside: not the run at the bottom, not the one at the top
+						if (top) in &= ~(0xffffffffu << (32 - top));
+						uint32_t r8 = in & (in >> 1);
+						r8 &= r8 >> 2;
+						r8 &= r8 >> 4;                                                      // bit p: the bases p .. p + 7 are equal
+						uint32_t starts = r8 & ~(r8 << 1);
+						while (starts) {
+							const int pp = __ffs((int)starts) - 1;
+							starts &= starts - 1;
+							emit(base + pp, __ffs((int)~(in >> pp)) - 1);
 						}
+						run = top;
 					}
 					if (run >= 8) {
 						int k = atomicAdd(&s_n, 1);
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 				}
 				__syncthreads();
 				n_runs = s_n;
-				if (n_runs > kFragMaxRuns) host = true;
+				if (n_runs > kFragMaxRuns) { host = true; why = 2; }
 				if (a.prof) c2 = clock64();
 			}
 			if (!host && n_runs > 0) {
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		if (lane == 0 && fast_num < 0) {
 			FragPairs v;
 			v.gPos = s_gPos; v.rPos = s_rPos; v.rLen = s_rLen; v.gLen = s_gLen; v.simple = s_simple; v.num = n_runs;
-			if (!host && !whole_job && n_runs > 0 && !identify_normal_pairs(rL, gL, v, s_byr, kFragMaxPairs)) host = true;
+			if (!host && !whole_job && n_runs > 0 && !identify_normal_pairs(rL, gL, v, s_byr, kFragMaxPairs)) { host = true; s_bad = 2; }
 			if (!host && !whole_job && v.num == 0) whole_job = true;            // no common 8-mer survived: the whole fragment is one alignment (:214-221)
 			s_n = host ? -1 : whole_job ? 0 : v.num;
 		}
@@ -430,6 +439,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		// atomic per list, then written, every lane its own pair (a lane-0 loop over ~27 pairs with a global store each was 95 k of a task's 320 k cycles)
 		const int num = s_n;                                // -1: outside the envelope; 0: one alignment for the whole fragment
 		host = num < 0;
+		if (host && why < 0) why = s_bad == 2 ? 3 : 2;
 		int first = 0, count = 0;
 		if (!host) {
 			// what pair i becomes: 0 nothing, 1 literal, 2 NW job, 3 sub-task
@@ -466,6 +476,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 			                  (n_sub == 0 || (task_at + (unsigned long long)n_sub <= (unsigned long long)a.task_capacity && level + 1 < kFragMaxDepth));
 			if (!room) {
 				host = true;
+				why = (n_sub != 0 && level + 1 >= kFragMaxDepth) ? 5 : 4;
 				// (the job slots reserved above stay behind: empty jobs, so that the NW kernels find nothing in them; sub-task slots beyond the
 				//  capacity were never written, the ones inside it become tasks of nothing)
 				if (jobs_fit)
@@ -518,7 +529,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		}
 		if (lane == 0) {
 			task.first = first; task.count = host ? 0 : count; task.status = host ? 1 : 0;
-			if (host) a.status[task.root] = 1;                                              // the whole request goes back to the caller
+			if (host) { a.status[task.root] = 1; atomicAdd(&a.ctl[FC_WHY + (why < 0 ? 4 : why)], 1ull); }                                              // the whole request goes back to the caller
 			if (a.prof) {
 				const long long c5 = clock64();
 				atomicAdd(&a.ctl[FC_PROF + 0], (unsigned long long)(c1 - c0)); atomicAdd(&a.ctl[FC_PROF + 1], (unsigned long long)(c2 - c1));
@@ -548,6 +559,7 @@ __global__ void frag_reset_kernel(FragArgs a)
 		a.ctl[FC_TASKS] = (unsigned long long)a.n; a.ctl[FC_PIECES] = 0; a.ctl[FC_JOBS] = 0; a.ctl[FC_OPS] = 0;
 		a.ctl[FC_LEVEL0] = 0; a.ctl[FC_LEVEL0 + 1] = (unsigned long long)a.n;
 		for (int k = 0; k < 8; ++k) a.ctl[FC_PROF + k] = 0;
+		for (int k = 0; k < 6; ++k) a.ctl[FC_WHY + k] = 0;
 		for (int l = 2; l <= kFragMaxDepth + 1; ++l) a.ctl[FC_LEVEL0 + l] = (unsigned long long)a.n;
 	}
 	for (int64_t r = i; r < a.n; r += (int64_t)gridDim.x * blockDim.x) {
@@ -559,13 +571,22 @@ __global__ void frag_reset_kernel(FragArgs a)
 	}
 }
 
-// One lane per request: its op string from the pieces, depth first
+// One lane per request: its op string from the pieces, depth first.  The bytes leave eight at a time (an accumulator per lane, unaligned 8-byte
+// stores; literal runs as a fill pattern, job op strings through unaligned 8-byte loads): one byte store per column and lane -- 64 different
+// cache lines per store instruction -- was 73 ms per 400 k long reads (profiles/r05f_pacbio_kernel_stats.csv).
 __global__ __launch_bounds__(256) void frag_stitch_kernel(FragArgs a)
 {
 	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += (int64_t)gridDim.x * blockDim.x) {
-		if (a.status[r]) { a.aln_len[r] = 0; continue; }
+		if (a.status[r]) { a.aln_len[r] = 0; if (a.runs) a.runs[r] = 0; continue; }
 		uint8_t *out = a.ops + a.ops_off[r];
-		int at = 0;
+		int at = 0, na = 0;                    // bytes stored; bytes waiting in acc
+		uint64_t acc = 0;
+		int nr = 0;                            // runs of equal ops so far
+		uint64_t last = 255;                   // the op written last
+		auto put = [&](uint64_t b) {
+			acc |= b << (8 * na);
+			if (++na == 8) { reinterpret_cast<FrU64u *>(out + at)->v = acc; at += 8; acc = 0; na = 0; }
+		};
 		int stack_task[kFragMaxDepth + 1], stack_piece[kFragMaxDepth + 1];
 		int sp = 0;
 		stack_task[0] = (int)r; stack_piece[0] = 0;
@@ -573,14 +594,30 @@ __global__ __launch_bounds__(256) void frag_stitch_kernel(FragArgs a)
 			const FragTask &t = a.tasks[stack_task[sp]];
 			if (stack_piece[sp] >= t.count) { sp--; continue; }
 			const FragPiece pc = a.pieces[t.first + stack_piece[sp]++];
-			if (pc.kind <= KG_OP_GAP2) { for (int k = 0; k < pc.v; ++k) out[at++] = (uint8_t)pc.kind; }
-			else if (pc.kind == FP_JOB) {
+			if (pc.kind <= KG_OP_GAP2) {
+				int v = pc.v;
+				if (v > 0 && (uint64_t)pc.kind != last) { nr++; last = (uint64_t)pc.kind; }
+				while (na != 0 && v > 0) { put((uint64_t)pc.kind); --v; }
+				const uint64_t pat = (uint64_t)pc.kind * 0x0101010101010101ull;
+				for (; v >= 8; v -= 8) { reinterpret_cast<FrU64u *>(out + at)->v = pat; at += 8; }
+				for (; v > 0; --v) put((uint64_t)pc.kind);
+			} else if (pc.kind == FP_JOB) {
 				const uint8_t *src = a.job_ops + a.jobs[pc.v].ops;
-				const int L = a.job_len[pc.v];
-				for (int k = 0; k < L; ++k) out[at++] = src[k];
+				int L = a.job_len[pc.v], k = 0;
+				while (na != 0 && k < L) { const uint64_t b = src[k++]; if (b != last) { nr++; last = b; } put(b); }
+				for (; k + 8 <= L; k += 8) {
+					const uint64_t w = reinterpret_cast<const FrU64u *>(src + k)->v;
+					const uint64_t y = w ^ ((w << 8) | last);                    // every byte against the one before it (ops are 0 .. 2)
+					nr += __popcll((y | (y >> 1)) & 0x0101010101010101ull);
+					last = w >> 56;
+					reinterpret_cast<FrU64u *>(out + at)->v = w; at += 8;
+				}
+				for (; k < L; ++k) { const uint64_t b = src[k]; if (b != last) { nr++; last = b; } put(b); }
 			} else if (sp < kFragMaxDepth) { sp++; stack_task[sp] = pc.v; stack_piece[sp] = 0; }
 		}
-		a.aln_len[r] = at;
+		for (int k = 0; k < na; ++k) out[at + k] = (uint8_t)(acc >> (8 * k));
+		a.aln_len[r] = at + na;
+		if (a.runs) a.runs[r] = nr;
 	}
 }
 

@@ -4,13 +4,16 @@
 
 namespace kg {
 
-constexpr int kFragMaxLen = 4096;        // longest side of a fragment the partition kernel takes (2-bit codes of both sides in the LDS)
-constexpr int kFragMaxRuns = 255;        // exact matches of >= 8 bases per fragment pair
+constexpr int kFragMaxLen = 8192;        // longest side of a fragment the partition kernel takes (2-bit codes of both sides in the LDS; 4096 until round 5:
+                                         // 1.2 % of 7 kb reads on the hg38-sized genome have a stretch of 4-7 kb without seeds -- inside a repeat copy every seed has more than 50 hits)
+constexpr int kFragMaxRuns = 383;        // exact matches of >= 8 bases per fragment pair (255 until round 5; a 7 kb stretch at 15 % error has ~290)
 constexpr int kFragMaxPairs = 2 * kFragMaxRuns + 2;   // ... and the normal pairs IdentifyNormalPairs makes of them
 constexpr int kFragMaxDepth = 6;         // levels of the -pacbio recursion (src/tools.cpp:197)
 
 enum { FP_JOB = 3, FP_TASK = 4 };        // FragPiece::kind beyond the literal runs KG_OP_DIAG / KG_OP_GAP1 / KG_OP_GAP2
-enum { FC_TASKS = 0, FC_PIECES = 1, FC_JOBS = 2, FC_OPS = 3, FC_LEVEL0 = 4, FC_PROF = FC_LEVEL0 + kFragMaxDepth + 2, FC_WORDS = FC_PROF + 8 };   // FC_PROF: wave cycles per phase (KG_FRAG_PROF)
+enum { FC_TASKS = 0, FC_PIECES = 1, FC_JOBS = 2, FC_OPS = 3, FC_LEVEL0 = 4, FC_PROF = FC_LEVEL0 + kFragMaxDepth + 2, FC_WHY = FC_PROF + 8, FC_WORDS = FC_WHY + 6 };   // FC_PROF: wave cycles per phase (KG_FRAG_PROF)
+// FC_WHY: tasks that sent their request back, by reason: [0] a side above kFragMaxLen, [1] a read character other than A/C/G/T, [2] more than kFragMaxRuns matches,
+// [3] more normal pairs than the LDS arrays hold, [4] a work list was full, [5] recursion deeper than kFragMaxDepth
 
 struct FragTask {
 	int64_t f1_off;       // the read fragment in the characters the caller uploaded
@@ -53,6 +56,7 @@ struct FragArgs {
 	uint8_t *ops;                   // the op strings, request r at ops_off[r] (room for rLen + gLen columns)
 	const int64_t *ops_off;         // [n]
 	int32_t *aln_len;               // [n]
+	int32_t *runs = nullptr;        // [n] or null: the number of runs of equal ops in every request's string (what its CIGAR takes at most)
 };
 
 hipError_t launch_frag_partition(const FragArgs &a, int n_cu, hipStream_t stream);   // levels 0 .. kFragMaxDepth - 1: pieces, NW jobs

@@ -191,7 +191,12 @@ public:
 		const char *pool = nullptr;
 		int64_t bytes = 0, n_host = 0;
 		double t0 = now_sec();
-		if (kg_longread_batch(ws_, &rec, &pool, &bytes, &n_host) != KG_OK) die("kg_longread_batch");
+		if (kg_longread_batch(ws_, &rec, &pool, &bytes, &n_host) != KG_OK) {
+			// (device memory for a very large batch beside a 168 GB index, ...: this batch's report is the host's, the run goes on)
+			static std::atomic<int> warned{0};
+			if (warned++ == 0) fprintf(stderr, "Warning! kg_longread_batch: %s -- the host maps this batch\n", kg_last_error());
+			return false;
+		}
 		double t1 = now_sec();
 		const size_t n_chunks = chunk_off.size() - 1;
 		chunk_stats.assign(n_chunks, kg_chunk_stats());
@@ -220,17 +225,18 @@ public:
 		if (kg_align_reasons(ws_, w) != KG_OK) return std::string();
 		static const char *const name[13] = {"candidate product", "mate-2 window", "window length", "mate characters/length", "runs per window", "rescued pairs", "seeds",
 		                                     "gap pairs", "8-mer partition", "list capacity", "CIGAR length", "score", "read length"};
-		char tb[512];
+		char tb[768];
 		snprintf(tb, sizeof(tb), "device stage seconds: seed (H2D + kernels) %.3f | chain + D2H %.3f | candidate copies %.3f | align (kernels + D2H) %.3f | record copy %.3f || ", t_seed, t_cands, t_copy, t_align, t_reccopy);
 		std::string s(tb);
 		if (long_used_) {
-			uint64_t lw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l1[8];
+			uint64_t lw[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, l1[16];
 			bool ok = false;
 			for (const Slot &sl : slots_)
-				if (sl.ws && kg_longread_reasons(sl.ws, l1) == KG_OK) { ok = true; for (int i = 0; i < 8; ++i) lw[i] += l1[i]; }
+				if (sl.ws && kg_longread_reasons(sl.ws, l1) == KG_OK) { ok = true; for (int i = 0; i < 16; ++i) lw[i] += l1[i]; }
 			if (ok) {
-				snprintf(tb, sizeof(tb), "long-read report on the device: %llu reads, %llu handed back (candidates: literal '-' %llu, fragment envelope %llu, seed order %llu, element pool %llu; sequential overlap check %llu) || ",
-				         (unsigned long long)lw[0], (unsigned long long)lw[1], (unsigned long long)lw[2], (unsigned long long)lw[3], (unsigned long long)lw[4], (unsigned long long)lw[5], (unsigned long long)lw[6]);
+				snprintf(tb, sizeof(tb), "long-read report on the device: %llu reads, %llu handed back (candidates: literal '-' %llu, fragment envelope %llu, seed order %llu, element pool %llu; sequential overlap check %llu; fragment tasks handed back: length %llu, characters %llu, matches %llu, pairs %llu, lists %llu, depth %llu) || ",
+				         (unsigned long long)lw[0], (unsigned long long)lw[1], (unsigned long long)lw[2], (unsigned long long)lw[3], (unsigned long long)lw[4], (unsigned long long)lw[5], (unsigned long long)lw[6],
+				         (unsigned long long)lw[8], (unsigned long long)lw[9], (unsigned long long)lw[10], (unsigned long long)lw[11], (unsigned long long)lw[12], (unsigned long long)lw[13]);
 				s += tb;
 			}
 		}

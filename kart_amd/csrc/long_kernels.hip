@@ -413,13 +413,13 @@ __global__ __launch_bounds__(64) void lr_finish_kernel(LrArgs a)
 		const int num = k.n_pairs;
 		LrPair *P = a.pool + k.pair_off;
 		const int64_t base = a.read_off[k.read];
-		// room for the merged elements: at most one per pair and one per column of its alignments
+		// room for the merged elements: at most two per pair (a soft clip beside a head's or tail's runs) and one per run of its alignments
 		long long need = 0;
 		bool host = false;
 		for (int j = lane; j < num; j += 64) {
 			const LrPair p = P[j];
 			need += 2;
-			if (p.kind == LP_REQ) { if (a.status[p.v]) host = true; else need += a.aln_len[p.v]; }
+			if (p.kind == LP_REQ) { if (a.status[p.v]) host = true; else need += a.runs[p.v]; }
 		}
 		for (int off = 32; off > 0; off >>= 1) need += shfl_i64(need, lane ^ off);
 		if (__ballot(host)) {

@@ -73,6 +73,7 @@ struct LrArgs {
 	// after the fragment kernels
 	const uint8_t *ops;
 	const int32_t *aln_len;
+	const int32_t *runs;            // runs of equal ops per request (frag_stitch_kernel): what its CIGAR takes at most
 	const uint8_t *status;
 	uint32_t *elems;
 	int64_t elem_capacity;

@@ -15,9 +15,9 @@ GOLD = os.path.join(ROOT, "tests", "golden", "fragments_small.npz")
 
 
 def _expected_status(r, glen):
-    # outside the kernels' envelope: both sides above 30 (src/tools.cpp:146) AND a read character other than A/C/G/T or a side above 4096
+    # outside the kernels' envelope: both sides above 30 (src/tools.cpp:146) AND a read character other than A/C/G/T or a side above 8192 (kFragMaxLen)
     plain = all(c in b"ACGTacgt" for c in r)
-    return 1 if (len(r) > 30 and glen > 30 and (not plain or len(r) > 4096 or glen > 4096)) else 0
+    return 1 if (len(r) > 30 and glen > 30 and (not plain or len(r) > 8192 or glen > 8192)) else 0
 
 
 @pytest.mark.parametrize("mode", ["pacbio", "illumina"])
@@ -44,7 +44,7 @@ def test_fragments_random_vs_oracle(gpu_index_full, oracle_small):
     frags, gpos, glen = [], [], []
     acgt = np.frombuffer(b"ACGT", np.uint8)
     for it in range(400):
-        gl = int(rng.integers(1, (60, 400, 1500, 4300)[it % 4]))
+        gl = int(rng.integers(1, (60, 400, 1500, 4300, 9000)[it % 5]))
         gp = int(rng.integers(3000, L - gl - 1))
         gseq = text[gp:gp + gl]
         if (gseq == ord("N")).any():
@@ -60,7 +60,9 @@ def test_fragments_random_vs_oracle(gpu_index_full, oracle_small):
         frags.append(r.tobytes()); gpos.append(gp); glen.append(gl)
     got, status = gpu_index_full.GenerateNormalPairAlignment(frags, gpos, glen, text, pacbio=True)
     for i, r in enumerate(frags):
-        assert int(status[i]) == _expected_status(r, glen[i]), (i, len(r), glen[i])
+        # (a fragment of several thousand noisy bases may also exceed the kernel's 383 exact matches: handed back as well; whatever IS served must be right)
+        if max(len(r), glen[i]) <= 4096 or _expected_status(r, glen[i]):
+            assert int(status[i]) == _expected_status(r, glen[i]), (i, len(r), glen[i])
         if not status[i]:
             assert got[i] == oracle_small.normal_pair_alignment(r, text[gpos[i]:gpos[i] + glen[i]].tobytes(), True, 5), (i, len(r), glen[i])
     assert (np.asarray(status) == 1).any() and (np.asarray(status) == 0).sum() > 300

@@ -8,8 +8,8 @@ CMD=$(python3 -c "import json; d=json.load(open('gpurun_out/ab_long_first.json')
 echo "command: $CMD"
 show() { grep -E "^mapping seconds|^cpu seconds|^device report: [0-9]|^worker thread|^stage seconds|long-read report" $1 | cut -c1-420 | sed 's/^/    /'; grep -o "long-read report on the device[^|]*" $1 | head -1 | sed 's/^/    /'; }
 run() { echo "== $1"; env KART_AMD_VERBOSE=1 $1 $CMD > /tmp/ab_long.log 2>&1; show /tmp/ab_long.log; }
-for c in ${CHUNKS:-2048 4096 8192}; do
-  run "KART_AMD_PACBIO_CHUNKS=$c KART_AMD_PACBIO_MAX_CHUNKS=$c"
+for c in ${CHUNKS:-2048:2048 4096:4096 8192:8192}; do
+  run "KART_AMD_PACBIO_CHUNKS=${c%:*} KART_AMD_PACBIO_MAX_CHUNKS=${c#*:}"
 done
 run "KART_AMD_HOST_LONG=1"
 if [ "$CHECK" -gt 0 ]; then
