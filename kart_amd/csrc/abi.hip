@@ -456,7 +456,8 @@ int kg_workspace_create(kg_index *ix, int64_t max_reads, int64_t max_bases, kg_w
 	ws->max_bases = max_bases;
 	// every hit consumes at least 13 read bases (MinSeedLength >= 13), plus one per read of slack
 	// ... plus the slack of the per-wave slot pools (one 256-slot chunk per resident wave)
-	ws->max_hits = max_bases / 13 + max_reads + (int64_t)ix->n_cu * 32 * 256 + 4096;
+	// (a hit per 13 bases is the most one walk over a read can leave; + a quarter for the walks from the segment starts of a long read that merge into it, search.inc)
+	ws->max_hits = max_bases / 13 + max_bases / 52 + max_reads + (int64_t)ix->n_cu * 32 * 256 + 4096;
 	HIP_TRY(hipMalloc((void **)&ws->d_hits, sizeof(Hit) * (size_t)ws->max_hits));
 	HIP_TRY(hipMalloc((void **)&ws->d_packed, 8 * (size_t)(max_bases / 16 + 3 * max_reads + 64)));
 	HIP_TRY(hipMalloc((void **)&ws->d_seeds_per_read, 4 * (size_t)max_reads));
@@ -488,7 +489,7 @@ void kg_workspace_destroy(kg_workspace *ws)
 		if (ws->ring_seeds[i]) (void)hipHostFree(ws->ring_seeds[i]);
 		if (ws->ring_records[i]) (void)hipHostFree(ws->ring_records[i]);
 	}
-	void *ptrs[] = {ws->d_sort_keys, ws->d_sort_temp, ws->d_plans, ws->d_tasks, ws->d_aln_cand, ws->d_aln_read, ws->d_spill, ws->d_jobs, ws->d_job_ops, ws->d_job_len, ws->d_chunk_off, ws->d_chunk_paired, ws->d_chunk_stats, ws->d_aln_ctl, ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds};
+	void *ptrs[] = {ws->d_sort_keys, ws->d_sort_temp, ws->d_plans, ws->d_tasks, ws->d_aln_cand, ws->d_aln_read, ws->d_spill, ws->d_jobs, ws->d_job_ops, ws->d_job_len, ws->d_chunk_off, ws->d_chunk_paired, ws->d_chunk_stats, ws->d_aln_ctl, ws->d_used, ws->d_cand_off, ws->d_cseed_off, ws->d_dense_cands, ws->d_dense_seeds, ws->d_cands, ws->d_cand_seeds, ws->d_n_cands, ws->d_taken, ws->d_hits, ws->d_packed, ws->d_seeds_per_read, ws->d_ctl, ws->d_scan_temp, ws->d_enc, ws->d_read_off, ws->d_seed_off, ws->d_seeds, ws->d_vr_n, ws->d_vr_off, ws->d_vr_read, ws->d_vr_pos, ws->d_claim, ws->d_step};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	if (ws->h_seeds) (void)hipHostFree(ws->h_seeds);
@@ -638,6 +639,26 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	a.seed_capacity = seed_capacity;
 	a.read_len = nullptr; a.n_seg = 0; a.seg_stride = 0;
 	for (int64_t &x : a.seg_prefix) x = 0;
+	// long reads in SensitiveMode: walks from every segment start instead of one lane per read (seed_kernels.hpp, SeedArgs::vr_read)
+	// (KG_NO_SEGMENTS / KG_SEG_LEN are read per call: A/B runs and the tests switch them inside one process)
+	const bool no_segments = getenv("KG_NO_SEGMENTS") != nullptr;
+	const int seg_len = getenv("KG_SEG_LEN") ? std::max(128, atoi(getenv("KG_SEG_LEN"))) : 512;
+	if (a.mode == KG_MODE_SENSITIVE && !no_segments && ws->group_segments == 0 && n_bases >= 4 * (int64_t)seg_len * n_reads) {
+		if (!ws->d_vr_n) {
+			ws->vr_capacity = ws->max_bases / 128 + ws->max_reads + 64;
+			HIP_TRY(hipMalloc((void **)&ws->d_vr_n, 4 * (size_t)(ws->max_reads + 2)));
+			HIP_TRY(hipMalloc((void **)&ws->d_vr_off, 8 * (size_t)(ws->max_reads + 2)));
+			HIP_TRY(hipMalloc((void **)&ws->d_vr_read, 4 * (size_t)ws->vr_capacity));
+			HIP_TRY(hipMalloc((void **)&ws->d_vr_pos, 4 * (size_t)ws->vr_capacity));
+			HIP_TRY(hipMalloc((void **)&ws->d_claim, 4 * (size_t)((ws->max_bases >> 5) + ws->max_reads + 64)));
+			HIP_TRY(hipMalloc((void **)&ws->d_step, (size_t)ws->max_bases + 64));
+		}
+		a.seg_len = seg_len;
+		a.vr_read = ws->d_vr_read; a.vr_pos = ws->d_vr_pos;
+		a.vr_total = reinterpret_cast<const unsigned long long *>(ws->d_vr_off + n_reads);
+		a.claim = ws->d_claim; a.step = ws->d_step;
+		HIP_TRY(launch_seed_segments(a, ws->d_vr_n, ws->d_vr_off, ws->d_vr_read, ws->d_vr_pos, ws->d_scan_temp, ws->scan_bytes, ws->ix->n_cu, st));
+	}
 	if (ws->group_segments > 0) {          // (kgi_seed_group: one launch over several lanes' batches)
 		a.read_len = ws->group_read_len;
 		a.n_seg = ws->group_segments;

@@ -128,6 +128,12 @@ struct kg_workspace {
 	int64_t last_cand_seeds = 0;        // ... and their seeds
 	bool last_pacbio = false;           // ... chained for long reads (GenerateAlignmentCandidateForPacBioSeq)
 	void *lr = nullptr;                 // scratch of the long-read report (abi_long.hip: kg_longread_batch)
+	// SensitiveMode within a read in parallel (SeedArgs::vr_read): allocated with the first long-read batch
+	int32_t *d_vr_n = nullptr, *d_vr_read = nullptr, *d_vr_pos = nullptr;
+	int64_t *d_vr_off = nullptr;
+	uint32_t *d_claim = nullptr;
+	uint8_t *d_step = nullptr;
+	int64_t vr_capacity = 0;
 	bool last_ascii = false;            // the resident reads are characters (KG_INPUT_ASCII)
 	void *d_aln_cand = nullptr;         // per-candidate state, one block
 	int64_t aln_cand_capacity = 0;

@@ -53,6 +53,20 @@ struct SeedArgs {
 	uint32_t *sort_keys;      // [4 * max_reads]: keys in, keys out, ids in, ids out
 	void *sort_temp;
 	size_t sort_temp_bytes;
+	// SensitiveMode within a read in parallel (long reads): the search of IdentifySeedPairs_SensitiveMode at read position p depends on the read
+	// alone (it sees at most the 30 bases behind p, src/AlignmentCandidates.cpp:132-169), and where the loop goes next depends only on its result --
+	// the loop is a walk p -> next(p).  A read is cut into segments of seg_len bases; a lane starts a walk at every segment start (a "virtual read":
+	// vr_read / vr_pos).  Before a lane searches at p it CLAIMS p (one bit per read position, atomicOr): a position somebody claimed already is
+	// searched exactly once by that somebody, who walks on from it -- the lane's walk has merged and ends.  The walk from position 0 is therefore
+	// covered link by link whichever lane ran which part; every search writes its advance to step[p]; seg_path_kernel follows the links from 0 and
+	// marks them; seg_filter_kernel keeps the hits of marked positions and gives them their places in the read's seed list.  The walks from the later
+	// starts that were not on the path (they merge after ~160 bases at 15 % error) are the price: ~15 % more searches for a chain of ~45 dependent
+	// searches instead of ~470 per 7 kb read.  null vr_read: one lane per read, as the reference's loop.
+	const int32_t *vr_read = nullptr, *vr_pos = nullptr;
+	const unsigned long long *vr_total = nullptr;      // number of virtual reads (device)
+	uint32_t *claim = nullptr;                        // read r's bits start at word (read_off[r] >> 5) + r
+	uint8_t *step = nullptr;                          // [n_bases]: advance of the search (or skip) at every position visited; bit 7: on the walk from 0
+	int seg_len = 0;
 	Hit *hits;
 	int64_t max_hits;
 	int32_t *seeds_per_read;
@@ -67,6 +81,8 @@ size_t scan_temp_bytes(int64_t max_reads);
 size_t sort_temp_bytes(int64_t max_reads);
 // ev: optional array of 5 events recorded before/after the four phases (search | scan | locate | sort)
 hipError_t launch_seed_batch(const SeedArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream, hipEvent_t *ev);
+// the virtual reads of a batch (segment starts): vr_n[r] = segments of read r, vr_off = their exclusive scan (vr_off[n_reads] = total), then the two lists
+hipError_t launch_seed_segments(const SeedArgs &a, int32_t *vr_n, int64_t *vr_off, int32_t *vr_read, int32_t *vr_pos, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream);
 hipError_t launch_build_planes(const uint32_t *occ, uint64_t n_blocks64, uint4 *planes, hipStream_t stream);
 hipError_t launch_build_planes_k(FmView ix, int k_steps, uint4 *planes_k, uint64_t n_lines, uint64_t *t2_dev, uint64_t *t3_dev, hipStream_t stream);
 hipError_t launch_planes2_check(const FmView &ix, uint64_t samples, uint64_t seed, unsigned long long *bad_dev, hipStream_t stream);

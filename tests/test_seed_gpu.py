@@ -30,6 +30,41 @@ def test_sensitive_mode_golden(golden, which, request):
     _check_reads(ix, split(golden["sens_enc"], golden["sens_off"]), split(golden["sens_seeds"], golden["sens_seed_off"]), 1)
 
 
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_dense8"])
+@pytest.mark.parametrize("seg_len", [128, 192, 512])
+def test_sensitive_mode_walks_from_segment_starts(golden, which, seg_len, request, oracle_small, monkeypatch):
+    """SensitiveMode within a read in parallel (SeedArgs::vr_read, search.inc): the loop of IdentifySeedPairs_SensitiveMode
+    (src/AlignmentCandidates.cpp:132-169) is a walk p -> next(p) whose links depend on the read alone; lanes start a walk at every segment
+    start, claim positions before they search them, and the walk from 0 is put together from the links afterwards.  Same seeds as the
+    reference's golden vectors and as the oracle on long reads with N runs, at three segment lengths, and as one lane per read (KG_NO_SEGMENTS)."""
+    import os
+    from kart_amd import synth
+    from kart_amd.index_build import read_fasta
+    from conftest import GOLDEN
+    ix = request.getfixturevalue(which)
+    monkeypatch.setenv("KG_SEG_LEN", str(seg_len))
+    reads = split(golden["sens_enc"], golden["sens_off"])
+    long_gold = [(r, w) for r, w in zip(reads, split(golden["sens_seeds"], golden["sens_seed_off"])) if len(r) >= 4 * seg_len]
+    if long_gold:
+        _check_reads(ix, [r for r, _ in long_gold], [w for _, w in long_gold], 1)
+    # long reads (7 kb at 15 % error, 3 kb at 2 %, N runs, a read that is ALL N, reads around the segment length) against the oracle
+    genome = {n: s_ for n, _, s_ in read_fasta(os.path.join(GOLDEN, "small.fa"))}
+    _, r1 = synth.simulate_long_reads(genome, 40, seed=3, read_len=7000, err=0.15, indel_err_frac=0.1)
+    _, r2 = synth.simulate_long_reads(genome, 20, seed=4, read_len=3000, err=0.02, indel_err_frac=0.3)
+    _, r3 = synth.simulate_long_reads(genome, 12, seed=5, read_len=4 * seg_len + 7, err=0.1)
+    rs = [synth.encode(np.array(r, dtype=np.uint8)) for r in list(r1) + list(r2) + list(r3)]
+    rs[2][1000:1100] = 4; rs[5][seg_len - 3:seg_len + 40] = 4; rs[9][:] = 4; rs[11][::17] = 4       # (no N run at a read's end: SURVEY App. B-10 is fenced off)
+    got = ix.IdentifySeedPairs_SensitiveMode(rs)
+    enc, off = api.concat_reads(rs)
+    so, seeds = oracle_small.seed_batch(enc, off, 1)
+    for i in range(len(rs)):
+        w = seeds[so[i]:so[i + 1]].astype(api.SEED_DT)
+        assert len(got[i]) == len(w) and (got[i] == w).all(), (i, len(got[i]), len(w))
+    monkeypatch.setenv("KG_NO_SEGMENTS", "1")
+    again = ix.IdentifySeedPairs_SensitiveMode(rs)
+    assert all(len(a) == len(b) and (a == b).all() for a, b in zip(got, again))
+
+
 def test_counters_match_oracle(golden, gpu_index, oracle_small):
     """the kernel's work counters are the ones the roofline figure is computed from"""
     oracle_small.counters(reset=True)

@@ -11,7 +11,8 @@ run() { echo "== $1"; env KART_AMD_VERBOSE=1 $1 $CMD > /tmp/ab_long.log 2>&1; sh
 for c in ${CHUNKS:-2048:2048 4096:4096 8192:8192}; do
   run "KART_AMD_PACBIO_CHUNKS=${c%:*} KART_AMD_PACBIO_MAX_CHUNKS=${c#*:}"
 done
-run "KART_AMD_HOST_LONG=1"
+IFS=";"; for v in ${VARIANTS:-}; do unset IFS; [ -n "$v" ] && run "$v"; IFS=";"; done; unset IFS
+[ -z "$NO_HOST_LONG" ] && run "KART_AMD_HOST_LONG=1"
 if [ "$CHECK" -gt 0 ]; then
   FQ=$(echo $CMD | sed 's/.*-f \([^ ]*\) .*/\1/')
   head -n $((4 * CHECK)) $FQ > /tmp/ab_long_check.fq
