@@ -132,6 +132,18 @@ class StreamTiming(C.Structure):
 _lib = None
 
 
+def _check_one_hip_runtime(L):
+    """Two copies of libamdhip64 in one process (PyTorch's and /opt/rocm's) each own a HIP runtime, and the one that touches the device second
+    finds none: kg_device_count() then returns 0 with no hint why.  Say so at load time -- only when that is what happened."""
+    try:
+        paths = {l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}
+    except OSError:
+        return
+    if len({os.path.realpath(p_) for p_ in paths}) > 1 and "torch" in sys.modules and L.kg_device_count() <= 0:
+        raise KartAmdError("two HIP runtimes are loaded in this process (%s): import torch BEFORE kart_amd.api.load_library(), or set KART_AMD_NO_TORCH=1 and do "
+                           "not import torch afterwards" % ", ".join(sorted(paths)))
+
+
 def load_library() -> C.CDLL:
     """Load libkart_amd.so; fails loudly when the HIP extension has not been built."""
     global _lib
@@ -149,9 +161,10 @@ def load_library() -> C.CDLL:
     if "torch" not in sys.modules and not os.environ.get("KART_AMD_NO_TORCH"):
         try:
             import torch  # noqa: F401
-        except ImportError:
+        except Exception:          # (not installed, or installed and broken -- an OSError from a missing shared object, ...: the library then brings /opt/rocm's runtime)
             pass
     L = C.CDLL(LIB_PATH)
+    _check_one_hip_runtime(L)
     L.kg_last_error.restype = C.c_char_p
     L.kg_index_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.kg_index_destroy.argtypes = [C.c_void_p]

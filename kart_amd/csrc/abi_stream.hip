@@ -394,7 +394,11 @@ static int group_seed(kg_stream *s, int lane, int64_t n, int64_t n_bases, int64_
 	if (sg.aborted) return fail(KG_ERR_ARG, "kg_stream_map: the stream's seeding groups were aborted");
 	if (sg.absent_rounds[j] < 0) return fail(KG_ERR_ARG, "kg_stream_map: lane %d was declared absent until further notice (kg_stream_group_absent) and arrives with a batch", lane);
 	// (a lane that sits out a round and is back with a batch before that round has run waits for it)
-	sg.cv.wait(lk, [&]() { return sg.absent_rounds[j] == 0 || sg.aborted; });
+	if (!sg.cv.wait_for(lk, std::chrono::seconds(600), [&]() { return sg.absent_rounds[j] == 0 || sg.aborted; })) {
+		sg.aborted = true;
+		sg.cv.notify_all();
+		return fail(KG_ERR_ARG, "kg_stream_map: lane %d waited 600 s for the round it declared itself absent from", lane);
+	}
 	if (sg.aborted) return fail(KG_ERR_ARG, "kg_stream_map: the stream's seeding groups were aborted");
 	const int64_t my_round = sg.round;
 	sg.present[j] = true;
@@ -411,8 +415,11 @@ static int group_seed(kg_stream *s, int lane, int64_t n, int64_t n_bases, int64_
 		int rc = KG_OK;
 		for (int i = 0; i < sg.size && rc == KG_OK; ++i) {
 			counts[i] = sg.present[i] ? sg.n_reads[i] : 0;
-			if (sg.present[i]) { if (hipStreamWaitEvent(gw->stream, s->lanes[(size_t)(sg.first + i)].ev_parsed, 0) != hipSuccess) rc = fail(KG_ERR_NO_DEVICE, "kg_stream_map: hipStreamWaitEvent"); }
-			else if (hipMemsetAsync(gw->group_read_len + (int64_t)i * sg.stride, 0, 4 * (size_t)sg.stride, gw->stream) != hipSuccess) rc = fail(KG_ERR_NO_DEVICE, "kg_stream_map: hipMemsetAsync");
+			// every lane publishes its slots ON ITS OWN STREAM -- a batch in kg_stream_parse, an absence (all slots empty) in kg_stream_group_absent --
+			// and records ev_parsed behind it: the round waits for all of them.  (Round 4 zeroed an absent lane's slots here, on the group's
+			// stream: nothing ordered that against the lane's publish of its NEXT batch, which it may parse before this round has run --
+			// the memset could then wipe the lengths and the whole batch came out unmapped.)
+			if (hipStreamWaitEvent(gw->stream, s->lanes[(size_t)(sg.first + i)].ev_parsed, 0) != hipSuccess) rc = fail(KG_ERR_NO_DEVICE, "kg_stream_map: hipStreamWaitEvent");
 		}
 		if (rc == KG_OK) rc = kgi_seed_group(gw, KG_MODE_FAST | KG_INPUT_ASCII, s->min_seed_len, KG_OCC_THR_DEFAULT, sg.size, sg.stride, counts, sg.seed_base);
 		if (rc == KG_OK && (hipMemcpyAsync(sg.h_ctl, gw->d_ctl, 8 * kCtlWords, hipMemcpyDeviceToHost, gw->stream) != hipSuccess || kgi_sync(gw) != hipSuccess))
@@ -641,12 +648,27 @@ int kg_stream_group_absent(kg_stream *s, int lane, int rounds)
 	const int j = lane - sg.first;
 	std::unique_lock<std::mutex> lk(sg.mu);
 	if (sg.present[j]) return fail(KG_ERR_ARG, "kg_stream_group_absent: lane %d is inside a round", lane);
+	if (rounds != 0) {
+		// the lane's slots of the group's batch are empty from here on (until its next kg_stream_parse publishes a batch): on the lane's own stream
+		Lane &l = s->lanes[(size_t)lane];
+		HIP_TRY(hipSetDevice(s->ix->device));
+		HIP_TRY(launch_group_publish(l.ws->d_read_off, 0, sg.stride, (int64_t)j * sg.seg_bases, sg.ws->d_read_off + (int64_t)j * sg.stride, sg.ws->group_read_len + (int64_t)j * sg.stride,
+		                             s->ix->n_cu, l.ws->stream));
+		HIP_TRY(hipEventRecord(l.ev_parsed, l.ws->stream));
+	}
 	sg.absent_rounds[j] = rounds;
 	if (rounds == 0) sg.aborted = false;               // (a new run: the lanes take part again; an aborted run's half-finished round is forgotten)
 	// the round may be complete now: everybody else has arrived and waits
 	int accounted = sg.arrived;
 	for (int i = 0; i < sg.size; ++i) accounted += (!sg.present[i] && sg.absent_rounds[i] != 0) ? 1 : 0;
 	if (rounds != 0 && sg.arrived > 0 && accounted >= sg.size) sg.cv.notify_all();     // a waiting lane runs the round (group_seed's loop)
+	if (rounds > 0 && sg.arrived == 0 && accounted >= sg.size) {
+		// every lane of the group sits this round out: nobody will run it, so it is over here (the lanes would wait for it for ever)
+		for (int i = 0; i < sg.size; ++i)
+			if (sg.absent_rounds[i] > 0) sg.absent_rounds[i]--;
+		sg.round++;
+		sg.cv.notify_all();
+	}
 	return KG_OK;
 }
 
