@@ -95,9 +95,10 @@ __device__ bool resolve_overlap(FragPairs &v, int i, int j)
 	return master;
 }
 
-// IdentifyNormalPairs(rlen, glen, v) for a fragment (glen > 0), src/AlignmentCandidates.cpp:420-490, by ONE lane on the LDS arrays.
-// byr: scratch of v.num entries (read-position order).  false: more pairs than `cap`.
-__device__ bool identify_normal_pairs(int rlen, int glen, FragPairs &v, uint16_t *byr, int cap)
+// IdentifyNormalPairs(rlen, glen, v) for a fragment (glen > 0), src/AlignmentCandidates.cpp:420-490, by ONE lane on the LDS arrays, in two parts:
+// filter_pairs = the three seed filters (:426-428), gap_pairs = the gap pairs between neighbours and the head / tail pairs (:437-488).
+// byr: scratch of v.num entries (read-position order).  gap_pairs returns false for more pairs than `cap`.
+__device__ void filter_pairs(FragPairs &v, uint16_t *byr)
 {
 	if (v.num > 1) {
 		// RemoveTandemRepeatSeeds, :235-260: every read position hit by more than one seed goes
@@ -166,6 +167,12 @@ __device__ bool identify_normal_pairs(int rlen, int glen, FragPairs &v, uint16_t
 			}
 			if (any) erase_empty(v);
 		}
+	}
+}
+
+__device__ bool gap_pairs(int rlen, int glen, FragPairs &v, int cap)
+{
+	if (v.num > 1) {
 		// the gaps between consecutive seeds, appended and then moved to their place in (gPos, rPos) order (:437-455; the keys are distinct)
 		const int num = v.num;
 		int added = 0;
@@ -227,6 +234,7 @@ __device__ bool identify_normal_pairs(int rlen, int glen, FragPairs &v, uint16_t
 // changes nothing).  Then the result is the matches with the gap pairs between neighbours interleaved -- a gap pair sorts right behind
 // the match it follows: its genome position is the match's end, at most the next match's start, and at a tie its read position is
 // smaller -- plus the head and tail pairs (:437-488).  Returns the new count, or -1 without touching anything when the case is not that.
+template <int kC>
 __device__ int identify_normal_pairs_wave(int rlen, int glen, int n, int lane, int16_t *, frp_t *gPos, frp_t *rPos, frp_t *rLen, frp_t *gLen, uint8_t *simple)
 {
 	bool ok = true;
@@ -234,8 +242,7 @@ __device__ int identify_normal_pairs_wave(int rlen, int glen, int n, int lane, i
 		ok = ok && rPos[i] < rPos[i + 1] && rPos[i] + rLen[i] - 1 < rPos[i + 1] && gPos[i] + gLen[i] - 1 < gPos[i + 1];
 	if (__ballot(!ok)) return -1;
 	const bool head = rPos[0] > 0 || gPos[0] > 0;             // (:457-470; glen > 0 here: the genome side's gap is gPos[0])
-	// every lane takes its matches (one per 64: n <= kFragMaxRuns) and the gap pair behind each into registers, then all write
-	constexpr int kC = (kFragMaxRuns + 63) / 64;
+	// every lane takes its matches (one per 64: n <= 64 kC) and the gap pair behind each into registers, then all write
 	int mg[kC], mr[kC], ml_r[kC], ml_g[kC], dst[kC], gr[kC], gg[kC];
 	bool has[kC];
 	int before = head ? 1 : 0;                                  // output slots in front of this chunk
@@ -282,17 +289,37 @@ __device__ int identify_normal_pairs_wave(int rlen, int glen, int n, int lane, i
 }  // namespace
 
 // One wave per task of the level [level_begin[level], level_begin[level + 1]).
+// Two instantiations can share a level (round 5, KG_FRAG_TWO_TIERS=1; off by default -- no gain, see launch_frag_partition): the SMALL one (sides up to kFragSmallLen, up to kFragSmallRuns matches: 4 KB of LDS, the CU's wave slots full)
+// takes what fits it -- nearly every task: a fragment pair of a 7 kb read is ~350 x 350 bases with ~14 matches -- and leaves the rest (task.status 2) to the
+// full-size one (15 KB, 10 waves per CU), which runs behind it on the same stream.  The kernel waits on the LDS in two thirds of its wave cycles
+// (profiles/r05o_pacbio_pmc_summary.json): more waves per SIMD is what hides that.
+template <int kMaxLen, int kMaxRuns, bool kSmall>
 __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int level)
 {
-	__shared__ uint64_t s_rd[kFragMaxLen / 32 + 2], s_tx[kFragMaxLen / 32 + 2];
-	__shared__ frp_t s_gPos[kFragMaxPairs], s_rPos[kFragMaxPairs], s_rLen[kFragMaxPairs], s_gLen[kFragMaxPairs];
-	__shared__ uint8_t s_simple[kFragMaxPairs];
-	__shared__ frp_t s_run_r[kFragMaxRuns], s_run_d[kFragMaxRuns], s_run_l[kFragMaxRuns];
-	__shared__ uint16_t s_byr[kFragMaxPairs];
+	constexpr int kMaxPairs = 2 * kMaxRuns + 2;
+	constexpr int kC = (kMaxRuns + 63) / 64;
+	__shared__ uint64_t s_rd[kMaxLen / 32 + 2], s_tx[kMaxLen / 32 + 2];
+	__shared__ frp_t s_gPos[kMaxPairs], s_rPos[kMaxPairs], s_rLen[kMaxPairs], s_gLen[kMaxPairs];
+	__shared__ uint8_t s_simple[kMaxPairs];
+	__shared__ frp_t s_run_r[kMaxRuns], s_run_d[kMaxRuns], s_run_l[kMaxRuns];
+	__shared__ uint16_t s_byr[kMaxPairs];
 	__shared__ int s_n, s_bad;
 	const int lane = threadIdx.x;
 	const unsigned long long t0 = a.ctl[FC_LEVEL0 + level], t1 = a.ctl[FC_LEVEL0 + level + 1];
-	for (unsigned long long ti = t0 + blockIdx.x; ti < t1; ti += gridDim.x) {
+	// 64 tasks are looked at per step, one per lane: which of them are this instantiation's (the small one marks what outgrows it, status 2; with
+	// a.one_tier the full-size one takes everything); the wave then works through those one after the other
+	for (unsigned long long tb = t0 + (unsigned long long)blockIdx.x * 64; tb < t1; tb += (unsigned long long)gridDim.x * 64) {
+	bool mine = false;
+	if (tb + lane < t1) {
+		FragTask &tk = a.tasks[tb + lane];
+		const bool small_fits = tk.rL <= kFragSmallLen && tk.gL <= kFragSmallLen;
+		if (kSmall) { mine = small_fits; if (!small_fits) tk.status = 2; }
+		else mine = a.one_tier || tk.status == 2 || !small_fits;
+	}
+	uint64_t todo = __ballot(mine);
+	while (todo) {
+		const unsigned long long ti = tb + (unsigned long long)(__ffsll((unsigned long long)todo) - 1);
+		todo &= todo - 1;
 		FragTask &task = a.tasks[ti];
 		const long long c0 = a.prof ? clock64() : 0;
 		long long c1 = c0, c2 = c0, c3 = c0, c4 = c0;
@@ -303,7 +330,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		bool whole_job = !(rL > 30 && gL > 30);            // src/tools.cpp:146
 		bool host = false;
 		int why = -1;                                      // (diagnostics: which limit sent the request back, FC_WHY)
-		if (!whole_job && (rL > kFragMaxLen || gL > kFragMaxLen)) { host = true; why = 0; }
+		if (!whole_job && (rL > kMaxLen || gL > kMaxLen)) { host = true; why = 0; }
 		int n_runs = 0;
 		if (!whole_job && !host) {
 			int max_shift;
@@ -380,7 +407,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 						if (m == 0xffffffffu) { run += 32; continue; }
 						auto emit = [&](int start, int len) {
 							int k = atomicAdd(&s_n, 1);
-							if (k < kFragMaxRuns) { s_run_r[k] = start; s_run_d[k] = d; s_run_l[k] = len; }
+							if (k < kMaxRuns) { s_run_r[k] = start; s_run_d[k] = d; s_run_l[k] = len; }
 						};
 						const int t = __ffs((int)~m) - 1;                                   // equal bases from position 0 up
 						if (run + t >= 8) emit(base - run, run + t);
@@ -400,12 +427,15 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 					}
 					if (run >= 8) {
 						int k = atomicAdd(&s_n, 1);
-						if (k < kFragMaxRuns) { s_run_r[k] = t_hi - run; s_run_d[k] = d; s_run_l[k] = run; }
+						if (k < kMaxRuns) { s_run_r[k] = t_hi - run; s_run_d[k] = d; s_run_l[k] = run; }
 					}
 				}
 				__syncthreads();
 				n_runs = s_n;
-				if (n_runs > kFragMaxRuns) { host = true; why = 2; }
+				if (n_runs > kMaxRuns) {
+					if (kSmall) { if (lane == 0) task.status = 2; __syncthreads(); continue; }       // (more matches than the small arrays hold: the full-size kernel's)
+					host = true; why = 2;
+				}
 				if (a.prof) c2 = clock64();
 			}
 			if (!host && n_runs > 0) {
@@ -423,16 +453,32 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		}
 		// IdentifyNormalPairs on the LDS arrays: by the whole wave where the seed filters have nothing to do, else by lane 0 (they are
 		// sequential by nature)
+		// (round 5: where the filters DO have something to do -- four tasks in ten carry a chance match on a foreign diagonal -- lane 0 runs the filters
+		//  alone and the whole wave then interleaves the gap pairs as in the clean case; inserting them one by one into the sorted LDS arrays was most
+		//  of what the kernel waited for: 2.3 k LDS instructions per task, 67 % of its wave cycles waiting, profiles/r05o_pacbio_pmc_summary.json)
 		int fast_num = -1;
-		if (!host && !whole_job && n_runs > 0 && !a.no_fast_pairs) fast_num = identify_normal_pairs_wave(rL, gL, n_runs, lane, nullptr, s_gPos, s_rPos, s_rLen, s_gLen, s_simple);
-		if (lane == 0 && fast_num >= 0) s_n = fast_num;
-		if (lane == 0 && fast_num < 0) {
+		const bool eligible = !host && !whole_job && n_runs > 0;
+		if (eligible && !a.no_fast_pairs) fast_num = identify_normal_pairs_wave<kC>(rL, gL, n_runs, lane, nullptr, s_gPos, s_rPos, s_rLen, s_gLen, s_simple);
+		if (fast_num < 0) {
 			FragPairs v;
 			v.gPos = s_gPos; v.rPos = s_rPos; v.rLen = s_rLen; v.gLen = s_gLen; v.simple = s_simple; v.num = n_runs;
-			if (!host && !whole_job && n_runs > 0 && !identify_normal_pairs(rL, gL, v, s_byr, kFragMaxPairs)) { host = true; s_bad = 2; }
-			if (!host && !whole_job && v.num == 0) whole_job = true;            // no common 8-mer survived: the whole fragment is one alignment (:214-221)
-			s_n = host ? -1 : whole_job ? 0 : v.num;
+			if (lane == 0) {
+				if (eligible) filter_pairs(v, s_byr);
+				s_n = eligible ? v.num : 0;
+			}
+			__syncthreads();
+			const int n2 = s_n;
+			__syncthreads();
+			if (eligible && n2 > 0 && !a.no_fast_pairs) fast_num = identify_normal_pairs_wave<kC>(rL, gL, n2, lane, nullptr, s_gPos, s_rPos, s_rLen, s_gLen, s_simple);
+			if (lane == 0 && fast_num < 0) {
+				v.num = n2;
+				bool h2 = host, wj = whole_job;
+				if (eligible && n2 > 0 && !gap_pairs(rL, gL, v, kMaxPairs)) { h2 = true; s_bad = 2; }
+				if (eligible && v.num == 0) wj = true;                       // no common 8-mer survived: the whole fragment is one alignment (:214-221)
+				s_n = h2 ? -1 : wj ? 0 : v.num;
+			}
 		}
+		if (lane == 0 && fast_num >= 0) s_n = fast_num;
 		__syncthreads();
 		if (a.prof) c4 = clock64();
 		// ... and the whole wave turns the pairs into the task's pieces: literal runs, NW jobs, sub-tasks -- counted first, reserved with ONE
@@ -540,6 +586,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		}
 		__syncthreads();
 	}
+	}
 }
 
 // the tasks appended while `level` was processed are the next level
@@ -635,7 +682,13 @@ hipError_t launch_frag_partition(const FragArgs &a, int n_cu, hipStream_t stream
 	for (int level = 0; level < kFragMaxDepth; ++level) {
 		// (the level's task count lives on the device: the grid is sized for the requests at level 0 and for a share of them below)
 		const int64_t guess = level == 0 ? a.n : a.n / 4 + 1024;
-		hipLaunchKernelGGL(frag_partition_kernel, dim3(grid_of(guess, 1, n_cu * 32)), dim3(64), 0, stream, a, level);
+		// (tried in round 5 and left as an A/B aid, KG_FRAG_TWO_TIERS=1: the small instantiation in front -- 4 KB of LDS, the CU's wave slots full -- changes
+		//  nothing, 4.83 s against 4.74 s per 2 M long reads, profiles/r05r_ab_long_2m.log: the kernel keeps the LDS pipeline itself busy -- SQ_ACTIVE_INST_LDS
+		//  ~ SQ_BUSY_CYCLES in profiles/r05o_pacbio_pmc_summary.json -- so more waves only queue for it)
+		FragArgs b = a;
+		b.one_tier = getenv("KG_FRAG_TWO_TIERS") != nullptr ? 0 : 1;
+		if (!b.one_tier) hipLaunchKernelGGL((frag_partition_kernel<kFragSmallLen, kFragSmallRuns, true>), dim3(grid_of(guess / 64 + 1, 1, n_cu * 32)), dim3(64), 0, stream, b, level);
+		hipLaunchKernelGGL((frag_partition_kernel<kFragMaxLen, kFragMaxRuns, false>), dim3(grid_of(guess / 64 + 1, 1, n_cu * 10)), dim3(64), 0, stream, b, level);
 		hipLaunchKernelGGL(frag_level_kernel, dim3(1), dim3(64), 0, stream, a, level);
 	}
 	return hipGetLastError();

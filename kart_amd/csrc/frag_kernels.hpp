@@ -7,6 +7,7 @@ namespace kg {
 constexpr int kFragMaxLen = 8192;        // longest side of a fragment the partition kernel takes (2-bit codes of both sides in the LDS; 4096 until round 5:
                                          // 1.2 % of 7 kb reads on the hg38-sized genome have a stretch of 4-7 kb without seeds -- inside a repeat copy every seed has more than 50 hits)
 constexpr int kFragMaxRuns = 383;        // exact matches of >= 8 bases per fragment pair (255 until round 5; a 7 kb stretch at 15 % error has ~290)
+constexpr int kFragSmallLen = 1024, kFragSmallRuns = 127;   // the partition kernel's small instantiation (frag_kernels.hip)
 constexpr int kFragMaxPairs = 2 * kFragMaxRuns + 2;   // ... and the normal pairs IdentifyNormalPairs makes of them
 constexpr int kFragMaxDepth = 6;         // levels of the -pacbio recursion (src/tools.cpp:197)
 
@@ -41,6 +42,7 @@ struct FragArgs {
 	int pacbio, max_gaps;
 	int no_fast_pairs;              // KG_FRAG_NO_FAST_PAIRS (A/B aid): IdentifyNormalPairs always by lane 0
 	int prof;                       // KG_FRAG_PROF: wave cycles per phase of the partition kernel into ctl[FC_PROF ..]
+	int one_tier = 0;               // KG_FRAG_ONE_TIER (A/B aid): the partition kernel's full-size instantiation takes every task
 	// work lists
 	FragTask *tasks;
 	int64_t task_capacity;
