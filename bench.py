@@ -721,6 +721,14 @@ def run(args, fallback_note):
             line["other_configs"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     sess.close()
     torch.cuda.empty_cache()
+    if world == 1 and large and not args.no_other_configs:
+        # configs[1] has an index of its own: a second session, opened once the large one has left the device (beside its 168 GB + the
+        # stream's lanes a second stream does not fit: the first attempt ended the run with an allocation failure, profiles/r05s)
+        try:
+            mem1 = host_memory()
+            line.setdefault("other_configs", {})["configs[1]"] = config1(args, workdir, dev, threads, (mem1.get("usable") or (64 << 30)) * MEM_SHARE, os.path.join(ROOT, "oracle", "_ref", "kart"))
+        except Exception as exc:      # a side measurement must never cost the line
+            line.setdefault("other_configs", {})["configs[1]"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     if world == 1 and not args.no_seeding_leg:
         try:
             seed = seeding_leg(args, api, prefix, codes, dev, n_reads_leg=min(n_reads, 20_000_000), oracle_sample=0 if args.no_parity else 200_000)
@@ -984,6 +992,8 @@ def other_configs(args, sess, prefix, workdir, codes, dev, threads, cores, mem):
     fq = os.path.join(workdir, "cfg3_long.fq")
     write_long_reads(codes, n_long, read_len, 31, fq, dev)
     sam = os.path.join(workdir, "cfg3.sam")
+    sess.map(["-silent", "-f", fq, "-pacbio", "-o", sam])               # (warm-up: the two long-read workspaces, their scratch and the page-locked result arrays grow to the batch size)
+    os.remove(sam)
     st = sess.map(["-silent", "-f", fq, "-pacbio", "-o", sam])
     c3 = {"workload": "configs[3]: %d x %d bp single-end reads at 15 %% error, -pacbio, hg38-sized index" % (n_long, read_len),
           "value": (st.total_reads - st.unmapped) / st.map_seconds, "unit": "mapped reads/s", "map_seconds": round(st.map_seconds, 3), "sam_bytes": os.path.getsize(sam)}
@@ -1001,11 +1011,6 @@ def other_configs(args, sess, prefix, workdir, codes, dev, threads, cores, mem):
             os.remove(f)
     out["configs[3]"] = c3
     os.remove(fq)
-    # ---- configs[1]: E. coli-sized index --------------------------------------------------------------------------------
-    try:
-        out["configs[1]"] = config1(args, workdir, dev, threads, budget, ref)
-    except Exception as exc:      # a side measurement must never cost the line
-        out["configs[1]"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     return out
 
 
@@ -1016,7 +1021,7 @@ def config1(args, workdir, dev, threads, budget, ref):
     from kart_amd import api
     a1 = argparse.Namespace(genome_len=GENOME_LEN, bucketed=None, repeat_frac=0.45)
     prefix1, codes1, _ = prepare_index(a1, dev, 0, workdir, lambda: None)
-    n_pairs = int(max(100_000, min(10_000_000, budget // (2 * REC_BYTES + 2 * 450))))
+    n_pairs = int(max(100_000, min(5_000_000, budget // (2 * REC_BYTES + 2 * 450))))          # (10 M reads: "10M x 150 bp PE")
     f1, f2 = os.path.join(workdir, "cfg1_1.fq"), os.path.join(workdir, "cfg1_2.fq")
     write_fastq_pairs(codes1, n_pairs, 7, f1, f2, dev)
     del codes1
@@ -1040,11 +1045,13 @@ def config1(args, workdir, dev, threads, budget, ref):
         for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
             if f.endswith("_ecoli_pmc_summary.json"):
                 try:
-                    c1["l2"] = dict(json.load(open(os.path.join(pdir, f))).get("_l2", {}), source="profiles/" + f)
+                    l2 = json.load(open(os.path.join(pdir, f))).get("_l2")
+                    if l2:
+                        c1["l2"] = dict(l2, source="profiles/" + f)
                 except Exception:
                     pass
         if os.path.exists(ref) and not args.no_parity:
-            k = min(n_pairs, 200_000)
+            k = min(n_pairs, 100_000)
             p1, p2 = os.path.join(workdir, "cfg1_p1.fq"), os.path.join(workdir, "cfg1_p2.fq")
             for src, dst in ((f1, p1), (f2, p2)):
                 with open(src, "rb") as fi, open(dst, "wb") as fo:
@@ -1198,43 +1205,72 @@ def kernel_entries(stats, steps, n_reads, search_ms_per_step, args):
     return out
 
 
+_HOSTOUT_WORKER = r"""
+import mmap, os, sys, time
+import numpy as np
+path, total, blk, k, n, cpus = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+if cpus:
+    try:
+        os.sched_setaffinity(0, {int(c) for c in cpus.split(",")})
+    except OSError:
+        pass
+fd = os.open(path, os.O_RDWR)
+mm = mmap.mmap(fd, total)
+dst = np.frombuffer(mm, dtype=np.uint8)
+src = np.full(blk, 65, dtype=np.uint8)
+sys.stdout.write("ready\n"); sys.stdout.flush()
+sys.stdin.readline()                      # all workers start together
+t0 = time.perf_counter()
+for at in range(k * blk, total, n * blk):
+    np.copyto(dst[at:at + blk], src)
+sys.stdout.write("%.6f\n" % (time.perf_counter() - t0)); sys.stdout.flush()
+"""
+
+
+def _one_l3_domain():
+    """the CPUs that share a last-level cache with the CPU this process runs on (the pipeline keeps its writers on one such domain)"""
+    try:
+        cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else 0
+        txt = open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % cpu).read().strip()
+        cpus = []
+        for part in txt.split(","):
+            a, _, b = part.partition("-")
+            cpus.extend(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0)
+        return [c for c in cpus if c in allowed]
+    except Exception:
+        return []
+
+
 def host_output_entry(workdir, sam_bytes, step_seconds, threads):
     """What bounds a step is the host side of the output: fresh page-cache pages of the SAM file.  peak = this box's
-    rate for exactly that, measured here: N threads copying 64 MB blocks into shared mappings of ONE fresh file in the same directory
-    (numpy copies release the GIL; every 4 KB page is a write fault that allocates it), N = the writer threads the pipeline uses."""
-    import mmap
-    import threading
-    n_thr = max(2, min(8, threads * 7 // 16 + 1))
-    total = 6 << 30
-    blk = 64 << 20
+    rate for exactly that, measured here: N processes (no GIL between them), kept on the CPUs of ONE last-level cache as the pipeline's
+    writers are, copying 16 MB blocks into shared mappings of one fresh file in the same directory -- every 4 KB page a write fault that
+    allocates it; N = 8, one more than the pipeline's mapping writers."""
+    n_w = 8
+    total, blk = 8 << 30, 16 << 20
     path = os.path.join(workdir, "kart_bench_hostout_%d.bin" % os.getpid())
-    src = np.full(blk, 65, dtype=np.uint8)
+    cpus = _one_l3_domain()
     fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)
+    procs = []
     try:
         os.ftruncate(fd, total)
-        mm = mmap.mmap(fd, total)
-        dst = np.frombuffer(mm, dtype=np.uint8)
-        nxt = [0]
-        lock = threading.Lock()
-
-        def work():
-            while True:
-                with lock:
-                    at = nxt[0]
-                    nxt[0] += blk
-                if at >= total:
-                    return
-                np.copyto(dst[at:at + blk], src)
-        th = [threading.Thread(target=work) for _ in range(n_thr)]
+        for k in range(n_w):
+            procs.append(subprocess.Popen([sys.executable, "-c", _HOSTOUT_WORKER, path, str(total), str(blk), str(k), str(n_w), ",".join(map(str, cpus))],
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
+        for p_ in procs:
+            assert p_.stdout.readline().strip() == b"ready"
         t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        for p_ in procs:
+            p_.stdin.write(b"go\n"); p_.stdin.flush()
+        per = [float(p_.stdout.readline()) for p_ in procs]
         dt = time.perf_counter() - t0
-        del dst
-        mm.close()
+        for p_ in procs:
+            p_.wait(timeout=60)
     finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
         os.close(fd)
         try:
             os.remove(path)
@@ -1243,9 +1279,10 @@ def host_output_entry(workdir, sam_bytes, step_seconds, threads):
     peak = total / dt / 1e9
     achieved = sam_bytes / step_seconds / 1e9
     return {"bound": "host page cache", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak, "bytes_per_step": sam_bytes,
-            "peak_source": "%d threads x 64 MB copies into mappings of one fresh %d GB file in %s, measured in this run (%.2f s)" % (n_thr, total >> 30, workdir, dt),
-            "note": "the step's SAM text over the step's wall time against the rate at which this box hands out fresh pages of one tmpfs file: the pipeline's writers "
-                    "(mapped copies + one pwrite thread, kept on one L3 domain) run beside the lanes' input copies on the same cores"}
+            "peak_source": "%d processes on the %d CPUs of one last-level cache, 16 MB copies into mappings of one fresh %d GB file in %s, measured in this run (%.2f s; the "
+                           "slowest worker %.2f s)" % (n_w, len(cpus), total >> 30, workdir, dt, max(per)),
+            "note": "the step's SAM text over the step's wall time against the rate at which this box hands out fresh pages of one tmpfs file to eight writers on one cache "
+                    "domain; the pipeline's seven mapping writers + one pwrite thread share their cores with nothing, but the lanes' input copies and page-locked transfers run beside them"}
 
 
 def measured_traffic(n_reads, args, tag=None):

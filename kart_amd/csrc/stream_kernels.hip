@@ -209,23 +209,62 @@ __device__ __forceinline__ uint8_t comp_char(uint8_t c)
 	return u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : 'N';
 }
 
-// one wave per read: its characters into the batch's character array, reverse-complemented for the second read of a pair
+// ---- one line by ONE lane, 16 bytes per load and store (round 5).  Rounds 3-4 moved a line with all 64 lanes, a byte per lane and instruction: 31 bytes per
+// store instruction, the largest kernel of a run; assembling lines in the LDS first (the verdict's suggestion) was slower still -- 41 ms against 31 ms per 20 M
+// reads at 4 KB, 61 ms at 16 KB: fewer waves per CU for the same byte-wide loads (profiles/r05t_ab_sam_buf.log).  Here every lane copies its OWN read's line
+// piece by piece with unaligned 16-byte accesses: a wave instruction moves 1 KB, and the 64 lines of a wave are consecutive in the output.  A piece's last
+// partial word is copied whole where the line still has room behind it (the next piece overwrites the surplus), byte by byte at the line's end.
+struct __attribute__((packed, aligned(1))) SamU128 { uint64_t lo, hi; };
+
+__device__ __forceinline__ uint64_t comp8(uint64_t x)          // GetComplementaryBase (src/tools.cpp:3-17) on eight characters
+{
+	const uint64_t u = x & 0xDFDFDFDFDFDFDFDFull;
+	auto is = [&](uint64_t c) { const uint64_t t = u ^ (c * 0x0101010101010101ull); return ((~(((t & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | t | 0x7F7F7F7F7F7F7F7Full)) >> 7) * 0xFFull; };
+	const uint64_t mA = is(0x41), mC = is(0x43), mG = is(0x47), mT = is(0x54);
+	return (mA & 0x5454545454545454ull) | (mC & 0x4747474747474747ull) | (mG & 0x4343434343434343ull) | (mT & 0x4141414141414141ull) | (~(mA | mC | mG | mT) & 0x4E4E4E4E4E4E4E4Eull);
+}
+
+// n bytes of src to p; `end` = the end of the line (writing up to 15 bytes past the piece is fine below it)
+__device__ __forceinline__ uint8_t *lane_copy(uint8_t *p, const uint8_t *end, const uint8_t *src, int n)
+{
+	int k = 0;
+	for (; k + 16 <= n; k += 16) *reinterpret_cast<SamU128 *>(p + k) = *reinterpret_cast<const SamU128 *>(src + k);
+	if (k < n) {
+		if (p + k + 16 <= end) *reinterpret_cast<SamU128 *>(p + k) = *reinterpret_cast<const SamU128 *>(src + k);
+		else for (; k < n; ++k) p[k] = src[k];
+	}
+	return p + n;
+}
+
+// the same with the source read backwards (qualities reversed; kComp: the reverse complement of the bases, GetComplementarySeq src/tools.cpp:19-29)
+template <bool kComp>
+__device__ __forceinline__ uint8_t *lane_copy_reversed(uint8_t *p, const uint8_t *src, int n)
+{
+	int k = 0;
+	for (; k + 16 <= n; k += 16) {
+		const SamU128 v = *reinterpret_cast<const SamU128 *>(src + n - 16 - k);
+		SamU128 o;
+		o.lo = __builtin_bswap64(v.hi); o.hi = __builtin_bswap64(v.lo);
+		if (kComp) { o.lo = comp8(o.lo); o.hi = comp8(o.hi); }
+		*reinterpret_cast<SamU128 *>(p + k) = o;
+	}
+	for (; k < n; ++k) p[k] = kComp ? comp_char(src[n - 1 - k]) : src[n - 1 - k];
+	return p + n;
+}
+
+// one LANE per read (round 5; a wave per read and a byte per lane before): its characters into the batch's character array, reverse-complemented for the
+// second read of a pair -- 16 bytes per load and store; the reads lie back to back in the array, so a read's last partial word goes byte by byte
 __global__ __launch_bounds__(256) void fq_materialise_kernel(FqArgs a)
 {
-	const int lane = threadIdx.x & 63;
-	const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-	for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < a.n_reads; i += waves) {
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_reads; i += (int64_t)gridDim.x * blockDim.x) {
 		const int f = a.two_files ? (int)(i & 1) : 0;
 		const int64_t j = a.two_files ? i >> 1 : i;
 		const FqWindow &w = a.w[f];
 		const uint8_t *src = w.text + w.rec_seq[j];
 		const int n = w.rec_rlen[j];
 		uint8_t *dst = a.enc + a.read_off[i];
-		if (a.paired && (i & 1)) {
-			for (int k = lane; k < n; k += 64) dst[k] = comp_char(src[n - 1 - k]);
-		} else {
-			for (int k = lane; k < n; k += 64) dst[k] = src[k];
-		}
+		if (a.paired && (i & 1)) lane_copy_reversed<true>(dst, src, n);
+		else lane_copy(dst, dst + n, src, n);
 	}
 }
 
@@ -338,8 +377,7 @@ __global__ __launch_bounds__(256) void sam_size_kernel(SamArgs a)
 // A read with further records chained behind it (-m) takes the record-by-record path (format_chain).
 namespace {
 
-constexpr int kFmtA = 16, kFmtB = 92, kFmtT = 52, kFmtSlot = kFmtA + kFmtB + kFmtT;     // bytes of a lane's strings
-constexpr int kFmtBuf = 16384;                                                          // bytes of consecutive lines assembled in the LDS before a flush
+constexpr int kFmtA = 16, kFmtB = 96, kFmtT = 64, kFmtSlot = kFmtA + kFmtB + kFmtT;     // bytes of a lane's strings (every string 16-byte aligned: they are read back 16 bytes at a time)
 
 struct FmtDesc {                       // what phase 2 needs for one read
 	const uint8_t *name, *qual, *seq, *chr;
@@ -406,8 +444,7 @@ __device__ __forceinline__ uint8_t *copy_line(uint8_t *__restrict__ p, int lane,
 
 __global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
 {
-	__shared__ char str[64 * kFmtSlot];
-	__shared__ __attribute__((aligned(16))) uint8_t buf[kFmtBuf + 32];
+	__shared__ __attribute__((aligned(16))) char str[64 * kFmtSlot];
 	__shared__ FmtDesc desc[64];
 	__shared__ int chain_len[3];
 	const int lane = threadIdx.x;
@@ -444,55 +481,29 @@ __global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
 			desc[lane] = d;
 		}
 		__syncthreads();
-		// ---- phase 2: all lanes per read ------------------------------------------------------------------------------------
-		// The lines of consecutive reads are consecutive in a.sam (sam_off is a prefix sum): runs of them are assembled in the LDS and
-		// flushed with 16-byte stores (1 KB per wave instruction) -- one byte per lane and store, as rounds 3-4 wrote them, made this the
-		// largest kernel of a run at 31 bytes per store instruction (profiles/r04zg).  A line the buffer cannot hold, or one with chained
-		// records (-m), is written straight to a.sam as before.
+		// ---- phase 2: every lane its own line (the strings it printed in phase 1 lie in its LDS slot) ------------------------------
+		{
+			const FmtDesc d = desc[lane];
+			if ((d.flags & 1) && !(d.flags & 8)) {
+				const uint8_t *S = reinterpret_cast<const uint8_t *>(str) + lane * kFmtSlot;
+				uint8_t *p = d.out;
+				const uint8_t *const end = d.out + d.room_end_lo;
+				p = lane_copy(p, end, d.name, d.name_len);
+				p = lane_copy(p, end, S, d.nA);
+				p = lane_copy(p, end, d.chr, d.n_chr);
+				p = lane_copy(p, end, S + kFmtA, d.nB);
+				// the read as the record shows it: as held, or its reverse complement (GetComplementarySeq) with the qualities reversed
+				p = (d.flags & 2) ? lane_copy_reversed<true>(p, d.seq, d.rlen) : lane_copy(p, end, d.seq, d.rlen);
+				*p++ = '\t';
+				p = (d.flags & 4) ? lane_copy_reversed<false>(p, d.qual, d.qlen) : lane_copy(p, end, d.qual, d.qlen);
+				p = lane_copy(p, end, S + kFmtA + kFmtB, d.nT);
+				if (p != end) atomicAdd(&a.ctl[1], 1ull);
+			}
+		}
+		__syncthreads();
+		// ... and, all lanes per read, the rare ones with chained records (-m) or beyond the 16-bit fields
 		for (int i = 0; i < 64;) {
-			if (!(desc[i].flags & 1)) { ++i; continue; }
-			const bool direct = (desc[i].flags & 8) || desc[i].room_end_lo > kFmtBuf - 16;
-			if (!direct) {
-				uint8_t *const g0 = desc[i].out;
-				uint8_t *const g0a = g0 - ((uintptr_t)g0 & 15);                  // the buffer starts at the 16-byte word that holds the first byte
-				uint8_t *g1 = g0;
-				int j = i;
-				for (; j < 64; ++j) {
-					const FmtDesc &d = desc[j];
-					if (!(d.flags & 1)) continue;                               // (a read handed back: no line)
-					if ((d.flags & 8) || d.out != g1 || (d.out - g0a) + d.room_end_lo > kFmtBuf) break;
-					const char *S = str + j * kFmtSlot;
-					uint8_t *e = copy_line(buf + (d.out - g0a), lane, d.name, d.name_len, S, d.nA, d.chr, d.n_chr, S + kFmtA, d.nB, d.seq, d.rlen, (d.flags & 2) != 0, d.qual, d.qlen,
-					                       (d.flags & 4) != 0, S + kFmtA + kFmtB, d.nT);
-					if (lane == 0 && (int32_t)(e - (buf + (d.out - g0a))) != d.room_end_lo) atomicAdd(&a.ctl[1], 1ull);
-					g1 = d.out + d.room_end_lo;
-				}
-				__syncthreads();
-				// flush [g0, g1): the partial words at either end byte by byte (a neighbouring wave owns the rest of them), whole words in between
-				uint8_t *const w0 = g0a + (g0 == g0a ? 0 : 16), *const w1 = g1 - ((uintptr_t)g1 & 15);
-				if (w0 >= w1 + 16 || w1 < w0) {                                    // (less than one whole word)
-					for (uint8_t *q = g0 + lane; q < g1; q += 64) *q = buf[q - g0a];
-				} else {
-					if (g0 + lane < w0) g0[lane] = buf[(g0 - g0a) + lane];
-					const uint4 *src = reinterpret_cast<const uint4 *>(buf + (w0 - g0a));
-					uint4 *dst = reinterpret_cast<uint4 *>(w0);
-					const int n_words = (int)((w1 - w0) >> 4);
-					for (int k = lane; k < n_words; k += 64) dst[k] = src[k];
-					if (w1 + lane < g1) w1[lane] = buf[(w1 - g0a) + lane];
-				}
-				__syncthreads();
-				i = j;
-				continue;
-			}
-			const FmtDesc &d = desc[i];
-			if (!(d.flags & 8)) {
-				const char *S = str + i * kFmtSlot;
-				uint8_t *e = copy_line(d.out, lane, d.name, d.name_len, S, d.nA, d.chr, d.n_chr, S + kFmtA, d.nB, d.seq, d.rlen, (d.flags & 2) != 0, d.qual, d.qlen, (d.flags & 4) != 0,
-				                       S + kFmtA + kFmtB, d.nT);
-				if (lane == 0 && (int32_t)(e - d.out) != d.room_end_lo) atomicAdd(&a.ctl[1], 1ull);
-				++i;
-				continue;
-			}
+			if (!(desc[i].flags & 1) || !(desc[i].flags & 8)) { ++i; continue; }
 			// -m: every record chained behind the read's own, one after the other (lane 0 prints the fields of each)
 			const int64_t r = (g << 6) + i;
 			const ReadText t = read_text(a, r);
@@ -581,7 +592,7 @@ hipError_t launch_fq_materialise(const FqArgs &a, int n_cu, hipStream_t stream)
 {
 	if (a.n_reads <= 0) return hipSuccess;
 	kt_begin(KT_FQ_MATERIALISE, stream);
-	hipLaunchKernelGGL(fq_materialise_kernel, dim3(grid_of(a.n_reads, 4, n_cu * 32)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(fq_materialise_kernel, dim3(grid_of(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
 	kt_end(KT_FQ_MATERIALISE, stream);
 	return hipGetLastError();
 }
