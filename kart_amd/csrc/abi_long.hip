@@ -145,7 +145,8 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 		f.f1 = (const char *)ws->d_enc; f.off1 = a.req_f1; f.rlen = a.req_rl; f.gpos = a.req_g; f.glen = a.req_gl; f.n = n_req;
 		f.text = ix->d_text; f.two_genome_size = 2 * ix->l_pac;
 		f.pacbio = 1; f.max_gaps = 0;
-		f.prof = 0;
+		static const bool frag_prof = getenv("KG_FRAG_PROF") != nullptr;     // diagnostics: wave cycles per phase of the partition kernel
+		f.prof = frag_prof ? 1 : 0;
 		static const bool no_fast_pairs = getenv("KG_FRAG_NO_FAST_PAIRS") != nullptr;
 		f.no_fast_pairs = no_fast_pairs ? 1 : 0;
 		f.tasks = (FragTask *)(fw + w_tasks); f.task_capacity = task_cap;
@@ -166,6 +167,15 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 		HIP_TRY(launch_frag_stitch(f, ix->n_cu, st));
 		HIP_TRY(hipMemcpyAsync(ls->h_why, f.ctl + FC_WHY, 8 * 6, hipMemcpyDeviceToHost, st));
 		have_why = true;
+		if (frag_prof) {
+			unsigned long long pc[FC_WORDS];
+			HIP_TRY(hipMemcpyAsync(pc, f.ctl, 8 * FC_WORDS, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			const double nt = (double)std::max(1ull, pc[FC_PROF + 5]);
+			fprintf(stderr, "kg_longread_batch: %lld requests, %llu tasks, %llu pieces, %llu NW jobs | wave cycles per task: load+pack %.0f, diagonal scan %.0f, sort %.0f, normal pairs %.0f, pieces %.0f | runs per task %.1f, columns per task %.0f\n",
+			        (long long)n_req, pc[FC_PROF + 5], pc[FC_PIECES], pc[FC_JOBS], (double)pc[FC_PROF] / nt, (double)pc[FC_PROF + 1] / nt, (double)pc[FC_PROF + 2] / nt, (double)pc[FC_PROF + 3] / nt,
+			        (double)pc[FC_PROF + 4] / nt, (double)pc[FC_PROF + 6] / nt, (double)pc[FC_PROF + 7] / nt);
+		}
 	}
 
 	// ---- pass 2, the records, the CIGAR strings ----

@@ -37,7 +37,7 @@ for k, cs in list(out.items()):
                                   "l2_hit_rate": hit / (hit + miss) if hit + miss else None, "TCC_HIT": hit, "TCC_MISS": miss,
                                   "note": "gfx950: read traffic = RDREQ_128B x 128 + RDREQ_64B x 64 (FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); "
                                           "WRITE_SIZE in KiB; separate passes; per launch = the sum over the run's launches / their number (ramp-up launches included, as in roofline.achieved)"}
-# per-kernel counter traffic per step, for the `kernels` entries of the bench line (the passes ran steps + warmup = 3 steps)
+# per-kernel counter traffic per step, for the "kernels" entries of the bench line (the passes ran steps + warmup = 3 steps)
 slots = {"chain": ["chain_kernel"], "aln_pair": ["aln_pair_kernel"], "aln_rescue": ["aln_rescue_kernel", "aln_post_rescue_kernel"], "aln_plan_fast": ["aln_plan_fast_kernel"],
          "aln_plan": ["aln_plan_kernel"], "aln_partition": ["aln_partition_kernel"], "nw": ["nw_small8_kernel", "nw_small32_kernel", "nw_big_kernel", "nw_classify_kernel"],
          "aln_finish": ["aln_finish_kernel"], "aln_final": ["aln_final_kernel"], "sam_size": ["sam_size_kernel"], "sam_format": ["sam_format_kernel"],
