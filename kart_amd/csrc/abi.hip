@@ -981,7 +981,7 @@ int kgi_nw_launch(kg_index *ix, NwArgs &a, int64_t max_len, hipStream_t st)
 		t1_words = (size_t)a.t1_waves * (size_t)a.t1_dir_words_per_wave;
 	}
 	NwScratch *sc = nullptr;
-	int rc = nw_acquire(ix, 3 * (size_t)n, dir_words + t1_words, st, &sc);
+	int rc = nw_acquire(ix, 4 * (size_t)n, dir_words + t1_words, st, &sc);
 	if (rc != KG_OK) return rc;
 	a.big_list = sc->lists;
 	a.queue = sc->queue;

@@ -66,7 +66,8 @@ extern "C" int kg_fragments_batch(kg_index *ix, const char *frag1, const int64_t
 	const int64_t b1 = off1[n];
 	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	// every request becomes at most a few dozen pieces per 100 columns; lists that run full send their request back (status 1)
-	const int64_t task_cap = n + n / 2 + cols / 300 + 4096, piece_cap = 4 * n + cols / 8 + 4096, job_cap = 2 * n + cols / 16 + 4096, jops_cap = cols + 4096;
+	const int64_t pool_waves = frag_pool_waves(n, ix->n_cu);        // (what the partition kernel's waves leave unused of the stretches they reserve)
+	const int64_t task_cap = n + n / 2 + cols / 300 + 4096, piece_cap = 4 * n + cols / 8 + 4096 + pool_waves * kFragPieceChunk, job_cap = 2 * n + cols / 16 + 4096 + pool_waves * kFragJobChunk, jops_cap = cols + 4096 + pool_waves * kFragOpsChunk;
 	size_t p_f1 = 0, p_off = p_f1 + up((size_t)b1 + 64), p_g = p_off + up(8 * (size_t)(n + 1)), p_gl = p_g + up(8 * (size_t)n), p_oo = p_gl + up(4 * (size_t)n),
 	       in_total = p_oo + up(8 * (size_t)n);
 	size_t w_tasks = 0, w_pieces = w_tasks + up(sizeof(FragTask) * (size_t)task_cap), w_jobs = w_pieces + up(sizeof(FragPiece) * (size_t)piece_cap),

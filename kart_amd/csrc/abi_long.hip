@@ -127,7 +127,8 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 	if (n_req > 0x7ffffff0) return fail(KG_ERR_ARG, "kg_longread_batch: too many fragment pairs in one batch (%lld)", (long long)n_req);
 
 	// ---- GenerateNormalPairAlignment for the requests (frag_kernels.hip), on the arrays pass 1 left on the device ----
-	const int64_t task_cap = n_req + n_req / 2 + cols / 300 + 4096, piece_cap = 4 * n_req + cols / 8 + 4096, job_cap = 2 * n_req + cols / 16 + 4096, jops_cap = cols + 4096;
+	const int64_t pool_waves = frag_pool_waves(n_req, ix->n_cu);        // (what the partition kernel's waves leave unused of the stretches they reserve)
+	const int64_t task_cap = n_req + n_req / 2 + cols / 300 + 4096, piece_cap = 4 * n_req + cols / 8 + 4096 + pool_waves * kFragPieceChunk, job_cap = 2 * n_req + cols / 16 + 4096 + pool_waves * kFragJobChunk, jops_cap = cols + 4096 + pool_waves * kFragOpsChunk;
 	const size_t w_tasks = 0, w_pieces = w_tasks + up(sizeof(FragTask) * (size_t)task_cap), w_jobs = w_pieces + up(sizeof(FragPiece) * (size_t)piece_cap),
 	             w_jops = w_jobs + up(sizeof(NwJobDesc) * (size_t)job_cap), w_jlen = w_jops + up((size_t)jops_cap + 64), w_ctl = w_jlen + up(4 * (size_t)job_cap),
 	             w_status = w_ctl + up(8 * FC_WORDS), w_ops = w_status + up((size_t)n_req + 64), w_len = w_ops + up((size_t)cols + 64), w_runs = w_len + up(4 * (size_t)n_req + 64), work_total = w_runs + up(4 * (size_t)n_req + 64);
@@ -164,6 +165,28 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 		w.ops = f.job_ops; w.aln_len = f.job_len;
 		rc = kgi_nw_launch(ix, w, max_len, st);
 		if (rc != KG_OK) return rc;
+		if (getenv("KG_LONG_DEBUG_JOBS")) {
+			// diagnostics: the NW jobs of this batch by their longer side -- count and cells per class
+			unsigned long long nj = 0;
+			HIP_TRY(hipStreamSynchronize(st));
+			(void)hipMemcpy(&nj, f.ctl + FC_JOBS, 8, hipMemcpyDeviceToHost);
+			nj = std::min<unsigned long long>(nj, (unsigned long long)job_cap);
+			std::vector<NwJobDesc> jd((size_t)nj);
+			if (nj) (void)hipMemcpy(jd.data(), f.jobs, sizeof(NwJobDesc) * (size_t)nj, hipMemcpyDeviceToHost);
+			static const int edge[] = {0, 8, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 1 << 30};
+			unsigned long long cnt[12] = {}, cells[12] = {};
+			int longest = 0;
+			for (const NwJobDesc &j : jd) {
+				const int mx = std::max(j.m, j.n);
+				int b = 0;
+				while (mx > edge[b]) ++b;
+				cnt[b]++; cells[b] += (unsigned long long)j.m * (unsigned long long)j.n;
+				longest = std::max(longest, mx);
+			}
+			fprintf(stderr, "KG_LONG_DEBUG_JOBS %llu job slots (longest side %d):", nj, longest);
+			for (int b = 0; b < 12; ++b) if (cnt[b]) fprintf(stderr, " <=%d: %llu jobs %.1f Mcells;", edge[b], cnt[b], 1e-6 * (double)cells[b]);
+			fprintf(stderr, "\n");
+		}
 		HIP_TRY(launch_frag_stitch(f, ix->n_cu, st));
 		HIP_TRY(hipMemcpyAsync(ls->h_why, f.ctl + FC_WHY, 8 * 6, hipMemcpyDeviceToHost, st));
 		have_why = true;

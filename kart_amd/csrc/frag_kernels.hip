@@ -43,6 +43,42 @@ __device__ __forceinline__ uint64_t codes32(const uint64_t *w, int n_words, int 
 	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 
+// 32 read characters as four 8-byte words (the uploaded characters have 64 bytes of slack behind them); words at or beyond rL are not loaded
+__device__ __forceinline__ void load_chars32(const uint8_t *f1, int w, int rL, uint64_t c[4])
+{
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const int i0 = (w << 5) + 8 * q;
+		c[q] = i0 < rL ? reinterpret_cast<const FrU64u *>(f1 + i0)->v : 0ull;
+	}
+}
+
+// ... converted eight at a time: code in bits 2:1 of the letter (Gray), packed to 2 bits per base; `bad`: a character other than A/C/G/T in either case
+__device__ __forceinline__ uint64_t pack_chars32(const uint64_t c[4], int w, int rL, uint64_t &bad)
+{
+	uint64_t word = 0;
+	bad = 0;
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const int i0 = (w << 5) + 8 * q;
+		if (i0 >= rL) break;
+		const uint64_t c8 = c[q];
+		const uint64_t u = c8 & 0xDFDFDFDFDFDFDFDFull;
+		auto zero_bytes = [](uint64_t t) { return ~(((t & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | t | 0x7F7F7F7F7F7F7F7Full); };
+		uint64_t ok = zero_bytes(u ^ 0x4141414141414141ull) | zero_bytes(u ^ 0x4343434343434343ull) | zero_bytes(u ^ 0x4747474747474747ull) | zero_bytes(u ^ 0x5454545454545454ull);
+		const int n = rL - i0 < 8 ? rL - i0 : 8;
+		const uint64_t in = n >= 8 ? 0x8080808080808080ull : ((1ull << (8 * n)) - 1) & 0x8080808080808080ull;
+		bad |= ~ok & in;
+		uint64_t g2 = (c8 >> 1) & 0x0303030303030303ull;
+		uint64_t code = g2 ^ ((g2 >> 1) & 0x0101010101010101ull);                 // A 0, C 1, G 2, T 3
+		code = (code | (code >> 6)) & 0x000F000F000F000Full;
+		code = (code | (code >> 12)) & 0x000000FF000000FFull;
+		code = (code | (code >> 24)) & 0xFFFFull;
+		word |= code << (16 * q);
+	}
+	return word;
+}
+
 __device__ __forceinline__ unsigned long long shfl_u64_frag(unsigned long long v, int src)
 {
 	return ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src);
@@ -306,26 +342,57 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 	__shared__ int s_n, s_bad;
 	const int lane = threadIdx.x;
 	const unsigned long long t0 = a.ctl[FC_LEVEL0 + level], t1 = a.ctl[FC_LEVEL0 + level + 1];
+	// The wave's own stretch of each work list (pieces, NW jobs, their op bytes): one atomic per ~50 tasks instead of three per task.  The counters
+	// are device-scope atomics on ONE line that all eight XCDs share -- 2.3 M of them per 780 k tasks were what the kernel's two memory phases waited
+	// for (100 k + 129 k of a task's 295 k wave cycles, profiles/r05w_frag_prof.log).  What a wave leaves unused stays behind: pieces and op bytes
+	// nobody refers to, job slots as empty jobs.  Level 0 only -- the levels below hold a few hundred tasks.
+	const bool pooled = level == 0;
+	unsigned long long pc_next = 0, pc_end = 0, jb_next = 0, jb_end = 0, op_next = 0, op_end = 0;
+	auto empty_jobs = [&](unsigned long long from, unsigned long long to) {
+		if (to > (unsigned long long)a.job_capacity) to = (unsigned long long)a.job_capacity;
+		for (unsigned long long j = from + (unsigned long long)lane; j < to; j += 64) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[j] = jd; }
+	};
 	// 64 tasks are looked at per step, one per lane: which of them are this instantiation's (the small one marks what outgrows it, status 2; with
 	// a.one_tier the full-size one takes everything); the wave then works through those one after the other
 	for (unsigned long long tb = t0 + (unsigned long long)blockIdx.x * 64; tb < t1; tb += (unsigned long long)gridDim.x * 64) {
 	bool mine = false;
+	long long my_f1 = 0, my_g = 0;                     // this lane's task of the 64: what the wave needs of it when its turn comes
+	int my_rL = 0, my_gL = 0;
 	if (tb + lane < t1) {
 		FragTask &tk = a.tasks[tb + lane];
-		const bool small_fits = tk.rL <= kFragSmallLen && tk.gL <= kFragSmallLen;
+		my_f1 = tk.f1_off; my_g = tk.g; my_rL = tk.rL; my_gL = tk.gL;
+		const bool small_fits = my_rL <= kFragSmallLen && my_gL <= kFragSmallLen;
 		if (kSmall) { mine = small_fits; if (!small_fits) tk.status = 2; }
 		else mine = a.one_tier || tk.status == 2 || !small_fits;
 	}
 	uint64_t todo = __ballot(mine);
+	// The first 64 words (2048 bases) of both sides of the NEXT task are fetched while the wave works on this one: a task was a chain of six
+	// dependent trips to memory -- its record, four character words behind a loop exit each, the text -- with two or three waves per SIMD to hide them
+	// (the LDS arrays), 120 k of its 220 k wave cycles (profiles/r05x_ab_long_2m.log)
+	uint64_t pf_c[4] = {0, 0, 0, 0}, pf_t = 0;
+	int pf_for = -1;
+	auto fetch = [&](int idx) {
+		const long long f1o = (long long)shfl_u64_frag((unsigned long long)my_f1, idx), gg = (long long)shfl_u64_frag((unsigned long long)my_g, idx);
+		const int rl = __shfl(my_rL, idx), gl = __shfl(my_gL, idx);
+		pf_for = idx;
+		if (!(rl > 30 && gl > 30) || rl > kMaxLen || gl > kMaxLen) return;
+		if (lane < ((rl + 31) >> 5)) load_chars32(reinterpret_cast<const uint8_t *>(a.f1) + f1o, lane, rl, pf_c);
+		if (lane < ((gl + 31) >> 5)) pf_t = text_word32_at(a.text, a.two_genome_size, gg + ((int64_t)lane << 5));
+	};
 	while (todo) {
-		const unsigned long long ti = tb + (unsigned long long)(__ffsll((unsigned long long)todo) - 1);
+		const int cur = __ffsll((unsigned long long)todo) - 1;
+		const unsigned long long ti = tb + (unsigned long long)cur;
 		todo &= todo - 1;
 		FragTask &task = a.tasks[ti];
 		const long long c0 = a.prof ? clock64() : 0;
 		long long c1 = c0, c2 = c0, c3 = c0, c4 = c0;
-		const int rL = task.rL, gL = task.gL;
-		const uint8_t *f1 = reinterpret_cast<const uint8_t *>(a.f1) + task.f1_off;
-		const int64_t g = task.g;
+		const int rL = __shfl(my_rL, cur), gL = __shfl(my_gL, cur);
+		const long long task_f1_off = (long long)shfl_u64_frag((unsigned long long)my_f1, cur);
+		const uint8_t *f1 = reinterpret_cast<const uint8_t *>(a.f1) + task_f1_off;
+		const int64_t g = (int64_t)shfl_u64_frag((unsigned long long)my_g, cur);
+		if (pf_for != cur) fetch(cur);
+		const uint64_t cc0 = pf_c[0], cc1 = pf_c[1], cc2 = pf_c[2], cc3 = pf_c[3], ct = pf_t;
+		if (todo) fetch(__ffsll((unsigned long long)todo) - 1);       // in flight until the next turn of this loop
 		// lane 0 decides the task's pieces; everybody else helps with the runs
 		bool whole_job = !(rL > 30 && gL > 30);            // src/tools.cpp:146
 		bool host = false;
@@ -344,30 +411,14 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 			// A/C/G/T in either case is what a comparison of 2-bit codes reproduces; anything else goes back to the caller) ----
 			const int rw = (rL + 31) >> 5, gw = (gL + 31) >> 5;
 			for (int w = lane; w < rw; w += 64) {
-				// 32 characters = four unaligned 8-byte loads (the uploaded characters have 64 bytes of slack behind them), converted
-				// eight at a time: code in bits 2:1 of the letter (Gray), packed to 2 bits per base
-				uint64_t word = 0, bad = 0;
-				for (int q = 0; q < 4; ++q) {
-					const int i0 = (w << 5) + 8 * q;
-					if (i0 >= rL) break;
-					const uint64_t c8 = reinterpret_cast<const FrU64u *>(f1 + i0)->v;
-					const uint64_t u = c8 & 0xDFDFDFDFDFDFDFDFull;
-					auto zero_bytes = [](uint64_t t) { return ~(((t & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | t | 0x7F7F7F7F7F7F7F7Full); };
-					uint64_t ok = zero_bytes(u ^ 0x4141414141414141ull) | zero_bytes(u ^ 0x4343434343434343ull) | zero_bytes(u ^ 0x4747474747474747ull) | zero_bytes(u ^ 0x5454545454545454ull);
-					const int n = rL - i0 < 8 ? rL - i0 : 8;
-					const uint64_t in = n >= 8 ? 0x8080808080808080ull : ((1ull << (8 * n)) - 1) & 0x8080808080808080ull;
-					bad |= ~ok & in;
-					uint64_t g2 = (c8 >> 1) & 0x0303030303030303ull;
-					uint64_t code = g2 ^ ((g2 >> 1) & 0x0101010101010101ull);                 // A 0, C 1, G 2, T 3
-					code = (code | (code >> 6)) & 0x000F000F000F000Full;
-					code = (code | (code >> 12)) & 0x000000FF000000FFull;
-					code = (code | (code >> 24)) & 0xFFFFull;
-					word |= code << (16 * q);
-				}
-				s_rd[w] = word;
+				// 32 characters = four unaligned 8-byte loads, converted eight at a time (pack_chars32); the first 64 words came with the prefetch
+				uint64_t c[4], bad;
+				if (w < 64) { c[0] = cc0; c[1] = cc1; c[2] = cc2; c[3] = cc3; }
+				else load_chars32(f1, w, rL, c);
+				s_rd[w] = pack_chars32(c, w, rL, bad);
 				if (bad) s_bad = 1;
 			}
-			for (int w = lane; w < gw; w += 64) s_tx[w] = text_word32_at(a.text, a.two_genome_size, g + ((int64_t)w << 5));
+			for (int w = lane; w < gw; w += 64) s_tx[w] = w < 64 ? ct : text_word32_at(a.text, a.two_genome_size, g + ((int64_t)w << 5));
 			__syncthreads();
 			if (a.prof) c1 = clock64();
 			if (s_bad) { host = true; why = 1; }
@@ -510,12 +561,27 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 				n_ops += o;
 			}
 			unsigned long long piece_at = 0, job_at = 0, ops_at = 0, task_at = 0;
-			if (lane == 0) {
-				piece_at = atomicAdd(&a.ctl[FC_PIECES], (unsigned long long)n_pieces);
-				if (n_jobs) { job_at = atomicAdd(&a.ctl[FC_JOBS], (unsigned long long)n_jobs); ops_at = atomicAdd(&a.ctl[FC_OPS], (unsigned long long)n_ops); }
-				if (n_sub) task_at = atomicAdd(&a.ctl[FC_TASKS], (unsigned long long)n_sub);
+			{
+				const bool np = pc_next + (unsigned long long)n_pieces > pc_end;
+				const bool nj = n_jobs && jb_next + (unsigned long long)n_jobs > jb_end;
+				const bool no = n_jobs && op_next + (unsigned long long)n_ops > op_end;
+				const unsigned long long wp = pooled && n_pieces < kFragPieceChunk ? (unsigned long long)kFragPieceChunk : (unsigned long long)n_pieces;
+				const unsigned long long wj = pooled && n_jobs < kFragJobChunk ? (unsigned long long)kFragJobChunk : (unsigned long long)n_jobs;
+				const unsigned long long wo = pooled && n_ops < kFragOpsChunk ? (unsigned long long)kFragOpsChunk : (unsigned long long)n_ops;
+				if (nj) empty_jobs(jb_next, jb_end);                 // what is left of the old stretch
+				unsigned long long bp = 0, bj = 0, bo = 0;
+				if (lane == 0) {
+					if (np) bp = atomicAdd(&a.ctl[FC_PIECES], wp);
+					if (nj) bj = atomicAdd(&a.ctl[FC_JOBS], wj);
+					if (no) bo = atomicAdd(&a.ctl[FC_OPS], wo);
+					if (n_sub) task_at = atomicAdd(&a.ctl[FC_TASKS], (unsigned long long)n_sub);
+				}
+				if (np) { pc_next = shfl_u64_frag(bp, 0); pc_end = pc_next + wp; }
+				if (nj) { jb_next = shfl_u64_frag(bj, 0); jb_end = jb_next + wj; }
+				if (no) { op_next = shfl_u64_frag(bo, 0); op_end = op_next + wo; }
+				task_at = shfl_u64_frag(task_at, 0);
+				piece_at = pc_next; job_at = jb_next; ops_at = op_next;
 			}
-			piece_at = shfl_u64_frag(piece_at, 0); job_at = shfl_u64_frag(job_at, 0); ops_at = shfl_u64_frag(ops_at, 0); task_at = shfl_u64_frag(task_at, 0);
 			const bool jobs_fit = job_at + (unsigned long long)n_jobs <= (unsigned long long)a.job_capacity;
 			const bool room = piece_at + (unsigned long long)n_pieces <= (unsigned long long)a.piece_capacity && jobs_fit &&
 			                  ops_at + (unsigned long long)n_ops <= (unsigned long long)a.ops_capacity &&
@@ -523,19 +589,18 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 			if (!room) {
 				host = true;
 				why = (n_sub != 0 && level + 1 >= kFragMaxDepth) ? 5 : 4;
-				// (the job slots reserved above stay behind: empty jobs, so that the NW kernels find nothing in them; sub-task slots beyond the
-				//  capacity were never written, the ones inside it become tasks of nothing)
-				if (jobs_fit)
-					for (int j = lane; j < n_jobs; j += 64) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[job_at + (unsigned long long)j] = jd; }
+				// (nothing is taken from the wave's stretches -- what is left of them ends as empty jobs, so that the NW kernels find nothing there; sub-task
+				//  slots beyond the capacity were never written, the ones inside it become tasks of nothing)
 				for (int j = lane; j < n_sub; j += 64)
 					if (task_at + (unsigned long long)j < (unsigned long long)a.task_capacity) {
 						FragTask sub;
-						sub.f1_off = task.f1_off; sub.g = g; sub.rL = 0; sub.gL = 0; sub.first = 0; sub.count = 0; sub.status = 0; sub.root = task.root;
+						sub.f1_off = task_f1_off; sub.g = g; sub.rL = 0; sub.gL = 0; sub.first = 0; sub.count = 0; sub.status = 0; sub.root = task.root;
 						a.tasks[task_at + (unsigned long long)j] = sub;
 					}
 			} else {
 				first = (int)piece_at;
 				count = n_pieces;
+				pc_next += (unsigned long long)n_pieces; jb_next += (unsigned long long)n_jobs; op_next += (unsigned long long)n_ops;
 				unsigned long long p_run = piece_at, j_run = job_at, o_run = ops_at, t_run = task_at;
 				for (int base = 0; base < n_items; base += 64) {
 					const int i = base + lane;
@@ -555,13 +620,13 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 						} else if (kd == 2) {
 							const unsigned long long jx = j_run + (unsigned long long)__popcll(mj & below);
 							NwJobDesc jd;
-							jd.o1 = task.f1_off + rp; jd.o2 = g + gp; jd.ops = (int64_t)(o_run + (unsigned long long)(incl - o)); jd.m = prl; jd.n = pgl;
+							jd.o1 = task_f1_off + rp; jd.o2 = g + gp; jd.ops = (int64_t)(o_run + (unsigned long long)(incl - o)); jd.m = prl; jd.n = pgl;
 							a.jobs[jx] = jd;
 							pc.kind = FP_JOB; pc.v = (int32_t)jx;
 						} else {
 							const unsigned long long tx = t_run + (unsigned long long)__popcll(ms & below);
 							FragTask sub;
-							sub.f1_off = task.f1_off + rp; sub.g = g + gp; sub.rL = prl; sub.gL = pgl;
+							sub.f1_off = task_f1_off + rp; sub.g = g + gp; sub.rL = prl; sub.gL = pgl;
 							sub.first = 0; sub.count = 0; sub.status = 0; sub.root = task.root;
 							a.tasks[tx] = sub;
 							pc.kind = FP_TASK; pc.v = (int32_t)tx;
@@ -587,6 +652,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		__syncthreads();
 	}
 	}
+	empty_jobs(jb_next, jb_end);
 }
 
 // the tasks appended while `level` was processed are the next level
@@ -676,6 +742,13 @@ static inline int grid_of(int64_t items, int block, int max_blocks)
 	return (int)g;
 }
 
+int64_t frag_pool_waves(int64_t n_requests, int n_cu)
+{
+	const int64_t g = n_requests / 64 + 1;
+	const int64_t big = std::min<int64_t>(g, (int64_t)n_cu * kFragWavesPerCu), small = getenv("KG_FRAG_TWO_TIERS") ? std::min<int64_t>(g, (int64_t)n_cu * kFragSmallWavesPerCu) : 0;
+	return big + small;
+}
+
 hipError_t launch_frag_partition(const FragArgs &a, int n_cu, hipStream_t stream)
 {
 	hipLaunchKernelGGL(frag_reset_kernel, dim3(grid_of(a.n, 256, n_cu * 8)), dim3(256), 0, stream, a);
@@ -687,8 +760,8 @@ hipError_t launch_frag_partition(const FragArgs &a, int n_cu, hipStream_t stream
 		//  ~ SQ_BUSY_CYCLES in profiles/r05o_pacbio_pmc_summary.json -- so more waves only queue for it)
 		FragArgs b = a;
 		b.one_tier = getenv("KG_FRAG_TWO_TIERS") != nullptr ? 0 : 1;
-		if (!b.one_tier) hipLaunchKernelGGL((frag_partition_kernel<kFragSmallLen, kFragSmallRuns, true>), dim3(grid_of(guess / 64 + 1, 1, n_cu * 32)), dim3(64), 0, stream, b, level);
-		hipLaunchKernelGGL((frag_partition_kernel<kFragMaxLen, kFragMaxRuns, false>), dim3(grid_of(guess / 64 + 1, 1, n_cu * 10)), dim3(64), 0, stream, b, level);
+		if (!b.one_tier) hipLaunchKernelGGL((frag_partition_kernel<kFragSmallLen, kFragSmallRuns, true>), dim3(grid_of(guess / 64 + 1, 1, n_cu * kFragSmallWavesPerCu)), dim3(64), 0, stream, b, level);
+		hipLaunchKernelGGL((frag_partition_kernel<kFragMaxLen, kFragMaxRuns, false>), dim3(grid_of(guess / 64 + 1, 1, n_cu * kFragWavesPerCu)), dim3(64), 0, stream, b, level);
 		hipLaunchKernelGGL(frag_level_kernel, dim3(1), dim3(64), 0, stream, a, level);
 	}
 	return hipGetLastError();

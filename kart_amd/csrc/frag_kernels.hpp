@@ -11,6 +11,12 @@ constexpr int kFragSmallLen = 1024, kFragSmallRuns = 127;   // the partition ker
 constexpr int kFragMaxPairs = 2 * kFragMaxRuns + 2;   // ... and the normal pairs IdentifyNormalPairs makes of them
 constexpr int kFragMaxDepth = 6;         // levels of the -pacbio recursion (src/tools.cpp:197)
 
+// the partition kernel's waves take their pieces / NW jobs / op bytes from stretches of the lists they reserve at level 0 (one atomic per ~50 tasks);
+// the lists need room for what the waves leave unused: frag_pool_slack()
+constexpr int kFragPieceChunk = 1536, kFragJobChunk = 512, kFragOpsChunk = 24576;
+constexpr int kFragWavesPerCu = 10, kFragSmallWavesPerCu = 32;      // the full-size instantiation: 15 KB of LDS per wave; the small one (KG_FRAG_TWO_TIERS): the CU's wave slots
+int64_t frag_pool_waves(int64_t n_requests, int n_cu);              // waves of a level-0 launch that may leave a stretch of each list behind
+
 enum { FP_JOB = 3, FP_TASK = 4 };        // FragPiece::kind beyond the literal runs KG_OP_DIAG / KG_OP_GAP1 / KG_OP_GAP2
 enum { FC_TASKS = 0, FC_PIECES = 1, FC_JOBS = 2, FC_OPS = 3, FC_LEVEL0 = 4, FC_PROF = FC_LEVEL0 + kFragMaxDepth + 2, FC_WHY = FC_PROF + 8, FC_WORDS = FC_WHY + 6 };   // FC_PROF: wave cycles per phase (KG_FRAG_PROF)
 // FC_WHY: tasks that sent their request back, by reason: [0] a side above kFragMaxLen, [1] a read character other than A/C/G/T, [2] more than kFragMaxRuns matches,

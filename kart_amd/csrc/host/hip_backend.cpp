@@ -103,6 +103,7 @@ public:
 	// long reads: the batches alternate between two workspaces, so that the report of batch k (kg_longread_batch: the fragment and NW
 	// kernels, instruction-bound) runs beside the seeding of batch k + 1 (the FM-index search, latency-bound) on streams of their own
 	int long_slot() const override { return cur_; }
+	bool long_overlap() const override { return !getenv("KART_AMD_LONG_NO_OVERLAP"); }
 	~HipBackend() override
 	{
 		stream_.reset();

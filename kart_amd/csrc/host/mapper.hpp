@@ -163,6 +163,7 @@ struct KernelBackend {
 	}
 	virtual int long_slot() const { return 0; }
 	virtual bool long_enabled() const { return false; }
+	virtual bool long_overlap() const { return false; }       // two workspaces: align_long(slot) may run beside the next batch's seed_and_chain()
 	// diagnostics of the stage above (why pairs came back for the host), empty when there is none
 	virtual std::string align_diagnostics() { return std::string(); }
 };

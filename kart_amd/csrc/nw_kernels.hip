@@ -89,40 +89,43 @@ __global__ void nw_reset_kernel(unsigned long long *queue)
 	if (threadIdx.x < 8) queue[threadIdx.x] = 0;
 }
 
-// queue words: [0..2] list sizes of the three classes, [3] class-2 work queue head, [4] the same for the launch of the longer pairs (two tiers)
-// Every block takes ONE contiguous range of pairs: it counts its pairs per class, reserves its share of the three lists with three
-// atomics, and fills it -- the waves drawing their places from counters in the LDS.  (One global atomic per wave and class, as
+// queue words: [0..2] list sizes of the three classes, [3] class-2 work queue head, [4] the same for the launch of the longer pairs (two tiers),
+// [5] the number of those longer pairs (a fourth list, a.tier_len > 0: they were part of list 2 until round 5, and the launch made for them -- two
+// waves per CU -- walked all 720 k entries of a long-read batch's list to find its ~50: 15 of the batch's 90 ms, profiles/r05z_pacbio_kernel_trace)
+// Every block takes ONE contiguous range of pairs: it counts its pairs per class, reserves its share of the lists with one atomic each, and fills
+// it -- the waves drawing their places from counters in the LDS.  (One global atomic per wave and class, as
 // before, was the kernel: 125 k same-address atomics for 8 M tiny pairs = 1.5 ms of the call's 3.4 ms.)
 __global__ __launch_bounds__(256) void nw_classify_kernel(NwArgs a)
 {
-	__shared__ unsigned int s_cnt[3];
-	__shared__ unsigned long long s_next[3];
+	__shared__ unsigned int s_cnt[4];
+	__shared__ unsigned long long s_next[4];
 	const int64_t count = nw_count(a);
 	const int64_t per = (count + gridDim.x - 1) / gridDim.x;
 	const int64_t b0 = (int64_t)blockIdx.x * per, b1 = b0 + per < count ? b0 + per : count;
-	if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+	if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
+	const int tier_len = a.tier_len > 0 ? a.tier_len : 0x7fffffff;
 	auto cls_of = [&](int64_t p) {
 		const NwPair q = nw_pair(a, p);
 		const int mx = q.m > q.n ? q.m : q.n;
-		return mx <= 8 ? 0 : mx <= 32 ? 1 : 2;
+		return mx <= 8 ? 0 : mx <= 32 ? 1 : mx <= tier_len ? 2 : 3;
 	};
-	unsigned int mine[3] = {0, 0, 0};
+	unsigned int mine[4] = {0, 0, 0, 0};
 	for (int64_t p = b0 + threadIdx.x; p < b1; p += blockDim.x) mine[cls_of(p)]++;
 #pragma unroll
-	for (int c = 0; c < 3; ++c) {
+	for (int c = 0; c < 4; ++c) {
 		unsigned int v = mine[c];
 		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
 		if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt[c], v);
 	}
 	__syncthreads();
-	if (threadIdx.x < 3) s_next[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(a.queue + threadIdx.x, (unsigned long long)s_cnt[threadIdx.x]) : 0;
+	if (threadIdx.x < 4) s_next[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(a.queue + (threadIdx.x < 3 ? threadIdx.x : 5), (unsigned long long)s_cnt[threadIdx.x]) : 0;
 	__syncthreads();
 	for (int64_t base = b0; base < b1; base += blockDim.x) {
 		const int64_t p = base + threadIdx.x;
 		const int cls = p < b1 ? cls_of(p) : -1;
 #pragma unroll
-		for (int c = 0; c < 3; ++c) {
+		for (int c = 0; c < 4; ++c) {
 			const uint64_t mask = __ballot(cls == c);
 			if (mask == 0) continue;
 			const int leader = __ffsll((unsigned long long)mask) - 1;
@@ -458,26 +461,35 @@ __device__ __forceinline__ int nw_walk(int lane, int m, int n, const uint64_t *d
 // kGlobal: fragments longer than kNwMaxLen -- the boundary column and the sequence-1 codes no longer fit the LDS and
 // live in a per-wave HBM slab behind the direction words instead (same sweep; the reference's nw_alignment has no length
 // limit, src/nw_alignment.cpp:24-33, so neither has this path).
-// tier: 0 = every pair of the class; 1 = the pairs up to a.tier_len (slabs a.t1_*); 2 = the longer ones
+// tier: 0 = every pair of the class; 1 = the pairs up to a.tier_len (list 2, slabs a.t1_*); 2 = the longer ones (list 3)
 template <bool kGlobal>
 __global__ __launch_bounds__(64) void nw_big_kernel(NwArgs a, int tier)
 {
 	extern __shared__ int lds_dyn[];
 	const int lane = threadIdx.x;
-	const unsigned long long count = a.queue[2];
-	const int32_t *list = a.big_list + 2 * a.n;
+	const unsigned long long count = a.queue[tier == 2 ? 5 : 2];
+	const int32_t *list = a.big_list + (tier == 2 ? 3 : 2) * a.n;
 	uint32_t *dir = tier == 1 ? a.t1_dir_scratch + (int64_t)blockIdx.x * a.t1_dir_words_per_wave : a.dir_scratch + (int64_t)blockIdx.x * a.dir_words_per_wave;
 	unsigned long long *const ticket = a.queue + (tier == 2 ? 4 : 3);
+	// tickets are drawn up to 16 at a time where the list is long: the counter is ONE address for the whole device, ~12 ns per atomic whoever asks --
+	// 700 k pairs of a long-read batch took 8.4 of the launch's 9.1 ms to hand out one by one (profiles/r05q_pacbio_kernel_stats.csv, r05w)
+	const unsigned long long share = count / ((unsigned long long)gridDim.x * 4ull);
+	const unsigned long long take = share < 1 ? 1ull : share > 16 ? 16ull : share;
+	unsigned long long t_next = 0, t_end = 0;
 	for (;;) {
-		unsigned long long t = 0;
-		if (lane == 0) t = atomicAdd(ticket, 1ull);
-		t = __shfl(t, 0);
-		if (t >= count) break;
+		if (t_next == t_end) {
+			unsigned long long t0 = 0;
+			if (lane == 0) t0 = atomicAdd(ticket, take);
+			t0 = __shfl(t0, 0);
+			if (t0 >= count) break;
+			t_next = t0;
+			t_end = t0 + take < count ? t0 + take : count;
+		}
+		const unsigned long long t = t_next++;
 		int64_t p = list[t];
 		const NwPair q = nw_pair(a, p);
 		const int64_t o1 = q.o1, o2 = q.o2;
 		const int m = q.m, n = q.n;
-		if (tier != 0 && ((m > n ? m : n) <= a.tier_len) != (tier == 1)) continue;      // the other launch's pair
 		int *lds = kGlobal ? reinterpret_cast<int *>(dir + a.gb_offset_words) : lds_dyn;
 		int2 *bSR = reinterpret_cast<int2 *>(lds);                                   // boundary column: {S, R} of rows 0..m
 		unsigned char *s1c = reinterpret_cast<unsigned char *>(lds + 2 * (m + 1));  // fits: see nw_big_lds_bytes()
