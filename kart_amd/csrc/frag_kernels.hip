@@ -206,6 +206,123 @@ __device__ void filter_pairs(FragPairs &v, uint16_t *byr)
 	}
 }
 
+// filter_pairs for up to 64 seeds by the whole wave, the seeds one per lane in REGISTERS (lane i holds seed i of the genome order): the same
+// sequential algorithm, statement for statement, but every array access is a v_readlane (a write: compare + select) with a wave-uniform index (a few cycles)
+// instead of a trip to the LDS by one lane (~100 cycles each, ~500 of them per task with 14 seeds: 53 k of a task's 84 k wave cycles in four
+// tasks of ten, profiles/r05ze_frag_prof.log).  Only the two O(n^2) steps are done the parallel way (same result): the tandem marks (a lane
+// compares its read position with everybody's) and the read-position order (rank by counting; the positions are distinct by then).
+// Returns the new number of seeds, lane i holding seed i again.
+__device__ __forceinline__ int rl_(int v, int idx) { return __builtin_amdgcn_readlane(v, idx); }
+__device__ __forceinline__ void wl_(int &v, int idx, int val) { v = (int)(threadIdx.x & 63) == idx ? val : v; }     // (compare + select: this compiler has no writelane builtin)
+
+__device__ int compact_seeds_wave(int num, int lane, int &G, int &R, int &L, int &GL)
+{
+	const uint64_t keep = __ballot(lane < num && L != 0);
+	const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	const int cnt = __popcll(keep);
+	const bool mine = (keep >> lane) & 1;
+	const int dst = mine ? __popcll(keep & below) : cnt + __popcll(~keep & below);      // a permutation of the 64 lanes: the kept seeds first, in order
+	G = __builtin_amdgcn_ds_permute(dst << 2, G); R = __builtin_amdgcn_ds_permute(dst << 2, R);
+	L = __builtin_amdgcn_ds_permute(dst << 2, L); GL = __builtin_amdgcn_ds_permute(dst << 2, GL);
+	return cnt;
+}
+
+__device__ bool resolve_overlap_wave(int &G, int &R, int &L, int &GL, int i, int j)      // resolve_overlap() on the lanes' registers
+{
+	bool master = true;
+	int ov;
+	if ((ov = rl_(R, i) + rl_(L, i) - rl_(R, j)) > 0) {
+		const int li = rl_(L, i), lj = rl_(L, j);
+		if (li < lj) {
+			master = false;
+			if (li > ov) { wl_(L, i, li - ov); wl_(GL, i, li - ov); }
+			else { wl_(L, i, 0); wl_(GL, i, 0); }
+		} else if (lj > ov) {
+			wl_(R, j, rl_(R, j) + ov); wl_(G, j, rl_(G, j) + ov); wl_(L, j, lj - ov); wl_(GL, j, lj - ov);
+		} else { wl_(L, j, 0); wl_(GL, j, 0); }
+	}
+	if (rl_(L, i) > 0 && rl_(L, j) > 0 && (ov = rl_(G, i) + rl_(GL, i) - rl_(G, j)) > 0) {
+		const int li = rl_(L, i), lj = rl_(L, j);
+		if (rl_(GL, i) < rl_(GL, j)) {
+			master = false;
+			if (li > ov) { wl_(L, i, li - ov); wl_(GL, i, li - ov); }
+			else { wl_(L, i, 0); wl_(GL, i, 0); }
+		} else if (lj > ov) {
+			wl_(R, j, rl_(R, j) + ov); wl_(G, j, rl_(G, j) + ov); wl_(L, j, lj - ov); wl_(GL, j, lj - ov);
+		} else { wl_(L, j, 0); wl_(GL, j, 0); }
+	}
+	return master;
+}
+
+__device__ int filter_pairs_wave(int num, int lane, int &G, int &R, int &L, int &GL)
+{
+	if (num <= 1) return num;
+	// RemoveTandemRepeatSeeds, :235-260
+	{
+		bool dup = false;
+		for (int j = 0; j < num; ++j) {
+			const int rj = rl_(R, j);
+			dup = dup || (lane < num && j != lane && rj == R);
+		}
+		if (__ballot(dup)) {
+			if (dup) L = GL = 0;
+			num = compact_seeds_wave(num, lane, G, R, L, GL);
+		}
+	}
+	// RemoveTranslocatedSeeds, :262-321: B = byr, lane k holds the index (in genome order) of the seed with the k-th smallest read position
+	if (num > 1) {
+		int rank = 0;
+		for (int j = 0; j < num; ++j) rank += rl_(R, j) < R ? 1 : 0;
+		const int B = __builtin_amdgcn_ds_permute((lane < num ? rank : lane) << 2, lane);
+		bool any = false;
+		for (int i = 0; i < num; ++i) {
+			const int bi = rl_(B, i);
+			if (bi == i) continue;
+			any = true;
+			int hi = bi;
+			for (int j = i + 1; j <= hi; ++j) { const int bj = rl_(B, j); if (bj > hi) hi = bj; }
+			int s1 = 0, s2 = 0;
+			for (int k = i; k <= hi; ++k) {
+				const int bk = rl_(B, k), lk = rl_(L, bk);
+				if (k < bk) s1 += lk; else s2 += lk;
+			}
+			for (int k = i; k <= hi; ++k) {
+				const int bk = rl_(B, k);
+				const bool drop = s1 > s2 ? k > bk : k < bk;
+				if (drop) { wl_(L, bk, 0); wl_(GL, bk, 0); }
+			}
+			i = hi;
+		}
+		if (any) num = compact_seeds_wave(num, lane, G, R, L, GL);
+	}
+	// CheckOverlappingSeeds, :375-418
+	if (num > 1) {
+		bool any = false;
+		for (int i = 0; i < num;) {
+			const int li = rl_(L, i);
+			if (li > 0) {
+				const int r_end = rl_(R, i) + li - 1, g_end = rl_(G, i) + rl_(GL, i) - 1;
+				for (int j = i + 1; j < num; ++j) {
+					if (rl_(L, j) == 0) continue;
+					if (r_end < rl_(R, j) && g_end < rl_(G, j)) break;
+					if (!resolve_overlap_wave(G, R, L, GL, i, j)) break;
+				}
+				if (rl_(L, i) == 0) {
+					any = true;
+					int q = i - 1;
+					while (q > 0 && rl_(L, q) == 0) q--;
+					i = q < 0 ? 0 : q;
+				} else i++;
+			} else {
+				any = true;
+				i++;
+			}
+		}
+		if (any) num = compact_seeds_wave(num, lane, G, R, L, GL);
+	}
+	return num;
+}
+
 __device__ bool gap_pairs(int rlen, int glen, FragPairs &v, int cap)
 {
 	if (v.num > 1) {
@@ -347,6 +464,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 	// for (100 k + 129 k of a task's 295 k wave cycles, profiles/r05w_frag_prof.log).  What a wave leaves unused stays behind: pieces and op bytes
 	// nobody refers to, job slots as empty jobs.  Level 0 only -- the levels below hold a few hundred tasks.
 	const bool pooled = level == 0;
+	unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long pc_next = 0, pc_end = 0, jb_next = 0, jb_end = 0, op_next = 0, op_end = 0;
 	auto empty_jobs = [&](unsigned long long from, unsigned long long to) {
 		if (to > (unsigned long long)a.job_capacity) to = (unsigned long long)a.job_capacity;
@@ -513,7 +631,14 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		if (fast_num < 0) {
 			FragPairs v;
 			v.gPos = s_gPos; v.rPos = s_rPos; v.rLen = s_rLen; v.gLen = s_gLen; v.simple = s_simple; v.num = n_runs;
-			if (lane == 0) {
+			if (eligible && n_runs <= 64 && !a.no_fast_pairs) {
+				int G = 0, R = 0, L = 0, GL = 0;
+				if (lane < n_runs) { G = s_gPos[lane]; R = s_rPos[lane]; L = s_rLen[lane]; GL = s_gLen[lane]; }
+				const int kept = filter_pairs_wave(n_runs, lane, G, R, L, GL);
+				__syncthreads();
+				if (lane < kept) { s_gPos[lane] = (frp_t)G; s_rPos[lane] = (frp_t)R; s_rLen[lane] = (frp_t)L; s_gLen[lane] = (frp_t)GL; s_simple[lane] = 1; }
+				if (lane == 0) s_n = kept;
+			} else if (lane == 0) {
 				if (eligible) filter_pairs(v, s_byr);
 				s_n = eligible ? v.num : 0;
 			}
@@ -643,16 +768,17 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 			if (host) { a.status[task.root] = 1; atomicAdd(&a.ctl[FC_WHY + (why < 0 ? 4 : why)], 1ull); }                                              // the whole request goes back to the caller
 			if (a.prof) {
 				const long long c5 = clock64();
-				atomicAdd(&a.ctl[FC_PROF + 0], (unsigned long long)(c1 - c0)); atomicAdd(&a.ctl[FC_PROF + 1], (unsigned long long)(c2 - c1));
-				atomicAdd(&a.ctl[FC_PROF + 2], (unsigned long long)(c3 - c2)); atomicAdd(&a.ctl[FC_PROF + 3], (unsigned long long)(c4 - c3));
-				atomicAdd(&a.ctl[FC_PROF + 4], (unsigned long long)(c5 - c4)); atomicAdd(&a.ctl[FC_PROF + 5], 1ull);
-				atomicAdd(&a.ctl[FC_PROF + 6], (unsigned long long)n_runs); atomicAdd(&a.ctl[FC_PROF + 7], (unsigned long long)(rL + gL));
+				prof_acc[0] += (unsigned long long)(c1 - c0); prof_acc[1] += (unsigned long long)(c2 - c1); prof_acc[2] += (unsigned long long)(c3 - c2);
+				prof_acc[3] += (unsigned long long)(c4 - c3); prof_acc[4] += (unsigned long long)(c5 - c4); prof_acc[5] += 1ull;
+				prof_acc[6] += (unsigned long long)n_runs; prof_acc[7] += (unsigned long long)(rL + gL);
 			}
 		}
 		__syncthreads();
 	}
 	}
 	empty_jobs(jb_next, jb_end);
+	if (a.prof && lane == 0)                        // (per wave, not per task: eight atomics per task on one line were a fifth of the profiled run)
+		for (int k = 0; k < 8; ++k) atomicAdd(&a.ctl[FC_PROF + k], prof_acc[k]);
 }
 
 // the tasks appended while `level` was processed are the next level
