@@ -1515,6 +1515,7 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 		const int num = v.num;
 		bool host = false, jobs = false, pending = false;
 		int why = WHY_PARTITION;
+		int n_new_jobs = 0, new_ops = 0, n_pending = 0;
 		for (int j = 0; j < num && !host; ++j) {
 			w.kind[j] = W_NONE; w.op[j] = 0; w.op_len[j] = 0; w.val[j] = 0;
 			const int rL = v.rLen[j], gL = v.gLen[j];
@@ -1556,17 +1557,12 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 				// pair, so almost every wave would walk the long path for a few lanes -- the pair is handed to the dense
 				// aln_partition_kernel instead (one task per lane), which writes its outcome into the parked candidate
 				w.kind[j] = W_PENDING;
-				jobs = true; pending = true;
+				jobs = true; pending = true; n_pending++;
 				continue;
 			}
-			// nw_alignment(rL, frag1, gL, frag2): a job for the NW kernels
-			unsigned long long slot = atomicAdd(&a.ctl[1], 1ull);
-			unsigned long long ops_at = atomicAdd(&a.ctl[2], (unsigned long long)(rL + gL));
-			if (slot >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(rL + gL) > (unsigned long long)a.ops_capacity) { host = true; why = WHY_CAPACITY; break; }
-			NwJobDesc jd;
-			jd.o1 = rbase + v.rPos[j]; jd.o2 = v.gPos[j]; jd.ops = (int64_t)ops_at; jd.m = rL; jd.n = gL;
-			a.jobs[slot] = jd;
-			w.kind[j] = W_JOB; w.val[j] = (int32_t)slot;
+			// nw_alignment(rL, frag1, gL, frag2): a job for the NW kernels (its slot and op bytes are reserved below, with everything else the candidate needs)
+			w.kind[j] = W_JOB; w.val[j] = -1;
+			n_new_jobs++; new_ops += rL + gL;
 			jobs = true;
 		}
 		if (host) { flag_host(a, r, why); continue; }
@@ -1574,9 +1570,27 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			if (!finish_candidate(a, cand, first, rd, v, w)) flag_host(a, r, WHY_CIGAR);
 			continue;
 		}
-		// park the candidate until its alignments exist
+		// park the candidate until its alignments exist.  What it needs of the lists -- a spill slot, its NW jobs and their op bytes --
+		// is reserved in ONE round of atomics (a returning atomic is a trip to the memory side; they used to follow each other pair by pair, each waited for)
 		unsigned long long sp = atomicAdd(&a.ctl[0], 1ull);
+		unsigned long long job_at = n_new_jobs ? atomicAdd(&a.ctl[1], (unsigned long long)n_new_jobs) : 0ull;
+		unsigned long long ops_at = n_new_jobs ? atomicAdd(&a.ctl[2], (unsigned long long)new_ops) : 0ull;
 		if (sp >= (unsigned long long)a.spill_capacity) { flag_host(a, r, WHY_CAPACITY); continue; }
+		if (job_at + (unsigned long long)n_new_jobs > (unsigned long long)a.job_capacity || ops_at + (unsigned long long)new_ops > (unsigned long long)a.ops_capacity) {
+			// (the job slots it took inside the list become empty jobs: the NW kernels must not find an earlier batch's descriptors there)
+			for (unsigned long long k = job_at; k < job_at + (unsigned long long)n_new_jobs && k < (unsigned long long)a.job_capacity; ++k) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[k] = jd; }
+			flag_host(a, r, WHY_CAPACITY);
+			continue;
+		}
+		for (int j = 0; j < num; ++j) {
+			if (w.kind[j] != W_JOB) continue;
+			const int rL = v.rLen[j], gL = v.gLen[j];
+			NwJobDesc jd;
+			jd.o1 = rbase + v.rPos[j]; jd.o2 = v.gPos[j]; jd.ops = (int64_t)ops_at; jd.m = rL; jd.n = gL;
+			a.jobs[job_at] = jd;
+			w.val[j] = (int32_t)job_at;
+			job_at++; ops_at += (unsigned long long)(rL + gL);
+		}
 		AlnSpill &o = a.spill[sp];
 		o.cand = (int32_t)cand;
 		o.num = num;
@@ -1587,10 +1601,13 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			o.p[j] = q;
 		}
 		if (pending) {
+			// (about one parked candidate in thirteen: a second round for those)
+			unsigned long long task_at = atomicAdd(&a.ctl[3], (unsigned long long)n_pending);
+			if (task_at + (unsigned long long)n_pending > (unsigned long long)a.job_capacity) flag_host(a, r, WHY_CAPACITY);
 			for (int j = 0; j < num; ++j) {
 				if (w.kind[j] != W_PENDING) continue;
-				unsigned long long t = atomicAdd(&a.ctl[3], 1ull);
-				if (t >= (unsigned long long)a.job_capacity) { flag_host(a, r, WHY_CAPACITY); break; }
+				const unsigned long long t = task_at++;
+				if (t >= (unsigned long long)a.job_capacity) break;          // (the read is the host's, flagged above; every slot inside the list is written)
 				PartTask pt;
 				pt.enc_off = rbase + v.rPos[j]; pt.g = v.gPos[j]; pt.spill = (int32_t)sp; pt.j = j; pt.read = (int32_t)r;
 				pt.rL = (int16_t)v.rLen[j]; pt.gL = (int16_t)v.gLen[j];
