@@ -323,7 +323,9 @@ def main():
     ap.add_argument("--one-file", action="store_true", help="N > 1: all ranks write into ONE shared SAM file by offset (the ranks then meet at that file's page-cache locks: ~20 GB/s from one L3 domain, less from several)")
     ap.add_argument("--leg", choices=["all", "seeding"], default="all", help="seeding: only the GPU seeding step on resident reads (what the rocprofv3 passes profile)")
     ap.add_argument("--seed-steps", type=int, default=5, help="timed launches of the seeding-stage leg")
-    ap.add_argument("--sa", choices=["sampled", "full", "compact", "dense4", "dense8"], default="full", help="suffix array placement (seeding-stage leg and, via KART_AMD_SA, the mapping runs): dense4 / dense8 = the smaller index")
+    ap.add_argument("--sa", choices=["auto", "sampled", "full", "compact", "dense4", "dense8"], default="auto",
+                    help="suffix array placement (seeding-stage leg and, via KART_AMD_SA, the mapping runs); auto = the product's default: full below 2^32 text symbols, compact (67 GB for a human-sized "
+                         "index instead of 168) above; dense4 / dense8 = the smaller index")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the reference -t 1 identity leg and the oracle sample")
     ap.add_argument("--no-seeding-leg", action="store_true")
@@ -498,7 +500,7 @@ def run(args, fallback_note):
     cores = effective_cores()
     threads = args.threads or max(2, cores // world)
     t0 = time.time()
-    if args.sa != "full":
+    if args.sa != "auto":
         os.environ["KART_AMD_SA"] = args.sa          # (read by the host library when it loads the index)
     sess = api.HostSession(prefix, local, threads)
     t_load = time.time() - t0
@@ -606,6 +608,7 @@ def run(args, fallback_note):
                    "parallelism": "%d process(es), one GPU + index replica each, contiguous chunk ranges of the same input, SAM merged by file offset" % world,
                    "files": "page-cache resident (%s)" % workdir,
                    "seed_group": seed_group_setting()[0], "stream_lanes": seed_group_setting()[1], "stream_reads": stream_reads_setting(),
+                   "sa_mode": resolved_sa(args),
                    "seeding": ("ONE search launch per round over the parsed batches of %d stream lanes (%d lanes in flight, 1.12 M-read batches)" % seed_group_setting()) if seed_group_setting()[0]
                               else "every stream lane seeds its own 1.12 M-read batch (%d lanes)" % seed_group_setting()[1],
                    "sam_bytes_per_step": sum(os.path.getsize(f) for f in out_files(outs[-1])),
@@ -837,7 +840,7 @@ def seeding_leg(args, api, prefix, codes, dev, n_reads_leg, oracle_sample):
     n_reads = n_reads_leg & ~1
     n_bases = n_reads * READ_LEN
     large = args.genome_len >= 300_000_000
-    ix = api.Index(prefix, dev.index or 0, {"full": api.KG_SA_FULL, "sampled": api.KG_SA_SAMPLED, "compact": api.KG_SA_FULL40, "dense4": api.KG_SA_DENSE4, "dense8": api.KG_SA_DENSE8}[args.sa])
+    ix = api.Index(prefix, dev.index or 0, {"auto": api.KG_SA_AUTO, "full": api.KG_SA_FULL, "sampled": api.KG_SA_SAMPLED, "compact": api.KG_SA_FULL40, "dense4": api.KG_SA_DENSE4, "dense8": api.KG_SA_DENSE8}[args.sa])
     batches = [gen_reads_device(codes, n_reads // 2, seed=1000 + b, err=0.011, dev=dev) for b in range(2)]
     seed_cap = (12 if large else 6) * n_reads + 1024
     d_seed_off = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)
@@ -897,7 +900,7 @@ def seeding_leg(args, api, prefix, codes, dev, n_reads_leg, oracle_sample):
     out.update({
         "value": n_reads * args.seed_steps / elapsed, "unit": "reads/s", "reads_per_launch": n_reads, "launches": args.seed_steps,
         "what": "kg_seed_batch_device on HBM-resident reads: pack + search + scan + locate + sort (last round's `value`)",
-        "sa_mode": args.sa, "index_bytes": int(ix.info.device_bytes),
+        "sa_mode": SA_NAMES.get(int(ix.info.sa_mode), args.sa), "index_bytes": int(ix.info.device_bytes),
         "kernels_ms": {"search": search_ms, "scan": float(kms[:, 1].mean()), "locate": float(kms[:, 2].mean()), "sort": float(kms[:, 3].mean())},
         "fetched_per_read": {k2: v / n_reads for k2, v in tr.as_dict().items() if k2 != "sa_entry_bytes"},
         "reference_algorithm_per_read": {k2: v / n_reads for k2, v in c.items()},
@@ -1105,6 +1108,14 @@ def seed_group_setting():
     return g, lanes
 
 
+def resolved_sa(args):
+    """the index mode `--sa auto` becomes (kg_index_load: full below 2^32 text symbols -- both strands --, compact above)"""
+    if args.sa != "auto":
+        return args.sa
+    return "compact" if 2 * int(args.genome_len or HG38_LEN) >= 0xFFFFFFFF else "full"
+
+
+SA_NAMES = {0: "sampled", 1: "full", 5: "compact", 4: "dense4", 8: "dense8"}
 KERNEL_SLOTS = ("chain", "aln_pair", "aln_rescue", "aln_plan_fast", "aln_plan", "aln_partition", "nw", "aln_finish", "aln_final", "sam_size", "sam_format",
                 "fq_parse", "fq_materialise")
 VALU_INT32_PEAK_TOPS = 78.0       # int32 VALU lane-operations per second of the device, in 1e12 (VERDICT r4 #6's figure; ~12 of them per DP cell)
@@ -1146,6 +1157,8 @@ def kernel_traffic(args):
         if not t or t.get("pairs_per_step") != getattr(args, "pairs", None) or t.get("genome_len", GENOME_LEN) != args.genome_len:
             continue
         if t.get("seed_group") != seed_group_setting()[0] or t.get("stream_lanes") != seed_group_setting()[1] or t.get("stream_reads") != stream_reads_setting():
+            continue
+        if t.get("sa_mode", "full") != resolved_sa(args):
             continue
         best = (t.get("bytes_per_step", {}), "profiles/" + f)
     return best
@@ -1302,6 +1315,8 @@ def measured_traffic(n_reads, args, tag=None):
             if not t or t.get("tag") != tag or t.get("genome_len", GENOME_LEN) != args.genome_len:
                 continue
             if tag is None and t.get("reads_per_launch") != n_reads:
+                continue
+            if t.get("sa_mode", "full") != resolved_sa(args):
                 continue
             # the timed region: the same reads per step and the same seeding configuration as the profiled run (a launch of a run with
             # other batch sizes fetches other bytes -- round 3 quoted the 20 M-read run's figure for the 100 M-read run)

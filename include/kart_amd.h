@@ -62,6 +62,10 @@ extern "C" {
 /* the compact index: the whole suffix array in 5-byte entries (4-byte ones where the text allows), a q-mer table of a quarter the
  * size, no triple planes -- ~66 GB instead of ~168 GB for a human genome, no walks */
 #define KG_SA_FULL40         5
+/* what the host pipeline asks for unless told otherwise: KG_SA_FULL for a text of fewer than 2^32 symbols (forward + reverse strand; there the
+ * whole index is a few hundred MB either way), KG_SA_FULL40 above -- a human-sized index then takes 67 GB of a GPU's 288 instead of 168, at
+ * -1 % of the FASTQ -> SAM rate (profiles/r05zg_ab_sa.log).  kg_index_info::sa_mode reports what it became. */
+#define KG_SA_AUTO           (-1)
 
 typedef struct kg_index kg_index;
 typedef struct kg_workspace kg_workspace;

@@ -27,6 +27,7 @@ KG_OK = 0
 KG_MODE_FAST, KG_MODE_SENSITIVE = 0, 1
 KG_INPUT_ASCII = 0x100   # OR into mode: reads are given as characters, encoded on the device
 KG_SA_SAMPLED, KG_SA_FULL = 0, 1
+KG_SA_AUTO = -1                        # full below 2^32 text symbols, compact above (the host pipeline's default)
 KG_SA_FULL40 = 5                       # the compact index: 5-byte suffix-array entries, a quarter of the q-mer table, no triple planes
 KG_SA_DENSE4, KG_SA_DENSE8 = 4, 8       # the smaller index: every 4th / 8th suffix-array entry resident, no triple planes
 KG_OCC_THR_DEFAULT = 50

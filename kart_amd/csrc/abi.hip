@@ -118,6 +118,7 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	v.L2[0] = 0;
 	memcpy(&v.L2[1], bwt.data() + 8, 32);
 	v.seq_len = v.L2[4];
+	if (sa_mode == KG_SA_AUTO) ix->sa_mode = sa_mode = v.seq_len < 0xFFFFFFFFull ? KG_SA_FULL : KG_SA_FULL40;
 	size_t n_words = (bwt.size() - 40) / 4;
 	{
 		// 16 symbols per word, 8 count words in front of every 128-symbol block, one trailing count record

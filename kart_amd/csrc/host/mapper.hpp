@@ -42,7 +42,7 @@ struct Options {
 	bool parts = false;             // -parts: a sharded run writes one file per shard, <out>.<r>; `cat <out>.0 <out>.1 ...` is the single-process file.
 	                                // One file takes ~10-13 GB/s of text on the 2-socket box however many processes write it: with several
 	                                // GPUs that is the run's ceiling; parts have no such common ceiling.
-	int sa_mode = KG_SA_FULL;
+	int sa_mode = KG_SA_AUTO;
 	int64_t batch_reads = default_batch_reads();   // reads seeded per GPU call (a whole number of 4000-read chunks; KART_AMD_BATCH_READS overrides)
 	int64_t stream_reads = default_stream_reads();   // reads per batch of the device's FASTQ-in / SAM-out stream (KART_AMD_STREAM_READS overrides)
 	static int64_t default_stream_reads() { const char *e = getenv("KART_AMD_STREAM_READS"); long long v = e ? atoll(e) : 0; return v >= 4000 ? (int64_t)v : 1120000; }   // (280 chunks: four lanes' batches = 4.3 M reads per seeding launch, roofline.frac 0.157-0.159 in product; 1.0 M: 0.149-0.151, 1.2 M: 0.164, the FASTQ -> SAM rate alike within its noise, profiles/r04zf_ab_stream_reads.log)

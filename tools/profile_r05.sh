@@ -32,7 +32,7 @@ for k, cs in list(out.items()):
         wr_b = wr["sum"] * 1024 * (n / max(1, wr["dispatches"]))
         hit, miss = cs.get("TCC_HIT_sum", {"sum": 0})["sum"], cs.get("TCC_MISS_sum", {"sum": 0})["sum"]
         out["_search_traffic"] = {"tag": "timed", "kernel": k.replace("kg::", ""), "genome_len": 3100000000, "launches": n, "pairs_per_step": $PAIRS,
-                                  "seed_group": cfg.get("seed_group"), "stream_lanes": cfg.get("stream_lanes"), "stream_reads": cfg.get("stream_reads"),
+                                  "seed_group": cfg.get("seed_group"), "stream_lanes": cfg.get("stream_lanes"), "stream_reads": cfg.get("stream_reads"), "sa_mode": cfg.get("sa_mode", "full"),
                                   "read_bytes_corrected": rd, "WRITE_SIZE_bytes": wr_b, "traffic_bytes_per_launch": (rd + wr_b) / n,
                                   "l2_hit_rate": hit / (hit + miss) if hit + miss else None, "TCC_HIT": hit, "TCC_MISS": miss,
                                   "note": "gfx950: read traffic = RDREQ_128B x 128 + RDREQ_64B x 64 (FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); "
@@ -54,7 +54,7 @@ for slot, names in slots.items():
         wr += cs.get("WRITE_SIZE", {"sum": 0})["sum"] * 1024
         hit += cs.get("TCC_HIT_sum", {"sum": 0})["sum"]; miss += cs.get("TCC_MISS_sum", {"sum": 0})["sum"]
     if rd + wr > 0: kt[slot] = {"bytes": (rd + wr) / STEPS, "read": rd / STEPS, "written": wr / STEPS, "l2_hit_rate": hit / (hit + miss) if hit + miss else None}
-out["_kernel_traffic"] = {"pairs_per_step": $PAIRS, "genome_len": 3100000000, "seed_group": cfg.get("seed_group"), "stream_lanes": cfg.get("stream_lanes"), "stream_reads": cfg.get("stream_reads"),
+out["_kernel_traffic"] = {"pairs_per_step": $PAIRS, "genome_len": 3100000000, "seed_group": cfg.get("seed_group"), "stream_lanes": cfg.get("stream_lanes"), "stream_reads": cfg.get("stream_reads"), "sa_mode": cfg.get("sa_mode", "full"),
                           "steps_profiled": STEPS, "bytes_per_step": {k: v["bytes"] for k, v in kt.items()}, "detail": kt,
                           "note": "per kernel: (RDREQ_128B x 128 + RDREQ_64B x 64 + WRITE_SIZE KiB x 1024) summed over the run's launches / the 3 steps the passes ran"}
 json.dump(out, open("gpurun_out/${TAG}_bench_pmc_summary.json", "w"), indent=1, sort_keys=True)
