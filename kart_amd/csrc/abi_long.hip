@@ -195,9 +195,10 @@ extern "C" int kg_longread_batch(kg_workspace *ws, const kg_aln_record **records
 			HIP_TRY(hipMemcpyAsync(pc, f.ctl, 8 * FC_WORDS, hipMemcpyDeviceToHost, st));
 			HIP_TRY(hipStreamSynchronize(st));
 			const double nt = (double)std::max(1ull, pc[FC_PROF + 5]);
-			fprintf(stderr, "kg_longread_batch: %lld requests, %llu tasks, %llu pieces, %llu NW jobs | wave cycles per task: load+pack %.0f, diagonal scan %.0f, sort %.0f, normal pairs %.0f, pieces %.0f | runs per task %.1f, columns per task %.0f\n",
+			fprintf(stderr, "kg_longread_batch: %lld requests, %llu tasks, %llu pieces, %llu NW jobs | wave cycles per task: load+pack %.0f, diagonal scan %.0f, sort %.0f, normal pairs %.0f, pieces %.0f | runs per task %.1f, columns per task %.0f | seed filters in %.1f %% of the tasks (%.0f wave cycles each), lane-0 gap pairs in %.1f %% (%.0f each)\n",
 			        (long long)n_req, pc[FC_PROF + 5], pc[FC_PIECES], pc[FC_JOBS], (double)pc[FC_PROF] / nt, (double)pc[FC_PROF + 1] / nt, (double)pc[FC_PROF + 2] / nt, (double)pc[FC_PROF + 3] / nt,
-			        (double)pc[FC_PROF + 4] / nt, (double)pc[FC_PROF + 6] / nt, (double)pc[FC_PROF + 7] / nt);
+			        (double)pc[FC_PROF + 4] / nt, (double)pc[FC_PROF + 6] / nt, (double)pc[FC_PROF + 7] / nt,
+			        100.0 * (double)pc[FC_PROF + 8] / nt, (double)pc[FC_PROF + 10] / (double)std::max(1ull, pc[FC_PROF + 8]), 100.0 * (double)pc[FC_PROF + 9] / nt, (double)pc[FC_PROF + 11] / (double)std::max(1ull, pc[FC_PROF + 9]));
 		}
 	}
 

@@ -134,11 +134,11 @@ __device__ bool resolve_overlap(FragPairs &v, int i, int j)
 // IdentifyNormalPairs(rlen, glen, v) for a fragment (glen > 0), src/AlignmentCandidates.cpp:420-490, by ONE lane on the LDS arrays, in two parts:
 // filter_pairs = the three seed filters (:426-428), gap_pairs = the gap pairs between neighbours and the head / tail pairs (:437-488).
 // byr: scratch of v.num entries (read-position order).  gap_pairs returns false for more pairs than `cap`.
-__device__ void filter_pairs(FragPairs &v, uint16_t *byr)
+__device__ void filter_pairs(FragPairs &v, uint16_t *byr, bool tandem_done = false, bool byr_done = false)
 {
 	if (v.num > 1) {
 		// RemoveTandemRepeatSeeds, :235-260: every read position hit by more than one seed goes
-		{
+		if (!tandem_done) {
 			bool any = false;
 			for (int i = 0; i < v.num; ++i) byr[i] = 0;
 			for (int i = 0; i < v.num; ++i)
@@ -153,7 +153,7 @@ __device__ void filter_pairs(FragPairs &v, uint16_t *byr)
 		// RemoveTranslocatedSeeds, :262-321: byr[k] = index (in genome order) of the seed with the k-th smallest read position
 		if (v.num > 1) {
 			const int num = v.num;
-			for (int i = 0; i < num; ++i) {
+			for (int i = 0; i < num && !byr_done; ++i) {
 				int p = i;
 				while (p > 0 && v.rPos[byr[p - 1]] > v.rPos[i]) { byr[p] = byr[p - 1]; --p; }
 				byr[p] = (uint16_t)i;
@@ -256,6 +256,7 @@ __device__ bool resolve_overlap_wave(int &G, int &R, int &L, int &GL, int i, int
 
 __device__ int filter_pairs_wave(int num, int lane, int &G, int &R, int &L, int &GL)
 {
+	num = __builtin_amdgcn_readfirstlane(num);          // (wave-uniform, and the compiler must know: the loops below are scalar loops then, not masked vector ones)
 	if (num <= 1) return num;
 	// RemoveTandemRepeatSeeds, :235-260
 	{
@@ -321,6 +322,50 @@ __device__ int filter_pairs_wave(int num, int lane, int &G, int &R, int &L, int 
 		if (any) num = compact_seeds_wave(num, lane, G, R, L, GL);
 	}
 	return num;
+}
+
+// filter_pairs for more than 64 seeds (a fragment of thousands of bases inside a repeat): the two quadratic steps by the whole wave on the LDS arrays -- the
+// tandem marks (every lane compares the read positions of its seeds with everybody's) and the read-position order (rank by counting: the positions
+// are distinct once the tandem seeds are gone) --, the sequential rest by lane 0 as before.  By one lane the insertion sort alone was ~10 M wave cycles
+// for 380 seeds: a handful of such tasks set the duration of the whole launch.  n_shared: the seed count as lane 0 publishes it.
+__device__ void filter_pairs_wide(FragPairs &v, uint16_t *byr, int lane, int *n_shared)
+{
+	int num = __builtin_amdgcn_readfirstlane(v.num);
+	if (num > 1) {
+		bool mine = false;
+		for (int i = lane; i < num; i += 64) {
+			const int ri = v.rPos[i];
+			bool dup = false;
+			for (int j = 0; j < num; ++j) dup = dup || (j != i && v.rPos[j] == ri);
+			byr[i] = dup ? 1 : 0;
+			mine = mine || dup;
+		}
+		const bool any = __ballot(mine) != 0;
+		__syncthreads();
+		if (any) {
+			if (lane == 0) {
+				for (int i = 0; i < num; ++i)
+					if (byr[i]) v.rLen[i] = v.gLen[i] = 0;
+				erase_empty(v);
+				*n_shared = v.num;
+			}
+			__syncthreads();
+			num = __builtin_amdgcn_readfirstlane(*n_shared);
+		}
+		__syncthreads();
+		for (int i = lane; i < num; i += 64) {
+			const int ri = v.rPos[i];
+			int rank = 0;
+			for (int j = 0; j < num; ++j) rank += v.rPos[j] < ri ? 1 : 0;
+			byr[rank] = (uint16_t)i;
+		}
+		__syncthreads();
+	}
+	if (lane == 0) {
+		v.num = num;
+		filter_pairs(v, byr, true, true);
+		*n_shared = v.num;
+	}
 }
 
 __device__ bool gap_pairs(int rlen, int glen, FragPairs &v, int cap)
@@ -464,7 +509,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 	// for (100 k + 129 k of a task's 295 k wave cycles, profiles/r05w_frag_prof.log).  What a wave leaves unused stays behind: pieces and op bytes
 	// nobody refers to, job slots as empty jobs.  Level 0 only -- the levels below hold a few hundred tasks.
 	const bool pooled = level == 0;
-	unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // [8] tasks whose seeds went through the filters, [9] ... whose gap pairs lane 0 made, [10] / [11] the wave cycles of either
 	unsigned long long pc_next = 0, pc_end = 0, jb_next = 0, jb_end = 0, op_next = 0, op_end = 0;
 	auto empty_jobs = [&](unsigned long long from, unsigned long long to) {
 		if (to > (unsigned long long)a.job_capacity) to = (unsigned long long)a.job_capacity;
@@ -504,7 +549,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		FragTask &task = a.tasks[ti];
 		const long long c0 = a.prof ? clock64() : 0;
 		long long c1 = c0, c2 = c0, c3 = c0, c4 = c0;
-		const int rL = __shfl(my_rL, cur), gL = __shfl(my_gL, cur);
+		const int rL = __builtin_amdgcn_readlane(my_rL, cur), gL = __builtin_amdgcn_readlane(my_gL, cur);       // (uniform, in scalar registers)
 		const long long task_f1_off = (long long)shfl_u64_frag((unsigned long long)my_f1, cur);
 		const uint8_t *f1 = reinterpret_cast<const uint8_t *>(a.f1) + task_f1_off;
 		const int64_t g = (int64_t)shfl_u64_frag((unsigned long long)my_g, cur);
@@ -600,7 +645,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 					}
 				}
 				__syncthreads();
-				n_runs = s_n;
+				n_runs = __builtin_amdgcn_readfirstlane(s_n);
 				if (n_runs > kMaxRuns) {
 					if (kSmall) { if (lane == 0) task.status = 2; __syncthreads(); continue; }       // (more matches than the small arrays hold: the full-size kernel's)
 					host = true; why = 2;
@@ -631,6 +676,8 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 		if (fast_num < 0) {
 			FragPairs v;
 			v.gPos = s_gPos; v.rPos = s_rPos; v.rLen = s_rLen; v.gLen = s_gLen; v.simple = s_simple; v.num = n_runs;
+			const long long cf0 = a.prof ? clock64() : 0;
+			if (a.prof && eligible) prof_acc[8] += 1;
 			if (eligible && n_runs <= 64 && !a.no_fast_pairs) {
 				int G = 0, R = 0, L = 0, GL = 0;
 				if (lane < n_runs) { G = s_gPos[lane]; R = s_rPos[lane]; L = s_rLen[lane]; GL = s_gLen[lane]; }
@@ -638,14 +685,18 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 				__syncthreads();
 				if (lane < kept) { s_gPos[lane] = (frp_t)G; s_rPos[lane] = (frp_t)R; s_rLen[lane] = (frp_t)L; s_gLen[lane] = (frp_t)GL; s_simple[lane] = 1; }
 				if (lane == 0) s_n = kept;
-			} else if (lane == 0) {
+			} else if (eligible && !a.no_fast_pairs) filter_pairs_wide(v, s_byr, lane, &s_n);
+			else if (lane == 0) {
 				if (eligible) filter_pairs(v, s_byr);
 				s_n = eligible ? v.num : 0;
 			}
 			__syncthreads();
-			const int n2 = s_n;
+			if (a.prof) prof_acc[10] += (unsigned long long)(clock64() - cf0);
+			const int n2 = __builtin_amdgcn_readfirstlane(s_n);
 			__syncthreads();
 			if (eligible && n2 > 0 && !a.no_fast_pairs) fast_num = identify_normal_pairs_wave<kC>(rL, gL, n2, lane, nullptr, s_gPos, s_rPos, s_rLen, s_gLen, s_simple);
+			const long long cg0 = a.prof ? clock64() : 0;
+			if (a.prof && fast_num < 0 && eligible && n2 > 0) prof_acc[9] += 1;
 			if (lane == 0 && fast_num < 0) {
 				v.num = n2;
 				bool h2 = host, wj = whole_job;
@@ -653,13 +704,14 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 				if (eligible && v.num == 0) wj = true;                       // no common 8-mer survived: the whole fragment is one alignment (:214-221)
 				s_n = h2 ? -1 : wj ? 0 : v.num;
 			}
+			if (a.prof && fast_num < 0) { __syncthreads(); prof_acc[11] += (unsigned long long)(clock64() - cg0); }
 		}
 		if (lane == 0 && fast_num >= 0) s_n = fast_num;
 		__syncthreads();
 		if (a.prof) c4 = clock64();
 		// ... and the whole wave turns the pairs into the task's pieces: literal runs, NW jobs, sub-tasks -- counted first, reserved with ONE
 		// atomic per list, then written, every lane its own pair (a lane-0 loop over ~27 pairs with a global store each was 95 k of a task's 320 k cycles)
-		const int num = s_n;                                // -1: outside the envelope; 0: one alignment for the whole fragment
+		const int num = __builtin_amdgcn_readfirstlane(s_n);     // -1: outside the envelope; 0: one alignment for the whole fragment
 		host = num < 0;
 		if (host && why < 0) why = s_bad == 2 ? 3 : 2;
 		int first = 0, count = 0;
@@ -778,7 +830,7 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 	}
 	empty_jobs(jb_next, jb_end);
 	if (a.prof && lane == 0)                        // (per wave, not per task: eight atomics per task on one line were a fifth of the profiled run)
-		for (int k = 0; k < 8; ++k) atomicAdd(&a.ctl[FC_PROF + k], prof_acc[k]);
+		for (int k = 0; k < 12; ++k) atomicAdd(&a.ctl[FC_PROF + k], prof_acc[k]);
 }
 
 // the tasks appended while `level` was processed are the next level
@@ -797,7 +849,7 @@ __global__ void frag_reset_kernel(FragArgs a)
 	if (i == 0) {
 		a.ctl[FC_TASKS] = (unsigned long long)a.n; a.ctl[FC_PIECES] = 0; a.ctl[FC_JOBS] = 0; a.ctl[FC_OPS] = 0;
 		a.ctl[FC_LEVEL0] = 0; a.ctl[FC_LEVEL0 + 1] = (unsigned long long)a.n;
-		for (int k = 0; k < 8; ++k) a.ctl[FC_PROF + k] = 0;
+		for (int k = 0; k < 12; ++k) a.ctl[FC_PROF + k] = 0;
 		for (int k = 0; k < 6; ++k) a.ctl[FC_WHY + k] = 0;
 		for (int l = 2; l <= kFragMaxDepth + 1; ++l) a.ctl[FC_LEVEL0 + l] = (unsigned long long)a.n;
 	}

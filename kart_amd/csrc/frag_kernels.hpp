@@ -18,7 +18,7 @@ constexpr int kFragWavesPerCu = 10, kFragSmallWavesPerCu = 32;      // the full-
 int64_t frag_pool_waves(int64_t n_requests, int n_cu);              // waves of a level-0 launch that may leave a stretch of each list behind
 
 enum { FP_JOB = 3, FP_TASK = 4 };        // FragPiece::kind beyond the literal runs KG_OP_DIAG / KG_OP_GAP1 / KG_OP_GAP2
-enum { FC_TASKS = 0, FC_PIECES = 1, FC_JOBS = 2, FC_OPS = 3, FC_LEVEL0 = 4, FC_PROF = FC_LEVEL0 + kFragMaxDepth + 2, FC_WHY = FC_PROF + 8, FC_WORDS = FC_WHY + 6 };   // FC_PROF: wave cycles per phase (KG_FRAG_PROF)
+enum { FC_TASKS = 0, FC_PIECES = 1, FC_JOBS = 2, FC_OPS = 3, FC_LEVEL0 = 4, FC_PROF = FC_LEVEL0 + kFragMaxDepth + 2, FC_WHY = FC_PROF + 12, FC_WORDS = FC_WHY + 6 };   // FC_PROF: wave cycles per phase (KG_FRAG_PROF)
 // FC_WHY: tasks that sent their request back, by reason: [0] a side above kFragMaxLen, [1] a read character other than A/C/G/T, [2] more than kFragMaxRuns matches,
 // [3] more normal pairs than the LDS arrays hold, [4] a work list was full, [5] recursion deeper than kFragMaxDepth
 
