@@ -34,15 +34,6 @@ __device__ __forceinline__ uint64_t text_word32_at(const uint8_t *text, int64_t 
 	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 
-// 32 codes (2 bits each) starting at base `at` of a packed LDS array of 64-bit words (32 bases per word); `at` may be negative
-// or beyond the end: bases outside [0, n) read as 0 (the caller masks them)
-__device__ __forceinline__ uint64_t codes32(const uint64_t *w, int n_words, int at)
-{
-	const int wi = at >> 5, sh = (at & 31) << 1;          // (arithmetic shift: at = -1 -> word -1)
-	uint64_t lo = (wi >= 0 && wi < n_words) ? w[wi] : 0, hi = (wi + 1 >= 0 && wi + 1 < n_words) ? w[wi + 1] : 0;
-	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-}
-
 // 32 read characters as four 8-byte words (the uploaded characters have 64 bytes of slack behind them); words at or beyond rL are not loaded
 __device__ __forceinline__ void load_chars32(const uint8_t *f1, int w, int rL, uint64_t c[4])
 {
@@ -590,40 +581,50 @@ __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int leve
 				for (int d = -(max_shift - 1) + lane; d <= max_shift - 1; d += 64) {
 					const int t_lo = d < 0 ? -d : 0, t_hi = rL < gL - d ? rL : gL - d;      // read positions t with 0 <= t + d < gL
 					int run = 0;
-					for (int base = t_lo & ~31; base < t_hi; base += 32) {
-						const uint64_t x = codes32(s_rd, rw, base) ^ codes32(s_tx, gw, base + d);
+					// (the read side is word-aligned: one LDS read; the text side at base + d keeps the upper word of a step as the lower one of the next:
+					//  two LDS reads per step instead of four.  Everything after the loads is 32-bit arithmetic: the 64-bit shifts this loop was made of --
+					//  the funnel shift of the text, the range masks, the test for eight equal bases in a row -- run at a quarter of the rate; the text
+					//  is shifted by v_alignbit on its 32-bit halves, the equal bases of each half are compressed to 16 bits, the rest works on one 32-bit mask)
+					int base = t_lo & ~31;
+					int wi = (base + d) >> 5;                           // (arithmetic shift: -1 for a start left of the text)
+					const int sh = ((base + d) & 31) << 1;
+					const bool wide = sh >= 32;
+					const uint32_t s5 = (uint32_t)sh & 31u;
+					uint64_t tlo = (wi >= 0 && wi < gw) ? s_tx[wi] : 0;
+					auto eq16 = [](uint32_t x) {                        // 16 bases of 2 bits: bit i = base i is 0 (equal)
+						uint32_t y = ~(x | (x >> 1)) & 0x55555555u;
+						y = (y | (y >> 1)) & 0x33333333u;
+						y = (y | (y >> 2)) & 0x0F0F0F0Fu;
+						y = (y | (y >> 4)) & 0x00FF00FFu;
+						return (y | (y >> 8)) & 0xFFFFu;
+					};
+					for (; base < t_hi; base += 32, ++wi) {
+						const uint64_t thi = (wi + 1 >= 0 && wi + 1 < gw) ? s_tx[wi + 1] : 0;
+						const uint64_t rdw = s_rd[base >> 5];
+						const uint32_t t0 = (uint32_t)tlo, t1 = (uint32_t)(tlo >> 32), t2 = (uint32_t)thi, t3 = (uint32_t)(thi >> 32);
+						tlo = thi;
+						const uint32_t a0 = wide ? t1 : t0, a1 = wide ? t2 : t1, a2 = wide ? t3 : t2;
+						const uint32_t xl = (uint32_t)rdw ^ __builtin_amdgcn_alignbit(a1, a0, s5), xh = (uint32_t)(rdw >> 32) ^ __builtin_amdgcn_alignbit(a2, a1, s5);
+						uint32_t m = eq16(xl) | (eq16(xh) << 16);                           // bit i: read base base + i equals text base base + d + i
 						const int lo = t_lo > base ? t_lo - base : 0, hi = t_hi - base < 32 ? t_hi - base : 32;
-						// 1 at the even bit of every equal base inside [lo, hi)
-						uint64_t e = ~(x | (x >> 1)) & 0x5555555555555555ull;
-						e &= (hi >= 32 ? ~0ull : ((1ull << (2 * hi)) - 1ull)) & ~((1ull << (2 * lo)) - 1ull);
+						if (lo != 0 || hi != 32) m &= (hi >= 32 ? ~0u : (1u << hi) - 1u) & ~((1u << lo) - 1u);
+						if (m == 0xffffffffu) { run += 32; continue; }
+						const int t = __ffs((int)~m) - 1;                                   // equal bases from position 0 up
 						// the common case -- 98 of 99 diagonals are not the alignment's -- has no 8 equal bases in a row in this word and the
 						// run carried in does not reach 8 either: only the equal bases at the top of the word are carried on
 						{
-							uint64_t e8 = e & (e >> 2);
-							e8 &= e8 >> 4;
-							e8 &= e8 >> 8;
-							const uint64_t ne = ~e & 0x5555555555555555ull;
-							const int low_ones = ne ? (__ffsll((unsigned long long)ne) - 1) >> 1 : 32;      // equal bases from position 0 up
-							if (e8 == 0 && run + low_ones < 8) {
-								run = ne ? (__clzll((long long)ne) >> 1) : 32;                               // equal bases at the top (position 31 down); ne != 0 here
-								continue;
-							}
+							uint32_t q8 = m & (m >> 1);
+							q8 &= q8 >> 2;
+							q8 &= q8 >> 4;
+							if (q8 == 0 && run + t < 8) { run = __clz((int)~m); continue; }
 						}
-						e = (e | (e >> 1)) & 0x3333333333333333ull;
-						e = (e | (e >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-						e = (e | (e >> 4)) & 0x00FF00FF00FF00FFull;
-						e = (e | (e >> 8)) & 0x0000FFFF0000FFFFull;
-						e = (e | (e >> 16)) & 0x00000000FFFFFFFFull;
-						const uint32_t m = (uint32_t)e;
 						// the runs of equal bases in this word, without walking every run and gap (a 15 %-error diagonal alternates ~10 times per word, and
 						// the whole wave waited for the one lane on the alignment's diagonal: round 5): the run entering the word ends at the first zero; runs
 						// of >= 8 inside the word start where eight ones in a row begin; the run touching the top is carried on
-						if (m == 0xffffffffu) { run += 32; continue; }
 						auto emit = [&](int start, int len) {
 							int k = atomicAdd(&s_n, 1);
 							if (k < kMaxRuns) { s_run_r[k] = start; s_run_d[k] = d; s_run_l[k] = len; }
 						};
-						const int t = __ffs((int)~m) - 1;                                   // equal bases from position 0 up
 						if (run + t >= 8) emit(base - run, run + t);
 						const int top = __clz((int)~m);                                     // equal bases from position 31 down (m != all ones)
 						uint32_t in = m & ~((2u << t) - 1u);                                // what lies strictly inside: not the run at the bottom, not the one at the top
