@@ -38,6 +38,18 @@ __device__ __forceinline__ char text_char(const AlnArgs &a, int64_t g)      // R
 	return c == 0 ? 'A' : c == 1 ? 'C' : c == 2 ? 'G' : 'T';
 }
 
+struct __attribute__((packed, aligned(1))) AlnU64u { uint64_t v; };
+
+// 32 bases of the 2-bit text from position p (base i in bits 2 i); beyond the end of the text: zeros
+__device__ __forceinline__ uint64_t text_word32(const AlnArgs &a, int64_t p)
+{
+	if (p > a.two_genome_size) return 0;                 // (the text buffer has 16 bytes of slack behind its last base)
+	const uint8_t *tp = a.ix.text + ((uint64_t)p >> 2);
+	uint64_t lo = reinterpret_cast<const AlnU64u *>(tp)->v, hi = tp[8];
+	int sh = ((int)p & 3) << 1;
+	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
 __device__ __forceinline__ int chunk_of(const AlnArgs &a, int64_t r)
 {
 	// (the chunks of a batch are equally long but for the last: the proportional guess is right, two independent loads confirm it;
@@ -795,17 +807,45 @@ struct Columns {
 	int64_t g;                      // text coordinate of the fragment
 };
 
+// The columns of an op string one after the other: the op, the read's character and the text's of each ('-' for a gap).  Ops and read characters come
+// eight per load, text bases 32 per load (all three buffers have slack behind their last byte) -- a byte load each per column, each waited for, was most
+// of what aln_finish_kernel did with its time.
+struct __attribute__((packed, aligned(1))) ColU64u { uint64_t v; };
+struct ColCursor {
+	int t, ri, gi;                  // the next column; read / text characters consumed before it
+	int op_at, rd_at, tx_at;        // the first index each loaded word holds
+	uint64_t opw, rdw, txw;
+	__device__ __forceinline__ ColCursor(int t0, int ri0, int gi0) : t(t0), ri(ri0), gi(gi0), op_at(t0 - 8), rd_at(ri0 - 8), tx_at(gi0 - 32), opw(0), rdw(0), txw(0) {}
+	__device__ __forceinline__ void next(const AlnArgs &a, const Columns &c, char &c1, char &c2)
+	{
+		if (t - op_at >= 8) { op_at = t; opw = reinterpret_cast<const ColU64u *>(c.ops + t)->v; }
+		const uint8_t op = (uint8_t)(opw >> (8 * (t - op_at)));
+		if (op == KG_OP_GAP1) c1 = '-';
+		else {
+			if (ri - rd_at >= 8) { rd_at = ri; rdw = reinterpret_cast<const ColU64u *>(c.rd + ri)->v; }
+			c1 = (char)(uint8_t)(rdw >> (8 * (ri - rd_at)));
+			ri++;
+		}
+		if (op == KG_OP_GAP2) c2 = '-';
+		else {
+			if (gi - tx_at >= 32) { tx_at = gi; txw = text_word32(a, c.g + gi); }
+			const int code = (int)((txw >> (2 * (gi - tx_at))) & 3);
+			c2 = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T';
+			gi++;
+		}
+		t++;
+	}
+};
+
 // AddNewCigarElements over columns [from, to), src/tools.cpp:49-104; (ri, gi) = characters consumed before `from`
 __device__ int add_cigar_columns(const AlnArgs &a, const Columns &c, int from, int to, int ri, int gi, Cigar &cig)
 {
 	char state = '*';
 	int cnt = 0, score = 0;
-	for (int t = from; t < to; ++t) {
-		uint8_t op = c.ops[t];
-		char c1 = op == KG_OP_GAP1 ? '-' : (char)c.rd[ri];
-		char c2 = op == KG_OP_GAP2 ? '-' : text_char(a, c.g + gi);
-		if (op != KG_OP_GAP1) ri++;
-		if (op != KG_OP_GAP2) gi++;
+	ColCursor k(from, ri, gi);
+	while (k.t < to) {
+		char c1, c2;
+		k.next(a, c, c1, c2);
 		char st;
 		if (c1 == '-') st = 'D';
 		else if (c2 == '-') st = 'I';
@@ -824,13 +864,11 @@ __device__ int add_cigar_columns(const AlnArgs &a, const Columns &c, int from, i
 // CheckLocalAlignmentQuality, src/tools.cpp:255-290
 __device__ bool local_quality_ok(const AlnArgs &a, const Columns &c)
 {
-	int type = -1, n = 0, mis = 0, runs = 0, ri = 0, gi = 0;
-	for (int t = 0; t < c.len; ++t) {
-		uint8_t op = c.ops[t];
-		char c1 = op == KG_OP_GAP1 ? '-' : (char)c.rd[ri];
-		char c2 = op == KG_OP_GAP2 ? '-' : text_char(a, c.g + gi);
-		if (op != KG_OP_GAP1) ri++;
-		if (op != KG_OP_GAP2) gi++;
+	int type = -1, n = 0, mis = 0, runs = 0;
+	ColCursor k(0, 0, 0);
+	while (k.t < c.len) {
+		char c1, c2;
+		k.next(a, c, c1, c2);
 		int ty;
 		if (c1 == '-') ty = 0;
 		else if (c2 == '-') ty = 1;
@@ -840,71 +878,59 @@ __device__ bool local_quality_ok(const AlnArgs &a, const Columns &c)
 	return !(runs >= 4 || (mis >= 3 && mis >= (int)(n * 0.3)));
 }
 
-// character of column t on either side ('-' for a gap); (ri, gi) advance
-__device__ __forceinline__ void column_chars(const AlnArgs &a, const Columns &c, int t, int &ri, int &gi, char &c1, char &c2)
-{
-	uint8_t op = c.ops[t];
-	c1 = op == KG_OP_GAP1 ? '-' : (char)c.rd[ri];
-	c2 = op == KG_OP_GAP2 ? '-' : text_char(a, c.g + gi);
-	if (op != KG_OP_GAP1) ri++;
-	if (op != KG_OP_GAP2) gi++;
-}
-
 // ProcessHeadSequencePair after the alignment, src/tools.cpp:314-339: leading gaps of either string are trimmed
 __device__ int finish_head(const AlnArgs &a, const Columns &c, int64_t &gPos, int &gLen, int &rPos, int &rLen, Cigar &cig)
 {
 	if (!local_quality_ok(a, c)) { cig.push(rLen, 'S'); return 0; }
-	int t = 0, ri = 0, gi = 0;
+	ColCursor k(0, 0, 0);
 	// leading '-' of the read side: genome characters without a partner
 	int p = 0;
-	for (;;) {
-		if (t >= c.len) break;
-		int r2 = ri, g2 = gi;
+	while (k.t < c.len) {
+		ColCursor k2 = k;
 		char c1, c2;
-		column_chars(a, c, t, r2, g2, c1, c2);
+		k2.next(a, c, c1, c2);
 		if (c1 != '-') break;
-		ri = r2; gi = g2; t++; p++;
+		k = k2; p++;
 	}
 	if (p > 0) { gPos += p; gLen -= p; }
 	p = 0;
-	for (;;) {
-		if (t >= c.len) break;
-		int r2 = ri, g2 = gi;
+	while (k.t < c.len) {
+		ColCursor k2 = k;
 		char c1, c2;
-		column_chars(a, c, t, r2, g2, c1, c2);
+		k2.next(a, c, c1, c2);
 		if (c2 != '-') break;
-		ri = r2; gi = g2; t++; p++;
+		k = k2; p++;
 	}
 	if (p > 0) { rPos += p; rLen -= p; cig.push(p, 'S'); }
-	return add_cigar_columns(a, c, t, c.len, ri, gi, cig);
+	return add_cigar_columns(a, c, k.t, c.len, k.ri, k.gi, cig);
 }
 
 // ProcessTailSequencePair after the alignment, src/tools.cpp:366-394
 __device__ int finish_tail(const AlnArgs &a, const Columns &c, int &gLen, int &rLen, Cigar &cig)
 {
 	if (!local_quality_ok(a, c)) { cig.push(rLen, 'S'); return 0; }
-	// characters of every column once (needed from the back)
+	// the characters of the last column are known after a walk over all columns before it (the tail is short: one walk per trimmed column)
 	int end = c.len;
+	auto last_chars = [&](int upto, char &c1, char &c2) {
+		ColCursor k(0, 0, 0);
+		c1 = 0; c2 = 0;
+		while (k.t < upto) k.next(a, c, c1, c2);
+	};
 	// trailing '-' of the read side
 	int cnt = 0;
-	{
-		// walk forward to know (ri, gi) at every column; the tail is short, so recompute by scanning
-		for (;;) {
-			if (end <= 0) break;
-			int ri = 0, gi = 0;
-			char c1 = 0, c2 = 0;
-			for (int t = 0; t < end; ++t) column_chars(a, c, t, ri, gi, c1, c2);
-			if (c1 != '-') break;
-			end--; cnt++;
-		}
+	for (;;) {
+		if (end <= 0) break;
+		char c1, c2;
+		last_chars(end, c1, c2);
+		if (c1 != '-') break;
+		end--; cnt++;
 	}
 	if (cnt > 0) gLen -= cnt;
 	int cnt2 = 0;
 	for (;;) {
 		if (end <= 0) break;
-		int ri = 0, gi = 0;
-		char c1 = 0, c2 = 0;
-		for (int t = 0; t < end; ++t) column_chars(a, c, t, ri, gi, c1, c2);
+		char c1, c2;
+		last_chars(end, c1, c2);
 		if (c2 != '-') break;
 		end--; cnt2++;
 	}
@@ -1053,28 +1079,8 @@ __device__ bool finish_candidate(const AlnArgs &a, int64_t cand, bool first, con
 	return true;
 }
 
-// raw-character mismatches of a read fragment against the text (CalFragPairMismatchBases, src/tools.cpp:40-47)
-__device__ __forceinline__ int mismatches(const AlnArgs &a, const uint8_t *rd, int64_t g, int len)
-{
-	int c = 0;
-	for (int i = 0; i < len; ++i)
-		if ((char)rd[i] != text_char(a, g + i)) c++;
-	return c;
-}
-
 }  // namespace
 
-struct __attribute__((packed, aligned(1))) AlnU64u { uint64_t v; };
-
-// 32 bases of the 2-bit text from position p (base i in bits 2 i); beyond the end of the text: zeros
-__device__ __forceinline__ uint64_t text_word32(const AlnArgs &a, int64_t p)
-{
-	if (p > a.two_genome_size) return 0;                 // (the text buffer has 16 bytes of slack behind its last base)
-	const uint8_t *tp = a.ix.text + ((uint64_t)p >> 2);
-	uint64_t lo = reinterpret_cast<const AlnU64u *>(tp)->v, hi = tp[8];
-	int sh = ((int)p & 3) << 1;
-	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-}
 
 // The runs plan_partition's scalar loop finds, bit-parallel: the read fragment (<= 256 characters) and the text around the
 // genome fragment as 2 bits per base in registers; per diagonal one XOR per 32 bases, the equality bits compressed to one per
@@ -1534,7 +1540,8 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			}
 			const uint8_t *f1 = rd + v.rPos[j];
 			if (rL == gL) {                                                     // the <= 2-mismatch shortcut, :240, :301, :352
-				int n = mismatches(a, f1, v.gPos[j], rL);
+				bool dash_ = false;
+				int n = fast_gap_mismatches(a, f1, v.gPos[j], rL, 3, dash_);      // (eight characters per load, stops at the third mismatch: only <= 2 matter here)
 				if (n <= 2 && n <= (int)(rL * 0.2)) {
 					w.kind[j] = W_IMMEDIATE; w.op[j] = 'M'; w.op_len[j] = rL; w.val[j] = rL - n;
 					continue;
