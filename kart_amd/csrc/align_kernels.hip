@@ -978,19 +978,35 @@ __device__ bool finish_candidate(const AlnArgs &a, int64_t cand, bool first, con
 			} else {
 				// the partitioned fragment: literal runs and the sub-fragments' op strings, one after the other (src/tools.cpp:165-208)
 				const AlnPlan pl = a.plans[w.val[j]];
+				// (the bytes leave eight at a time -- an accumulator, literal runs as a fill pattern, job op strings through 8-byte loads -- as in
+				//  frag_stitch_kernel: one byte load and store per column was most of this branch)
 				uint8_t *out = a.nw_ops + pl.ops;
-				int at = 0;
+				int at = 0, na = 0;
+				uint64_t acc = 0;
+				auto put = [&](uint64_t b) {
+					acc |= b << (8 * na);
+					if (++na == 8) { reinterpret_cast<ColU64u *>(out + at)->v = acc; at += 8; acc = 0; na = 0; }
+				};
 				for (int k = 0; k < pl.count; ++k) {
 					const AlnPiece pc = a.pieces[pl.first + k];
-					if (pc.kind <= KG_OP_GAP2) { for (int t = 0; t < pc.v; ++t) out[at++] = pc.kind; }
-					else {
+					if (pc.kind <= KG_OP_GAP2) {
+						int n = pc.v;
+						while (na != 0 && n > 0) { put((uint64_t)pc.kind); --n; }
+						const uint64_t pat = (uint64_t)pc.kind * 0x0101010101010101ull;
+						for (; n >= 8; n -= 8) { reinterpret_cast<ColU64u *>(out + at)->v = pat; at += 8; }
+						for (; n > 0; --n) put((uint64_t)pc.kind);
+					} else {
 						const uint8_t *src = a.nw_ops + a.jobs[pc.v].ops;
-						int L = a.nw_len[pc.v];
-						for (int t = 0; t < L; ++t) out[at++] = src[t];
+						const int L = a.nw_len[pc.v];
+						int t = 0;
+						while (na != 0 && t < L) put((uint64_t)src[t++]);
+						for (; t + 8 <= L; t += 8) { reinterpret_cast<ColU64u *>(out + at)->v = reinterpret_cast<const ColU64u *>(src + t)->v; at += 8; }
+						for (; t < L; ++t) put((uint64_t)src[t]);
 					}
 				}
+				for (int k = 0; k < na; ++k) out[at + k] = (uint8_t)(acc >> (8 * k));
 				c.ops = out;
-				c.len = at;
+				c.len = at + na;
 			}
 			c.rd = rd + v.rPos[j];
 			c.g = v.gPos[j];
@@ -1752,8 +1768,10 @@ __device__ void write_record_at(const AlnArgs &a, int64_t at, const ReadSum &s, 
 		o.chr = a.rep_chr[c]; o.pos = a.rep_pos[c];
 		int n = a.rep_cigar_len[c];
 		o.cigar_len = (uint8_t)n;
-		const char *src = a.rep_cigar + c * KG_ALN_CIGAR_MAX;
-		for (int i = 0; i < n; ++i) o.cigar[i] = src[i];
+		// (eight characters per load and store: both sides are 8-byte aligned and KG_ALN_CIGAR_MAX long; what lies behind cigar_len is nobody's)
+		const uint64_t *src = reinterpret_cast<const uint64_t *>(a.rep_cigar + c * KG_ALN_CIGAR_MAX);
+		uint64_t *dst = reinterpret_cast<uint64_t *>(o.cigar);
+		for (int i = 0; 8 * i < n; ++i) dst[i] = src[i];
 	}
 }
 
