@@ -252,19 +252,46 @@ __device__ __forceinline__ uint8_t *lane_copy_reversed(uint8_t *p, const uint8_t
 	return p + n;
 }
 
-// one LANE per read (round 5; a wave per read and a byte per lane before): its characters into the batch's character array, reverse-complemented for the
-// second read of a pair -- 16 bytes per load and store; the reads lie back to back in the array, so a read's last partial word goes byte by byte
+// ---- the long pieces (bases, qualities) by EIGHT lanes per line: lane `sub` of the eight moves bytes [16 sub + 128 k, 16 sub + 128 k + 16) -- the eight cover 128
+// consecutive bytes per step.  With a line per lane the 64 lanes of a load touched 64 different 128-byte lines for 16 bytes each, and the lines did not
+// stay in the L2 until the lane came back for the next 16: the counters showed 242 GB per 100 M reads moved by sam_format_kernel for 76 GB of text, 181 GB
+// by fq_materialise_kernel for 31 GB (profiles/r05zj_bench_pmc_summary.json).  Exact: nothing is written outside [p, p + n).
+__device__ __forceinline__ void group_copy(uint8_t *p, const uint8_t *src, int n, int sub)
+{
+	for (int off = sub << 4; off < n; off += 128) {
+		if (off + 16 <= n) *reinterpret_cast<SamU128 *>(p + off) = *reinterpret_cast<const SamU128 *>(src + off);
+		else for (int k = off; k < n; ++k) p[k] = src[k];
+	}
+}
+
+template <bool kComp>
+__device__ __forceinline__ void group_copy_reversed(uint8_t *p, const uint8_t *src, int n, int sub)
+{
+	for (int off = sub << 4; off < n; off += 128) {
+		if (off + 16 <= n) {
+			const SamU128 v = *reinterpret_cast<const SamU128 *>(src + n - 16 - off);
+			SamU128 o;
+			o.lo = __builtin_bswap64(v.hi); o.hi = __builtin_bswap64(v.lo);
+			if (kComp) { o.lo = comp8(o.lo); o.hi = comp8(o.hi); }
+			*reinterpret_cast<SamU128 *>(p + off) = o;
+		} else for (int k = off; k < n; ++k) p[k] = kComp ? comp_char(src[n - 1 - k]) : src[n - 1 - k];
+	}
+}
+
+// EIGHT lanes per read (round 5; a wave per read and a byte per lane in rounds 3-4, then a lane per read): its characters into the batch's character
+// array, reverse-complemented for the second read of a pair -- 16 bytes per lane, 128 consecutive bytes per group and step (group_copy above)
 __global__ __launch_bounds__(256) void fq_materialise_kernel(FqArgs a)
 {
-	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_reads; i += (int64_t)gridDim.x * blockDim.x) {
+	const int sub = threadIdx.x & 7;
+	for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < a.n_reads; i += ((int64_t)gridDim.x * blockDim.x) >> 3) {
 		const int f = a.two_files ? (int)(i & 1) : 0;
 		const int64_t j = a.two_files ? i >> 1 : i;
 		const FqWindow &w = a.w[f];
 		const uint8_t *src = w.text + w.rec_seq[j];
 		const int n = w.rec_rlen[j];
 		uint8_t *dst = a.enc + a.read_off[i];
-		if (a.paired && (i & 1)) lane_copy_reversed<true>(dst, src, n);
-		else lane_copy(dst, dst + n, src, n);
+		if (a.paired && (i & 1)) group_copy_reversed<true>(dst, src, n, sub);
+		else group_copy(dst, src, n, sub);
 	}
 }
 
@@ -447,6 +474,7 @@ __global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
 	__shared__ __attribute__((aligned(16))) char str[64 * kFmtSlot];
 	__shared__ FmtDesc desc[64];
 	__shared__ int chain_len[3];
+	__shared__ int chunk_pre[65];          // phase 2b: chunks of the lines before line i
 	const int lane = threadIdx.x;
 	const int64_t n_groups = (a.n_reads + 63) >> 6;
 	for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
@@ -488,16 +516,59 @@ __global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
 				const uint8_t *S = reinterpret_cast<const uint8_t *>(str) + lane * kFmtSlot;
 				uint8_t *p = d.out;
 				const uint8_t *const end = d.out + d.room_end_lo;
-				p = lane_copy(p, end, d.name, d.name_len);
-				p = lane_copy(p, end, S, d.nA);
-				p = lane_copy(p, end, d.chr, d.n_chr);
-				p = lane_copy(p, end, S + kFmtA, d.nB);
-				// the read as the record shows it: as held, or its reverse complement (GetComplementarySeq) with the qualities reversed
-				p = (d.flags & 2) ? lane_copy_reversed<true>(p, d.seq, d.rlen) : lane_copy(p, end, d.seq, d.rlen);
+				uint8_t *const bases = d.out + d.name_len + d.nA + d.n_chr + d.nB;      // (from here on other lanes write, phase 2b: no surplus past it)
+				p = lane_copy(p, bases, d.name, d.name_len);
+				p = lane_copy(p, bases, S, d.nA);
+				p = lane_copy(p, bases, d.chr, d.n_chr);
+				p = lane_copy(p, bases, S + kFmtA, d.nB);
+				p += d.rlen;
 				*p++ = '\t';
-				p = (d.flags & 4) ? lane_copy_reversed<false>(p, d.qual, d.qlen) : lane_copy(p, end, d.qual, d.qlen);
+				p += d.qlen;
 				p = lane_copy(p, end, S + kFmtA + kFmtB, d.nT);
 				if (p != end) atomicAdd(&a.ctl[1], 1ull);
+			}
+		}
+		// ---- phase 2b: the bases and the qualities of the 64 lines as ONE list of 16-byte chunks (a line's bases first, then its qualities; 20 chunks for a
+		//      150-base read), lane l taking chunks l, l + 64, ...: consecutive lanes move consecutive chunks of a line -- whole 128-byte lines of memory per
+		//      instruction on either side, every lane busy in every step.  The read as the record shows it: as held, or its reverse complement
+		//      (GetComplementarySeq) with the qualities reversed.  (A line per lane moved the same bytes with the same number of instructions but touched
+		//      64 different memory lines per instruction; eight or sixteen lanes per line left lanes idle: 83 ms against 77 per 100 M reads.)
+		{
+			const FmtDesc &dm = desc[lane];
+			const bool on = (dm.flags & 1) && !(dm.flags & 8);
+			const int mine = on ? ((dm.rlen + 15) >> 4) + ((dm.qlen + 15) >> 4) : 0;
+			const int incl = wave_inclusive_scan(mine);
+			if (lane == 0) chunk_pre[0] = 0;
+			chunk_pre[lane + 1] = incl;
+		}
+		__syncthreads();
+		{
+			const int total = chunk_pre[64];
+			int line = 0;
+			for (int idx = lane; idx < total; idx += 64) {
+				while (idx >= chunk_pre[line + 1]) ++line;
+				const FmtDesc &d = desc[line];
+				const int c = idx - chunk_pre[line];
+				const int n_seq = (d.rlen + 15) >> 4;
+				const bool is_seq = c < n_seq;
+				const int off = (is_seq ? c : c - n_seq) << 4, n = is_seq ? d.rlen : d.qlen;
+				const uint8_t *src = is_seq ? d.seq : d.qual;
+				uint8_t *dst = d.out + d.name_len + d.nA + d.n_chr + d.nB + (is_seq ? 0 : d.rlen + 1) + off;
+				const bool rev = is_seq ? (d.flags & 2) != 0 : (d.flags & 4) != 0;
+				if (off + 16 <= n) {
+					SamU128 v = *reinterpret_cast<const SamU128 *>(rev ? src + n - 16 - off : src + off);
+					if (rev) {
+						const uint64_t lo = __builtin_bswap64(v.hi), hi = __builtin_bswap64(v.lo);
+						v.lo = lo; v.hi = hi;
+						if (is_seq) { v.lo = comp8(v.lo); v.hi = comp8(v.hi); }
+					}
+					*reinterpret_cast<SamU128 *>(dst) = v;
+				} else {
+					for (int k = off; k < n; ++k) {
+						const uint8_t b = rev ? src[n - 1 - k] : src[k];
+						dst[k - off] = rev && is_seq ? comp_char(b) : b;
+					}
+				}
 			}
 		}
 		__syncthreads();
@@ -592,7 +663,7 @@ hipError_t launch_fq_materialise(const FqArgs &a, int n_cu, hipStream_t stream)
 {
 	if (a.n_reads <= 0) return hipSuccess;
 	kt_begin(KT_FQ_MATERIALISE, stream);
-	hipLaunchKernelGGL(fq_materialise_kernel, dim3(grid_of(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(fq_materialise_kernel, dim3(grid_of(a.n_reads * 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
 	kt_end(KT_FQ_MATERIALISE, stream);
 	return hipGetLastError();
 }
