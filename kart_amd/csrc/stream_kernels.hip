@@ -60,6 +60,9 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
 
 }  // namespace
 
+// sixteen bytes at any address (one unaligned load / store)
+struct __attribute__((packed, aligned(1))) SamU128 { uint64_t lo, hi; };
+
 // ---- lines ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fq_count_kernel(FqArgs a, int f, int64_t n_tiles)
 {
@@ -132,10 +135,18 @@ __global__ __launch_bounds__(256) void fq_record_kernel(FqArgs a, int f)
 		const uint8_t *h = w.text + l0;
 		int p1 = len - 1, p2 = len - 1;
 		bool f1 = false, f2 = false;
-		for (int i = 1; i < len && !(f1 && f2); ++i) {
-			const uint8_t c = h[i];
-			if (!f1 && c != '>' && c != '@') { p1 = i; f1 = true; }
-			if (!f2 && (c == ' ' || c == '/' || c == '\t')) { p2 = i; f2 = true; }
+		// (sixteen characters per load -- a header is two or three of them -- instead of a byte load per character, each at a different memory line
+		//  per lane; the window has 4 KB of slack behind its last byte)
+		for (int base = 0; base < len && !(f1 && f2); base += 16) {
+			const SamU128 u = *reinterpret_cast<const SamU128 *>(h + base);
+			const uint32_t x0 = (uint32_t)u.lo, x1 = (uint32_t)(u.lo >> 32), x2 = (uint32_t)u.hi, x3 = (uint32_t)(u.hi >> 32);
+			auto mask16 = [&](uint32_t pat) { return eq_mask4(x0, pat) | (eq_mask4(x1, pat) << 4) | (eq_mask4(x2, pat) << 8) | (eq_mask4(x3, pat) << 12); };
+			const int lo = base == 0 ? 1 : 0, hi = len - base < 16 ? len - base : 16;              // characters 1 .. len - 1 of the line
+			const uint32_t valid = (hi >= 16 ? 0xFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+			const uint32_t other = ~(mask16(0x3E3E3E3Eu) | mask16(0x40404040u)) & valid;          // not '>' and not '@'
+			const uint32_t sep = (mask16(0x20202020u) | mask16(0x2F2F2F2Fu) | mask16(0x09090909u)) & valid;   // ' ', '/', '\t'
+			if (!f1 && other) { p1 = base + __ffs((int)other) - 1; f1 = true; }
+			if (!f2 && sep) { p2 = base + __ffs((int)sep) - 1; f2 = true; }
 		}
 		const int name_len = p2 > p1 ? p2 - p1 : 0;
 		const int rlen = (int)(l2 - l1) - 1;
@@ -214,7 +225,6 @@ __device__ __forceinline__ uint8_t comp_char(uint8_t c)
 // reads at 4 KB, 61 ms at 16 KB: fewer waves per CU for the same byte-wide loads (profiles/r05t_ab_sam_buf.log).  Here every lane copies its OWN read's line
 // piece by piece with unaligned 16-byte accesses: a wave instruction moves 1 KB, and the 64 lines of a wave are consecutive in the output.  A piece's last
 // partial word is copied whole where the line still has room behind it (the next piece overwrites the surplus), byte by byte at the line's end.
-struct __attribute__((packed, aligned(1))) SamU128 { uint64_t lo, hi; };
 
 __device__ __forceinline__ uint64_t comp8(uint64_t x)          // GetComplementaryBase (src/tools.cpp:3-17) on eight characters
 {
