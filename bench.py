@@ -793,7 +793,7 @@ def reference_legs(args, sess, prefix, workdir, f1, f2, n_pairs, threads, cores,
     tiny1, tiny2 = prefix_files("tiny", 2)
     rc, load_s, _ = run_ref(tiny1, tiny2, cores, os.path.join(workdir, "tiny.sam"))          # ~ the reference's index load on this box
     if want == "identity":
-        p = min(n_pairs, 150_000)
+        p = min(n_pairs, int(os.environ.get("KART_BENCH_IDENT_PAIRS", "150000")))          # (a longer identity run: one reference thread maps ~9 k reads/s)
         g1, g2 = prefix_files("ident", p)
         sam_ref, sam_amd = os.path.join(workdir, "ident_ref.sam"), os.path.join(workdir, "ident_amd.sam")
         rc1, dt1, _ = run_ref(g1, g2, 1, sam_ref)
