@@ -28,7 +28,7 @@ from test_host_pipeline import UNSET_FLAG, assert_sam_equals_reference_with_its_
 
 pytestmark = pytest.mark.gpu
 KART_REF = os.path.join(ROOT, "oracle", "_ref", "kart")
-N_LONG, LONG_SLICES = 20_000, 8
+N_LONG, LONG_SLICES = int(os.environ.get("KART_TEST_N_LONG", "20000")), int(os.environ.get("KART_TEST_LONG_SLICES", "8"))      # (a longer run by hand: 100 000 reads in 16 slices)
 
 
 def odd_long_reads(path, n, read_len):
