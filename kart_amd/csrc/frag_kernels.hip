@@ -480,8 +480,8 @@ __device__ int identify_normal_pairs_wave(int rlen, int glen, int n, int lane, i
 // One wave per task of the level [level_begin[level], level_begin[level + 1]).
 // Two instantiations can share a level (round 5, KG_FRAG_TWO_TIERS=1; off by default -- no gain, see launch_frag_partition): the SMALL one (sides up to kFragSmallLen, up to kFragSmallRuns matches: 4 KB of LDS, the CU's wave slots full)
 // takes what fits it -- nearly every task: a fragment pair of a 7 kb read is ~350 x 350 bases with ~14 matches -- and leaves the rest (task.status 2) to the
-// full-size one (15 KB, 10 waves per CU), which runs behind it on the same stream.  The kernel waits on the LDS in two thirds of its wave cycles
-// (profiles/r05o_pacbio_pmc_summary.json): more waves per SIMD is what hides that.
+// full-size one (15 KB, 10 waves per CU), which runs behind it on the same stream.  (It was built on the reading that the kernel waits on the LDS in two
+// thirds of its wave cycles, profiles/r05o_pacbio_pmc_summary.json; what it waited for were the work lists' device-wide atomics -- see `pooled` below.)
 template <int kMaxLen, int kMaxRuns, bool kSmall>
 __global__ __launch_bounds__(64) void frag_partition_kernel(FragArgs a, int level)
 {
@@ -935,8 +935,8 @@ hipError_t launch_frag_partition(const FragArgs &a, int n_cu, hipStream_t stream
 		// (the level's task count lives on the device: the grid is sized for the requests at level 0 and for a share of them below)
 		const int64_t guess = level == 0 ? a.n : a.n / 4 + 1024;
 		// (tried in round 5 and left as an A/B aid, KG_FRAG_TWO_TIERS=1: the small instantiation in front -- 4 KB of LDS, the CU's wave slots full -- changes
-		//  nothing, 4.83 s against 4.74 s per 2 M long reads, profiles/r05r_ab_long_2m.log: the kernel keeps the LDS pipeline itself busy -- SQ_ACTIVE_INST_LDS
-		//  ~ SQ_BUSY_CYCLES in profiles/r05o_pacbio_pmc_summary.json -- so more waves only queue for it)
+		//  nothing, 4.83 s against 4.74 s per 2 M long reads, profiles/r05r_ab_long_2m.log -- more waves only queued for the same three atomic counters,
+		//  which is what bound the kernel then; measured again with the counters pooled: 4.54 against 4.64 s, profiles/r05y_ab_long_2m.log, inside the runs' spread)
 		FragArgs b = a;
 		b.one_tier = getenv("KG_FRAG_TWO_TIERS") != nullptr ? 0 : 1;
 		if (!b.one_tier) hipLaunchKernelGGL((frag_partition_kernel<kFragSmallLen, kFragSmallRuns, true>), dim3(grid_of(guess / 64 + 1, 1, n_cu * kFragSmallWavesPerCu)), dim3(64), 0, stream, b, level);
