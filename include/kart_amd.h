@@ -181,6 +181,11 @@ int  kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_
                           int64_t n_bases, int64_t *d_seed_offsets, kg_seed *d_seeds,
                           int64_t seed_capacity, void *stream);
 int64_t kg_workspace_overflow(kg_workspace *ws);   /* 0 = fitted, else seeds needed */
+/* SensitiveMode on long reads walks from every 512th position of a read at once (IdentifySeedPairs_SensitiveMode,
+ * src/AlignmentCandidates.cpp:132-169, is one walk per read); on exact long reads those walks never merge and the batch
+ * can outgrow the workspace's hit list.  kg_seed_batch then seeds the batch again with one walk per read -- same seeds --
+ * and this counts how often that happened on the workspace. */
+int64_t kg_workspace_segment_fallbacks(kg_workspace *ws);
 
 /* ---- chaining ----------------------------------------------------------------------------------- */
 /* Candidates of every read of the batch that the LAST kg_seed_batch call on this workspace seeded (its

@@ -40,7 +40,7 @@ CAND_DT = np.dtype([("posDiff", "<i8"), ("score", "<i4"), ("count", "<i4"), ("fi
 ABI_SYMBOLS = (
     "kg_last_error", "kg_device_count", "kg_index_load", "kg_index_destroy", "kg_index_info",
     "kg_index_contig", "kg_host_alloc", "kg_host_free", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters", "kg_workspace_traffic",
-    "kg_workspace_overflow", "kg_workspace_set_profiling", "kg_workspace_set_single_steps", "kg_index_selfcheck", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_align_batch", "kg_align_reasons", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
+    "kg_workspace_overflow", "kg_workspace_segment_fallbacks", "kg_workspace_set_profiling", "kg_workspace_set_single_steps", "kg_index_selfcheck", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_align_batch", "kg_align_reasons", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
     "kg_fragments_batch", "kg_longread_batch", "kg_longread_reasons",
     "kg_stream_open", "kg_stream_close", "kg_stream_staging", "kg_stream_upload", "kg_stream_parse", "kg_stream_map", "kg_stream_fetch_reads", "kg_stream_timing",
     "kg_stream_group_absent", "kg_stream_group_abort",
@@ -184,6 +184,8 @@ def load_library() -> C.CDLL:
     L.kg_index_selfcheck.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.kg_workspace_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float * 4)]
     L.kg_workspace_overflow.restype = C.c_int64
+    L.kg_workspace_segment_fallbacks.argtypes = [C.c_void_p]
+    L.kg_workspace_segment_fallbacks.restype = C.c_int64
     L.kg_seed_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                 C.c_void_p, C.POINTER(C.c_void_p)]
     L.kg_seed_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
@@ -258,6 +260,10 @@ class Workspace:
 
     def overflow(self) -> int:
         return int(self.lib.kg_workspace_overflow(self.h))
+
+    def segment_fallbacks(self) -> int:
+        """batches of long reads re-seeded with one walk per read because the segment walks outgrew the hit list"""
+        return int(self.lib.kg_workspace_segment_fallbacks(self.h))
 
     def set_single_steps(self, enabled: bool = True):
         """single extension steps only: the reference's lf1 / lf2 block accounting is then exact (kg_workspace_set_single_steps)"""

@@ -589,6 +589,11 @@ int64_t kg_workspace_overflow(kg_workspace *ws)
 	return (int64_t)v;
 }
 
+int64_t kg_workspace_segment_fallbacks(kg_workspace *ws)
+{
+	return ws ? ws->segment_fallbacks : -1;
+}
+
 static int check_seed_args(kg_workspace *ws, int mode, int min_seed_len, int occ_thr, int64_t n_reads, int64_t n_bases)
 {
 	if (!ws) return fail(KG_ERR_ARG, "kg_seed_batch: null workspace");
@@ -644,7 +649,9 @@ int kg_seed_batch_device(kg_workspace *ws, int mode, int min_seed_len, int occ_t
 	// (KG_NO_SEGMENTS / KG_SEG_LEN are read per call: A/B runs and the tests switch them inside one process)
 	const bool no_segments = getenv("KG_NO_SEGMENTS") != nullptr;
 	const int seg_len = getenv("KG_SEG_LEN") ? std::max(128, atoi(getenv("KG_SEG_LEN"))) : 512;
-	if (a.mode == KG_MODE_SENSITIVE && !no_segments && ws->group_segments == 0 && n_bases >= 4 * (int64_t)seg_len * n_reads) {
+	ws->last_segmented = false;
+	if (a.mode == KG_MODE_SENSITIVE && !no_segments && ws->segments_off_batches == 0 && ws->group_segments == 0 && n_bases >= 4 * (int64_t)seg_len * n_reads) {
+		ws->last_segmented = true;
 		if (!ws->d_vr_n) {
 			ws->vr_capacity = ws->max_bases / 128 + ws->max_reads + 64;
 			HIP_TRY(hipMalloc((void **)&ws->d_vr_n, 4 * (size_t)(ws->max_reads + 2)));
@@ -694,6 +701,7 @@ int kgi_seed_resident(kg_workspace *ws, int mode, int min_seed_len, int occ_thr,
 	// (sized for the workspace's largest batch at once: a reallocation synchronises the whole device, and batches grow while a run ramps up)
 	int64_t want = std::max<int64_t>(ws->seed_capacity, 8 * std::max(n_reads, ws->max_reads) + 1024);
 	int64_t total = 0;
+	bool retried_plain = false;
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		if (want > ws->seed_capacity) {
 			if (ws->d_seeds) HIP_TRY(hipFree(ws->d_seeds));
@@ -708,12 +716,27 @@ int kgi_seed_resident(kg_workspace *ws, int mode, int min_seed_len, int occ_thr,
 		HIP_TRY(hipMemcpyAsync(&h[0], ws->d_seed_off + n_reads, 8, hipMemcpyDeviceToHost, ws->stream));
 		HIP_TRY(hipMemcpyAsync(&h[1], ws->d_ctl + 11, 8, hipMemcpyDeviceToHost, ws->stream));
 		HIP_TRY(kgi_sync(ws));
-		if (h[1] == (~0ull >> 1)) return fail(KG_ERR_CAPACITY, "kg_seed_batch: the hit list of the workspace overflowed");
+		if (h[1] == (~0ull >> 1)) {
+			// The hit list is sized for ONE walk per read (a hit per 13 bases at most).  The walks from the segment starts of a long read add to
+			// that only until they merge, and they merge where an error resynchronises them: on exact or nearly exact long reads (HiFi, contigs)
+			// they never do -- every search returns 30 bases, 512 k mod 30 differs for every k -- and all of a read's walks run to its end,
+			// ~0.25 hits per base.  Such a batch is seeded again with one lane per read, the bound the list was sized for, and so are the
+			// workspace's next batches (the data set is what it is); segments are tried again after those.
+			if (ws->last_segmented && !retried_plain) {
+				retried_plain = true;
+				ws->segments_off_batches = 17;       // (this re-run and the next 16 batches)
+				ws->segment_fallbacks++;
+				--attempt;
+				continue;
+			}
+			return fail(KG_ERR_CAPACITY, "kg_seed_batch: the hit list of the workspace overflowed");
+		}
 		total = (int64_t)h[0];
 		if (total <= ws->seed_capacity) break;
 		want = total;
 		if (attempt == 1) return fail(KG_ERR_CAPACITY, "kg_seed_batch: seed buffer overflow persisted");
 	}
+	if (ws->segments_off_batches > 0) ws->segments_off_batches--;
 	ws->last_reads = n_reads;
 	ws->last_seeds = total;
 	ws->last_cands = -1;
@@ -897,7 +920,7 @@ static int nw_acquire(kg_index *ix, size_t list_words, size_t dir_words, hipStre
 	if (!pick) {
 		pick = new NwScratch();
 		HIP_TRY(hipEventCreateWithFlags(&pick->done, hipEventDisableTiming));
-		HIP_TRY(hipMalloc((void **)&pick->queue, 8 * 8));
+		HIP_TRY(hipMalloc((void **)&pick->queue, 8 * (size_t)kNwQueueWords));
 		ix->nw_pool.push_back(pick);
 	}
 	if (pick->list_words < list_words) {
@@ -1106,6 +1129,14 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 	}
 	a.spill = ws->d_spill; a.spill_capacity = ws->spill_capacity;
 	a.jobs = ws->d_jobs; a.job_capacity = ws->job_capacity; a.ops_capacity = ws->ops_capacity;
+	{
+		// test aid: the lists behave as if they were this short (the allocations stay), so that the overflow paths -- reads handed back to the
+		// host, empty entries for what was reserved inside the lists -- can be driven by a small batch (tests/test_sam_gpu.py)
+		static const char *e_sp = getenv("KG_DBG_SPILL_CAPACITY"), *e_job = getenv("KG_DBG_JOB_CAPACITY"), *e_ops = getenv("KG_DBG_OPS_CAPACITY");
+		if (e_sp) a.spill_capacity = std::min<int64_t>(a.spill_capacity, atoll(e_sp));
+		if (e_job) a.job_capacity = std::min<int64_t>(a.job_capacity, atoll(e_job));
+		if (e_ops) a.ops_capacity = std::min<int64_t>(a.ops_capacity, atoll(e_ops));
+	}
 	a.ctl = ws->d_aln_ctl;
 	a.nw_ops = ws->d_job_ops; a.nw_len = ws->d_job_len;
 	a.plans = (AlnPlan *)ws->d_plans; a.pieces = (AlnPiece *)((char *)ws->d_plans + sizeof(AlnPlan) * (size_t)ws->job_capacity);
@@ -1117,7 +1148,7 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 		NwArgs w;
 		w.desc = ws->d_jobs; w.text2 = ix->d_text; w.n_dev = ws->d_aln_ctl + 1;
 		w.f1 = (const char *)ws->d_enc; w.off1 = nullptr; w.f2 = nullptr; w.off2 = nullptr;
-		w.n = ws->job_capacity;
+		w.n = a.job_capacity;
 		w.ops = ws->d_job_ops; w.aln_len = ws->d_job_len;
 		w.big_lds_bytes = nw_big_lds_bytes(kAlnMaxFrag);
 		w.gb_offset_words = 0;
@@ -1239,7 +1270,7 @@ int kg_nw_batch(kg_index *ix, const char *frag1, const int64_t *off1, const char
 			if (!io) {
 				io = new NwScratch();
 				HIP_TRY(hipEventCreateWithFlags(&io->done, hipEventDisableTiming));
-				HIP_TRY(hipMalloc((void **)&io->queue, 8 * 4));
+				HIP_TRY(hipMalloc((void **)&io->queue, 8 * (size_t)kNwQueueWords));
 				ix->nw_pool.push_back(io);
 			}
 			if (io->io) HIP_TRY(hipFree(io->io));

@@ -98,6 +98,11 @@ struct kg_workspace {
 	int64_t last_reads = 0, last_seeds = 0;   // batch the staging buffers currently hold (kg_seed_batch)
 	// a group's workspace (kgi_seed_group): the batch is n segments of `group_stride` read slots, group_prefix = reads before each
 	int group_segments = 0;
+	// SensitiveMode's segment walks (abi.hip, kg_seed_batch_device): whether the last launch used them; batches left for which they stay off
+	// after a hit-list overflow (kgi_seed_resident re-runs such a batch with one lane per read); how often that happened
+	bool last_segmented = false;
+	int segments_off_batches = 0;
+	int64_t segment_fallbacks = 0;
 	int64_t group_stride = 0, group_prefix[kMaxSeedSegments + 1] = {0};
 	int32_t *group_read_len = nullptr;        // [max_reads] length of the read in every slot (0: empty)
 	bool enc_borrowed = false;                // d_enc is a part of a group's array (a stream lane): not this workspace's to free

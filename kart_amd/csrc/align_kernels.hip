@@ -1598,9 +1598,14 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 		unsigned long long sp = atomicAdd(&a.ctl[0], 1ull);
 		unsigned long long job_at = n_new_jobs ? atomicAdd(&a.ctl[1], (unsigned long long)n_new_jobs) : 0ull;
 		unsigned long long ops_at = n_new_jobs ? atomicAdd(&a.ctl[2], (unsigned long long)new_ops) : 0ull;
-		if (sp >= (unsigned long long)a.spill_capacity) { flag_host(a, r, WHY_CAPACITY); continue; }
-		if (job_at + (unsigned long long)n_new_jobs > (unsigned long long)a.job_capacity || ops_at + (unsigned long long)new_ops > (unsigned long long)a.ops_capacity) {
-			// (the job slots it took inside the list become empty jobs: the NW kernels must not find an earlier batch's descriptors there)
+		const bool sp_ok = sp < (unsigned long long)a.spill_capacity;
+		const bool jobs_ok = job_at + (unsigned long long)n_new_jobs <= (unsigned long long)a.job_capacity && ops_at + (unsigned long long)new_ops <= (unsigned long long)a.ops_capacity;
+		if (!sp_ok || !jobs_ok) {
+			// A list is full: the read is the host's.  Everything this lane took INSIDE the lists is still written, whichever list overflowed --
+			// aln_finish_kernel walks every spill slot below ctl[0] and the NW kernels every job below ctl[1], and neither may find an
+			// earlier batch's entry there: the spill slot names this candidate with no pairs (its read is flagged, aln_finish skips it),
+			// the job slots become empty jobs
+			if (sp_ok) { a.spill[sp].cand = (int32_t)cand; a.spill[sp].num = 0; }
 			for (unsigned long long k = job_at; k < job_at + (unsigned long long)n_new_jobs && k < (unsigned long long)a.job_capacity; ++k) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[k] = jd; }
 			flag_host(a, r, WHY_CAPACITY);
 			continue;
@@ -1656,7 +1661,11 @@ __global__ __launch_bounds__(256) void aln_partition_kernel(AlnArgs a)
 		// no common 8-mer survived: the whole fragment is one alignment (src/tools.cpp:214-221)
 		unsigned long long slot = atomicAdd(&a.ctl[1], 1ull);
 		unsigned long long ops_at = atomicAdd(&a.ctl[2], (unsigned long long)(pt.rL + pt.gL));
-		if (slot >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(pt.rL + pt.gL) > (unsigned long long)a.ops_capacity) { flag_host(a, pt.read, WHY_CAPACITY); continue; }
+		if (slot >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(pt.rL + pt.gL) > (unsigned long long)a.ops_capacity) {
+			if (slot < (unsigned long long)a.job_capacity) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[slot] = jd; }      // (inside the list: an empty job, not an earlier batch's)
+			flag_host(a, pt.read, WHY_CAPACITY);
+			continue;
+		}
 		NwJobDesc jd;
 		jd.o1 = pt.enc_off; jd.o2 = pt.g; jd.ops = (int64_t)ops_at; jd.m = pt.rL; jd.n = pt.gL;
 		a.jobs[slot] = jd;

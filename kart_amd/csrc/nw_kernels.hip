@@ -86,7 +86,7 @@ __device__ __forceinline__ void append(bool want, unsigned long long *count, int
 // (a hipMemsetAsync of freshly pool-allocated words was observed to land after the classify kernel)
 __global__ void nw_reset_kernel(unsigned long long *queue)
 {
-	if (threadIdx.x < 8) queue[threadIdx.x] = 0;
+	if (threadIdx.x < kNwQueueWords) queue[threadIdx.x] = 0;
 }
 
 // queue words: [0..2] list sizes of the three classes, [3] class-2 work queue head, [4] the same for the launch of the longer pairs (two tiers),

@@ -138,6 +138,7 @@ struct NwJobDesc {
 	int32_t m, n;
 };
 
+constexpr int kNwQueueWords = 8;   // the NW kernels' queue block: every allocation of it and nw_reset_kernel use this one number
 struct NwArgs {
 	// descriptor mode (jobs written on the device by the alignment stage): desc[p] instead of the offset arrays, sequence 2
 	// from the 2-bit text, the job count from device memory (n = capacity of the lists)

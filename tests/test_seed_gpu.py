@@ -65,6 +65,33 @@ def test_sensitive_mode_walks_from_segment_starts(golden, which, seg_len, reques
     assert all(len(a) == len(b) and (a == b).all() for a, b in zip(got, again))
 
 
+def test_exact_long_reads_fall_back_to_one_walk_per_read(gpu_index_full, oracle_small, monkeypatch):
+    """Error-free 7 kb reads: every SensitiveMode search returns its 30 bases, the walks from the segment starts never merge
+    (512 k mod 30 differs for all k) and leave ~0.25 hits per base where the workspace's hit list holds one walk's worth (~0.1):
+    the batch is re-seeded with one walk per read instead of failing (kgi_seed_resident), the seeds are the oracle's."""
+    import os
+    from kart_amd.index_build import read_fasta
+    from conftest import GOLDEN
+    ix = gpu_index_full
+    genome = np.concatenate([synth.encode(np.asarray(s_, dtype=np.uint8)) for _, _, s_ in read_fasta(os.path.join(GOLDEN, "small.fa"))])
+    rng = np.random.default_rng(11)
+    n, rlen = 6000, 7000
+    starts = rng.integers(0, len(genome) - rlen, n)
+    enc = np.concatenate([genome[s_:s_ + rlen] for s_ in starts])
+    enc[enc > 3] = 0
+    off = np.arange(n + 1, dtype=np.int64) * rlen
+    ws = ix.workspace(n, len(enc))
+    so, seeds = ws.seed_batch(enc, off, api.KG_MODE_SENSITIVE)
+    assert ws.segment_fallbacks() == 1, "the segment walks of exact reads were expected to outgrow the hit list"
+    sub = 40
+    so_o, seeds_o = oracle_small.seed_batch(enc[:sub * rlen], off[:sub + 1], 1)
+    assert (so[:sub + 1] == so_o).all() and (seeds[:so[sub]] == seeds_o.astype(api.SEED_DT)).all()
+    # the next batch on this workspace goes straight to one walk per read; noisy reads afterwards get their segments back
+    so2, seeds2 = ws.seed_batch(enc, off, api.KG_MODE_SENSITIVE)
+    assert ws.segment_fallbacks() == 1 and (so2 == so).all() and (seeds2 == seeds).all()
+    ws.close()
+
+
 def test_counters_match_oracle(golden, gpu_index, oracle_small):
     """the kernel's work counters are the ones the roofline figure is computed from"""
     oracle_small.counters(reset=True)
