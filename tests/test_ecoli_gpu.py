@@ -27,7 +27,8 @@ def ecoli(built_lib, tmp_path_factory):
     args = argparse.Namespace(genome_len=bench.GENOME_LEN, bucketed=None, repeat_frac=0.45)
     prefix, codes, _ = bench.prepare_index(args, dev, 0, work, lambda: None)
     f1, f2 = os.path.join(work, "e_1.fq"), os.path.join(work, "e_2.fq")
-    bench.write_fastq_pairs(codes, N_PAIRS, 7, f1, f2, dev)
+    bench.write_fastq_pairs(codes, N_PAIRS, 7, f1, f2, dev, err=0.01)
+    bench.release_haplotypes()
     del codes
     torch.cuda.empty_cache()
     ref_out = os.path.join(work, "ref.sam")
@@ -39,8 +40,7 @@ def ecoli(built_lib, tmp_path_factory):
     # the first 40 000 pairs again through the host reader (no device stream; the switch is read once per process: the product binary)
     p1, p2 = os.path.join(work, "p_1.fq"), os.path.join(work, "p_2.fq")
     for src, dst in ((f1, p1), (f2, p2)):
-        with open(src, "rb") as fi, open(dst, "wb") as fo:
-            fo.write(fi.read(40_000 * bench.REC_BYTES))
+        bench.copy_records(src, dst, 40_000)
     r = subprocess.run([os.path.join(ROOT, "kart_amd", "bin", "kart-amd"), "-silent", "-i", prefix, "-f", p1, "-f2", p2, "-o", out, "-t", "8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        env=dict(os.environ, KART_AMD_NO_STREAM="1", KART_AMD_VERBOSE="1"))
     assert r.returncode == 0, r.stdout.decode()[-600:]

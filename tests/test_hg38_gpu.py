@@ -32,16 +32,17 @@ N_LONG, LONG_SLICES = int(os.environ.get("KART_TEST_N_LONG", "20000")), int(os.e
 
 
 def odd_long_reads(path, n, read_len):
-    """a few records of bench.write_long_reads' fixed-width file get what real long reads have and the generator does not: N runs (no seeds, no
+    """a few records of bench.write_long_reads' file get what real long reads have and the generator has next to none of: N runs (no seeds, no
     8-mers across them: the fragment kernels hand such fragments back), lower-case letters (raw-character comparisons) and a literal '-'
     (the reference's CIGAR scans take it for a gap column: such a read is the host's, KG_ALN_HOST)"""
     import numpy as np
-    rec = 2 * read_len + 16
+    from benchkit.reads import record_starts
+    seq_start, seq_len = record_starts(path)
+    assert len(seq_start) == n and (seq_len == read_len).all()
     mm = np.memmap(path, dtype=np.uint8, mode="r+")
-    assert mm.size == rec * n
     rng = np.random.default_rng(5)
     for i in rng.choice(n, 60, replace=False):
-        at = int(i) * rec + 12
+        at = int(seq_start[int(i)])
         kind = int(i) % 3
         if kind == 0:
             p = int(rng.integers(100, read_len - 200))
@@ -83,17 +84,15 @@ def hg38(built_lib):
     t_index = time.time() - t0
     tag = os.path.join(workdir, "t38_%d" % os.getpid())
     files = {"pe": (tag + "_pe_1.fq", tag + "_pe_2.fq"), "mh": (tag + "_mh_1.fq", tag + "_mh_2.fq"), "long": (tag + "_long.fq",)}
-    bench.write_fastq_pairs(codes, 250_000, 5, files["pe"][0], files["pe"][1], dev)                 # the first 0.5 M reads of bench.py's timed files
-    bench.write_fastq_pairs(codes, 100_000, 41, files["mh"][0], files["mh"][1], dev, err=0.021)     # ... of its configs[4] files
-    bench.write_long_reads(codes, N_LONG, 7000, 31, files["long"][0], dev)                          # ... of its configs[3] file
+    # bench.py's generators (wgsim's model incl. haplotype indels, benchkit/reads.py) with the seeds and rates of its timed files, configs[4] and configs[3]
+    gen = {"pe": bench.write_fastq_pairs(codes, 250_000, 5, files["pe"][0], files["pe"][1], dev, err=0.01),
+           "mh": bench.write_fastq_pairs(codes, 100_000, 41, files["mh"][0], files["mh"][1], dev, err=0.02),
+           "long": bench.write_long_reads(codes, N_LONG, 7000, 31, files["long"][0], dev)}
+    bench.release_haplotypes()
+    assert gen["pe"]["pairs_with_indel"] > 0.02 * 250_000 and gen["long"]["reads_with_indel"] > 0.4 * N_LONG, gen      # the reads DO carry wgsim's indels
     odd_long_reads(files["long"][0], N_LONG, 7000)
-    slices = []
-    rec = 2 * 7000 + 16
-    with open(files["long"][0], "rb") as fh:
-        for k in range(LONG_SLICES):
-            slices.append(tag + "_long_%d.fq" % k)
-            with open(slices[-1], "wb") as fo:
-                fo.write(fh.read(rec * (N_LONG // LONG_SLICES)))
+    slices = [tag + "_long_%d.fq" % k for k in range(LONG_SLICES)]
+    bench.split_records(files["long"][0], slices, N_LONG // LONG_SLICES)
     del codes
     torch.cuda.empty_cache()
     assert api.device_count() > 0, "the library lost the device after the read generators"

@@ -12,7 +12,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT, SMALL_PREFIX
 from test_host_pipeline import (CASES, UNSET_FLAG, assert_sam_equals_reference_with_its_own_mask, assert_same_sam_up_to_unset_flags,
-                                reference_sam_and_never_assigned_flags, run_case)
+                                reference_sam_and_never_assigned_flags, run_case, run_case_env)
 
 pytestmark = pytest.mark.gpu
 KART_AMD = os.path.join(ROOT, "kart_amd", "bin", "kart-amd")
@@ -29,6 +29,20 @@ def product_binary(built_lib):
 def test_golden_sam(case, product_binary, tmp_path):
     got, want, _ = run_case(product_binary, case, str(tmp_path))
     assert got == want
+
+
+@pytest.mark.parametrize("env", [{"KG_DBG_JOB_CAPACITY": "9"}, {"KG_DBG_OPS_CAPACITY": "150"}, {"KG_DBG_SPILL_CAPACITY": "5"},
+                                 {"KG_DBG_JOB_CAPACITY": "40", "KG_DBG_OPS_CAPACITY": "700", "KG_DBG_SPILL_CAPACITY": "30"}])
+def test_full_lists_hand_their_reads_to_the_host(env, product_binary, tmp_path):
+    """aln_plan_kernel / aln_partition_kernel with the spill, job or op-byte list full (lists as short as a few entries, abi.hip
+    KG_DBG_*_CAPACITY): the candidates beyond go back to the host, and what they had already taken INSIDE the lists is left as an
+    empty entry -- aln_finish_kernel and the NW kernels walk every entry below the counters.  Several batches on one workspace, so
+    that a stale entry of the batch before would be found.  Same SAM as the reference's."""
+    for case in ("pe", "pe_m"):
+        if case not in CASES:
+            continue
+        got, want, log = run_case_env(product_binary, case, str(tmp_path), ["-t", "1"], dict(env, KART_AMD_BATCH_READS="4000"))
+        assert got == want, (case, env)
 
 
 @pytest.mark.parametrize("flags", [[], ["-m"], ["-g", "40"]])       # (-g 40: MaxGaps beyond what the packed partition scan takes -- its scalar form)

@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--genome-len", type=int, default=50_000_000)
 ap.add_argument("--pairs", type=int, default=100_000)
 ap.add_argument("--workdir", required=True)
-ap.add_argument("--err", type=float, default=0.011)
+ap.add_argument("--err", type=float, default=0.01)
 ap.add_argument("--seed", type=int, default=17)
 args = ap.parse_args()
 dev = torch.device("cuda", 0)

@@ -32,7 +32,7 @@ if not all(os.path.exists(prefix + e) for e in (".bwt", ".sa", ".pac", ".ann", "
     anns = [("decoy", "(null)", 0, bench.DECOY_LEN, 0)] + [(nm, "(null)", off, ln, 0) for nm, off, ln in bench.contig_table(L)]
     index_build.build_index_from_codes(codes.cpu().numpy(), anns, [], prefix, device=str(dev))
     torch.cuda.empty_cache()
-enc, off = bench.gen_reads_device(codes, n_reads // 2, seed=args.seed, err=0.011, dev=dev)
+enc, off = bench.gen_reads_device(codes, n_reads // 2, seed=args.seed, err=0.01, dev=dev)
 del codes
 ix = api.Index(prefix, 0, api.KG_SA_FULL if args.sa == "full" else api.KG_SA_SAMPLED)
 enc_h, off_h = enc.cpu().numpy(), off.cpu().numpy()

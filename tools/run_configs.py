@@ -114,8 +114,8 @@ def config3():
 # ---- configs[4]: -m, 2 % error ---------------------------------------------------------------------------------------------------
 def config4():
     f1, f2 = os.path.join(wd, "cfg4_1.fq"), os.path.join(wd, "cfg4_2.fq")
-    bench.write_fastq_pairs(codes, n_mh, 41, f1, f2, dev, err=0.021)
-    c4 = {"reads": 2 * n_mh, "error": 0.021}
+    bench.write_fastq_pairs(codes, n_mh, 41, f1, f2, dev, err=0.02)
+    c4 = {"reads": 2 * n_mh, "error": 0.02}
     a = run([exe, "-silent", "-i", prefix, "-f", f1, "-f2", f2, "-m", "-t", str(cores), "-o", os.path.join(wd, "cfg4_amd.sam")])
     c4["kart_amd"] = dict(a, reads_per_s_mapping_phase=round(2 * n_mh / a["mapping_seconds"]) if a.get("mapping_seconds") else None, reads_per_s_process=round(2 * n_mh / a["process_seconds"]))
     # the same reads without -m (same device report, one record per read)
