@@ -243,10 +243,11 @@ def main():
     ap.add_argument("--one-file", action="store_true", help="N > 1: all ranks write into ONE shared SAM file by offset (the ranks then meet at that file's page-cache locks: ~20 GB/s from one L3 domain, less from several)")
     ap.add_argument("--leg", choices=["all", "seeding"], default="all", help="seeding: only the GPU seeding step on resident reads (what the rocprofv3 passes profile)")
     ap.add_argument("--seed-steps", type=int, default=5, help="timed launches of the seeding-stage leg")
-    ap.add_argument("--sa", choices=["auto", "sampled", "full", "compact", "dense4", "dense8"], default="auto",
-                    help="suffix array placement (seeding-stage leg and, via KART_AMD_SA, the mapping runs); auto = the product's default: full below 2^32 text symbols, compact (67 GB for a human-sized "
-                         "index instead of 168) above; dense4 / dense8 = the smaller index")
+    ap.add_argument("--sa", choices=["auto", "sampled", "full", "compact", "wide", "dense4", "dense8"], default="auto",
+                    help="suffix array placement (seeding-stage leg and, via KART_AMD_SA, the mapping runs); auto = the product's default: full below 2^32 text symbols; above, wide (5-byte suffix array, full q-mer table, "
+                         "triple planes: ~150 GB for a human-sized index) where the device has the room, else compact (67 GB); dense4 / dense8 = the smaller index")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gpu-pipeline", action="store_true", help="skip the secondary leg whose text goes to /dev/null (gpu_pipeline_value)")
     ap.add_argument("--no-parity", action="store_true", help="skip the reference -t 1 identity leg and the oracle sample")
     ap.add_argument("--no-seeding-leg", action="store_true")
     ap.add_argument("--bucketed", action="store_true", default=None, help="force the bucketed (large-N) suffix-array builder")
@@ -424,6 +425,7 @@ def run(args, fallback_note):
     t0 = time.time()
     if args.sa != "auto":
         os.environ["KART_AMD_SA"] = args.sa          # (read by the host library when it loads the index)
+    resolved_sa(args, dev)
     sess = api.HostSession(prefix, local, threads)
     t_load = time.time() - t0
     # At most TWO step outputs exist at any time: step k writes a fresh file (a mapping run creates its output -- reusing a
@@ -470,9 +472,14 @@ def run(args, fallback_note):
                 os.remove(os.path.join(workdir, f))
     clean_rendezvous()
     barrier()
+    # (the warm-up runs also sum their SAM text on the device -- KG_STREAM_CHECKSUM, ~12 ms per run, untimed: the gpu_pipeline leg below,
+    #  whose text never reaches a file, must have made the same text)
+    warm_stats = []
+    os.environ["KG_STREAM_CHECKSUM"] = "1"
     for w in range(args.warmup):
-        step("w%d" % w)
+        warm_stats.append(step("w%d" % w))
         between_steps()
+    del os.environ["KG_STREAM_CHECKSUM"]
     torch.cuda.synchronize(dev)
     barrier()
     t0 = time.perf_counter()
@@ -503,6 +510,45 @@ def run(args, fallback_note):
     elapsed = float(sum(step_max))                                # the K timed steps; what lies between them (removing old outputs) is not a mapping run
     bracket = shard.max_over_ranks(bracket, device=cdev)
     clean_rendezvous()
+    # ---- the ranks one by one: what each one's device, copy engines and lane threads did per step (rank order) ------------------------
+    K_ = float(args.steps)
+    lanes_here = max(1, int(stats[-1].lanes))
+    rank_rows = shard.gather_rows([
+        sum(float(st.stage_ms[i]) for st in stats for i in range(5)) / K_,          # kernels of all lanes, summed (lanes overlap)
+        sum(float(st.stage_ms[5]) for st in stats) / K_,                             # copies back to the host
+        sum(float(st.lane_seconds[0]) for st in stats) / K_ / lanes_here * 1e3,      # per lane: held back by the writer
+        sum(float(st.lane_seconds[4]) for st in stats) / K_ / lanes_here * 1e3,      # per lane: inside the device call
+        sum(float(st.lane_seconds[5]) for st in stats) / K_ / lanes_here * 1e3,      # per lane: the reads handed back
+        sum(float(st.map_seconds) for st in stats) / K_ * 1e3,
+        cpu_steps / K_, float(lanes_here), sum(float(st.total_reads) for st in stats) / K_], device=cdev)
+    # ---- secondary: the same steps with the text left in the lanes' page-locked buffers (output to /dev/null, KART_AMD_OUTPUT_NULL) and
+    #      summed on the device instead: what the GPU pipeline + copy engines deliver when the host's page cache is out of the way.  Never the headline.
+    pipe = None
+    if not args.no_gpu_pipeline:
+        os.environ["KART_AMD_OUTPUT_NULL"] = "1"; os.environ["KG_STREAM_CHECKSUM"] = "1"
+        try:
+            p_wall, p_stats = [], []
+            for s_ in range(min(args.steps, 3)):
+                between_steps()
+                torch.cuda.synchronize(dev)
+                ts = time.perf_counter()
+                # (not through step(): no output file comes of it, `outs` keeps naming the last real one)
+                p_stats.append(shard.map_shard(sess.map, ["-silent", "-f", f1, "-f2", f2], os.path.join(workdir, "bench_null_%d.sam" % s_), rank, world, os.path.join(workdir, "rdv_p%d" % s_), True))
+                torch.cuda.synchronize(dev)
+                p_wall.append(time.perf_counter() - ts)
+            between_steps()
+        finally:
+            del os.environ["KART_AMD_OUTPUT_NULL"]; del os.environ["KG_STREAM_CHECKSUM"]
+        p_max = shard.max_over_ranks(p_wall, device=cdev)
+        p_tot = shard.allreduce_counters([sum(int(st.total_reads - st.unmapped) for st in p_stats), int(p_stats[-1].text_checksum[0]), int(p_stats[-1].text_checksum[1]),
+                                          int(warm_stats[-1].text_checksum[0]) if warm_stats else 0, int(warm_stats[-1].text_checksum[1]) if warm_stats else 0,
+                                          int(p_stats[-1].text_out_bytes), int(warm_stats[-1].text_out_bytes) if warm_stats else 0], device=cdev)
+        pipe = {"value": p_tot[0] / float(sum(p_max)), "unit": "reads/s", "steps": len(p_max), "ms_per_step": [round(x * 1e3, 1) for x in p_max],
+                "what": "NOT the metric: the same mapping runs with the SAM text left in the lanes' page-locked buffers (written to /dev/null) and summed on the device "
+                        "(sam_checksum_kernel) -- the rate of the GPU pipeline and the copy engines with the host's copy into fresh page-cache pages out of the way; "
+                        "beside `value` it tells device scaling from page-cache scaling in an N > 1 line",
+                "device_text_bytes": p_tot[5], "device_text_byte_sum": p_tot[1], "device_text_lines": p_tot[2],
+                "same_text_as_a_file_writing_run": (bool(p_tot[1] == p_tot[3] and p_tot[2] == p_tot[4] and p_tot[5] == p_tot[6]) if warm_stats else None)}
     if rank != 0:
         sess.close()
         if world > 1:
@@ -576,6 +622,16 @@ def run(args, fallback_note):
                         "note": "user + system CPU seconds of the rank processes inside the timed steps (reading + uploading the FASTQ text, the handed-back reads, the output copies and "
                                 "their page faults) per read; quota / that = the rate at which this host saturates however many GPUs feed it -- the bound on 1 -> N scaling on this "
                                 "host shape (unmeasured beyond the GPUs this run had)"}
+    # ---- the ranks one by one, and the secondary rate without the host's output copy: what makes an N > 1 line readable ----------------
+    names = ("device_kernels_ms_per_step_summed_over_lanes", "copy_engine_ms_per_step", "lane_held_back_by_writer_ms_per_step", "lane_in_device_call_ms_per_step",
+             "lane_host_reads_ms_per_step", "map_ms_per_step", "cpu_seconds_per_step", "lanes", "reads_per_step")
+    line["per_rank"] = {"what": "rank order; per timed step.  device_kernels: HIP-event time of the stages parse .. format, summed over the rank's lanes (lanes overlap on the device, so "
+                                "it can exceed the step); copy_engine: the copies back to the host; lane_*: averages over the rank's lane threads -- held back by the writer = waiting "
+                                "until the host has copied the lane's previous text into the output file's pages (page-cache side), in the device call = kernels + copies of "
+                                "the lane's batch (device side)",
+                        "ranks": [{n: (round(v, 3) if n != "reads_per_step" else int(v)) for n, v in zip(names, row)} for row in rank_rows]}
+    if pipe is not None:
+        line["gpu_pipeline_value"] = pipe
     # ---- every kernel of the timed region with a share of the step: HIP events around each launch on the lanes' streams (kg_stream_timing_t::
     # kernel_ms), against the bytes the kernel has to touch (its inputs and outputs as laid out in HBM) ----------------
     line["kernels"] = kernel_entries(stats, args.steps, n_reads, sk_ms / args.steps if sk_n else 0.0, args)
@@ -610,7 +666,7 @@ def run(args, fallback_note):
     if stage_ms["align"] > 0 and n_cand > 0:
         aln_bytes = n_reads * (READ_LEN + READ_LEN / 4 + 112) + n_cand * (32 + 78) + n_cseed * 16
         aln_gbs = aln_bytes / (stage_ms["align"] * 1e-3) / 1e9
-        line["alignment_stage"] = {"bound": "hbm", "kernels": "aln_pair, aln_rescue, aln_bin, aln_plan_fast, aln_plan, aln_partition, nw_*, aln_finish, aln_final",
+        line["alignment_stage"] = {"bound": "hbm", "kernels": "aln_trivial, aln_pair, aln_rescue, aln_bin, aln_plan_fast, aln_plan, aln_partition, nw_*, aln_finish, aln_final",
                                    "ms_per_step": stage_ms["align"], "candidates_per_read": n_cand / n_reads, "candidate_seeds_per_read": n_cseed / n_reads,
                                    "algorithmic_bytes_per_step": aln_bytes, "algorithmic_bytes_per_read": aln_bytes / n_reads,
                                    "achieved": aln_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": aln_gbs / HBM_PEAK_GBS,
@@ -759,7 +815,7 @@ def seeding_leg(args, api, prefix, codes, dev, n_reads_leg, oracle_sample):
     n_reads = n_reads_leg & ~1
     n_bases = n_reads * READ_LEN
     large = args.genome_len >= 300_000_000
-    ix = api.Index(prefix, dev.index or 0, {"auto": api.KG_SA_AUTO, "full": api.KG_SA_FULL, "sampled": api.KG_SA_SAMPLED, "compact": api.KG_SA_FULL40, "dense4": api.KG_SA_DENSE4, "dense8": api.KG_SA_DENSE8}[args.sa])
+    ix = api.Index(prefix, dev.index or 0, {"auto": api.KG_SA_AUTO, "full": api.KG_SA_FULL, "sampled": api.KG_SA_SAMPLED, "compact": api.KG_SA_FULL40, "wide": api.KG_SA_FULL40_WIDE, "dense4": api.KG_SA_DENSE4, "dense8": api.KG_SA_DENSE8}[args.sa])
     batches = [gen_reads_device(codes, n_reads // 2, seed=1000 + b, err=0.01, dev=dev) for b in range(2)]
     release_haplotypes()
     seed_cap = (12 if large else 6) * n_reads + 1024
@@ -862,7 +918,7 @@ def other_configs(args, sess, prefix, workdir, codes, dev, threads, cores, mem):
 
     # ---- configs[4]: -m ------------------------------------------------------------------------------------------------
     budget = (mem.get("usable") or (64 << 30)) * MEM_SHARE          # each leg's files (input + ONE output at a time) stay within the same share of host memory as the steps'
-    n_mh = int(max(100_000, min(10_000_000, budget // (2 * REC_BYTES + 2 * 500))))
+    n_mh = int(max(100_000, min(50_000_000, budget // (2 * REC_BYTES + 2 * 500))))          # (configs[4]'s literal size: 100 M reads, when the host holds the files)
     f1, f2 = os.path.join(workdir, "cfg4_1.fq"), os.path.join(workdir, "cfg4_2.fq")
     mh_stats = write_fastq_pairs(codes, n_mh, 41, f1, f2, dev, err=0.02)
     sam = os.path.join(workdir, "cfg4.sam")
@@ -872,32 +928,47 @@ def other_configs(args, sess, prefix, workdir, codes, dev, threads, cores, mem):
     c4 = {"workload": "configs[4]: %d x 150 bp paired-end reads, wgsim model -e 0.02 -r 0.001 (haplotype indels incl.), -m (multi-hit output), hg38-sized index" % (2 * n_mh),
           "pairs_with_indel_share": mh_stats["pairs_with_indel"] / max(1, mh_stats["pairs"]),
           "value": (st.total_reads - st.unmapped) / st.map_seconds, "unit": "mapped reads/s", "map_seconds": round(st.map_seconds, 3),
-          "reads_through_the_device_stream": int(st.stream_reads), "sam_bytes": os.path.getsize(sam)}
+          "reads_through_the_device_stream": int(st.stream_reads), "sam_bytes": os.path.getsize(sam),
+          "device_ms": {nm: float(st.stage_ms[i]) for i, nm in enumerate(("parse", "seed", "chain", "align", "format", "copy_out"))},
+          "kernels_ms": {nm: round(float(st.kernel_ms[i]), 2) for i, nm in enumerate(KERNEL_SLOTS) if float(st.kernel_ms[i]) > 0},
+          "rescue_windows": float(st.aln_counts[4]), "pairs_decided_by_aln_trivial": float(st.aln_counts[6])}
     os.remove(sam)
     if os.path.exists(ref) and not args.no_parity:
-        k = 100_000
-        p1, p2 = os.path.join(workdir, "cfg4_p1.fq"), os.path.join(workdir, "cfg4_p2.fq")
-        copy_records(f1, p1, k); copy_records(f2, p2, k)
-        sa, sr = os.path.join(workdir, "cfg4_p_amd.sam"), os.path.join(workdir, "cfg4_p_ref.sam")
+        # 1 M reads of the leg's files against the reference's -t 1: slices of whole chunks, one reference process each (a slice starts
+        # its own EstDistance history, in the reference and here alike), this pipeline on the same slices one after the other
+        n_sl = max(1, min(8, cores // 2))
+        per = min(int(os.environ.get("KART_BENCH_MH_IDENT_PAIRS", "500000")), n_mh) // n_sl // 2000 * 2000
+        jobs = []
+        for i in range(n_sl):
+            p1, p2 = os.path.join(workdir, "cfg4_p%d_1.fq" % i), os.path.join(workdir, "cfg4_p%d_2.fq" % i)
+            copy_records(f1, p1, per, skip_records=i * per); copy_records(f2, p2, per, skip_records=i * per)
+            sr = os.path.join(workdir, "cfg4_p%d_ref.sam" % i)
+            jobs.append((p1, p2, sr, subprocess.Popen([ref, "-silent", "-i", prefix, "-f", p1, "-f2", p2, "-m", "-o", sr, "-t", "1"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+        ok, masked, t0 = True, 0, time.perf_counter()
         os.environ["KART_AMD_UNSET_FLAG"] = str(UNSET)
         try:
-            sess.map(["-silent", "-f", p1, "-f2", p2, "-m", "-o", sa])
+            for i, (p1, p2, sr, proc) in enumerate(jobs):
+                sa = os.path.join(workdir, "cfg4_p%d_amd.sam" % i)
+                sess.map(["-silent", "-f", p1, "-f2", p2, "-m", "-o", sa])
         finally:
             del os.environ["KART_AMD_UNSET_FLAG"]
-        rc, _ = ref_run(["-m"], [p1, p2], sr, 1)
-        la, lb = open(sr, "rb").read().split(b"\n"), open(sa, "rb").read().split(b"\n")
-        ok, masked = rc == 0 and len(la) == len(lb), 0
-        for x, y in zip(la, lb) if ok else ():
-            if x == y:
-                continue
-            fx, fy = x.split(b"\t"), y.split(b"\t")
-            if len(fy) < 2 or int(fy[1]) != UNSET or fx[:1] + fx[2:] != fy[:1] + fy[2:]:
-                ok = False
-                break
-            masked += 1
-        c4["sam_vs_reference_t1"] = {"reads": 2 * k, "identical_up_to_never_assigned_flags": bool(ok), "records_with_never_assigned_flag": masked}
-        for f in (p1, p2, sa, sr):
-            os.remove(f)
+        for i, (p1, p2, sr, proc) in enumerate(jobs):
+            sa = os.path.join(workdir, "cfg4_p%d_amd.sam" % i)
+            rc = proc.wait()
+            la, lb = open(sr, "rb").read().split(b"\n"), open(sa, "rb").read().split(b"\n")
+            ok = ok and rc == 0 and len(la) == len(lb)
+            for x, y in zip(la, lb) if ok else ():
+                if x == y:
+                    continue
+                fx, fy = x.split(b"\t"), y.split(b"\t")
+                if len(fy) < 2 or int(fy[1]) != UNSET or fx[:1] + fx[2:] != fy[:1] + fy[2:]:
+                    ok = False
+                    break
+                masked += 1
+            for f in (p1, p2, sa, sr):
+                os.remove(f)
+        c4["sam_vs_reference_t1"] = {"reads": 2 * per * n_sl, "slices": n_sl, "identical_up_to_never_assigned_flags": bool(ok), "records_with_never_assigned_flag": masked,
+                                     "seconds": round(time.perf_counter() - t0, 1)}
     out["configs[4]"] = c4
     for f in (f1, f2):
         os.remove(f)
@@ -1036,16 +1107,24 @@ def seed_group_setting():
     return g, lanes
 
 
-def resolved_sa(args):
-    """the index mode `--sa auto` becomes (kg_index_load: full below 2^32 text symbols -- both strands --, compact above)"""
+def resolved_sa(args, dev=None):
+    """the index mode `--sa auto` becomes (kg_index_load's rule: full below 2^32 text symbols -- both strands --; above, wide -- 5-byte suffix
+    array, full q-mer table, triple planes -- where the device keeps 64 GiB free behind its ~24.5 bytes per symbol, else compact).  Asked with
+    `dev` right before the index is loaded (the same free-memory figure the library sees), remembered for the callers without one."""
     if args.sa != "auto":
         return args.sa
-    return "compact" if 2 * int(args.genome_len or HG38_LEN) >= 0xFFFFFFFF else "full"
+    n_sym = 2 * int(args.genome_len or HG38_LEN)
+    if n_sym < 0xFFFFFFFF:
+        return "full"
+    if dev is not None:
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        args.sa_resolved = "wide" if (free_b > 24.5 * n_sym + (64 << 30) and not os.environ.get("KG_AUTO_COMPACT")) else "compact"
+    return getattr(args, "sa_resolved", "compact")
 
 
-SA_NAMES = {0: "sampled", 1: "full", 5: "compact", 4: "dense4", 8: "dense8"}
+SA_NAMES = {0: "sampled", 1: "full", 5: "compact", 6: "wide", 4: "dense4", 8: "dense8"}
 KERNEL_SLOTS = ("chain", "aln_pair", "aln_rescue", "aln_plan_fast", "aln_plan", "aln_partition", "nw", "aln_finish", "aln_final", "sam_size", "sam_format",
-                "fq_parse", "fq_materialise")
+                "fq_parse", "fq_materialise", "locate_sort", "aln_trivial")
 VALU_INT32_PEAK_TOPS = 78.0       # int32 VALU lane-operations per second of the device, in 1e12 (VERDICT r4 #6's figure; ~12 of them per DP cell)
 NW_OPS_PER_CELL = 12.0
 
@@ -1102,19 +1181,23 @@ def kernel_entries(stats, steps, n_reads, search_ms_per_step, args):
     t_in = sum(float(st.text_in_bytes) for st in stats) / steps
     t_out = sum(float(st.text_out_bytes) for st in stats) / steps
     R = float(n_reads)
-    spills, jobs, op_bytes, part_tasks, resc_tasks, slow = cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[7]
+    spills, jobs, op_bytes, part_tasks, resc_tasks, trivial_pairs, slow = cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[6], cnt[7]
+    # aln_trivial_kernel decides the trivial pairs start to finish; the kernels behind it see the candidates / reads of the other pairs only
+    share = 1.0 - (2 * trivial_pairs / R if R else 0.0)
+    C_all, S_all, R_all = C, S, R
     per_cand = 32 + 78 + READ_LEN + READ_LEN / 4          # candidate, its report, the read's characters, the text under it
     # bytes every kernel has to move (inputs read once + outputs written once, HBM layout of DESIGN.md section 3)
     alg = {
         "chain": 32 * S + 32 * C + 24 * R,                                           # seeds in (16 B), candidate seeds out (16 B), candidates (32 B), per-read counts / offsets
-        "aln_pair": 32 * C + 12 * C + 16 * R,                                        # candidates in, score / mate / read per candidate out, per-read flags
+        "aln_trivial": 24 * R_all + 32 * C_all + 16 * S_all + (1 - share) * (2 * R_all + 4 * C_all) + (2 * trivial_pairs) * (112 + 8 + 8),   # every pair's offsets, candidates and seeds in; the lists of what it leaves; per decided read: the record, the gap characters and text words it compares
+        "aln_pair": share * (32 * C + 12 * C + 16 * R),                              # candidates in, score / mate / read per candidate out, per-read flags
         "aln_rescue": resc_tasks * (40 + 1650 / 4 + READ_LEN + 12 * 16),             # task, window text (2 bit/base), the mate's characters, the rescued seeds
-        "aln_plan_fast": C * per_cand + 16 * S + 4 * C,                              # every candidate + its seeds; the list of the ones it leaves
+        "aln_plan_fast": share * (C * per_cand + 16 * S + 4 * C),                              # every candidate + its seeds; the list of the ones it leaves
         "aln_plan": slow * (per_cand + 536) + 16 * S * (slow / C if C else 0) + 24 * jobs,   # the candidates left to it, their spill slots (536 B), job descriptors
         "aln_partition": part_tasks * (32 + 2 * 255 / 2 + 64),                       # task, both fragments (characters / 2-bit text), plan + pieces
         "nw": None,
         "aln_finish": spills * (536 + 78) + 2 * op_bytes + spills * READ_LEN,        # spill slot in, report out, op strings, the read's characters
-        "aln_final": 112 * R + 78 * C + 12 * C,                                      # record out, reports + scores / mates in
+        "aln_final": share * (112 * R + 78 * C + 12 * C),                                      # record out, reports + scores / mates in
         "sam_size": (112 + 24 + 4) * R,                                              # record + record table in, length out
         "sam_format": t_in * 0.75 + t_out + (112 + 24 + 8) * R,                      # name + bases + qualities of the FASTQ text (the '+' line and newlines are not read), SAM text out, records
         "fq_parse": 2 * t_in + 16 * R + 24 * R,                                      # the text twice (line count, line index), line ends (4 x 4 B), record table
@@ -1126,7 +1209,8 @@ def kernel_entries(stats, steps, n_reads, search_ms_per_step, args):
                    "they took from it); achieved = algorithmic bytes / that time; peak = %.0f GB/s (HBM); traffic = counter bytes of the same command "
                    "(profiles/, null when no pass of this run's shape is committed)" % HBM_PEAK_GBS,
            "timed_kernel_ms_per_step": total, "counts_per_step": {"candidates": C, "candidate_seeds": S, "parked_candidates": spills, "nw_jobs": jobs, "nw_op_bytes": op_bytes,
-                                                                 "partition_tasks": part_tasks, "rescue_windows": resc_tasks, "candidates_left_to_aln_plan": slow},
+                                                                 "partition_tasks": part_tasks, "rescue_windows": resc_tasks, "candidates_left_to_aln_plan": slow,
+                                                                 "pairs_decided_by_aln_trivial": trivial_pairs, "share_of_pairs_left_to_the_general_kernels": share},
            "traffic_source": traffic_src}
     for i, name in enumerate(KERNEL_SLOTS):
         if ms[i] <= 0:
@@ -1135,7 +1219,7 @@ def kernel_entries(stats, steps, n_reads, search_ms_per_step, args):
         if name == "nw":
             e.update({"bound": "valu", "note": "integer max-plus DP: priced in cells per second by the nw_kernels leg of this line (GCUPS per size class against %.0f T int32 "
                                                "VALU operations/s at ~%.0f per cell); in the timed region: %.0f jobs, %.0f op bytes per step" % (VALU_INT32_PEAK_TOPS, NW_OPS_PER_CELL, jobs, op_bytes)})
-        elif alg[name]:
+        elif alg.get(name):
             gbs = alg[name] / (ms[i] * 1e-3) / 1e9
             e.update({"bound": "hbm", "algorithmic_bytes_per_step": alg[name], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
         t = traffic.get(name)
@@ -1189,7 +1273,10 @@ def host_output_entry(workdir, sam_bytes, step_seconds, threads):
     writers are, copying 16 MB blocks into shared mappings of one fresh file in the same directory -- every 4 KB page a write fault that
     allocates it; N = 8, one more than the pipeline's mapping writers."""
     n_w = 8
-    total, blk = 8 << 30, 16 << 20
+    blk = 16 << 20
+    # (the probe's file lives where the outputs live -- tmpfs pages are RAM: 8 GB where the host has plenty, else a twentieth of what it can still hold, at least 1 GB)
+    usable = host_memory().get("usable")
+    total = (8 << 30) if usable is None or usable >= (160 << 30) else max(1 << 30, int(usable * 0.05) // blk * blk)
     path = os.path.join(workdir, "kart_bench_hostout_%d.bin" % os.getpid())
     cpus = _one_l3_domain()
     fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o600)

@@ -62,9 +62,12 @@ extern "C" {
 /* the compact index: the whole suffix array in 5-byte entries (4-byte ones where the text allows), a q-mer table of a quarter the
  * size, no triple planes -- ~66 GB instead of ~168 GB for a human genome, no walks */
 #define KG_SA_FULL40         5
+/* the 5-byte suffix array with everything that saves rank steps: the full q-mer table (4^q ~ text length) and the triple planes --
+ * ~150 GB for a human genome, three read bases per rank pair */
+#define KG_SA_FULL40_WIDE    6
 /* what the host pipeline asks for unless told otherwise: KG_SA_FULL for a text of fewer than 2^32 symbols (forward + reverse strand; there the
- * whole index is a few hundred MB either way), KG_SA_FULL40 above -- a human-sized index then takes 67 GB of a GPU's 288 instead of 168, at
- * -1 % of the FASTQ -> SAM rate (profiles/r05zg_ab_sa.log).  kg_index_info::sa_mode reports what it became. */
+ * whole index is a few hundred MB either way); above, KG_SA_FULL40_WIDE where the device keeps 64 GB free behind it (one process on a 288 GB
+ * device) and KG_SA_FULL40 -- 67 GB -- where it does not (several processes sharing a device).  kg_index_info::sa_mode reports what it became. */
 #define KG_SA_AUTO           (-1)
 
 typedef struct kg_index kg_index;
@@ -84,7 +87,7 @@ typedef struct {
 	uint64_t primary;
 	int32_t  n_contigs;
 	int32_t  min_seed_len;   /* 13..16, src/Mapping.cpp:645 */
-	int32_t  sa_mode;        /* KG_SA_SAMPLED / KG_SA_FULL / KG_SA_FULL40 / KG_SA_DENSE4 / KG_SA_DENSE8 */
+	int32_t  sa_mode;        /* KG_SA_SAMPLED / KG_SA_FULL / KG_SA_FULL40 / KG_SA_FULL40_WIDE / KG_SA_DENSE4 / KG_SA_DENSE8 */
 	int32_t  device;
 	uint64_t device_bytes;   /* HBM held by the index */
 } kg_index_info_t;
@@ -411,12 +414,16 @@ typedef struct {
 	double candidates, candidate_seeds;     /* chained candidates and their seeds of the batches (what the alignment stage reads per candidate) */
 	/* the batches' kernels one by one (HIP events around each launch on the lane's stream; other lanes' kernels share the device):
 	 * [0] chain, [1] aln_pair, [2] aln_rescue + post_rescue, [3] aln_plan_fast, [4] aln_plan, [5] aln_partition, [6] the NW kernels,
-	 * [7] aln_finish, [8] aln_final, [9] sam_size + scan, [10] sam_format, [11] fq_count / index / record / plan, [12] fq_materialise */
+	 * [7] aln_finish, [8] aln_final, [9] sam_size + scan, [10] sam_format, [11] fq_count / index / record / plan, [12] fq_materialise,
+	 * [13] locate + sort, [14] aln_trivial */
 	double kernel_ms[16];
 	int64_t kernel_launches[16];
 	/* what the alignment stage's lists held, summed over the batches: [0] candidates parked for NW, [1] NW jobs, [2] bytes of their op strings,
-	 * [3] fragment pairs through the 8-mer partition, [4] rescue windows, [5] partition plans, [6] their pieces, [7] candidates aln_plan_fast left to aln_plan */
+	 * [3] fragment pairs through the 8-mer partition, [4] rescue windows, [5] partition plans, [6] pairs aln_trivial decided start to finish, [7] candidates aln_plan_fast left to aln_plan */
 	double aln_counts[8];
+	/* KG_STREAM_CHECKSUM set (a measurement aid): the SAM text of the batches summed on the device -- [0] the sum of its bytes, [1] its line feeds
+	 * (exact: both stay far below 2^53) -- so that a run whose output is never copied into file pages still names the text it made; else 0 */
+	double text_checksum[2];
 } kg_stream_timing_t;
 int   kg_stream_timing(kg_stream *s, kg_stream_timing_t *out, int reset);
 

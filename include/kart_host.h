@@ -49,6 +49,14 @@ typedef struct {
 	double  kernel_ms[16];           /* the batches' kernels one by one (kg_stream_timing_t::kernel_ms: chain, aln_pair, aln_rescue, aln_plan_fast, ...) */
 	int64_t kernel_launches[16];
 	double  aln_counts[8];           /* kg_stream_timing_t::aln_counts */
+	/* what the lanes' host threads spent their time on, seconds summed over the `lanes` lane threads of the run's device stream:
+	 * [0] waiting for the writer to have copied the lane's previous text out (the output side holds the lane back), [1] reading + uploading
+	 * the input block, [2] waiting for the batch before to be parsed, [3] the parse call, [4] the map call (the lane's batch on the device,
+	 * its copies back included), [5] the reads handed back to the host */
+	double  lane_seconds[6];
+	int32_t lanes;
+	int32_t pad2;
+	double  text_checksum[2];        /* kg_stream_timing_t::text_checksum (KG_STREAM_CHECKSUM) */
 } kh_stats_t;
 
 const char *kh_last_error(void);
@@ -61,6 +69,8 @@ int  kh_open(const char *index_prefix, int device, int threads, kh_session **out
  * <files>] -o|-bo <out> [-m] [-p] [-pacbio] [-g INT] [-silent], plus this pipeline's -shard r/N -rendezvous FILE; -i, -t and
  * -gpu are fixed by the session.  Returns 0 on success. */
 int  kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats);
+/* (measurement aid: with KART_AMD_OUTPUT_NULL=1 in the environment of a kh_map call the text goes to /dev/null instead of the file named by
+ *  -o -- everything up to the host's copy into the file's pages runs as usual; bench.py's gpu_pipeline leg) */
 
 void kh_close(kh_session *s);
 

@@ -27,8 +27,9 @@ KG_OK = 0
 KG_MODE_FAST, KG_MODE_SENSITIVE = 0, 1
 KG_INPUT_ASCII = 0x100   # OR into mode: reads are given as characters, encoded on the device
 KG_SA_SAMPLED, KG_SA_FULL = 0, 1
-KG_SA_AUTO = -1                        # full below 2^32 text symbols, compact above (the host pipeline's default)
+KG_SA_AUTO = -1                        # full below 2^32 text symbols; above: wide where the device has room, else compact (the host pipeline's default)
 KG_SA_FULL40 = 5                       # the compact index: 5-byte suffix-array entries, a quarter of the q-mer table, no triple planes
+KG_SA_FULL40_WIDE = 6                  # 5-byte suffix-array entries with the full q-mer table and the triple planes
 KG_SA_DENSE4, KG_SA_DENSE8 = 4, 8       # the smaller index: every 4th / 8th suffix-array entry resident, no triple planes
 KG_OCC_THR_DEFAULT = 50
 KG_OP_DIAG, KG_OP_GAP1, KG_OP_GAP2 = 0, 1, 2
@@ -124,7 +125,7 @@ class StreamResult(C.Structure):
 class StreamTiming(C.Structure):
     _fields_ = [("batches", C.c_int64), ("reads", C.c_int64)] + [(n, C.c_double) for n in ("parse_ms", "seed_ms", "chain_ms", "align_ms", "format_ms", "copy_ms", "search_kernel_ms")] + \
                [("search_kernel_launches", C.c_int64)] + [(n, C.c_double) for n in ("search_useful_bytes", "text_in_bytes", "text_out_bytes", "candidates", "candidate_seeds")] + \
-               [("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_int64 * 16), ("aln_counts", C.c_double * 8)]
+               [("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_int64 * 16), ("aln_counts", C.c_double * 8), ("text_checksum", C.c_double * 2)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n.startswith(("kernel_", "aln_counts")) else getattr(self, n)) for n, _ in self._fields_}
@@ -536,7 +537,8 @@ class HostStats(C.Structure):
                 ("respeculated", C.c_int64), ("map_seconds", C.c_double), ("sharded", C.c_int32), ("pad", C.c_int32),
                 ("stream_reads", C.c_int64), ("stream_batches", C.c_int64), ("stage_ms", C.c_double * 6), ("search_kernel_ms", C.c_double),
                 ("search_kernel_launches", C.c_int64), ("search_useful_bytes", C.c_double), ("text_in_bytes", C.c_double), ("text_out_bytes", C.c_double),
-                ("candidates", C.c_double), ("candidate_seeds", C.c_double), ("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_int64 * 16), ("aln_counts", C.c_double * 8)]
+                ("candidates", C.c_double), ("candidate_seeds", C.c_double), ("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_int64 * 16), ("aln_counts", C.c_double * 8),
+                ("lane_seconds", C.c_double * 6), ("lanes", C.c_int32), ("pad2", C.c_int32), ("text_checksum", C.c_double * 2)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n.startswith(("kernel_", "stage_", "aln_counts")) else getattr(self, n)) for n, _ in self._fields_}

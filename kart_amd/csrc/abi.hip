@@ -118,7 +118,19 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	v.L2[0] = 0;
 	memcpy(&v.L2[1], bwt.data() + 8, 32);
 	v.seq_len = v.L2[4];
-	if (sa_mode == KG_SA_AUTO) ix->sa_mode = sa_mode = v.seq_len < 0xFFFFFFFFull ? KG_SA_FULL : KG_SA_FULL40;
+	if (sa_mode == KG_SA_AUTO) {
+		// below 2^32 text symbols the whole index is a few hundred MB: everything.  Above: the 5-byte suffix array with the full q-mer table and the
+		// triple planes (KG_SA_FULL40_WIDE, ~9.5 bytes per text symbol more than the compact index: 150 GB for a human genome) where the
+		// device keeps 64 GB for the workspaces behind it -- a 288 GB device running one process does --, else the compact index
+		sa_mode = KG_SA_FULL;
+		if (v.seq_len >= 0xFFFFFFFFull) {
+			size_t free_b = 0, total_b = 0;
+			const double wide_bytes = 24.5 * (double)v.seq_len;          // planes 1 + planes2 2.29 + planes3 9.14 + SA 5 + text 0.25 + table ~5.5 + the .bwt / .sa images in passing
+			sa_mode = KG_SA_FULL40;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > wide_bytes + (double)((size_t)64 << 30) && !getenv("KG_AUTO_COMPACT")) sa_mode = KG_SA_FULL40_WIDE;
+		}
+		ix->sa_mode = sa_mode;
+	}
 	size_t n_words = (bwt.size() - 40) / 4;
 	{
 		// 16 symbols per word, 8 count words in front of every 128-symbol block, one trailing count record
@@ -277,7 +289,8 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	v.qmer = 0;
 
 	const bool dense = sa_mode == KG_SA_DENSE4 || sa_mode == KG_SA_DENSE8;
-	const bool compact = sa_mode == KG_SA_FULL40;          // 5-byte entries, a smaller q-mer table, no triple planes
+	const bool wide = sa_mode == KG_SA_FULL40_WIDE;        // 5-byte entries with the full q-mer table and the triple planes
+	const bool compact = sa_mode == KG_SA_FULL40 || wide;  // 5-byte entries (KG_SA_FULL40 alone: a smaller q-mer table, no triple planes)
 	if (sa_mode == KG_SA_FULL || dense || compact) {
 		bool narrow = v.seq_len < 0xFFFFFFFFull && !getenv("KG_FORCE_U64");
 		const bool packed = compact && !narrow;
@@ -303,7 +316,7 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 		bool narrow = v.seq_len < 0xFFFFFF00ull && !getenv("KG_FORCE_U64");
 		int q = kQmerMin;
 		while (q < kQmerMax && ((uint64_t)1 << (2 * q + 1)) <= v.seq_len) q++;      // round(log4(2L))
-		if (compact && q > kQmerMin) q--;                                           // a quarter of the table: one more rank step per search
+		if (compact && !wide && q > kQmerMin) q--;                                  // a quarter of the table: one more rank step per search
 		if (const char *env = getenv("KG_QMER")) { int t = atoi(env); if (t >= kQmerMin && t <= kQmerMax) q = t; }   // tuning knob
 		size_t tab_bytes = ((size_t)1 << (2 * q)) * 8;
 		// the table is an accelerator, not a requirement: when the device cannot hold 4^q entries (34 GB at q = 16) take a smaller q
@@ -339,7 +352,7 @@ int kg_index_load(const char *prefix, int device, int sa_mode, kg_index **out)
 	}
 	// three-step rank structure (9.14 bytes/symbol: 56.7 GB for hg38), last and only where the device keeps room for the
 	// workspaces after it (a 288 GB device does, with the 111 GB of everything else): searches then take three bases per rank pair
-	if (v.planes2 && !dense && !compact && !getenv("KG_NO_PLANES3")) {
+	if (v.planes2 && !dense && (!compact || wide) && !getenv("KG_NO_PLANES3")) {
 		uint64_t n_lines = (v.seq_len + kPlane2Rows - 1) / kPlane2Rows;
 		size_t bytes = (size_t)n_lines * 64 * 128, free_b = 0, total_b = 0;
 		const size_t reserve = (size_t)48 << 30;
@@ -499,8 +512,10 @@ void kg_workspace_destroy(kg_workspace *ws)
 	for (hipEvent_t e : ws->ev)
 		if (e) (void)hipEventDestroy(e);
 	for (int i = 0; i < KT_SLOTS; ++i) {
-		if (ws->kt.b[i]) (void)hipEventDestroy(ws->kt.b[i]);
-		if (ws->kt.e[i]) (void)hipEventDestroy(ws->kt.e[i]);
+		for (int j = 0; j < kKtRing; ++j) {
+			if (ws->kt.b[i][j]) (void)hipEventDestroy(ws->kt.b[i][j]);
+			if (ws->kt.e[i][j]) (void)hipEventDestroy(ws->kt.e[i][j]);
+		}
 	}
 	delete ws;
 }
@@ -564,8 +579,9 @@ int kg_workspace_set_profiling(kg_workspace *ws, int enabled)
 	HIP_TRY(hipSetDevice(ws->ix->device));
 	if (enabled && !ws->ev[0])
 		for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&ws->ev[i]));
-	if (enabled && !ws->kt.b[0])
-		for (int i = 0; i < KT_SLOTS; ++i) { HIP_TRY(hipEventCreate(&ws->kt.b[i])); HIP_TRY(hipEventCreate(&ws->kt.e[i])); }
+	if (enabled && !ws->kt.b[0][0])
+		for (int i = 0; i < KT_SLOTS; ++i)
+			for (int j = 0; j < kKtRing; ++j) { HIP_TRY(hipEventCreate(&ws->kt.b[i][j])); HIP_TRY(hipEventCreate(&ws->kt.e[i][j])); }
 	ws->profiling = enabled != 0;
 	return KG_OK;
 }
@@ -1036,7 +1052,7 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 		if (ws->d_aln_cand) HIP_TRY(hipFree(ws->d_aln_cand));
 		ws->d_aln_cand = nullptr;
 		int64_t cap = std::max<int64_t>(nc + nc / 4, 3 * ws->max_reads) + task_cap + task_cap / 4 + ws->max_reads / 4 + 4096;
-		HIP_TRY(hipMalloc(&ws->d_aln_cand, up(4 * (size_t)cap) * 7 + up(8 * (size_t)cap) + up((size_t)cap) * 2 + up((size_t)cap * KG_ALN_CIGAR_MAX)));
+		HIP_TRY(hipMalloc(&ws->d_aln_cand, up(4 * (size_t)cap) * 10 + up(8 * (size_t)cap) + up((size_t)cap) * 2 + up((size_t)cap * KG_ALN_CIGAR_MAX)));      // (cap >= n: the slab of the pair list holds n / 2 entries)
 		ws->aln_cand_capacity = cap;
 	}
 	if (n + 2 > ws->aln_read_capacity) {
@@ -1112,6 +1128,14 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 		p += up(4 * cap);
 		static const bool no_fast = getenv("KG_ALN_NO_FAST") != nullptr;      // A/B aid: every candidate takes the general plan kernel
 		a.plan_slow = no_fast ? nullptr : (int32_t *)p;
+		p += up(4 * cap);
+		// the trivial pairs (one candidate per mate, mated, both decided in registers) are finished by aln_trivial_kernel; the other pairs and
+		// their candidates are listed for the kernels behind it.  Paired batches only; KG_ALN_NO_TRIVIAL (A/B aid): every pair takes the general kernels
+		static const bool no_trivial = getenv("KG_ALN_NO_TRIVIAL") != nullptr;
+		const bool trivial = a.all_paired && !no_trivial && !no_fast;
+		a.slow_cands = trivial ? (int32_t *)p : nullptr;
+		p += up(4 * cap);
+		a.slow_pairs = trivial ? (int32_t *)p : nullptr;
 		char *q = (char *)ws->d_aln_read;
 		size_t rcap = (size_t)ws->aln_read_capacity;
 		a.r_host = (uint8_t *)q; q += up(rcap);

@@ -578,6 +578,9 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 		HIP_TRY(hipHostMalloc((void **)&l.h_cand_seeds, sizeof(kg_seed) * (size_t)l.h_cand_capacity, hipHostMallocDefault));
 	}
 	HIP_TRY(launch_sam_format(q, ix->n_cu, st));
+	// measurement aid (bench.py's gpu_pipeline leg): the text summed on the device, for runs that never copy it into file pages (read per call: a session switches it on and off)
+	const bool checksum = getenv("KG_STREAM_CHECKSUM") != nullptr;
+	if (checksum) HIP_TRY(launch_sam_checksum(q, ix->n_cu, st));
 	HIP_TRY(hipEventRecord(l.ev[5], st));
 	// (grouped seeding) the turn is kept until the batch is back on the host.  Passing it on here -- so that this lane's copies overlap the
 	// next lane's kernels, KG_GROUP_TURN_EARLY=1 -- gives the same FASTQ -> SAM rate at 100 M reads (29.4-29.9 M against 29.8-30.4 M
@@ -598,6 +601,9 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 	HIP_TRY(hipMemcpyAsync(&tot[2], l.d_sam_ctl + 1, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&tot[8], ws->d_aln_ctl, 8 * 7, hipMemcpyDeviceToHost, st));          // the alignment stage's list sizes of this batch ...
 	HIP_TRY(hipMemcpyAsync(&tot[15], ws->d_aln_ctl + 32, 8, hipMemcpyDeviceToHost, st));        // ... and the candidates its fast plan kernel left to the general one
+	tot[16] = tot[17] = 0;
+	if (checksum) HIP_TRY(hipMemcpyAsync(&tot[16], l.d_sam_ctl + 2, 16, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&tot[14], ws->d_aln_ctl + 36, 8, hipMemcpyDeviceToHost, st));        // ... and the pairs aln_trivial_kernel decided (in the place of the piece count, which nobody reads)
 	HIP_TRY(hipEventRecord(l.ev[6], st));
 	HIP_TRY(kgi_sync(ws));
 	if (tot[2] != 0) return fail(KG_ERR_NO_DEVICE, "kg_stream_map: %lld records were formatted to a size other than the one announced", (long long)tot[2]);
@@ -629,12 +635,14 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 		t.text_out_bytes += (double)sam_bytes;
 		t.candidates += (double)totals[0]; t.candidate_seeds += (double)totals[1];
 		for (int i = 0; i < 8; ++i) t.aln_counts[i] += (double)tot[8 + i];
+		t.text_checksum[0] += (double)(uint64_t)tot[16]; t.text_checksum[1] += (double)(uint64_t)tot[17];
 		// the kernels' own launches of this batch (events around each, the lane's stream is synchronised)
 		for (int i = 0; i < KT_SLOTS; ++i) {
-			if (!ws->kt.armed[i]) continue;
-			ws->kt.armed[i] = false;
-			t.kernel_ms[i] += elapsed(ws->kt.b[i], ws->kt.e[i]);
-			t.kernel_launches[i] += 1;
+			const int used = ws->kt.used[i];
+			if (!used) continue;
+			ws->kt.used[i] = 0;
+			for (int j = 0; j < used; ++j) t.kernel_ms[i] += elapsed(ws->kt.b[i][j], ws->kt.e[i][j]);
+			t.kernel_launches[i] += used;
 		}
 	}
 	return KG_OK;

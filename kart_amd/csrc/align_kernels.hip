@@ -312,13 +312,14 @@ __device__ __forceinline__ void pair_one(const AlnArgs &a, const int64_t r, int 
 // chunk: a wave's 64 lanes hit one address); now a wave whose pairs lie in one chunk sends one pair of atomics.
 __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 {
-	const int64_t n_units = a.all_paired ? a.n_reads >> 1 : a.n_reads;
+	// (a.slow_pairs: the pairs aln_trivial_kernel did not decide, ctl[35] of them; else every pair / read of the batch)
+	const int64_t n_units = a.slow_pairs ? (int64_t)a.ctl[35] : a.all_paired ? a.n_reads >> 1 : a.n_reads;
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (int64_t u0 = (int64_t)blockIdx.x * blockDim.x; u0 < n_units; u0 += stride) {
 		const int64_t u = u0 + threadIdx.x;
 		int ck = -1;
 		long long lo = -1, hi = 0x7fffffffffffffffll;
-		if (u < n_units) pair_one(a, a.all_paired ? u << 1 : u, ck, lo, hi);
+		if (u < n_units) pair_one(a, a.slow_pairs ? (int64_t)a.slow_pairs[u] << 1 : a.all_paired ? u << 1 : u, ck, lo, hi);
 		// ---- the chunk's interval: lo = max over the pairs, hi = min ----
 		const uint64_t have = __ballot(ck >= 0);
 		if (have == 0) continue;
@@ -562,9 +563,11 @@ __global__ __launch_bounds__(64) void aln_rescue_kernel(AlnArgs a)
 // what follows RescueUnpairedAlignment for the pairs that had windows (src/Mapping.cpp:561-563)
 __global__ __launch_bounds__(256) void aln_post_rescue_kernel(AlnArgs a)
 {
-	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	for (; r < a.n_reads; r += stride) {
+	const int64_t n = a.slow_pairs ? (int64_t)a.ctl[35] : a.n_reads;          // (only the first mate of a pair is ever pending)
+	for (; x < n; x += stride) {
+		const int64_t r = a.slow_pairs ? (int64_t)a.slow_pairs[x] << 1 : x;
 		if (!a.r_pending[r] || a.r_host[r]) continue;
 		const CandList l1 = cand_list(a, r), l2 = cand_list(a, r + 1);
 		bool mated = false;
@@ -1345,6 +1348,128 @@ __device__ __forceinline__ int fast_gap_value(const AlnArgs &a, const uint8_t *r
 	return kFastSlow;
 }
 
+// What aln_plan_fast_kernel decides for one candidate (see above), as a value: both that kernel and aln_trivial_kernel use it.
+struct FastRep {
+	int state;                       // 0: decided (the fields below hold GenMappingReport's result), 1: the general kernel's, 2: CheckCoordinateValidity failed
+	int score, chr, cigar_len;
+	int64_t pos;
+	bool fwd;
+	uint64_t t0, t1;                 // the CIGAR text, at most 16 characters
+};
+enum { FAST_DECIDED = 0, FAST_SLOW = 1, FAST_INVALID = 2 };
+
+// lower_bound(g): index of the first ChrLocMap key >= g; end_at(i): key i (both read the block's copy in the LDS when it holds the keys)
+template <class LowerBound, class EndAt>
+__device__ __forceinline__ FastRep fast_report(const AlnArgs &a, int count, const kg_seed *seeds, int64_t rbase, int rlen, bool first, LowerBound lower_bound, EndAt end_at)
+{
+	FastRep o;
+	o.state = FAST_SLOW; o.score = 0; o.chr = 0; o.cigar_len = 0; o.pos = 0; o.fwd = true; o.t0 = o.t1 = 0;
+	bool slow = count < 1 || count > kFastSeeds || rlen > 4000;
+	// ---- the seeds: one diagonal, in order, no overlap; gaps of at most a text word ----
+	int64_t d = 0;
+	int prev_end = 0, first_r = 0, seed_bases = 0;
+	int gap_at[kFastSeeds + 1], gap_len[kFastSeeds + 1];      // (indexed by unrolled constants: registers)
+#pragma unroll
+	for (int i = 0; i < kFastSeeds; ++i) {
+		gap_at[i] = 0; gap_len[i] = 0;
+		if (!slow && i < count) {
+			const kg_seed sd = seeds[i];
+			const int64_t di = sd.gPos - (int64_t)sd.rPos;
+			if (i == 0) { d = di; first_r = sd.rPos; if (di < 0 || sd.rPos > kFastGap) slow = true; }
+			else {
+				if (di != d || sd.rPos < prev_end || sd.rPos - prev_end > kFastGap) slow = true;
+				gap_at[i] = prev_end; gap_len[i] = sd.rPos - prev_end;
+			}
+			prev_end = sd.rPos + sd.len;
+			seed_bases += sd.len;
+		}
+	}
+	const int tail_len = rlen - prev_end;
+	if (tail_len < 0 || tail_len > kFastGap) slow = true;
+	if (slow) return o;
+	// ---- CheckCoordinateValidity (:582-610) on [d, d + rlen - 1]: one strand copy, one contig ----
+	const int64_t g1 = d, g2 = d + rlen - 1, L = a.genome_size;
+	const int i1 = lower_bound(g1);
+	bool valid = !((g1 < L && g2 >= L) || (g1 >= L && g2 < L)) && i1 < a.n_ends;
+	if (valid && g2 > end_at(i1)) {
+		const int i2 = lower_bound(g2);
+		valid = i2 < a.n_ends && a.end_chr[i1] == a.end_chr[i2];
+		if (valid) return o;          // (two keys of one contig cannot lie in one strand copy: never taken; the general path decides)
+	}
+	if (!valid) { o.state = FAST_INVALID; return o; }          // no report, and no best/second-best step (:647)
+	// ---- the gap pairs ----
+	const uint8_t *rd = a.enc + rbase;
+	int score = seed_bases;
+	int head_val = 1, tail_val = 1;          // (> 0: scored; 0: an M element without identical bases; kFastClip: soft-clipped)
+	if (first_r > 0) { head_val = fast_gap_value(a, rd, d, first_r, 0); slow = head_val == kFastSlow; score += head_val > 0 ? head_val : 0; }
+#pragma unroll
+	for (int i = 1; i < kFastSeeds; ++i)
+		if (!slow && i < count && gap_len[i] > 0) {
+			const int v = fast_gap_value(a, rd + gap_at[i], d + gap_at[i], gap_len[i], 1);
+			slow = v == kFastSlow;
+			score += v > 0 ? v : 0;
+		}
+	if (!slow && tail_len > 0) { tail_val = fast_gap_value(a, rd + prev_end, d + prev_end, tail_len, 2); slow = tail_val == kFastSlow; score += tail_val > 0 ? tail_val : 0; }
+	if (slow) return o;
+	// ---- GenMappingReport's tail: GenCoordinateInfo (:515-562), GenerateCIGAR (:492-513) ----
+	const int64_t gPos = head_val > 0 ? d : d + first_r;                     // a head pair that scored nothing gives its place up (:674-686)
+	const int64_t end_gPos = (tail_val > 0 ? d + rlen : d + prev_end) - 1;   // ... and so does the tail pair
+	bool fwd;
+	int chr;
+	int64_t pos;
+	const bool rev = gPos >= L;
+	if (!rev) {
+		fwd = first;
+		if (a.n_chr == 1) { chr = 0; pos = gPos + 1; }
+		else { chr = a.end_chr[i1]; pos = gPos + 1 - a.chr_fwd_start[chr]; }
+	} else {
+		fwd = !first;
+		if (a.n_chr == 1) { chr = 0; pos = a.two_genome_size - end_gPos; }
+		else { pos = end_at(i1) - end_gPos + 1; chr = a.end_chr[i1]; }
+	}
+	// the elements: [head S] M [tail S] -- every M element merges into one; the reverse strand shows them in reverse order
+	const int clip_h = head_val == kFastClip ? first_r : 0, clip_t = tail_val == kFastClip ? tail_len : 0;
+	const int e_len[3] = {rev ? clip_t : clip_h, rlen - clip_h - clip_t, rev ? clip_h : clip_t};
+	char out[16];
+	int at = 0;
+#pragma unroll
+	for (int q = 0; q < 3; ++q) {
+		int nn = e_len[q];
+		if (nn <= 0) continue;
+		char buf[4];
+		int k = 0;
+		do { buf[k++] = (char)('0' + nn % 10); nn /= 10; } while (nn);
+		while (k) out[at++] = buf[--k];
+		out[at++] = q == 1 ? 'M' : 'S';
+	}
+	uint64_t t0 = 0, t1 = 0;
+#pragma unroll
+	for (int q = 0; q < 16; ++q) {
+		const uint64_t ch = q < at ? (uint64_t)(uint8_t)out[q] : 0ull;
+		if (q < 8) t0 |= ch << (8 * q); else t1 |= ch << (8 * (q - 8));
+	}
+	o.state = FAST_DECIDED;
+	o.t0 = t0; o.t1 = t1; o.cigar_len = at;
+	o.chr = chr; o.pos = pos; o.fwd = fwd;
+	o.score = pos <= 0 ? 0 : score;
+	return o;
+}
+
+// The candidates the planning kernels walk: every chained candidate and the slots of the rescue windows -- or, when aln_trivial_kernel
+// has decided the trivial pairs, the candidates of the OTHER pairs (a.slow_cands, ctl[34] of them) and the rescue slots.
+__device__ __forceinline__ int64_t plan_slots(const AlnArgs &a)
+{
+	unsigned long long n_tasks = a.ctl[4];
+	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
+	return (a.slow_cands ? (int64_t)a.ctl[34] : a.n_cands) + (int64_t)n_tasks;
+}
+__device__ __forceinline__ int64_t slot_cand(const AlnArgs &a, int64_t slot)
+{
+	if (!a.slow_cands) return slot;
+	const int64_t n = (int64_t)a.ctl[34];
+	return slot < n ? (int64_t)a.slow_cands[slot] : a.n_cands + (slot - n);
+}
+
 __global__ __launch_bounds__(256) void aln_plan_fast_kernel(AlnArgs a)
 {
 	__shared__ int64_t s_end[128];
@@ -1352,24 +1477,23 @@ __global__ __launch_bounds__(256) void aln_plan_fast_kernel(AlnArgs a)
 	if (ends_in_lds)
 		for (int i = threadIdx.x; i < a.n_ends; i += blockDim.x) s_end[i] = a.contig_end[i];
 	__syncthreads();
+	auto end_at = [&](int i) { return ends_in_lds ? s_end[i] : a.contig_end[i]; };
 	auto lower_bound = [&](int64_t g) {
 		int lo = 0, hi = a.n_ends;
 		while (lo < hi) {
 			int mid = (lo + hi) >> 1;
-			if ((ends_in_lds ? s_end[mid] : a.contig_end[mid]) < g) lo = mid + 1; else hi = mid;
+			if (end_at(mid) < g) lo = mid + 1; else hi = mid;
 		}
 		return lo;
 	};
-	unsigned long long n_tasks = a.ctl[4];
-	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
-	const int64_t n_all = a.n_cands + (int64_t)n_tasks;
+	const int64_t n_all = plan_slots(a);
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (int64_t slot0 = (int64_t)blockIdx.x * blockDim.x; slot0 < n_all; slot0 += stride) {
 		const int64_t slot = slot0 + threadIdx.x;
 		bool slow = false;
 		int64_t cand = 0;
 		if (slot < n_all) {
-			cand = a.plan_order ? (int64_t)a.plan_order[slot] : slot;
+			cand = a.plan_order ? (int64_t)a.plan_order[slot] : slot_cand(a, slot);
 			a.rep_score[cand] = 0; a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
 			const int64_t r = a.c_read[cand];
 			if (!a.r_host[r] && a.c_score[cand] != 0) {
@@ -1380,103 +1504,20 @@ __global__ __launch_bounds__(256) void aln_plan_fast_kernel(AlnArgs a)
 				else { const int64_t t = cand - a.n_cands; count = a.resc_count[t]; seeds = a.resc_seeds + t * kAlnMaxSeeds; }
 				const int64_t rbase = a.read_off[r];
 				const int rlen = (int)(a.read_off[r + 1] - rbase);
-				slow = count < 1 || count > kFastSeeds || rlen > 4000;
-				// ---- the seeds: one diagonal, in order, no overlap; gaps of at most a text word ----
-				int64_t d = 0;
-				int prev_end = 0, first_r = 0, seed_bases = 0;
-				int gap_at[kFastSeeds + 1], gap_len[kFastSeeds + 1];      // (indexed by unrolled constants: registers)
-#pragma unroll
-				for (int i = 0; i < kFastSeeds; ++i) {
-					gap_at[i] = 0; gap_len[i] = 0;
-					if (!slow && i < count) {
-						const kg_seed sd = seeds[i];
-						const int64_t di = sd.gPos - (int64_t)sd.rPos;
-						if (i == 0) { d = di; first_r = sd.rPos; if (di < 0 || sd.rPos > kFastGap) slow = true; }
-						else {
-							if (di != d || sd.rPos < prev_end || sd.rPos - prev_end > kFastGap) slow = true;
-							gap_at[i] = prev_end; gap_len[i] = sd.rPos - prev_end;
-						}
-						prev_end = sd.rPos + sd.len;
-						seed_bases += sd.len;
-					}
-				}
-				const int tail_len = rlen - prev_end;
-				if (tail_len < 0 || tail_len > kFastGap) slow = true;
-				if (!slow) {
-					// ---- CheckCoordinateValidity (:582-610) on [d, d + rlen - 1]: one strand copy, one contig ----
-					const int64_t g1 = d, g2 = d + rlen - 1, L = a.genome_size;
-					const int i1 = lower_bound(g1);
-					bool valid = !((g1 < L && g2 >= L) || (g1 >= L && g2 < L)) && i1 < a.n_ends;
-					if (valid && g2 > (ends_in_lds ? s_end[i1] : a.contig_end[i1])) {
-						const int i2 = lower_bound(g2);
-						valid = i2 < a.n_ends && a.end_chr[i1] == a.end_chr[i2];
-						slow = valid;          // (two keys of one contig cannot lie in one strand copy: never taken; the general path decides)
-					}
-					if (!valid) a.c_score[cand] = -1;          // no report, and no best/second-best step (:647)
-					else if (!slow) {
-						// ---- the gap pairs ----
-						const uint8_t *rd = a.enc + rbase;
-						int score = seed_bases;
-						int head_val = 1, tail_val = 1;          // (> 0: scored; 0: an M element without identical bases; kFastClip: soft-clipped)
-						if (first_r > 0) { head_val = fast_gap_value(a, rd, d, first_r, 0); slow = head_val == kFastSlow; score += head_val > 0 ? head_val : 0; }
-#pragma unroll
-						for (int i = 1; i < kFastSeeds; ++i)
-							if (!slow && i < count && gap_len[i] > 0) {
-								const int v = fast_gap_value(a, rd + gap_at[i], d + gap_at[i], gap_len[i], 1);
-								slow = v == kFastSlow;
-								score += v > 0 ? v : 0;
-							}
-						if (!slow && tail_len > 0) { tail_val = fast_gap_value(a, rd + prev_end, d + prev_end, tail_len, 2); slow = tail_val == kFastSlow; score += tail_val > 0 ? tail_val : 0; }
-						if (!slow) {
-							// ---- GenMappingReport's tail: GenCoordinateInfo (:515-562), GenerateCIGAR (:492-513) ----
-							const int ck = chunk_of(a, r);
-							const bool first = a.chunk_paired[ck] ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
-							const int64_t gPos = head_val > 0 ? d : d + first_r;                     // a head pair that scored nothing gives its place up (:674-686)
-							const int64_t end_gPos = (tail_val > 0 ? d + rlen : d + prev_end) - 1;   // ... and so does the tail pair
-							bool fwd;
-							int chr;
-							int64_t pos;
-							const bool rev = gPos >= L;
-							if (!rev) {
-								fwd = first;
-								if (a.n_chr == 1) { chr = 0; pos = gPos + 1; }
-								else { chr = a.end_chr[i1]; pos = gPos + 1 - a.chr_fwd_start[chr]; }
-							} else {
-								fwd = !first;
-								if (a.n_chr == 1) { chr = 0; pos = a.two_genome_size - end_gPos; }
-								else { pos = (ends_in_lds ? s_end[i1] : a.contig_end[i1]) - end_gPos + 1; chr = a.end_chr[i1]; }
-							}
-							// the elements: [head S] M [tail S] -- every M element merges into one; the reverse strand shows them in reverse order
-							const int clip_h = head_val == kFastClip ? first_r : 0, clip_t = tail_val == kFastClip ? tail_len : 0;
-							const int e_len[3] = {rev ? clip_t : clip_h, rlen - clip_h - clip_t, rev ? clip_h : clip_t};
-							char out[16];
-							int at = 0;
-#pragma unroll
-							for (int q = 0; q < 3; ++q) {
-								int nn = e_len[q];
-								if (nn <= 0) continue;
-								char buf[4];
-								int k = 0;
-								do { buf[k++] = (char)('0' + nn % 10); nn /= 10; } while (nn);
-								while (k) out[at++] = buf[--k];
-								out[at++] = q == 1 ? 'M' : 'S';
-							}
-							uint64_t t0 = 0, t1 = 0;
-#pragma unroll
-							for (int q = 0; q < 16; ++q) {
-								const uint64_t ch = q < at ? (uint64_t)(uint8_t)out[q] : 0ull;
-								if (q < 8) t0 |= ch << (8 * q); else t1 |= ch << (8 * (q - 8));
-							}
-							uint64_t *dst = reinterpret_cast<uint64_t *>(a.rep_cigar + cand * KG_ALN_CIGAR_MAX);
-							dst[0] = t0;
-							if (at > 8) dst[1] = t1;
-							a.rep_cigar_len[cand] = (uint8_t)at;
-							a.rep_chr[cand] = chr;
-							a.rep_pos[cand] = pos;
-							a.rep_fwd[cand] = fwd ? 1 : 0;
-							a.rep_score[cand] = pos <= 0 ? 0 : score;
-						}
-					}
+				const int ck = chunk_of(a, r);
+				const bool first = a.chunk_paired[ck] ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
+				const FastRep o = fast_report(a, count, seeds, rbase, rlen, first, lower_bound, end_at);
+				slow = o.state == FAST_SLOW;
+				if (o.state == FAST_INVALID) a.c_score[cand] = -1;
+				else if (o.state == FAST_DECIDED) {
+					uint64_t *dst = reinterpret_cast<uint64_t *>(a.rep_cigar + cand * KG_ALN_CIGAR_MAX);
+					dst[0] = o.t0;
+					if (o.cigar_len > 8) dst[1] = o.t1;
+					a.rep_cigar_len[cand] = (uint8_t)o.cigar_len;
+					a.rep_chr[cand] = o.chr;
+					a.rep_pos[cand] = o.pos;
+					a.rep_fwd[cand] = o.fwd ? 1 : 0;
+					a.rep_score[cand] = o.score;
 				}
 			}
 		}
@@ -1493,18 +1534,189 @@ __global__ __launch_bounds__(256) void aln_plan_fast_kernel(AlnArgs a)
 	}
 }
 
+// ---- pass 0: the trivial pairs, start to finish, one pair per lane ---------------------------------------------------------------
+// At 150 bp / 1 % error three pairs in four are trivial: each mate has ONE candidate, the two are each other's mate under
+// CheckPairedAlignmentCandidates (src/Mapping.cpp:348-400: 0 <= PosDiff2 - PosDiff1 < EstDistance), and both candidates are the kind
+// aln_plan_fast_kernel decides in registers.  For such a pair everything between chaining and the record is a function of ~200 bytes:
+//   RemoveUnMatedAlignmentCandidates adds the two scores (:402-427), RemoveRedundantCandidates sees one candidate (:317-346),
+//   GenMappingReport yields the two reports (fast_report), score > sub_score = 0 on both mates, the best candidates are mated so
+//   CheckPairedFinalAlignments leaves at once (:429-438; with -m its loops change nothing for one candidate per mate),
+//   SetPairedAlignmentFlag takes its first branch (:78-93), EvaluateMAPQ answers 60 (:160-175), OutputPairedAlignments prints the two
+//   records with RNEXT / PNEXT / TLEN (:177-270) and counts the pair into iPaired / iDistance (:209-213).
+// The per-candidate arrays (c_score, c_mate, rep_*) are never written or read for these pairs, none of the later kernels sees them:
+// the pairs this kernel does NOT take are listed (a.slow_pairs, ctl[35]) with their candidates (a.slow_cands, ctl[34]), and
+// aln_pair / aln_post_rescue / aln_bin / aln_plan_fast / aln_plan / aln_final walk those lists, densely.  The two 112-byte records
+// of a lane are assembled in registers, staged through the LDS 32 pairs at a time and leave as whole 16-byte chunks of consecutive
+// memory (aln_final_kernel writes a record field by field: 64 lanes, 64 lines per store).  KG_ALN_NO_TRIVIAL: off.
+static_assert(sizeof(kg_aln_record) == 112 && offsetof(kg_aln_record, kind) == 16 && offsetof(kg_aln_record, est_lo) == 44 && offsetof(kg_aln_record, has_mate) == 52 &&
+              offsetof(kg_aln_record, cigar) == 56 && offsetof(kg_aln_record, next) == 104 && offsetof(kg_aln_record, primary) == 108, "aln_trivial_kernel lays the record out by hand");
+
+__device__ __forceinline__ void stage_record(uint32_t *w, int64_t pos, int64_t mate_pos, int flag, int chr, int tlen, int score, int est_lo, bool flip, const FastRep &o)
+{
+	w[0] = (uint32_t)(uint64_t)pos; w[1] = (uint32_t)((uint64_t)pos >> 32);
+	w[2] = (uint32_t)(uint64_t)mate_pos; w[3] = (uint32_t)((uint64_t)mate_pos >> 32);
+	w[4] = KG_ALN_MAPPED; w[5] = (uint32_t)flag; w[6] = (uint32_t)chr; w[7] = 60; w[8] = (uint32_t)tlen;
+	w[9] = (uint32_t)score; w[10] = 0;                           // score, sub_score
+	w[11] = (uint32_t)est_lo; w[12] = 0x7fffffffu;               // the pair's own EstDistance interval (est_lo, est_hi]
+	w[13] = 1u | ((flip ? 1u : 0u) << 8) | ((uint32_t)o.cigar_len << 16);      // has_mate, flip, cigar_len, rescue = 0
+	w[14] = (uint32_t)o.t0; w[15] = (uint32_t)(o.t0 >> 32); w[16] = (uint32_t)o.t1; w[17] = (uint32_t)(o.t1 >> 32);
+#pragma unroll
+	for (int k = 18; k < 26; ++k) w[k] = 0;
+	w[26] = 0xffffffffu;                                         // next = -1
+	w[27] = 1;                                                   // primary, pad
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void aln_trivial_kernel(AlnArgs a)
+{
+	__shared__ int64_t s_end[128];
+	__shared__ __attribute__((aligned(16))) uint32_t s_rec[4][32 * 2 * 28];          // per wave: the records of 32 pairs (7168 bytes)
+	const bool ends_in_lds = a.n_ends <= 128;
+	if (ends_in_lds)
+		for (int i = threadIdx.x; i < a.n_ends; i += blockDim.x) s_end[i] = a.contig_end[i];
+	__syncthreads();
+	auto end_at = [&](int i) { return ends_in_lds ? s_end[i] : a.contig_end[i]; };
+	auto lower_bound = [&](int64_t g) {
+		int lo = 0, hi = a.n_ends;
+		while (lo < hi) {
+			int mid = (lo + hi) >> 1;
+			if (end_at(mid) < g) lo = mid + 1; else hi = mid;
+		}
+		return lo;
+	};
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t *const stage = s_rec[wave];
+	const int64_t n_pairs = a.n_reads >> 1;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	const long long est = a.est_distance;
+	for (int64_t u0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); u0 < n_pairs; u0 += stride) {      // u0: the wave's first pair
+		const int64_t u = u0 + lane;
+		const bool live = u < n_pairs;
+		const int64_t r = u << 1;
+		bool trivial = false;
+		int n1 = 0, n2 = 0;
+		int64_t c1 = 0;
+		FastRep o1, o2;
+		o1.state = o2.state = FAST_SLOW;
+		long long dist = 0;
+		int rl1 = 0, rl2 = 0;
+		if (live) {
+			c1 = a.cand_off[r];
+			const int64_t c2 = a.cand_off[r + 1], c3 = a.cand_off[r + 2];
+			n1 = (int)(c2 - c1); n2 = (int)(c3 - c2);
+			if (n1 == 1 && n2 == 1) {
+				const kg_candidate k1 = a.cands[c1], k2 = a.cands[c2];
+				dist = k2.posDiff - k1.posDiff;
+				// each is the other's only and best mate (score > 0; a tie or a better rival needs a second candidate), :362-391
+				if (k1.score > 0 && k2.score > 0 && dist >= 0 && dist < est) {
+					const int64_t b1 = a.read_off[r], b2 = a.read_off[r + 1], b3 = a.read_off[r + 2];
+					rl1 = (int)(b2 - b1); rl2 = (int)(b3 - b2);
+					o1 = fast_report(a, k1.count, a.cand_seeds + k1.first, b1, rl1, true, lower_bound, end_at);
+					if (o1.state == FAST_DECIDED && o1.score > 0)
+						o2 = fast_report(a, k2.count, a.cand_seeds + k2.first, b2, rl2, false, lower_bound, end_at);
+					trivial = o1.state == FAST_DECIDED && o2.state == FAST_DECIDED && o1.score > 0 && o2.score > 0 && o1.score <= kAlnMaxScore && o2.score <= kAlnMaxScore;
+				}
+			}
+		}
+		// ---- the pairs left to the general kernels, and their candidates, densely ----
+		{
+			const bool slow = live && !trivial;
+			const uint64_t mask = __ballot(slow);
+			if (mask) {
+				const int nc = slow ? n1 + n2 : 0;
+				int pre = nc;                                   // inclusive prefix sum of the lanes' candidate counts
+#pragma unroll
+				for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(pre, off); if (lane >= off) pre += t; }
+				const int total = __shfl(pre, 63);
+				const int leader = __ffsll((unsigned long long)mask) - 1;
+				unsigned long long at_p = 0, at_c = 0;
+				if (lane == leader) {
+					at_p = atomicAdd(&a.ctl[35], (unsigned long long)__popcll(mask));
+					if (total) at_c = atomicAdd(&a.ctl[34], (unsigned long long)total);
+				}
+				at_p = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(at_p >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)at_p, leader);
+				at_c = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(at_c >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)at_c, leader);
+				if (slow) {
+					const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+					a.slow_pairs[at_p + (unsigned long long)__popcll(mask & below)] = (int32_t)u;
+					int32_t *dst = a.slow_cands + at_c + (unsigned long long)(pre - nc);
+					for (int k = 0; k < nc; ++k) dst[k] = (int32_t)(c1 + k);
+				}
+			}
+		}
+		// ---- the trivial pairs' records ----
+		const uint64_t tmask = __ballot(trivial);
+		if (tmask == 0) continue;
+		int tl = 0;
+		long long ad = 0;
+		if (trivial) {
+			tl = (int)(o2.pos - o1.pos + (o1.fwd ? rl2 : 0 - rl1));      // :204-207
+			ad = tl < 0 ? -(long long)tl : (long long)tl;
+			if (ad >= 10000) ad = 0;                                        // :211
+		}
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			const bool mine = trivial && (lane >> 5) == half;
+			if (mine) {
+				uint32_t *w = stage + (lane & 31) * 56;
+				stage_record(w, o1.pos, o2.pos, 0x43 | (o1.fwd ? 0x20 : 0x10), o1.chr, tl, o1.score, (int)dist, !o1.fwd, o1);
+				stage_record(w + 28, o2.pos, o1.pos, 0x83 | (o2.fwd ? 0x20 : 0x10), o2.chr, 0 - tl, o2.score, (int)dist, o2.fwd, o2);
+			}
+			// (a wave's LDS traffic is in program order; the fences keep the compiler from moving the reads above the writes of OTHER lanes)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			const uint32_t hm = (uint32_t)(tmask >> (32 * half));
+			if (hm == 0) continue;
+			uint4 *const out = reinterpret_cast<uint4 *>(a.records + ((u0 + 32 * half) << 1));
+			const uint4 *const in = reinterpret_cast<const uint4 *>(stage);
+#pragma unroll
+			for (int it = 0; it < 7; ++it) {
+				const int q = it * 64 + lane;                   // 16-byte chunk of the half's 7168 bytes; 14 chunks per pair
+				if ((hm >> (q / 14)) & 1u) out[q] = in[q];
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+		// ---- what the pairs add to their chunks: iPaired / iDistance, the reads of MAPQ 60, the chunk's EstDistance interval ----
+		int ck = -1;
+		if (trivial) ck = chunk_of(a, r);
+		const int ck0 = __shfl(ck, __ffsll((unsigned long long)tmask) - 1);
+		if (__ballot(trivial && ck != ck0) == 0) {
+			long long lo = trivial ? dist : -1, sum = ad;
+			for (int off = 32; off > 0; off >>= 1) {
+				const long long l2 = __shfl_xor(lo, off);
+				lo = l2 > lo ? l2 : lo;
+				sum += __shfl_xor(sum, off);
+			}
+			if (lane == 0) {
+				kg_chunk_stats &cs = a.chunk_stats[ck0];
+				const int np = __popcll(tmask);
+				atomicAdd((unsigned long long *)&cs.paired, 2ull * (unsigned long long)np);
+				if (sum) atomicAdd((unsigned long long *)&cs.distance, (unsigned long long)sum);
+				atomicAdd(&cs.unique, 2 * np);
+				atomicMax((long long *)&cs.lo, lo);
+			}
+		} else if (trivial) {
+			kg_chunk_stats &cs = a.chunk_stats[ck];
+			atomicAdd((unsigned long long *)&cs.paired, 2ull);
+			if (ad) atomicAdd((unsigned long long *)&cs.distance, (unsigned long long)ad);
+			atomicAdd(&cs.unique, 2);
+			atomicMax((long long *)&cs.lo, dist);
+		}
+		if (lane == 0) atomicAdd(&a.ctl[36], (unsigned long long)__popcll(tmask));      // (pairs decided here, this batch)
+	}
+}
+
 // ---- pass 1: one candidate per lane -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 {
 	int64_t cand = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	unsigned long long n_tasks = a.ctl[4];
-	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
-	int64_t n_all = a.n_cands + (int64_t)n_tasks;                                // chained candidates, then the slots of the rescue windows
+	int64_t n_all = plan_slots(a);                                               // chained candidates (all, or those of the pairs aln_trivial_kernel left), then the slots of the rescue windows
 	if (a.plan_slow) n_all = (int64_t)a.ctl[32];                                 // ... or what aln_plan_fast_kernel left
 	for (int64_t slot = cand; slot < n_all; slot += stride) {
 		// (binned: lanes of a wave then hold candidates with the same number of seeds -- the loops below run equally long)
-		cand = a.plan_slow ? (int64_t)a.plan_slow[slot] : a.plan_order ? (int64_t)a.plan_order[slot] : slot;
+		cand = a.plan_slow ? (int64_t)a.plan_slow[slot] : a.plan_order ? (int64_t)a.plan_order[slot] : slot_cand(a, slot);
 		a.rep_score[cand] = 0; a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
 		const int64_t r = a.c_read[cand];
 		if (a.r_host[r]) continue;
@@ -1818,9 +2030,11 @@ __device__ int multi_flag(const AlnArgs &a, const ReadSum &me, const ReadSum &ot
 
 __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 {
-	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-	for (; r < a.n_reads; r += stride) {
+	const int64_t n_units = a.slow_pairs ? (int64_t)a.ctl[35] : a.n_reads;          // (the pairs aln_trivial_kernel left, or every read)
+	for (; x < n_units; x += stride) {
+		const int64_t r = a.slow_pairs ? (int64_t)a.slow_pairs[x] << 1 : x;
 		const int ck = chunk_of(a, r);
 		const bool paired = a.chunk_paired[ck] != 0;
 		if (paired && ((r - a.chunk_off[ck]) & 1)) continue;
@@ -2008,15 +2222,13 @@ __global__ __launch_bounds__(256) void aln_bin_kernel(AlnArgs a, int pass)
 {
 	__shared__ unsigned int s_cnt[4];
 	__shared__ unsigned long long s_next[4];
-	unsigned long long n_tasks = a.ctl[4];
-	if (n_tasks > (unsigned long long)a.task_capacity) n_tasks = (unsigned long long)a.task_capacity;
-	const int64_t n_all = a.n_cands + (int64_t)n_tasks;
+	const int64_t n_all = plan_slots(a);
 	const int64_t per = (n_all + gridDim.x - 1) / gridDim.x;
 	const int64_t b0 = (int64_t)blockIdx.x * per, b1 = b0 + per < n_all ? b0 + per : n_all;
 	if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	unsigned int mine[4] = {0, 0, 0, 0};
-	for (int64_t c = b0 + threadIdx.x; c < b1; c += blockDim.x) mine[plan_bin(a, c)]++;
+	for (int64_t c = b0 + threadIdx.x; c < b1; c += blockDim.x) mine[plan_bin(a, slot_cand(a, c))]++;
 #pragma unroll
 	for (int b = 0; b < 4; ++b) {
 		unsigned int v = mine[b];
@@ -2035,8 +2247,8 @@ __global__ __launch_bounds__(256) void aln_bin_kernel(AlnArgs a, int pass)
 	}
 	__syncthreads();
 	for (int64_t base = b0; base < b1; base += blockDim.x) {
-		const int64_t c = base + threadIdx.x;
-		const int bin = c < b1 ? plan_bin(a, c) : -1;
+		const int64_t c = base + threadIdx.x < b1 ? slot_cand(a, base + threadIdx.x) : -1;
+		const int bin = c >= 0 ? plan_bin(a, c) : -1;
 #pragma unroll
 		for (int b = 0; b < 4; ++b) {
 			const uint64_t mask = __ballot(bin == b);
@@ -2061,6 +2273,7 @@ __global__ void aln_reset_kernel(AlnArgs a)
 	if (i == 0) a.ctl[33] += a.ctl[32];                  // (running tally: candidates the fast plan kernel left to the general one)
 	if (i < 8) a.ctl[i] = 0;
 	if (i >= 24 && i < 33) a.ctl[i] = 0;
+	if (i >= 34 && i <= 36) a.ctl[i] = 0;                // (aln_trivial_kernel: candidates / pairs it leaves to the general kernels, pairs it decided)
 	for (int c = i; c < a.n_chunks; c += gridDim.x * blockDim.x) {
 		kg_chunk_stats z;
 		z.paired = 0; z.distance = 0; z.lo = -1; z.hi = 0x7fffffffffffffffll; z.unmapped = 0; z.unique = 0; z.host_pairs = 0; z.rescue_wanted = 0;
@@ -2080,6 +2293,11 @@ static inline int grid_for_aln(int64_t items, int block, int max_blocks)
 hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 {
 	hipLaunchKernelGGL(aln_reset_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	if (a.slow_pairs) {
+		kt_begin(KT_ALN_TRIVIAL, stream);
+		hipLaunchKernelGGL(aln_trivial_kernel, dim3(grid_for_aln(a.n_reads / 2 + 1, 256, n_cu * 16)), dim3(256), 0, stream, a);
+		kt_end(KT_ALN_TRIVIAL, stream);
+	}
 	kt_begin(KT_ALN_PAIR, stream);
 	hipLaunchKernelGGL(aln_pair_kernel, dim3(grid_for_aln(a.all_paired ? a.n_reads / 2 + 1 : a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
 	kt_end(KT_ALN_PAIR, stream);

@@ -131,6 +131,8 @@ struct AlnArgs {
 	AlnPiece *pieces;               // [4 * job_capacity]
 	PartTask *part_tasks;           // [job_capacity], handed out through ctl[3]
 	int32_t *plan_order;            // [n_cands + task_capacity] or null: the order in which aln_plan_kernel takes the candidates (binned by seed count, ctl[24..31])
+	int32_t *slow_pairs;            // [n_reads / 2] or null: the pairs aln_trivial_kernel did not decide (ctl[35] of them) -- the only ones the kernels behind it look at
+	int32_t *slow_cands;            // [n_cands]: the candidates of those pairs (ctl[34])
 	int32_t *plan_slow;             // [n_cands + task_capacity] or null: the candidates aln_plan_fast_kernel left to aln_plan_kernel (ctl[32] of them)
 	unsigned long long *ctl;        // [0] spill count, [1] job count, [2] ops bytes, [3] partition tasks, [4] rescue tasks, [5] plans, [6] pieces, [7] extra records (-m)
 	uint8_t *nw_ops;

@@ -103,6 +103,9 @@ int kh_map(kh_session *s, int argc, const char *const *argv, kh_stats_t *stats)
 		stats->candidates = st.device.candidates; stats->candidate_seeds = st.device.candidate_seeds;
 		for (int i = 0; i < 16; ++i) { stats->kernel_ms[i] = st.device.kernel_ms[i]; stats->kernel_launches[i] = st.device.kernel_launches[i]; }
 		for (int i = 0; i < 8; ++i) stats->aln_counts[i] = st.device.aln_counts[i];
+		for (int i = 0; i < 6; ++i) stats->lane_seconds[i] = st.lane_seconds[i];
+		stats->lanes = st.lanes; stats->pad2 = 0;
+		stats->text_checksum[0] = st.device.text_checksum[0]; stats->text_checksum[1] = st.device.text_checksum[1];
 	}
 	if (rc == 0) return 0;
 	const std::string why = kart::run_error_message();

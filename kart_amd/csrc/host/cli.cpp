@@ -18,6 +18,8 @@
 
 namespace kart {
 
+#include "knobs.inc"
+
 static void usage(const char *prog)
 {
 	fprintf(stdout, "kart v2.5.6 (MI355X-native hot path; CLI of Hsin-Nan Lin & Wen-Lian Hsu's kart)\n\n");
@@ -79,6 +81,11 @@ int parse_cli(int argc, char **argv, Options &opt)
 		else if (p == "-m") opt.multi_hit = true;
 		else if (p == "-pair" || p == "-p") opt.paired = true;
 		else if (p == "-v" || p == "--version") { fprintf(stdout, "kart v2.5.6\n\n"); return -1; }
+		else if (p == "-knobs") {          // the environment variables the product reads (host/knobs.inc): none is needed, none changes a result
+			fprintf(stdout, "%-28s %-4s %-7s %s\n", "variable", "kind", "where", "what (T tuning, A A/B aid, D diagnostics / test aid, M measurement aid)");
+			for (const Knob &k : kKnobs) fprintf(stdout, "%-28s %-4s %-7s %s%s\n", k.name, k.kind, k.where, k.what, getenv(k.name) ? "   [set]" : "");
+			return -1;
+		}
 		else {
 			fprintf(stdout, "Error! Unknown parameter: %s\n", argv[i]);
 			usage(argv[0]);

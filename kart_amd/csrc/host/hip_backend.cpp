@@ -384,7 +384,7 @@ private:
 KernelBackend *make_hip_backend(const Options &opt, std::string &err)
 {
 	kg_index *ix = nullptr;
-	// KART_AMD_SA = auto (default: full below 2^32 text symbols, compact above) | full | compact | dense4 | dense8 | sampled: how much of the suffix array
+	// KART_AMD_SA = auto (default: full below 2^32 text symbols; above, wide where the device has room, else compact) | full | compact | wide | dense4 | dense8 | sampled: how much of the suffix array
 	// stays on the device (include/kart_amd.h); the results are the same, the compact index takes 67 GB instead of 168 GB for a human genome
 	int sa_mode = opt.sa_mode;
 	if (const char *e = getenv("KART_AMD_SA")) {
@@ -392,10 +392,11 @@ KernelBackend *make_hip_backend(const Options &opt, std::string &err)
 		if (v == "auto") sa_mode = KG_SA_AUTO;
 		else if (v == "full") sa_mode = KG_SA_FULL;
 		else if (v == "compact") sa_mode = KG_SA_FULL40;
+		else if (v == "wide") sa_mode = KG_SA_FULL40_WIDE;
 		else if (v == "dense4") sa_mode = KG_SA_DENSE4;
 		else if (v == "dense8") sa_mode = KG_SA_DENSE8;
 		else if (v == "sampled") sa_mode = KG_SA_SAMPLED;
-		else { err = "KART_AMD_SA must be one of auto, full, compact, dense4, dense8, sampled"; return nullptr; }
+		else { err = "KART_AMD_SA must be one of auto, full, compact, wide, dense4, dense8, sampled"; return nullptr; }
 	}
 	if (kg_index_load(opt.index_prefix.c_str(), opt.device, sa_mode, &ix) != KG_OK) {
 		err = kg_last_error();

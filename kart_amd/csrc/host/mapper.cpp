@@ -54,6 +54,11 @@ namespace {
 #include "detail/bam.inc"
 #include "detail/reader.inc"
 #include "detail/shard.inc"
+#include "detail/chunk_state.inc"
+#include "detail/writer.inc"
+#include "detail/chunk_stages.inc"
+#include "detail/batch_reader.inc"
+#include "detail/deferred.inc"
 #include "detail/pipeline.inc"
 #include "detail/stream.inc"
 
@@ -309,6 +314,9 @@ std::string run_error_message()
 
 FILE *open_output(const std::string &path)
 {
+	// measurement aid (bench.py's gpu_pipeline leg): the run's text goes nowhere -- the device pipeline and the copies back to the host run as
+	// usual, what is left out is the host's copy into the output file's fresh pages
+	if (getenv("KART_AMD_OUTPUT_NULL")) return fopen("/dev/null", "w");
 	struct stat sb;
 	bool regular = stat(path.c_str(), &sb) != 0 || S_ISREG(sb.st_mode);
 	return fopen(path.c_str(), regular ? "w+" : "w");

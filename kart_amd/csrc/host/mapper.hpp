@@ -189,6 +189,8 @@ struct Stats {
 	int64_t rewritten_chunks = 0;   // (-parts, a later shard) chunks whose text was written a second time because settling changed a chunk in front of them
 	int64_t stream_reads = 0;   // reads that went through the device's FASTQ-in / SAM-out stream
 	kg_stream_timing_t device{};   // ... and what their batches cost on the device (HIP events on the lanes' streams, summed)
+	double lane_seconds[6] = {0, 0, 0, 0, 0, 0};   // ... and what the lanes' host threads waited for / worked on (kh_stats_t::lane_seconds), summed over `lanes` threads
+	int lanes = 0;
 	bool sharded = false;       // the totals above are this process's shard only (kart::shard_totals() gives the run's)
 };
 

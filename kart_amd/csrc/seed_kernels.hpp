@@ -96,14 +96,31 @@ hipError_t launch_sample_sa(const uint32_t *fsa32, const uint64_t *fsa64, uint64
 // thread's current timer, the launchers bracket their kernels with its events on the launch stream, and the entry point reads the
 // durations once the stream has been synchronised.
 enum { KT_CHAIN = 0, KT_ALN_PAIR, KT_ALN_RESCUE, KT_ALN_PLAN_FAST, KT_ALN_PLAN, KT_ALN_PARTITION, KT_NW, KT_ALN_FINISH, KT_ALN_FINAL,
-       KT_SAM_SIZE, KT_SAM_FORMAT, KT_FQ_PARSE, KT_FQ_MATERIALISE, KT_LOCATE_SORT, KT_SLOTS = 16 };
+       KT_SAM_SIZE, KT_SAM_FORMAT, KT_FQ_PARSE, KT_FQ_MATERIALISE, KT_LOCATE_SORT, KT_ALN_TRIVIAL, KT_SLOTS = 16 };
+// (a slot may be bracketed more than once per batch -- the NW kernels run for the batch and again for what comes back from the partition --: every
+//  bracket takes the slot's next pair of events, up to kKtRing of them between two reads of the timer; the reader sums the pairs used)
+constexpr int kKtRing = 4;
 struct KernelTimer {
-	hipEvent_t b[KT_SLOTS] = {}, e[KT_SLOTS] = {};
-	bool armed[KT_SLOTS] = {};
+	hipEvent_t b[KT_SLOTS][kKtRing] = {}, e[KT_SLOTS][kKtRing] = {};
+	int used[KT_SLOTS] = {};          // brackets closed since the last read (those beyond kKtRing re-use the last pair: counted, not timed twice)
+	int open_at[KT_SLOTS] = {};
 };
 extern thread_local KernelTimer *kt_current;
-inline void kt_begin(int slot, hipStream_t st) { KernelTimer *k = kt_current; if (k && k->b[slot]) (void)hipEventRecord(k->b[slot], st); }
-inline void kt_end(int slot, hipStream_t st) { KernelTimer *k = kt_current; if (k && k->e[slot]) { (void)hipEventRecord(k->e[slot], st); k->armed[slot] = true; } }
+inline void kt_begin(int slot, hipStream_t st)
+{
+	KernelTimer *k = kt_current;
+	if (!k || !k->b[slot][0]) return;
+	const int i = k->used[slot] < kKtRing ? k->used[slot] : kKtRing - 1;
+	k->open_at[slot] = i;
+	(void)hipEventRecord(k->b[slot][i], st);
+}
+inline void kt_end(int slot, hipStream_t st)
+{
+	KernelTimer *k = kt_current;
+	if (!k || !k->e[slot][0]) return;
+	(void)hipEventRecord(k->e[slot][k->open_at[slot]], st);
+	if (k->used[slot] < kKtRing) k->used[slot]++;
+}
 struct KtUse {                     // the calling thread's launches are timed by `k` (null: not at all) while this object lives
 	KernelTimer *prev;
 	explicit KtUse(KernelTimer *k) : prev(kt_current) { kt_current = k; }

@@ -616,7 +616,34 @@ __global__ __launch_bounds__(64) void sam_format_kernel(SamArgs a)
 
 __global__ void sam_reset_kernel(SamArgs a)
 {
-	if (threadIdx.x < 2) a.ctl[threadIdx.x] = 0;
+	if (threadIdx.x < 4) a.ctl[threadIdx.x] = 0;
+}
+
+// Measurement aid (KG_STREAM_CHECKSUM, bench.py's gpu_pipeline leg): the batch's SAM text summed on the device -- ctl[2] += the sum of its bytes,
+// ctl[3] += its line feeds -- so that a run whose text is never copied into file pages still shows WHICH text it made (both figures are
+// independent of how the text is cut into batches).  16 bytes per lane and step, one pair of atomics per wave.
+__global__ __launch_bounds__(256) void sam_checksum_kernel(SamArgs a)
+{
+	const int64_t bytes = a.sam_off[a.n_reads];
+	const int64_t n16 = bytes >> 4;
+	unsigned long long sum = 0, lines = 0;
+	const uint4 *src = reinterpret_cast<const uint4 *>(a.sam);
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+		const uint4 v = src[i];
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			sum += (w[k] & 255u) + ((w[k] >> 8) & 255u) + ((w[k] >> 16) & 255u) + (w[k] >> 24);
+			const uint32_t x = w[k] ^ 0x0A0A0A0Au;                                   // a zero byte where the text holds '\n'
+			lines += __popc(((x - 0x01010101u) & ~x) & 0x80808080u);
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) {
+		const uint8_t c = a.sam[(n16 << 4) + threadIdx.x];
+		sum += c; lines += c == 10 ? 1 : 0;
+	}
+	for (int off = 32; off > 0; off >>= 1) { sum += __shfl_down(sum, off); lines += __shfl_down(lines, off); }
+	if ((threadIdx.x & 63) == 0 && (sum | lines)) { atomicAdd(&a.ctl[2], sum); atomicAdd(&a.ctl[3], lines); }
 }
 
 // ---- launches ------------------------------------------------------------------------------------------------------------------
@@ -730,6 +757,13 @@ hipError_t launch_sam_format(const SamArgs &a, int n_cu, hipStream_t stream)
 	kt_begin(KT_SAM_FORMAT, stream);
 	hipLaunchKernelGGL(sam_format_kernel, dim3(grid_of((a.n_reads + 63) / 64, 1, n_cu * 64)), dim3(64), 0, stream, a);
 	kt_end(KT_SAM_FORMAT, stream);
+	return hipGetLastError();
+}
+
+hipError_t launch_sam_checksum(const SamArgs &a, int n_cu, hipStream_t stream)
+{
+	if (a.n_reads <= 0) return hipSuccess;
+	hipLaunchKernelGGL(sam_checksum_kernel, dim3(n_cu * 8), dim3(256), 0, stream, a);
 	return hipGetLastError();
 }
 

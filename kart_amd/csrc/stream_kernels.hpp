@@ -70,7 +70,7 @@ struct SamArgs {
 	uint8_t *sam;                    // the text
 	int64_t sam_capacity;
 	int32_t *host_list;              // reads handed back (KG_ALN_HOST), in no particular order
-	unsigned long long *ctl;         // [0] entries of host_list, [1] format errors (a record whose text is not the size announced)
+	unsigned long long *ctl;         // [0] entries of host_list, [1] format errors (a record whose text is not the size announced), [2] / [3] sam_checksum_kernel's sums
 };
 
 size_t fq_scan_temp_bytes(int64_t max_items);
@@ -79,6 +79,7 @@ hipError_t launch_fq_parse(const FqArgs &a, void *scan_temp, size_t scan_temp_by
 hipError_t launch_fq_materialise(const FqArgs &a, int n_cu, hipStream_t stream);
 hipError_t launch_sam_size(const SamArgs &a, void *scan_temp, size_t scan_temp_bytes, int n_cu, hipStream_t stream);
 hipError_t launch_sam_format(const SamArgs &a, int n_cu, hipStream_t stream);
+hipError_t launch_sam_checksum(const SamArgs &a, int n_cu, hipStream_t stream);      // measurement aid: ctl[2] += byte sum, ctl[3] += line feeds of the text
 // grouped seeding: a lane's parsed batch published as a segment of its group's batch; the lane's seed offsets cut out of the group's
 hipError_t launch_group_publish(const int64_t *local_off, int64_t n, int64_t slots, int64_t enc_base, int64_t *g_off, int32_t *g_len, int n_cu, hipStream_t stream);
 hipError_t launch_group_rebase(const int64_t *g_seed_off, int64_t n, int64_t first, int64_t *seed_off, int n_cu, hipStream_t stream);

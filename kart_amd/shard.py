@@ -39,6 +39,17 @@ def max_over_ranks(value, device=None):
     return float(t[0].item()) if scalar else [float(x) for x in t.tolist()]
 
 
+def gather_rows(values, device=None):
+    """Every rank's list of floats, as a list of rows in rank order, on every rank (one all-gather of a small tensor; a single
+    process gets its own row)."""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        rows = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, t)
+        return [[float(x) for x in r.tolist()] for r in rows]
+    return [[float(x) for x in t.tolist()]]
+
+
 # ---- a sharded mapping run, rank by rank ---------------------------------------------------------------------------------
 # One process per GPU maps the contiguous range of whole 4000-read chunks that falls into its byte slice of the input files
 # (kart_amd/csrc/host/detail/shard.inc; the reference's counterpart is the chunk fan-out to its worker threads,

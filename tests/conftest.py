@@ -88,6 +88,13 @@ def gpu_index_compact(built_lib):
 
 
 @pytest.fixture(scope="session")
+def gpu_index_wide(built_lib):
+    ix = _dense_index(built_lib, "KG_SA_FULL40_WIDE")  # 5-byte suffix-array entries where the text needs them, the full q-mer table, triple planes: what KG_SA_AUTO takes for a human-sized text
+    yield ix
+    ix.close()
+
+
+@pytest.fixture(scope="session")
 def gpu_index_dense8(built_lib):
     ix = _dense_index(built_lib, "KG_SA_DENSE8")
     yield ix

@@ -18,19 +18,19 @@ def _check_reads(ix, reads, want, mode):
         assert (g == w.astype(api.SEED_DT)).all(), i
 
 
-@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_dense4", "gpu_index_dense8"])
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_wide", "gpu_index_dense4", "gpu_index_dense8"])
 def test_fast_mode_golden(golden, which, request):
     ix = request.getfixturevalue(which)
     _check_reads(ix, split(golden["fast_enc"], golden["fast_off"]), split(golden["fast_seeds"], golden["fast_seed_off"]), 0)
 
 
-@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_dense4", "gpu_index_dense8"])
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_wide", "gpu_index_dense4", "gpu_index_dense8"])
 def test_sensitive_mode_golden(golden, which, request):
     ix = request.getfixturevalue(which)
     _check_reads(ix, split(golden["sens_enc"], golden["sens_off"]), split(golden["sens_seeds"], golden["sens_seed_off"]), 1)
 
 
-@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_dense8"])
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_wide", "gpu_index_dense8"])
 @pytest.mark.parametrize("seg_len", [128, 192, 512])
 def test_sensitive_mode_walks_from_segment_starts(golden, which, seg_len, request, oracle_small, monkeypatch):
     """SensitiveMode within a read in parallel (SeedArgs::vr_read, search.inc): the loop of IdentifySeedPairs_SensitiveMode
@@ -161,7 +161,7 @@ def test_empty_and_tiny_batches(gpu_index):
     assert [len(o) for o in out] == [0, 0, 0]
 
 
-@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_dense4", "gpu_index_dense8"])
+@pytest.mark.parametrize("which", ["gpu_index", "gpu_index_full", "gpu_index_compact", "gpu_index_wide", "gpu_index_dense4", "gpu_index_dense8"])
 def test_random_pairs_vs_oracle(which, request, oracle_small):
     """20k reads of 150 bp with 2 % errors + N's, ragged lengths mixed in; both modes"""
     ix = request.getfixturevalue(which)
@@ -219,7 +219,7 @@ def test_wide_index_instantiation(golden, built_lib, gpu_index_full, tmp_path, r
         from kart_amd import api
         g = np.load(%r, allow_pickle=True)
         e = np.load(%r)
-        for sa_mode in (api.KG_SA_SAMPLED, api.KG_SA_FULL, api.KG_SA_FULL40, api.KG_SA_DENSE4, api.KG_SA_DENSE8):
+        for sa_mode in (api.KG_SA_SAMPLED, api.KG_SA_FULL, api.KG_SA_FULL40, api.KG_SA_FULL40_WIDE, api.KG_SA_DENSE4, api.KG_SA_DENSE8):
             ix = api.Index(%r, 0, sa_mode)
             for mode, key in ((0, "fast"), (1, "sens")):
                 ws = ix.workspace(len(g[key + "_off"]) - 1, len(g[key + "_enc"]))
