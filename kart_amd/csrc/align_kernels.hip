@@ -78,6 +78,27 @@ __device__ __forceinline__ int end_lower_bound(const AlnArgs &a, int64_t g)
 	return lo;
 }
 
+// A lane's share of a list whose end is a device counter: the wave's requests are summed and ONE returning atomic takes them all.
+// (Every lane asking for itself was the stage's hidden cost: the counters are single addresses -- ctl[0..6] --, fifty million returning
+// atomics per 100 M-read step queue at one L2 channel at about one per clock, ~25 ms per kernel whatever else the kernel does.)
+// EVERY lane of the wave calls it, at a point where the wave has reconverged (need = 0: nothing for this lane).
+__device__ __forceinline__ unsigned long long wave_reserve(unsigned long long *counter, unsigned long long need)
+{
+	const int lane = threadIdx.x & 63;
+	unsigned long long incl = need;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const unsigned long long t = ((unsigned long long)(uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off) << 32) | (uint32_t)__shfl_up((int)(uint32_t)incl, off);
+		if (lane >= off) incl += t;
+	}
+	const unsigned long long total = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)incl, 63);
+	if (total == 0) return 0;
+	unsigned long long base = 0;
+	if (lane == 63) base = atomicAdd(counter, total);
+	base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 63);
+	return base + incl - need;
+}
+
 // why a pair went back to the host (kg_align_reasons)
 enum { WHY_PAIR_PRODUCT = 0, WHY_RESCUE_DIR1 = 1, WHY_RESCUE_WINDOW = 2, WHY_RESCUE_READ = 3, WHY_RESCUE_RUNS = 4, WHY_RESCUE_SEEDS = 5, WHY_SEEDS = 6,
        WHY_GAPS = 7, WHY_PARTITION = 8, WHY_CAPACITY = 9, WHY_CIGAR = 10, WHY_SCORE = 11, WHY_READ_LEN = 12 };
@@ -147,9 +168,49 @@ __device__ void remove_unmated(const AlnArgs &a, const CandList &l1, const CandL
 
 // ---- pairing ---------------------------------------------------------------------------------------------------------------
 // one pair (or one single-end read): CheckPairedAlignmentCandidates and what follows it.  out_ck / out_lo / out_hi: the pair's
-// contribution to its chunk's EstDistance validity interval (out_ck < 0: none) -- merged per wave by the kernel
-__device__ __forceinline__ void pair_one(const AlnArgs &a, const int64_t r, int &out_ck, long long &out_lo, long long &out_hi)
+// contribution to its chunk's EstDistance validity interval (out_ck < 0: none) -- merged per wave by the kernel.
+// In two halves: pair_front runs up to the point where the pair knows how many rescue windows it wants (st.nt; 0: it is done), the kernel
+// reserves the task slots of the whole wave with one atomic (wave_reserve), pair_back writes the windows and finishes the pair.
+struct PairState {
+	int64_t a1;
+	int ck, n1, n2, sc1, rl1, rl2, est_r, thr, nt;
+};
+
+// the windows of mate 1 next to the candidates of mate 2 (src/AlignmentRescue.cpp:127-165): counted (tasks == nullptr) or written from slot `base` on.
+// Returns their number; host: a window beyond what the rescue kernel takes
+__device__ __forceinline__ int rescue_windows(const AlnArgs &a, int64_t r, const PairState &st, bool write, unsigned long long base, bool &host, int &why)
 {
+	int k = 0;
+	for (int j = 0; j < st.n2; ++j) {
+		if (a.c_score[st.a1 + j] < st.thr) continue;
+		int64_t pd = a.cands[st.a1 + j].posDiff;
+		int64_t left = pd - st.est_r, right = pd + st.rl2;
+		int it = end_lower_bound(a, right);
+		if (it == a.n_ends) continue;
+		int chr = a.end_chr[it];
+		int64_t fs = a.chr_fwd_start[chr], rs = a.chr_rev_start[chr], cl = a.chr_len[chr];
+		if (left < a.genome_size && left < (fs - cl)) left = fs - cl + 1;
+		else if (right >= a.genome_size && left < (rs - cl)) left = rs - cl + 1;
+		int slen = (int)(right - left);
+		if (slen < st.rl1) continue;
+		if (left < 0) { left = 0; slen = (int)(right - left); if (slen < st.rl1) continue; }
+		if (right > a.two_genome_size) continue;
+		if (slen > kRescueMaxWindow) { host = true; why = WHY_RESCUE_WINDOW; break; }
+		if (write) {
+			RescueTask t;
+			t.left = left; t.read = (int32_t)r; t.j = j; t.slen = slen; t.score1 = st.sc1; t.ordinal = k;
+			a.tasks[base + k] = t;
+			int64_t slot = a.n_cands + (int64_t)(base + k);
+			a.c_score[slot] = 0; a.c_mate[slot] = -1; a.c_read[slot] = (int32_t)r;
+		}
+		k++;
+	}
+	return k;
+}
+
+__device__ __forceinline__ void pair_front(const AlnArgs &a, const int64_t r, int &out_ck, long long &out_lo, long long &out_hi, PairState &st)
+{
+		st.nt = 0;
 		const int ck = chunk_of(a, r);
 		const bool paired = a.chunk_paired[ck] != 0;
 		const int64_t in_chunk = r - a.chunk_off[ck];
@@ -250,76 +311,331 @@ __device__ __forceinline__ void pair_one(const AlnArgs &a, const int64_t r, int 
 			}
 			int nt = 0;
 			if (!host && (strategy == 2 || strategy == 3)) {
-				// mate 1 next to the candidates of mate 2 (:127-165): one task per window
-				int thr = sc2 - 30;                       // (nothing was appended to mate 2's list above)
-				if (thr < 50) thr = 50;
-				// pass 1 counts the windows, pass 2 writes them
-				for (int pass = 0; pass < 2 && !host; ++pass) {
-					unsigned long long base = 0;
-					if (pass == 1) {
-						if (nt == 0) break;
-						base = atomicAdd(&a.ctl[4], (unsigned long long)nt);
-						if (base + (unsigned long long)nt > (unsigned long long)a.task_capacity || nt > 200) { host = true; why = WHY_CAPACITY; break; }
-					}
-					int k = 0;
-					for (int j = 0; j < n2; ++j) {
-						if (a.c_score[a1 + j] < thr) continue;
-						int64_t pd = a.cands[a1 + j].posDiff;
-						int64_t left = pd - est_r, right = pd + rl2;
-						int it = end_lower_bound(a, right);
-						if (it == a.n_ends) continue;
-						int chr = a.end_chr[it];
-						int64_t fs = a.chr_fwd_start[chr], rs = a.chr_rev_start[chr], cl = a.chr_len[chr];
-						if (left < a.genome_size && left < (fs - cl)) left = fs - cl + 1;
-						else if (right >= a.genome_size && left < (rs - cl)) left = rs - cl + 1;
-						int slen = (int)(right - left);
-						if (slen < rl1) continue;
-						if (left < 0) { left = 0; slen = (int)(right - left); if (slen < rl1) continue; }
-						if (right > a.two_genome_size) continue;
-						if (slen > kRescueMaxWindow) { host = true; why = WHY_RESCUE_WINDOW; break; }
-						if (pass == 1) {
-							RescueTask t;
-							t.left = left; t.read = (int32_t)r; t.j = j; t.slen = slen; t.score1 = sc1; t.ordinal = k;
-							a.tasks[base + k] = t;
-							int64_t slot = a.n_cands + (int64_t)(base + k);
-							a.c_score[slot] = 0; a.c_mate[slot] = -1; a.c_read[slot] = (int32_t)r;
-						}
-						k++;
-					}
-					if (pass == 0) nt = k;
-					else { a.resc_off[r] = (int32_t)base; a.resc_n[r] = (uint8_t)nt; }
-				}
-				if (!host && nt > 0) {
-					// the 8-mer code skips 'N' and maps everything else through nst_nt4_table (src/KmerAnalysis.cpp:25-32, 56-102);
-					// the kernel compares 2-bit codes, which is the same thing for reads made of A/C/G/T in either case
-					if (rl1 > kRescueMaxRead || rl1 < 8) { host = true; why = WHY_RESCUE_READ; }
-					const uint8_t *rd = a.enc + a.read_off[r];
-					for (int i = 0; i < rl1 && !host; ++i) {
-						unsigned u = rd[i] & 0xDFu;
-						if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) { host = true; why = WHY_RESCUE_READ; }
-					}
-				}
+				// mate 1 next to the candidates of mate 2 (:127-165): one task per window -- counted here, written by pair_back
+				st.a1 = a1; st.ck = ck; st.n1 = n1; st.n2 = n2; st.sc1 = sc1; st.rl1 = rl1; st.rl2 = rl2; st.est_r = est_r;
+				st.thr = sc2 - 30;                        // (nothing was appended to mate 2's list above)
+				if (st.thr < 50) st.thr = 50;
+				nt = rescue_windows(a, r, st, false, 0, host, why);
+				if (!host && nt > 200) { host = true; why = WHY_CAPACITY; }
 			}
 			if (host) { a.resc_n[r] = 0; flag_host(a, r, why); return; }
-			if (nt > 0) { a.r_pending[r] = 1; return; }           // filters follow once the windows are scanned (aln_post_rescue_kernel)
+			if (nt > 0) { st.nt = nt; return; }                    // the windows are written once the wave has its task slots (pair_back)
 		}
 		remove_redundant(a, l1);                                     // src/Mapping.cpp:563
 		remove_redundant(a, l2);
 }
 
+// a pair with st.nt rescue windows, task slots [base, base + nt) reserved
+__device__ __forceinline__ void pair_back(const AlnArgs &a, const int64_t r, const PairState &st, unsigned long long base)
+{
+	bool host = false;
+	int why = 0;
+	if (base + (unsigned long long)st.nt > (unsigned long long)a.task_capacity) { host = true; why = WHY_CAPACITY; }
+	else {
+		(void)rescue_windows(a, r, st, true, base, host, why);
+		a.resc_off[r] = (int32_t)base; a.resc_n[r] = (uint8_t)st.nt;
+		// the 8-mer code skips 'N' and maps everything else through nst_nt4_table (src/KmerAnalysis.cpp:25-32, 56-102);
+		// the kernel compares 2-bit codes, which is the same thing for reads made of A/C/G/T in either case
+		if (st.rl1 > kRescueMaxRead || st.rl1 < 8) { host = true; why = WHY_RESCUE_READ; }
+		const uint8_t *rd = a.enc + a.read_off[r];
+		for (int i0 = 0; i0 < st.rl1 && !host; i0 += 8) {          // (eight characters per load: the character array has 64 bytes of slack)
+			const uint64_t w = reinterpret_cast<const AlnU64u *>(rd + i0)->v;
+			const int m = st.rl1 - i0 < 8 ? st.rl1 - i0 : 8;
+			for (int i = 0; i < m; ++i) {
+				unsigned u = (unsigned)((w >> (8 * i)) & 0xDFu);
+				if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) { host = true; why = WHY_RESCUE_READ; }
+			}
+		}
+	}
+	if (host) { a.resc_n[r] = 0; flag_host(a, r, why); return; }
+	a.r_pending[r] = 1;                                              // filters follow once the windows are scanned (aln_post_rescue_kernel)
+}
+
+// ---- the same for a pair with MANY candidates, the whole wave on it ----------------------------------------------------------------
+// A pair out of a repeat family comes with tens of candidates per mate: CheckPairedAlignmentCandidates is a loop over n1 x n2 of them, the
+// filters and the rescue windows loops over each list, every step a dependent trip to the per-candidate arrays -- and a wave costs what its
+// heaviest lane costs (64 consecutive pairs of the hg38-sized workload: the heaviest lane carries tens of times the wave's mean, tools/cand_histogram.py).
+// Pairs above kPairHeavy candidate pairs are therefore taken out of the lanes' loop and done by the wave together, one after the other:
+// lane j holds candidate j of a list (j + 64, ... where a list is longer), the inner loop of :362-391 is one step per candidate of mate 1 --
+// the best score among the admissible candidates of mate 2 and whether a single one reaches it, by wave reductions; the order in which the
+// reference walks mate 2's list does not matter for that --, the mate book-keeping stays sequential in the candidates of mate 1 as in
+// the reference (a later candidate may take an earlier one's mate, :381-388).  Same arrays, same results as pair_front / pair_back.
+constexpr int kPairHeavy = 128;
+
+__device__ __forceinline__ void wave_sync_mem()          // the wave's stores to the per-candidate arrays are visible to all its lanes
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ int wave_max(int v) { for (int off = 32; off > 0; off >>= 1) { const int t = __shfl_xor(v, off); v = t > v ? t : v; } return v; }
+__device__ __forceinline__ int wave_sum(int v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
+
+// RemoveRedundantCandidates (src/Mapping.cpp:317-346), the wave on one list
+__device__ void remove_redundant_wave(const AlnArgs &a, const CandList &l)
+{
+	const int n = l.n(), lane = threadIdx.x & 63;
+	if (n <= 1) return;
+	int s1 = 0, s2 = 0;
+	for (int i = lane; i < n; i += 64) {
+		const int s = a.c_score[l.at(i)];
+		if (s > s2) {
+			if (s >= s1) { s2 = s1; s1 = s; }
+			else s2 = s;
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1) {                // the two largest of the union (a value twice: both)
+		const int b1 = __shfl_xor(s1, off), b2 = __shfl_xor(s2, off);
+		const int hi = s1 > b1 ? s1 : b1, lo = s1 > b1 ? b1 : s1, rest = s2 > b2 ? s2 : b2;
+		s1 = hi; s2 = lo > rest ? lo : rest;
+	}
+	const int thr = (s1 == s2 || s1 - s2 > 20) ? s1 : s2;
+	for (int i = lane; i < n; i += 64)
+		if (a.c_score[l.at(i)] < thr) a.c_score[l.at(i)] = 0;
+	wave_sync_mem();
+}
+
+// rescue_windows, lanes over the candidates of mate 2 (ordinals in list order, as the loop of :127-165 hands them out)
+__device__ int rescue_windows_wave(const AlnArgs &a, int64_t r, const PairState &st, bool write, unsigned long long base, bool &host, int &why)
+{
+	const int lane = threadIdx.x & 63;
+	int k_total = 0;
+	for (int j0 = 0; j0 < st.n2; j0 += 64) {
+		const int j = j0 + lane;
+		bool valid = false, too_big = false;
+		int64_t left = 0;
+		int slen = 0;
+		if (j < st.n2 && a.c_score[st.a1 + j] >= st.thr) {
+			const int64_t pd = a.cands[st.a1 + j].posDiff;
+			left = pd - st.est_r;
+			const int64_t right = pd + st.rl2;
+			const int it = end_lower_bound(a, right);
+			if (it != a.n_ends) {
+				const int chr = a.end_chr[it];
+				const int64_t fs = a.chr_fwd_start[chr], rs = a.chr_rev_start[chr], cl = a.chr_len[chr];
+				if (left < a.genome_size && left < (fs - cl)) left = fs - cl + 1;
+				else if (right >= a.genome_size && left < (rs - cl)) left = rs - cl + 1;
+				slen = (int)(right - left);
+				valid = slen >= st.rl1;
+				if (valid && left < 0) { left = 0; slen = (int)(right - left); valid = slen >= st.rl1; }
+				if (valid && right > a.two_genome_size) valid = false;
+				if (valid && slen > kRescueMaxWindow) { too_big = true; valid = false; }
+			}
+		}
+		// (the reference's loop stops at the first window beyond the kernel's reach; whatever it had counted before, the pair is the host's)
+		if (__ballot(too_big)) { host = true; why = WHY_RESCUE_WINDOW; return k_total; }
+		const uint64_t mask = __ballot(valid);
+		if (write && valid) {
+			const int k = k_total + __popcll(mask & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+			RescueTask t;
+			t.left = left; t.read = (int32_t)r; t.j = j; t.slen = slen; t.score1 = st.sc1; t.ordinal = k;
+			a.tasks[base + k] = t;
+			const int64_t slot = a.n_cands + (int64_t)(base + k);
+			a.c_score[slot] = 0; a.c_mate[slot] = -1; a.c_read[slot] = (int32_t)r;
+		}
+		k_total += __popcll(mask);
+	}
+	return k_total;
+}
+
+// pair_front for the pair of reads (r, r + 1) of an all-paired batch, every lane of the wave in it; the results are the same in all lanes
+__device__ void pair_front_wave(const AlnArgs &a, const int64_t r, int &out_ck, long long &out_lo, long long &out_hi, PairState &st)
+{
+	const int lane = threadIdx.x & 63;
+	st.nt = 0;
+	const int ck = chunk_of(a, r);
+	const CandList l1 = cand_list(a, r), l2 = cand_list(a, r + 1);          // (no rescue slots yet: resc_n is zero)
+	const int64_t a0 = l1.c0, a1 = l2.c0;
+	const int n1 = l1.nd, n2 = l2.nd;
+	for (int i = lane; i < n1; i += 64) { a.c_score[a0 + i] = a.cands[a0 + i].score; a.c_mate[a0 + i] = -1; a.c_read[a0 + i] = (int32_t)r; }
+	for (int j = lane; j < n2; j += 64) { a.c_score[a1 + j] = a.cands[a1 + j].score; a.c_mate[a1 + j] = -1; a.c_read[a1 + j] = (int32_t)(r + 1); }
+	if (lane == 0) {
+		a.records[r].est_lo = -1; a.records[r].est_hi = 0x7fffffff; a.records[r].rescue = 0;
+		a.records[r + 1].est_lo = -1; a.records[r + 1].est_hi = 0x7fffffff; a.records[r + 1].rescue = 0;
+	}
+	wave_sync_mem();
+	if ((int64_t)n1 * n2 > kAlnPairProduct) { if (lane == 0) flag_host(a, r, WHY_PAIR_PRODUCT); return; }
+	// CheckPairedAlignmentCandidates, src/Mapping.cpp:348-400
+	if (n1 * n2 > 1000) { remove_redundant_wave(a, l1); remove_redundant_wave(a, l2); }
+	bool pairing = false;
+	long long lo = -1, hi = 0x7fffffffffffffffll;            // (lane-local until the loop is through)
+	const long long est = a.est_distance;
+	for (int i = 0; i < n1; ++i) {
+		const int si = a.c_score[a0 + i];
+		if (si == 0) continue;
+		const int64_t pd1 = a.cands[a0 + i].posDiff;
+		int m = 0, cnt = 0, arg = -1;                        // of this lane's candidates of mate 2: the best admissible score, how many reach it, the first that does
+		for (int j = lane; j < n2; j += 64) {
+			const int sj = a.c_score[a1 + j];
+			const int64_t pd2 = a.cands[a1 + j].posDiff;
+			if (sj == 0 || pd2 < pd1) continue;
+			const long long dist = pd2 - pd1;
+			if (dist < est) {
+				if (dist > lo) lo = dist;
+				if (sj > m) { m = sj; cnt = 1; arg = j; }
+				else if (sj == m) cnt++;
+			} else if (dist < hi) hi = dist;
+		}
+		const int s = wave_max(m);
+		if (s <= 0) continue;
+		const int mine = m == s ? cnt : 0;
+		if (wave_sum(mine) != 1) continue;                   // two candidates of the best score: no mate for this one (:374-375)
+		const int best = __shfl(arg, __ffsll((unsigned long long)__ballot(mine == 1)) - 1);
+		const int mj = a.c_mate[a1 + best];
+		if (mj == -1) {
+			pairing = true;
+			if (lane == 0) { a.c_mate[a0 + i] = best; a.c_mate[a1 + best] = i; }
+		} else if (si > a.c_score[a0 + mj]) {
+			if (lane == 0) { a.c_mate[a0 + mj] = -1; a.c_mate[a0 + i] = best; a.c_mate[a1 + best] = i; }
+		}
+		wave_sync_mem();
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		const long long l2_ = __shfl_xor(lo, off), h2_ = __shfl_xor(hi, off);
+		lo = l2_ > lo ? l2_ : lo;
+		hi = h2_ < hi ? h2_ : hi;
+	}
+	out_ck = ck; out_lo = lo; out_hi = hi;
+	if (lane == 0) {
+		int32_t plo = (int32_t)lo, phi = hi > 0x7fffffffll ? 0x7fffffff : (int32_t)hi;
+		a.records[r].est_lo = plo; a.records[r].est_hi = phi;
+		a.records[r + 1].est_lo = plo; a.records[r + 1].est_hi = phi;
+	}
+	if (pairing) {
+		// RemoveUnMatedAlignmentCandidates, src/Mapping.cpp:402-427 (the mates are a matching: no two candidates of mate 1 share one of mate 2)
+		for (int i = lane; i < n1; i += 64) {
+			const int j = a.c_mate[a0 + i];
+			if (j == -1) a.c_score[a0 + i] = 0;
+			else { const int sum = a.c_score[a0 + i] + a.c_score[a1 + j]; a.c_score[a0 + i] = sum; a.c_score[a1 + j] = sum; }
+		}
+		wave_sync_mem();
+		for (int j = lane; j < n2; j += 64)
+			if (a.c_mate[a1 + j] == -1) a.c_score[a1 + j] = 0;
+		wave_sync_mem();
+	} else {
+		// RescueUnpairedAlignment is due (src/Mapping.cpp:559-560; src/AlignmentRescue.cpp:73-170)
+		if (lane == 0) { a.chunk_stats[ck].rescue_wanted = 1; a.records[r].rescue = 1; a.records[r + 1].rescue = 1; }
+		int sc1 = 0, sc2 = 0;
+		for (int i = lane; i < n1; i += 64) sc1 = max(sc1, a.c_score[a0 + i]);
+		for (int j = lane; j < n2; j += 64) sc2 = max(sc2, a.c_score[a1 + j]);
+		sc1 = wave_max(sc1); sc2 = wave_max(sc2);
+		const int rl1 = (int)(a.read_off[r + 1] - a.read_off[r]), rl2 = (int)(a.read_off[r + 2] - a.read_off[r + 1]);
+		int strategy;
+		if (sc1 == 0 && sc2 == 0) strategy = 0;
+		else if (sc1 < (int)(rl1 * 0.1) && sc2 < (int)(rl2 * 0.1)) strategy = 4;
+		else if (sc1 > sc2 && sc1 - sc2 > 50) strategy = 1;
+		else if (sc2 > sc1 && sc2 - sc1 > 50) strategy = 2;
+		else strategy = 3;
+		const int est_r = a.est_distance > a.max_insert ? a.max_insert : a.est_distance;
+		bool host = false;
+		int why = 0;
+		if (strategy == 1 || strategy == 3) {
+			// mate 2 next to the candidates of mate 1 (:97-125): a window that would be scanned after all goes to the host (pair_front)
+			int thr = sc1 - 30;
+			if (thr < 50) thr = 50;
+			bool found = false;
+			for (int i = lane; i < n1; i += 64) {
+				if (a.c_score[a0 + i] < thr) continue;
+				int64_t left = a.cands[a0 + i].posDiff, right = left + est_r + rl2;
+				const int it = end_lower_bound(a, left);
+				if (it == a.n_ends) continue;
+				const int chr = a.end_chr[it];
+				if (right < a.genome_size && right > a.chr_fwd_start[chr]) right = a.chr_fwd_start[chr] - 1;
+				else if (right >= a.genome_size && right > a.chr_rev_start[chr]) right = a.chr_rev_start[chr] - 1;
+				const int slen = (int)(right - left);
+				if (slen < rl2) continue;
+				if (left < 0 || right > a.two_genome_size) continue;
+				found = true;
+			}
+			if (__ballot(found)) { host = true; why = WHY_RESCUE_DIR1; }
+		}
+		int nt = 0;
+		if (!host && (strategy == 2 || strategy == 3)) {
+			st.a1 = a1; st.ck = ck; st.n1 = n1; st.n2 = n2; st.sc1 = sc1; st.rl1 = rl1; st.rl2 = rl2; st.est_r = est_r;
+			st.thr = sc2 - 30;
+			if (st.thr < 50) st.thr = 50;
+			nt = rescue_windows_wave(a, r, st, false, 0, host, why);
+			if (!host && nt > 200) { host = true; why = WHY_CAPACITY; }
+		}
+		if (host) { if (lane == 0) { a.resc_n[r] = 0; flag_host(a, r, why); } return; }
+		if (nt > 0) { st.nt = nt; return; }
+	}
+	remove_redundant_wave(a, l1);
+	remove_redundant_wave(a, l2);
+}
+
+__device__ void pair_back_wave(const AlnArgs &a, const int64_t r, const PairState &st, unsigned long long base)
+{
+	const int lane = threadIdx.x & 63;
+	bool host = false;
+	int why = 0;
+	if (base + (unsigned long long)st.nt > (unsigned long long)a.task_capacity) { host = true; why = WHY_CAPACITY; }
+	else {
+		(void)rescue_windows_wave(a, r, st, true, base, host, why);
+		if (lane == 0) { a.resc_off[r] = (int32_t)base; a.resc_n[r] = (uint8_t)st.nt; }
+		if (st.rl1 > kRescueMaxRead || st.rl1 < 8) { host = true; why = WHY_RESCUE_READ; }
+		const uint8_t *rd = a.enc + a.read_off[r];
+		bool bad = false;
+		for (int i = lane; i < st.rl1 && !host; i += 64) {
+			const unsigned u = rd[i] & 0xDFu;
+			bad = bad || !(u == 'A' || u == 'C' || u == 'G' || u == 'T');
+		}
+		if (__ballot(bad)) { host = true; why = WHY_RESCUE_READ; }
+	}
+	if (lane != 0) return;
+	if (host) { a.resc_n[r] = 0; flag_host(a, r, why); return; }
+	a.r_pending[r] = 1;
+}
+
 // One PAIR per lane (one read per lane where a chunk is not paired).  Rounds 2-3 ran one READ per lane and let the second mate's lane
 // leave at once -- half of every wave idle -- and sent two same-address atomics per pair at the chunk's interval (2000 pairs per
-// chunk: a wave's 64 lanes hit one address); now a wave whose pairs lie in one chunk sends one pair of atomics.
+// chunk: a wave's 64 lanes hit one address); now a wave whose pairs lie in one chunk sends one pair of atomics, the rescue
+// windows of the wave's pairs take their task slots with one atomic, and the pairs with many candidates are the whole wave's.
 __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 {
 	// (a.slow_pairs: the pairs aln_trivial_kernel did not decide, ctl[35] of them; else every pair / read of the batch)
 	const int64_t n_units = a.slow_pairs ? (int64_t)a.ctl[35] : a.all_paired ? a.n_reads >> 1 : a.n_reads;
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	const int lane = threadIdx.x & 63;
+	const bool heavy_on = a.all_paired && !a.dbg_no_heavy;
 	for (int64_t u0 = (int64_t)blockIdx.x * blockDim.x; u0 < n_units; u0 += stride) {
 		const int64_t u = u0 + threadIdx.x;
 		int ck = -1;
 		long long lo = -1, hi = 0x7fffffffffffffffll;
-		if (u < n_units) pair_one(a, a.slow_pairs ? (int64_t)a.slow_pairs[u] << 1 : a.all_paired ? u << 1 : u, ck, lo, hi);
+		PairState st;
+		st.nt = 0;
+		const int64_t r = u < n_units ? (a.slow_pairs ? (int64_t)a.slow_pairs[u] << 1 : a.all_paired ? u << 1 : u) : 0;
+		bool heavy = false;
+		if (u < n_units && heavy_on) {
+			const int64_t c0 = a.cand_off[r], c1 = a.cand_off[r + 1], c2 = a.cand_off[r + 2];
+			heavy = (c1 - c0) * (c2 - c1) > kPairHeavy;
+		}
+		if (u < n_units && !heavy) pair_front(a, r, ck, lo, hi, st);
+		uint64_t hm = __ballot(heavy);
+		while (hm) {
+			const int src = __ffsll((unsigned long long)hm) - 1;
+			hm &= hm - 1;
+			const int64_t rh = ((int64_t)__shfl((int)(uint32_t)((uint64_t)r >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)(uint64_t)r, src);
+			int ck_h = -1;
+			long long lo_h = -1, hi_h = 0x7fffffffffffffffll;
+			PairState st_h;
+			pair_front_wave(a, rh, ck_h, lo_h, hi_h, st_h);
+			if (lane == src) { ck = ck_h; lo = lo_h; hi = hi_h; st = st_h; }
+		}
+		const unsigned long long base = wave_reserve(&a.ctl[4], (unsigned long long)st.nt);
+		if (st.nt > 0 && !heavy) pair_back(a, r, st, base);
+		hm = __ballot(heavy && st.nt > 0);
+		while (hm) {
+			const int src = __ffsll((unsigned long long)hm) - 1;
+			hm &= hm - 1;
+			const int64_t rh = ((int64_t)__shfl((int)(uint32_t)((uint64_t)r >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)(uint64_t)r, src);
+			PairState st_h;
+			st_h.a1 = ((int64_t)__shfl((int)(uint32_t)((uint64_t)st.a1 >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)(uint64_t)st.a1, src);
+			st_h.ck = __shfl(st.ck, src); st_h.n1 = __shfl(st.n1, src); st_h.n2 = __shfl(st.n2, src); st_h.sc1 = __shfl(st.sc1, src);
+			st_h.rl1 = __shfl(st.rl1, src); st_h.rl2 = __shfl(st.rl2, src); st_h.est_r = __shfl(st.est_r, src); st_h.thr = __shfl(st.thr, src); st_h.nt = __shfl(st.nt, src);
+			const unsigned long long bh = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)base, src);
+			pair_back_wave(a, rh, st_h, bh);
+		}
 		// ---- the chunk's interval: lo = max over the pairs, hi = min ----
 		const uint64_t have = __ballot(ck >= 0);
 		if (have == 0) continue;
@@ -1196,12 +1512,13 @@ __device__ int partition_runs_packed(const AlnArgs &a, const uint8_t *f1, int64_
 // GenerateSimplePairsFromFragmentPair -- the common 8-mers of the two fragments whose positions differ by less than MaxShift,
 // merged into exact matches of at least 8 bases (src/KmerAnalysis.cpp:104-179) -- then IdentifyNormalPairs(rLen, gLen, ...) on
 // them, and per resulting piece either a literal stretch or a sub-fragment alignment.
-// Returns 1: the pair is planned (plan_index); 0: the partition is empty (the caller aligns the whole fragment);
-// -1: outside the envelope (host); -2: a device list is full (host).
-__device__ int plan_partition(const AlnArgs &a, int64_t enc_off, const uint8_t *f1, int64_t g, int rL, int gL, int32_t &plan_index)
+// In two halves around the reservation of its list entries (one wave_reserve per list for the whole wave, aln_partition_kernel):
+// partition_compute returns 1: the pair has a plan of n_pieces pieces, n_jobs of them sub-fragment alignments, ops_need op bytes in all;
+// 0: the partition is empty (the caller aligns the whole fragment); -1: outside the envelope (host).
+__device__ int partition_compute(const AlnArgs &a, const uint8_t *f1, int64_t g, int rL, int gL, Pairs &v, int &n_pieces, int &n_jobs, int &ops_need)
 {
-	Pairs v;
 	v.num = 0;
+	n_pieces = n_jobs = ops_need = 0;
 	const int mg = a.max_gaps;
 	if (mg >= 1 && mg <= 32 && g >= (int64_t)(mg - 1) && rL <= 256) {
 		int rc = partition_runs_packed(a, f1, g, rL, gL, mg, v);
@@ -1249,26 +1566,27 @@ __device__ int plan_partition(const AlnArgs &a, int64_t enc_off, const uint8_t *
 	}
 	if (!identify_normal_pairs(rL, gL, v)) return -1;
 	if (v.num == 0) return 0;
-	// the pieces
-	int n_jobs = 0, n_pieces = 0;
+	// the pieces; op strings: the assembled one (at most rL + gL columns) and one per sub-fragment
+	ops_need = rL + gL;
 	for (int i = 0; i < v.num; ++i) {
 		if (v.rLen[i] <= 0 && v.gLen[i] <= 0) continue;
 		n_pieces++;
 		bool lit = v.gLen[i] == 0 || v.rLen[i] == 0 || (v.rLen[i] == 1 && v.gLen[i] == 1) || v.simple[i];
-		if (!lit) n_jobs++;
+		if (!lit) { n_jobs++; ops_need += v.rLen[i] + v.gLen[i]; }
 	}
-	unsigned long long plan_at = atomicAdd(&a.ctl[5], 1ull);
-	unsigned long long piece_at = atomicAdd(&a.ctl[6], (unsigned long long)n_pieces);
-	unsigned long long job_at = n_jobs ? atomicAdd(&a.ctl[1], (unsigned long long)n_jobs) : 0;
-	// op strings: the assembled one (at most rL + gL columns) and one per sub-fragment
-	int ops_need = rL + gL;
-	for (int i = 0; i < v.num; ++i) {
-		bool lit = v.gLen[i] == 0 || v.rLen[i] == 0 || (v.rLen[i] == 1 && v.gLen[i] == 1) || v.simple[i];
-		if ((v.rLen[i] > 0 || v.gLen[i] > 0) && !lit) ops_need += v.rLen[i] + v.gLen[i];
-	}
-	unsigned long long ops_at = atomicAdd(&a.ctl[2], (unsigned long long)ops_need);
+	return 1;
+}
+
+// the plan of partition_compute into the entries reserved for it; false: a list is full (host) -- what was reserved INSIDE the job list is
+// left as empty jobs then (the NW kernels walk every job below the counter: none may be an earlier batch's)
+__device__ bool partition_write(const AlnArgs &a, int64_t enc_off, int64_t g, int rL, int gL, const Pairs &v, int n_pieces, int n_jobs, int ops_need,
+                                unsigned long long plan_at, unsigned long long piece_at, unsigned long long job_at, unsigned long long ops_at, int32_t &plan_index)
+{
 	if (plan_at >= (unsigned long long)a.job_capacity || piece_at + n_pieces > 4ull * (unsigned long long)a.job_capacity ||
-	    job_at + n_jobs > (unsigned long long)a.job_capacity || ops_at + ops_need > (unsigned long long)a.ops_capacity) return -2;
+	    job_at + n_jobs > (unsigned long long)a.job_capacity || ops_at + ops_need > (unsigned long long)a.ops_capacity) {
+		for (unsigned long long k = job_at; k < job_at + (unsigned long long)n_jobs && k < (unsigned long long)a.job_capacity; ++k) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[k] = jd; }
+		return false;
+	}
 	AlnPlan pl;
 	pl.ops = (int64_t)ops_at; pl.first = (int32_t)piece_at; pl.count = n_pieces;
 	a.plans[plan_at] = pl;
@@ -1292,7 +1610,7 @@ __device__ int plan_partition(const AlnArgs &a, int64_t enc_off, const uint8_t *
 		a.pieces[piece_at + pk++] = pc;
 	}
 	plan_index = (int32_t)plan_at;
-	return 1;
+	return true;
 }
 
 // ---- pass 1a: the candidates whose report needs no alignment and no private arrays -------------------------------------------------
@@ -1708,19 +2026,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ---- pass 1: one candidate per lane -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void aln_plan_kernel(AlnArgs a)
 {
-	int64_t cand = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	int64_t n_all = plan_slots(a);                                               // chained candidates (all, or those of the pairs aln_trivial_kernel left), then the slots of the rescue windows
 	if (a.plan_slow) n_all = (int64_t)a.ctl[32];                                 // ... or what aln_plan_fast_kernel left
-	for (int64_t slot = cand; slot < n_all; slot += stride) {
+	// (the wave's lanes stay together through the loop: what the parked candidates need of the lists is reserved for all of them by one atomic per list)
+	for (int64_t slot0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); slot0 < n_all; slot0 += stride) {
+		const int64_t slot = slot0 + (threadIdx.x & 63);
+		// what phase 1 leaves for phase 2 (a parked candidate)
+		Pairs v;
+		Work w;
+		int64_t cand = 0, r = 0, rbase = 0;
+		int num = 0, n_new_jobs = 0, new_ops = 0, n_pending = 0;
+		bool pending = false;
+		// ---- phase 1: up to the point where the candidate is finished, handed to the host, or has to be parked ----
+		bool park = false;
+		do {
+		if (slot >= n_all) break;
 		// (binned: lanes of a wave then hold candidates with the same number of seeds -- the loops below run equally long)
 		cand = a.plan_slow ? (int64_t)a.plan_slow[slot] : a.plan_order ? (int64_t)a.plan_order[slot] : slot_cand(a, slot);
 		a.rep_score[cand] = 0; a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
-		const int64_t r = a.c_read[cand];
-		if (a.r_host[r]) continue;
-		if (a.c_score[cand] == 0) continue;                                  // GenMappingReport skips it, :643
+		r = a.c_read[cand];
+		if (a.r_host[r]) break;
+		if (a.c_score[cand] == 0) break;                                  // GenMappingReport skips it, :643
 		const bool rescued = cand >= a.n_cands;
 		kg_candidate cd;
 		const kg_seed *seeds;
@@ -1730,26 +2059,23 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			cd.count = a.resc_count[t]; cd.first = 0; cd.posDiff = a.resc_posdiff[t]; cd.score = 0;
 			seeds = a.resc_seeds + t * kAlnMaxSeeds;
 		}
-		if (cd.count > kAlnMaxSeeds) { flag_host(a, r, WHY_SEEDS); continue; }
-		const int64_t rbase = a.read_off[r];
+		if (cd.count > kAlnMaxSeeds) { flag_host(a, r, WHY_SEEDS); break; }
+		rbase = a.read_off[r];
 		const int rlen = (int)(a.read_off[r + 1] - rbase);
 		const uint8_t *rd = a.enc + rbase;
 		const int ck = chunk_of(a, r);
 		const bool first = a.chunk_paired[ck] ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
-		Pairs v;
 		v.num = cd.count;
 		for (int i = 0; i < cd.count; ++i) {
 			kg_seed s = seeds[i];
 			v.gPos[i] = s.gPos; v.rPos[i] = s.rPos; v.rLen[i] = v.gLen[i] = s.len; v.simple[i] = 1;
 		}
-		if (rlen > 4000) { flag_host(a, r, WHY_READ_LEN); continue; }
-		if (!identify_normal_pairs(rlen, -1, v)) { flag_host(a, r, WHY_GAPS); continue; }
-		if (!coordinates_valid(a, v)) { a.c_score[cand] = -1; continue; }      // no report, and no best/second-best step (:647)
-		Work w;
-		const int num = v.num;
-		bool host = false, jobs = false, pending = false;
+		if (rlen > 4000) { flag_host(a, r, WHY_READ_LEN); break; }
+		if (!identify_normal_pairs(rlen, -1, v)) { flag_host(a, r, WHY_GAPS); break; }
+		if (!coordinates_valid(a, v)) { a.c_score[cand] = -1; break; }      // no report, and no best/second-best step (:647)
+		num = v.num;
+		bool host = false, jobs = false;
 		int why = WHY_PARTITION;
-		int n_new_jobs = 0, new_ops = 0, n_pending = 0;
 		for (int j = 0; j < num && !host; ++j) {
 			w.kind[j] = W_NONE; w.op[j] = 0; w.op_len[j] = 0; w.val[j] = 0;
 			const int rL = v.rLen[j], gL = v.gLen[j];
@@ -1800,26 +2126,35 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 			n_new_jobs++; new_ops += rL + gL;
 			jobs = true;
 		}
-		if (host) { flag_host(a, r, why); continue; }
+		if (host) { flag_host(a, r, why); break; }
 		if (!jobs) {
 			if (!finish_candidate(a, cand, first, rd, v, w)) flag_host(a, r, WHY_CIGAR);
-			continue;
+			break;
 		}
-		// park the candidate until its alignments exist.  What it needs of the lists -- a spill slot, its NW jobs and their op bytes --
-		// is reserved in ONE round of atomics (a returning atomic is a trip to the memory side; they used to follow each other pair by pair, each waited for)
-		unsigned long long sp = atomicAdd(&a.ctl[0], 1ull);
-		unsigned long long job_at = n_new_jobs ? atomicAdd(&a.ctl[1], (unsigned long long)n_new_jobs) : 0ull;
-		unsigned long long ops_at = n_new_jobs ? atomicAdd(&a.ctl[2], (unsigned long long)new_ops) : 0ull;
+		park = true;
+		} while (false);
+		// park the candidate until its alignments exist.  What the wave's candidates need of the lists -- a spill slot each, their NW jobs and op
+		// bytes, their partition tasks -- is reserved with ONE atomic per list for the whole wave (wave_reserve)
+		const unsigned long long sp = wave_reserve(&a.ctl[0], park ? 1ull : 0ull);
+		unsigned long long job_at = wave_reserve(&a.ctl[1], park ? (unsigned long long)n_new_jobs : 0ull);
+		unsigned long long ops_at = wave_reserve(&a.ctl[2], park ? (unsigned long long)new_ops : 0ull);
+		unsigned long long task_at = wave_reserve(&a.ctl[3], park ? (unsigned long long)n_pending : 0ull);
+		if (!park) continue;
 		const bool sp_ok = sp < (unsigned long long)a.spill_capacity;
 		const bool jobs_ok = job_at + (unsigned long long)n_new_jobs <= (unsigned long long)a.job_capacity && ops_at + (unsigned long long)new_ops <= (unsigned long long)a.ops_capacity;
 		if (!sp_ok || !jobs_ok) {
 			// A list is full: the read is the host's.  Everything this lane took INSIDE the lists is still written, whichever list overflowed --
-			// aln_finish_kernel walks every spill slot below ctl[0] and the NW kernels every job below ctl[1], and neither may find an
-			// earlier batch's entry there: the spill slot names this candidate with no pairs (its read is flagged, aln_finish skips it),
-			// the job slots become empty jobs
+			// aln_finish_kernel walks every spill slot below ctl[0], the NW kernels every job below ctl[1], aln_partition_kernel every task below
+			// ctl[3], and none may find an earlier batch's entry there: the spill slot names this candidate with no pairs (its read is flagged,
+			// aln_finish skips it), the job slots become empty jobs, the tasks name the flagged read
 			if (sp_ok) { a.spill[sp].cand = (int32_t)cand; a.spill[sp].num = 0; }
 			for (unsigned long long k = job_at; k < job_at + (unsigned long long)n_new_jobs && k < (unsigned long long)a.job_capacity; ++k) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[k] = jd; }
 			flag_host(a, r, WHY_CAPACITY);
+			for (unsigned long long k = task_at; k < task_at + (unsigned long long)n_pending && k < (unsigned long long)a.job_capacity; ++k) {
+				PartTask pt;
+				pt.enc_off = rbase; pt.g = 0; pt.spill = 0; pt.j = 0; pt.read = (int32_t)r; pt.rL = 0; pt.gL = 0;
+				a.part_tasks[k] = pt;
+			}
 			continue;
 		}
 		for (int j = 0; j < num; ++j) {
@@ -1842,7 +2177,6 @@ __global__ __launch_bounds__(256) void aln_plan_kernel(AlnArgs a)
 		}
 		if (pending) {
 			// (about one parked candidate in thirteen: a second round for those)
-			unsigned long long task_at = atomicAdd(&a.ctl[3], (unsigned long long)n_pending);
 			if (task_at + (unsigned long long)n_pending > (unsigned long long)a.job_capacity) flag_host(a, r, WHY_CAPACITY);
 			for (int j = 0; j < num; ++j) {
 				if (w.kind[j] != W_PENDING) continue;
@@ -1862,26 +2196,43 @@ __global__ __launch_bounds__(256) void aln_partition_kernel(AlnArgs a)
 {
 	unsigned long long n = a.ctl[3];
 	if (n > (unsigned long long)a.job_capacity) n = (unsigned long long)a.job_capacity;
-	for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * blockDim.x) {
-		const PartTask pt = a.part_tasks[t];
-		if (a.r_host[pt.read]) continue;
-		AlnSpillPair &q = a.spill[pt.spill].p[pt.j];
-		int32_t plan_index = 0;
-		int pr = plan_partition(a, pt.enc_off, a.enc + pt.enc_off, pt.g, pt.rL, pt.gL, plan_index);
-		if (pr < 0) { flag_host(a, pt.read, pr == -2 ? WHY_CAPACITY : WHY_PARTITION); continue; }
-		if (pr == 1) { q.kind = W_PLAN; q.val = plan_index; continue; }
-		// no common 8-mer survived: the whole fragment is one alignment (src/tools.cpp:214-221)
-		unsigned long long slot = atomicAdd(&a.ctl[1], 1ull);
-		unsigned long long ops_at = atomicAdd(&a.ctl[2], (unsigned long long)(pt.rL + pt.gL));
-		if (slot >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(pt.rL + pt.gL) > (unsigned long long)a.ops_capacity) {
-			if (slot < (unsigned long long)a.job_capacity) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[slot] = jd; }      // (inside the list: an empty job, not an earlier batch's)
-			flag_host(a, pt.read, WHY_CAPACITY);
-			continue;
+	const int lane = threadIdx.x & 63;
+	// (the wave's lanes stay together: the list entries of all of them are reserved by one atomic per list)
+	for (unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); t0 < n; t0 += (unsigned long long)gridDim.x * blockDim.x) {
+		const unsigned long long t = t0 + lane;
+		PartTask pt;
+		pt.enc_off = 0; pt.g = 0; pt.spill = 0; pt.j = 0; pt.read = 0; pt.rL = 0; pt.gL = 0;
+		bool go = false;
+		if (t < n) { pt = a.part_tasks[t]; go = !a.r_host[pt.read]; }
+		Pairs v;
+		int n_pieces = 0, n_jobs = 0, ops_need = 0, pr = -3;          // (-3: no task)
+		if (go) {
+			pr = partition_compute(a, a.enc + pt.enc_off, pt.g, pt.rL, pt.gL, v, n_pieces, n_jobs, ops_need);
+			if (pr < 0) flag_host(a, pt.read, WHY_PARTITION);
 		}
-		NwJobDesc jd;
-		jd.o1 = pt.enc_off; jd.o2 = pt.g; jd.ops = (int64_t)ops_at; jd.m = pt.rL; jd.n = pt.gL;
-		a.jobs[slot] = jd;
-		q.kind = W_JOB; q.val = (int32_t)slot;
+		// planned: a plan, its pieces, its jobs, its op bytes; no common 8-mer survived: the whole fragment is one alignment (src/tools.cpp:214-221)
+		const bool planned = pr == 1, whole = pr == 0;
+		const unsigned long long plan_at = wave_reserve(&a.ctl[5], planned ? 1ull : 0ull);
+		const unsigned long long piece_at = wave_reserve(&a.ctl[6], planned ? (unsigned long long)n_pieces : 0ull);
+		const unsigned long long job_at = wave_reserve(&a.ctl[1], planned ? (unsigned long long)n_jobs : whole ? 1ull : 0ull);
+		const unsigned long long ops_at = wave_reserve(&a.ctl[2], planned ? (unsigned long long)ops_need : whole ? (unsigned long long)(pt.rL + pt.gL) : 0ull);
+		if (planned) {
+			AlnSpillPair &q = a.spill[pt.spill].p[pt.j];
+			int32_t plan_index = 0;
+			if (partition_write(a, pt.enc_off, pt.g, pt.rL, pt.gL, v, n_pieces, n_jobs, ops_need, plan_at, piece_at, job_at, ops_at, plan_index)) { q.kind = W_PLAN; q.val = plan_index; }
+			else flag_host(a, pt.read, WHY_CAPACITY);
+		} else if (whole) {
+			AlnSpillPair &q = a.spill[pt.spill].p[pt.j];
+			if (job_at >= (unsigned long long)a.job_capacity || ops_at + (unsigned long long)(pt.rL + pt.gL) > (unsigned long long)a.ops_capacity) {
+				if (job_at < (unsigned long long)a.job_capacity) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[job_at] = jd; }      // (inside the list: an empty job, not an earlier batch's)
+				flag_host(a, pt.read, WHY_CAPACITY);
+			} else {
+				NwJobDesc jd;
+				jd.o1 = pt.enc_off; jd.o2 = pt.g; jd.ops = (int64_t)ops_at; jd.m = pt.rL; jd.n = pt.gL;
+				a.jobs[job_at] = jd;
+				q.kind = W_JOB; q.val = (int32_t)job_at;
+			}
+		}
 	}
 }
 
@@ -2030,20 +2381,26 @@ __device__ int multi_flag(const AlnArgs &a, const ReadSum &me, const ReadSum &ot
 
 __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 {
-	int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	const int64_t n_units = a.slow_pairs ? (int64_t)a.ctl[35] : a.n_reads;          // (the pairs aln_trivial_kernel left, or every read)
-	for (; x < n_units; x += stride) {
+	// (the wave's lanes stay together: what they add to their chunk's statistics is summed across the wave -- 64 lanes, mostly one chunk, one address)
+	for (int64_t x0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); x0 < n_units; x0 += stride) {
+		const int64_t x = x0 + (threadIdx.x & 63);
+		int ck = -1;
+		long long add_paired = 0, add_dist = 0;
+		int add_unmapped = 0, add_unique = 0, add_host = 0;
+		do {
+		if (x >= n_units) break;
 		const int64_t r = a.slow_pairs ? (int64_t)a.slow_pairs[x] << 1 : x;
-		const int ck = chunk_of(a, r);
-		const bool paired = a.chunk_paired[ck] != 0;
-		if (paired && ((r - a.chunk_off[ck]) & 1)) continue;
-		kg_chunk_stats &cs = a.chunk_stats[ck];
+		const int ck_r = chunk_of(a, r);
+		const bool paired = a.chunk_paired[ck_r] != 0;
+		if (paired && ((r - a.chunk_off[ck_r]) & 1)) break;
+		ck = ck_r;
 		if (a.r_host[r]) {
 			a.records[r].kind = KG_ALN_HOST;
 			if (paired) a.records[r + 1].kind = KG_ALN_HOST;
-			atomicAdd(&cs.host_pairs, paired ? 2 : 1);
-			continue;
+			add_host = paired ? 2 : 1;
+			break;
 		}
 		ReadSum s1;
 		summarise(a, r, s1);
@@ -2051,13 +2408,13 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 			atomicAdd(&a.ctl[8 + WHY_SCORE], 1ull);
 			a.records[r].kind = KG_ALN_HOST;
 			if (paired) a.records[r + 1].kind = KG_ALN_HOST;
-			continue;
+			break;
 		}
 		if (!paired) {
 			// SetSingleAlignmentFlag + EvaluateMAPQ + OutputSingledAlignments, src/Mapping.cpp:49-71, 160-175, 272-315
 			s1.mapq = eval_mapq(a, s1);
 			if (s1.score == 0) {
-				atomicAdd(&cs.unmapped, 1);
+				add_unmapped = 1;
 				write_record(a, r, s1, KG_ALN_UNMAPPED, 0x4, false, 0, 0, false);
 			} else {
 				// the candidates from `best` on whose score is the read's: the first one, or with -m all of them (:291-304); every
@@ -2071,18 +2428,18 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 					write_record_at(a, at, s1, i, KG_ALN_MAPPED, fwd ? 0 : 0x10, false, 0, 0, !fwd);
 					if (!a.multi_hit) break;
 				}
-				if (full) { atomicAdd(&a.ctl[8 + WHY_CAPACITY], 1ull); a.records[r].kind = KG_ALN_HOST; continue; }
+				if (full) { atomicAdd(&a.ctl[8 + WHY_CAPACITY], 1ull); a.records[r].kind = KG_ALN_HOST; break; }
 				if (last < 0) write_record(a, r, s1, KG_ALN_NONE, 0, false, 0, 0, false);
-				if (s1.mapq == 60) atomicAdd(&cs.unique, 1);
+				if (s1.mapq == 60) add_unique = 1;
 			}
-			continue;
+			break;
 		}
 		ReadSum s2;
 		summarise(a, r + 1, s2);
 		if (s2.score > kAlnMaxScore || s2.sub_score > kAlnMaxScore) {
 			atomicAdd(&a.ctl[8 + WHY_SCORE], 1ull);
 			a.records[r].kind = KG_ALN_HOST; a.records[r + 1].kind = KG_ALN_HOST;
-			continue;
+			break;
 		}
 		// CheckPairedFinalAlignments, src/Mapping.cpp:429-480 (bMultiHit false)
 		{
@@ -2143,8 +2500,6 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 		// OutputPairedAlignments, src/Mapping.cpp:177-270: the best candidate, or with -m every candidate from the best one on that
 		// still has a positive score
 		const bool both_unique = s1.score > s1.sub_score && s2.score > s2.sub_score;
-		long long add_paired = 0, add_dist = 0;
-		int add_unmapped = 0, add_unique = 0;
 		bool full = false;
 		if (s1.score == 0) {
 			add_unmapped++;
@@ -2197,16 +2552,32 @@ __global__ __launch_bounds__(256) void aln_final_kernel(AlnArgs a)
 		if (full) {                                    // no extra record slot left: the pair goes to the host
 			atomicAdd(&a.ctl[8 + WHY_CAPACITY], 1ull);
 			a.records[r].kind = KG_ALN_HOST; a.records[r + 1].kind = KG_ALN_HOST;
-			continue;
+			add_unmapped = 0; add_unique = 0; add_paired = 0; add_dist = 0;      // (nothing of a pair handed back is counted here)
+			break;
 		}
-		if (add_unmapped) atomicAdd(&cs.unmapped, add_unmapped);
-		if (add_unique) atomicAdd(&cs.unique, add_unique);
-		if (add_paired) {
-			atomicAdd((unsigned long long *)&cs.paired, (unsigned long long)add_paired);
+		} while (false);
+		// ---- into the chunks' statistics: one set of atomics per wave where its lanes share a chunk ----
+		const uint64_t have = __ballot(ck >= 0);
+		if (have == 0) continue;
+		const int ck0 = __shfl(ck, __ffsll((unsigned long long)have) - 1);
+		if (__ballot(ck >= 0 && ck != ck0) == 0) {
+			for (int off = 32; off > 0; off >>= 1) {
+				add_paired += __shfl_xor(add_paired, off); add_dist += __shfl_xor(add_dist, off);
+				add_unmapped += __shfl_xor(add_unmapped, off); add_unique += __shfl_xor(add_unique, off); add_host += __shfl_xor(add_host, off);
+			}
+			if ((threadIdx.x & 63) != 0) ck = -1;
+		}
+		if (ck >= 0) {
+			kg_chunk_stats &cs = a.chunk_stats[ck];
+			if (add_host) atomicAdd(&cs.host_pairs, add_host);
+			if (add_unmapped) atomicAdd(&cs.unmapped, add_unmapped);
+			if (add_unique) atomicAdd(&cs.unique, add_unique);
+			if (add_paired) atomicAdd((unsigned long long *)&cs.paired, (unsigned long long)add_paired);
 			if (add_dist) atomicAdd((unsigned long long *)&cs.distance, (unsigned long long)add_dist);
 		}
 	}
 }
+
 
 // The order in which aln_plan_kernel takes the candidates: four bins by the number of seeds (none or one / two / three / more), each
 // block a contiguous range of candidates -- pass 0 counts the bins (ctl[24..27]), pass 1 places the indices (ctl[28..31] run along).

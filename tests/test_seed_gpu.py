@@ -89,7 +89,7 @@ def test_exact_long_reads_fall_back_to_one_walk_per_read(gpu_index_full, oracle_
     # the next batch on this workspace goes straight to one walk per read; noisy reads afterwards get their segments back
     so2, seeds2 = ws.seed_batch(enc, off, api.KG_MODE_SENSITIVE)
     assert ws.segment_fallbacks() == 1 and (so2 == so).all() and (seeds2 == seeds).all()
-    ws.close()
+    # (the workspace is the index fixture's own, cached for the tests behind this one: not closed here)
 
 
 def test_counters_match_oracle(golden, gpu_index, oracle_small):
