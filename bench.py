@@ -519,6 +519,9 @@ def run(args, fallback_note):
         sum(float(st.lane_seconds[0]) for st in stats) / K_ / lanes_here * 1e3,      # per lane: held back by the writer
         sum(float(st.lane_seconds[4]) for st in stats) / K_ / lanes_here * 1e3,      # per lane: inside the device call
         sum(float(st.lane_seconds[5]) for st in stats) / K_ / lanes_here * 1e3,      # per lane: the reads handed back
+        sum(float(st.lane_seconds[1]) for st in stats) / K_ / lanes_here * 1e3,      # per lane: reading + uploading its input block
+        sum(float(st.lane_seconds[2]) for st in stats) / K_ / lanes_here * 1e3,      # per lane: waiting for the batch before to be parsed
+        sum(float(st.lane_seconds[3]) for st in stats) / K_ / lanes_here * 1e3,      # per lane: the parse call
         sum(float(st.map_seconds) for st in stats) / K_ * 1e3,
         cpu_steps / K_, float(lanes_here), sum(float(st.total_reads) for st in stats) / K_], device=cdev)
     # ---- secondary: the same steps with the text left in the lanes' page-locked buffers (output to /dev/null, KART_AMD_OUTPUT_NULL) and
@@ -528,6 +531,7 @@ def run(args, fallback_note):
         os.environ["KART_AMD_OUTPUT_NULL"] = "1"; os.environ["KG_STREAM_CHECKSUM"] = "1"
         try:
             p_wall, p_stats = [], []
+            ru_p0 = resource.getrusage(resource.RUSAGE_SELF)
             for s_ in range(min(args.steps, 3)):
                 between_steps()
                 torch.cuda.synchronize(dev)
@@ -543,7 +547,13 @@ def run(args, fallback_note):
         p_tot = shard.allreduce_counters([sum(int(st.total_reads - st.unmapped) for st in p_stats), int(p_stats[-1].text_checksum[0]), int(p_stats[-1].text_checksum[1]),
                                           int(warm_stats[-1].text_checksum[0]) if warm_stats else 0, int(warm_stats[-1].text_checksum[1]) if warm_stats else 0,
                                           int(p_stats[-1].text_out_bytes), int(warm_stats[-1].text_out_bytes) if warm_stats else 0], device=cdev)
+        ru_p1 = resource.getrusage(resource.RUSAGE_SELF)
+        lp = max(1, int(p_stats[-1].lanes))
         pipe = {"value": p_tot[0] / float(sum(p_max)), "unit": "reads/s", "steps": len(p_max), "ms_per_step": [round(x * 1e3, 1) for x in p_max],
+                "rank0_cpu_seconds_per_step": round(((ru_p1.ru_utime - ru_p0.ru_utime) + (ru_p1.ru_stime - ru_p0.ru_stime)) / len(p_max), 2),
+                "rank0_lane_ms_per_step": {nm: round(sum(float(st.lane_seconds[i]) for st in p_stats) / len(p_stats) / lp * 1e3, 1)
+                                           for i, nm in enumerate(("held_back_by_writer", "read_and_upload", "waiting_for_the_parse_before", "parse_call", "device_call", "host_reads"))},
+                "rank0_device_ms_per_step": {nm: round(sum(float(st.stage_ms[i]) for st in p_stats) / len(p_stats), 1) for i, nm in enumerate(("parse", "seed", "chain", "align", "format", "copy_out"))},
                 "what": "NOT the metric: the same mapping runs with the SAM text left in the lanes' page-locked buffers (written to /dev/null) and summed on the device "
                         "(sam_checksum_kernel) -- the rate of the GPU pipeline and the copy engines with the host's copy into fresh page-cache pages out of the way; "
                         "beside `value` it tells device scaling from page-cache scaling in an N > 1 line",
@@ -628,7 +638,8 @@ def run(args, fallback_note):
                                 "host shape (unmeasured beyond the GPUs this run had)"}
     # ---- the ranks one by one, and the secondary rate without the host's output copy: what makes an N > 1 line readable ----------------
     names = ("device_kernels_ms_per_step_summed_over_lanes", "copy_engine_ms_per_step", "lane_held_back_by_writer_ms_per_step", "lane_in_device_call_ms_per_step",
-             "lane_host_reads_ms_per_step", "map_ms_per_step", "cpu_seconds_per_step", "lanes", "reads_per_step")
+             "lane_host_reads_ms_per_step", "lane_read_and_upload_ms_per_step", "lane_waiting_for_the_parse_before_ms_per_step", "lane_parse_call_ms_per_step",
+             "map_ms_per_step", "cpu_seconds_per_step", "lanes", "reads_per_step")
     line["per_rank"] = {"what": "rank order; per timed step.  device_kernels: HIP-event time of the stages parse .. format, summed over the rank's lanes (lanes overlap on the device, so "
                                 "it can exceed the step); copy_engine: the copies back to the host; lane_*: averages over the rank's lane threads -- held back by the writer = waiting "
                                 "until the host has copied the lane's previous text into the output file's pages (page-cache side), in the device call = kernels + copies of "

@@ -360,7 +360,7 @@ __device__ __forceinline__ void pair_back(const AlnArgs &a, const int64_t r, con
 // the best score among the admissible candidates of mate 2 and whether a single one reaches it, by wave reductions; the order in which the
 // reference walks mate 2's list does not matter for that --, the mate book-keeping stays sequential in the candidates of mate 1 as in
 // the reference (a later candidate may take an earlier one's mate, :381-388).  Same arrays, same results as pair_front / pair_back.
-constexpr int kPairHeavy = 128;
+constexpr int kPairHeavy = 32;
 
 __device__ __forceinline__ void wave_sync_mem()          // the wave's stores to the per-candidate arrays are visible to all its lanes
 {
