@@ -190,7 +190,7 @@ def rank_bytes(lanes, large):
     """host memory of one rank process besides the files: the host copy of the reference (2 B per base: forward + reverse strand), the
     stream lanes' page-locked buffers (~1.8 GB each at 1 M-read batches: two text windows, the SAM text, records, candidates), and
     python + torch + the HIP runtime"""
-    return (2 * HG38_LEN if large else 2 * GENOME_LEN) + lanes * (1800 << 20) + (4 << 30)
+    return (2 * HG38_LEN if large else 2 * GENOME_LEN) + lanes * int((1800 << 20) * max(1.0, stream_reads_setting() / 1120000.0)) + (4 << 30)
 
 
 def pick_pairs(mem, large, world=1, lanes=8):

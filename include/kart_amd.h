@@ -374,6 +374,9 @@ int   kg_stream_parse(kg_stream *s, int lane, const kg_stream_window *w, kg_stre
 
 typedef struct {
 	int32_t est_distance, max_insert, max_gaps, multi_hit, unset_flag;   /* as kg_align_batch */
+	int32_t fetch_all;           /* != 0: records / cand_off / cands / cand_seeds of the result hold the whole batch; 0: they hold what kg_stream_fetch
+	                                brought over, and (multi_hit) the chained extra records -- the text, its offsets, the chunk statistics and the list
+	                                of reads handed back always come whole (a run touches the records and candidates of ~2 % of its chunks) */
 } kg_stream_params;
 typedef struct {
 	int64_t n_reads, n_chunks;
@@ -393,6 +396,12 @@ typedef struct {
 /* seeding (FastMode), chaining, the per-read report (kg_align_batch) and the SAM text for the batch kg_stream_parse left in the
  * lane.  The result's arrays belong to the lane: valid until its next kg_stream_parse. */
 int   kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream_result *out);
+/* The records, candidate offsets, candidates and candidate seeds of reads [first, first + count) of the batch the lane's last kg_stream_map call mapped
+ * -- still resident on the device until the lane's next kg_stream_parse -- into the arrays that call's result points at, at their own places
+ * (records[first ..], cand_off[first .. first + count], cands[cand_off[first] ..], ...).  What a caller needs for the reads the device handed back
+ * (KG_ALN_HOST: their candidates) and for a chunk it maps again under another EstDistance (the pairs' validity intervals in the records).  Blocks
+ * until the data is there; may be called from any thread while no other call is using the lane. */
+int   kg_stream_fetch(kg_stream *s, int lane, int64_t first, int64_t count);
 /* Seeding groups (seed_group > 1) work in ROUNDS: in every round each lane of a group either calls kg_stream_map with a parsed batch --
  * the call returns when the round's one seeding launch is done -- or is absent.  rounds > 0: lane `lane` has no batch for that many
  * rounds; < 0: until further notice (its input has ended); 0: it takes part again (call it for every lane before a run; also clears an

@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "kg_index_contig", "kg_host_alloc", "kg_host_free", "kg_rank_sa_batch", "kg_workspace_create", "kg_workspace_destroy", "kg_workspace_counters", "kg_workspace_traffic",
     "kg_workspace_overflow", "kg_workspace_segment_fallbacks", "kg_workspace_set_profiling", "kg_workspace_set_single_steps", "kg_index_selfcheck", "kg_workspace_kernel_ms", "kg_seed_batch", "kg_candidates_batch", "kg_align_batch", "kg_align_reasons", "kg_seed_batch_device", "kg_nw_batch", "kg_nw_batch_device",
     "kg_fragments_batch", "kg_longread_batch", "kg_longread_reasons",
-    "kg_stream_open", "kg_stream_close", "kg_stream_staging", "kg_stream_upload", "kg_stream_parse", "kg_stream_map", "kg_stream_fetch_reads", "kg_stream_timing",
+    "kg_stream_open", "kg_stream_close", "kg_stream_staging", "kg_stream_upload", "kg_stream_parse", "kg_stream_map", "kg_stream_fetch", "kg_stream_fetch_reads", "kg_stream_timing",
     "kg_stream_group_absent", "kg_stream_group_abort",
 )
 
@@ -113,7 +113,7 @@ class StreamParsed(C.Structure):
 
 
 class StreamParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("est_distance", "max_insert", "max_gaps", "multi_hit", "unset_flag")]
+    _fields_ = [(n, C.c_int32) for n in ("est_distance", "max_insert", "max_gaps", "multi_hit", "unset_flag", "fetch_all")]
 
 
 class StreamResult(C.Structure):
@@ -205,6 +205,7 @@ def load_library() -> C.CDLL:
     L.kg_stream_upload.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64]
     L.kg_stream_parse.argtypes = [C.c_void_p, C.c_int, C.POINTER(StreamWindow), C.POINTER(StreamParsed)]
     L.kg_stream_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(StreamParams), C.POINTER(StreamResult)]
+    L.kg_stream_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64]
     L.kg_stream_fetch_reads.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.kg_stream_group_absent.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.kg_stream_group_abort.argtypes = [C.c_void_p]
@@ -501,7 +502,7 @@ class Stream:
 
     def map(self, est_distance: int = 1500, max_insert: int = 1500, max_gaps: int = 5, multi_hit: bool = False, unset_flag: int = 0, lane: int = 0):
         """seeding .. SAM text for the parsed batch: (text per read, indices of the reads handed back)"""
-        prm = StreamParams(est_distance, max_insert, max_gaps, 1 if multi_hit else 0, unset_flag)
+        prm = StreamParams(est_distance, max_insert, max_gaps, 1 if multi_hit else 0, unset_flag, 1)
         res = StreamResult()
         _check(self.lib.kg_stream_map(self.h, lane, C.byref(prm), C.byref(res)), "kg_stream_map")
         n = res.n_reads

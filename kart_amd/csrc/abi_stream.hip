@@ -52,6 +52,8 @@ struct Lane {
 	int64_t h_cand_capacity = 0;
 	unsigned long long *h_ctl = nullptr;               // [kCtlWords] the search kernel's counters of the batch
 	// the batch in the lane
+	int64_t mapped_reads = 0;                          // reads of the batch the last kg_stream_map call mapped (still resident: kg_stream_fetch)
+	const kg_aln_record *d_records = nullptr;          // ... and where its records lie
 	kg_stream_window win{};
 	kg_stream_parsed parsed{};
 	bool have_batch = false;
@@ -590,14 +592,19 @@ int kg_stream_map(kg_stream *s, int lane, const kg_stream_params *prm, kg_stream
 	if (turn_early) turn.release();
 	if (sam_bytes > 0) HIP_TRY(hipMemcpyAsync(l.h_sam, l.d_sam, (size_t)sam_bytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(l.h_sam_off, l.d_sam_off, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(l.h_records, a.records, sizeof(kg_aln_record) * (size_t)(n + extra), hipMemcpyDeviceToHost, st));
+	// the records, candidate offsets, candidates and their seeds stay on the device unless the caller wants them all: it asks for the chunks it needs
+	// (kg_stream_fetch) -- 207 of the 605 bytes per read that used to cross the link
+	const bool all = prm->fetch_all != 0;
+	l.mapped_reads = n; l.d_records = a.records;
+	if (all) HIP_TRY(hipMemcpyAsync(l.h_records, a.records, sizeof(kg_aln_record) * (size_t)(n + extra), hipMemcpyDeviceToHost, st));
+	else if (extra > 0) HIP_TRY(hipMemcpyAsync(l.h_records + n, a.records + n, sizeof(kg_aln_record) * (size_t)extra, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(l.h_chunk_stats, ws->d_chunk_stats, sizeof(kg_chunk_stats) * (size_t)n_chunks, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(l.h_cand_off, ws->d_cand_off, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
+	if (all) HIP_TRY(hipMemcpyAsync(l.h_cand_off, ws->d_cand_off, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, st));
 	// the candidates travel with every batch: the reads handed back need them, and so does a pair the caller maps again because its
 	// speculated EstDistance did not hold
 	if (n_host > 0) HIP_TRY(hipMemcpyAsync(l.h_host_list, l.d_host_list, 4 * (size_t)n_host, hipMemcpyDeviceToHost, st));
-	if (totals[0] > 0) HIP_TRY(hipMemcpyAsync(l.h_cands, ws->d_dense_cands, sizeof(kg_candidate) * (size_t)totals[0], hipMemcpyDeviceToHost, st));
-	if (totals[1] > 0) HIP_TRY(hipMemcpyAsync(l.h_cand_seeds, ws->d_dense_seeds, sizeof(kg_seed) * (size_t)totals[1], hipMemcpyDeviceToHost, st));
+	if (all && totals[0] > 0) HIP_TRY(hipMemcpyAsync(l.h_cands, ws->d_dense_cands, sizeof(kg_candidate) * (size_t)totals[0], hipMemcpyDeviceToHost, st));
+	if (all && totals[1] > 0) HIP_TRY(hipMemcpyAsync(l.h_cand_seeds, ws->d_dense_seeds, sizeof(kg_seed) * (size_t)totals[1], hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&tot[2], l.d_sam_ctl + 1, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&tot[8], ws->d_aln_ctl, 8 * 7, hipMemcpyDeviceToHost, st));          // the alignment stage's list sizes of this batch ...
 	HIP_TRY(hipMemcpyAsync(&tot[15], ws->d_aln_ctl + 32, 8, hipMemcpyDeviceToHost, st));        // ... and the candidates its fast plan kernel left to the general one
@@ -700,6 +707,29 @@ int kg_stream_fetch_reads(kg_stream *s, int lane, uint8_t *enc, int64_t *read_of
 	HIP_TRY(kgi_sync(l.ws));
 	HIP_TRY(hipMemcpy(read_off, l.ws->d_read_off, 8 * (size_t)(l.parsed.n_reads + 1), hipMemcpyDeviceToHost));
 	if (enc && l.parsed.n_bases > 0) HIP_TRY(hipMemcpy(enc, l.ws->d_enc, (size_t)l.parsed.n_bases, hipMemcpyDeviceToHost));
+	return KG_OK;
+}
+
+int kg_stream_fetch(kg_stream *s, int lane, int64_t first, int64_t count)
+{
+	if (!s || lane < 0 || lane >= (int)s->lanes.size()) return fail(KG_ERR_ARG, "kg_stream_fetch: bad lane");
+	Lane &l = s->lanes[(size_t)lane];
+	if (first < 0 || count < 0 || first + count > l.mapped_reads || !l.d_records) return fail(KG_ERR_ARG, "kg_stream_fetch: reads [%lld, %lld) are not of the lane's mapped batch (%lld reads)", (long long)first, (long long)(first + count), (long long)l.mapped_reads);
+	if (count == 0) return KG_OK;
+	kg_workspace *ws = l.ws;
+	HIP_TRY(hipSetDevice(ws->ix->device));
+	hipStream_t st = ws->stream;
+	int64_t *tot = l.h_meta + FQM_WORDS;              // (words 18 .. 19 of the lane's page-locked scratch: the seed offsets at either end)
+	HIP_TRY(hipMemcpyAsync(l.h_records + first, l.d_records + first, sizeof(kg_aln_record) * (size_t)count, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(l.h_cand_off + first, ws->d_cand_off + first, 8 * (size_t)(count + 1), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&tot[18], ws->d_cseed_off + first, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&tot[19], ws->d_cseed_off + first + count, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(kgi_sync(ws));
+	const int64_t c0 = l.h_cand_off[first], c1 = l.h_cand_off[first + count], s0 = tot[18], s1 = tot[19];
+	if (c0 < 0 || c1 < c0 || c1 > l.h_cand_capacity || s0 < 0 || s1 < s0 || s1 > l.h_cand_capacity) return fail(KG_ERR_NO_DEVICE, "kg_stream_fetch: the batch's candidate offsets are not what kg_stream_map left");
+	if (c1 > c0) HIP_TRY(hipMemcpyAsync(l.h_cands + c0, ws->d_dense_cands + c0, sizeof(kg_candidate) * (size_t)(c1 - c0), hipMemcpyDeviceToHost, st));
+	if (s1 > s0) HIP_TRY(hipMemcpyAsync(l.h_cand_seeds + s0, ws->d_dense_seeds + s0, sizeof(kg_seed) * (size_t)(s1 - s0), hipMemcpyDeviceToHost, st));
+	HIP_TRY(kgi_sync(ws));
 	return KG_OK;
 }
 

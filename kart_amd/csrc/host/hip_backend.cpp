@@ -56,6 +56,10 @@ public:
 	{
 		if (kg_stream_map(s_, lane, &p, &out) != KG_OK) die("kg_stream_map");
 	}
+	void fetch(int lane, int64_t first, int64_t count) override
+	{
+		if (kg_stream_fetch(s_, lane, first, count) != KG_OK) die("kg_stream_fetch");
+	}
 	bool timing(kg_stream_timing_t &t, bool reset) override { return kg_stream_timing(s_, &t, reset ? 1 : 0) == KG_OK; }
 	int seed_group() const override { return cfg_.seed_group > 1 ? cfg_.seed_group : 0; }
 	void group_absent(int lane, int rounds) override

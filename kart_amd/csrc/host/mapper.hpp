@@ -83,6 +83,9 @@ struct StreamBackend {
 	virtual void upload(int lane, int file, int64_t from, int64_t to) = 0;           // asynchronous
 	virtual bool parse(int lane, const kg_stream_window &w, kg_stream_parsed &out) = 0;   // false: the window does not fit the lane (the caller's own reader takes over)
 	virtual void map(int lane, const kg_stream_params &p, kg_stream_result &out) = 0;
+	// the records and candidates of reads [first, first + count) of the lane's mapped batch into the result's arrays (kg_stream_fetch): a result made
+	// with p.fetch_all == 0 holds them only for what was fetched
+	virtual void fetch(int lane, int64_t first, int64_t count) { (void)lane; (void)first; (void)count; }
 	virtual bool timing(kg_stream_timing_t &t, bool reset) { (void)t; (void)reset; return false; }   // device time per stage since the last reset
 	// seeding groups (kg_stream_group_absent): lanes [g * seed_group(), (g + 1) * seed_group()) seed their batches in ONE launch per round;
 	// a lane without a batch for `rounds` rounds says so (< 0: until further notice, 0: it takes part again)
