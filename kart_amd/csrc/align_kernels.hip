@@ -1942,7 +1942,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 			o = fast_report(a, k.count, a.cand_seeds + k.first, rb, rl, !second, lower_bound, end_at);
 		}
 		const bool mine = pair_ok && o.state == FAST_DECIDED && o.score > 0 && o.score <= kAlnMaxScore;
-		const bool trivial = mine && __shfl_xor(mine ? 1 : 0, 1) != 0;
+		const int mine_o = __shfl_xor(mine ? 1 : 0, 1);              // (every lane takes part in the exchange: not behind `mine &&`)
+		const bool trivial = mine && mine_o != 0;
 		// ---- the pairs left to the general kernels, and their candidates, densely (the first mate's lane speaks for the pair) ----
 		{
 			const bool slow = live && !trivial && !second;

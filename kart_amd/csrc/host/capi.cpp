@@ -34,12 +34,31 @@ int fail(const char *fmt, ...)
 }
 }  // namespace
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
+namespace {
+// KART_AMD_BACKTRACE (diagnostics): a fault inside the library prints its frames as library offsets (addr2line -e libkart_host.so <offset>) before it ends the process
+void fault_backtrace(int sig)
+{
+	void *frames[48];
+	const int n = backtrace(frames, 48);
+	const char msg[] = "kart-amd: fatal signal, frames:\n";
+	(void)!write(2, msg, sizeof(msg) - 1);
+	backtrace_symbols_fd(frames, n, 2);
+	signal(sig, SIG_DFL);
+	raise(sig);
+}
+}
+
 extern "C" {
 
 const char *kh_last_error(void) { return g_err; }
 
 int kh_open(const char *index_prefix, int device, int threads, kh_session **out)
 {
+	if (getenv("KART_AMD_BACKTRACE")) { signal(SIGSEGV, fault_backtrace); signal(SIGABRT, fault_backtrace); }
 	if (!index_prefix || !out) return fail("kh_open: null argument");
 	*out = nullptr;
 	std::unique_ptr<kh_session> s(new kh_session());

@@ -21,10 +21,11 @@ struct Hit {
 //   [0] read queue head  [1] hit count  [2] locate queue head  [3] unused
 //   [4..11] counters: searches, lf1, lf2, inv, sa, seeds, bases, overflow(needed seeds or 0)
 //   [12..16] reads on the sort work lists: 9..16, 17..32, 33..64 seeds (4 / 2 / 1 lists per wave), 65..256 (small LDS),
-//            > 256 (large LDS)
+//            > 512 (large LDS)
 //   [17..21] what the search kernel itself fetched: q-mer table lookups, rank steps executed, those touching two 128-byte
 //            lines, text-comparison rounds, packed window words, two-line rank steps on intervals below 960, double steps, those with two lines, bytes their ranks read (kg_workspace_traffic)
-constexpr int kCtlWords = 27;
+//   [27] reads on the sixth sort work list: 257..512 seeds (medium LDS)
+constexpr int kCtlWords = 28;
 constexpr int kMaxSeedSegments = 8;
 
 struct SeedArgs {
