@@ -1863,8 +1863,8 @@ __global__ __launch_bounds__(256) void aln_plan_fast_kernel(AlnArgs a)
 //   records with RNEXT / PNEXT / TLEN (:177-270) and counts the pair into iPaired / iDistance (:209-213).
 // The per-candidate arrays (c_score, c_mate, rep_*) are never written or read for these pairs, none of the later kernels sees them:
 // the pairs this kernel does NOT take are listed (a.slow_pairs, ctl[35]) with their candidates (a.slow_cands, ctl[34]), and
-// aln_pair / aln_post_rescue / aln_bin / aln_plan_fast / aln_plan / aln_final walk those lists, densely.  The 112-byte record
-// of a lane is assembled in registers, staged through the LDS with the wave's other 63 and leaves as whole 16-byte chunks of consecutive
+// aln_pair / aln_post_rescue / aln_bin / aln_plan_fast / aln_plan / aln_final walk those lists, densely.  The two 112-byte records
+// of a lane are assembled in registers, staged through the LDS 32 pairs at a time and leave as whole 16-byte chunks of consecutive
 // memory (aln_final_kernel writes a record field by field: 64 lanes, 64 lines per store).  KG_ALN_NO_TRIVIAL: off.
 static_assert(sizeof(kg_aln_record) == 112 && offsetof(kg_aln_record, kind) == 16 && offsetof(kg_aln_record, est_lo) == 44 && offsetof(kg_aln_record, has_mate) == 52 &&
               offsetof(kg_aln_record, cigar) == 56 && offsetof(kg_aln_record, next) == 104 && offsetof(kg_aln_record, primary) == 108, "aln_trivial_kernel lays the record out by hand");
@@ -1884,18 +1884,13 @@ __device__ __forceinline__ void stage_record(uint32_t *w, int64_t pos, int64_t m
 	w[27] = 1;                                                   // primary, pad
 }
 
-__device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int m)
-{
-	return (int64_t)(((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)v >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)(uint64_t)v, m));
-}
-
-// One READ per lane, the two mates of a pair in neighbouring lanes (a wave: 32 pairs): each lane walks the chain of dependent loads of ONE
-// candidate -- offsets, candidate, seeds, the gap characters against the text -- and the mates exchange what the other's record needs
-// (position, strand, length) by a shuffle.  (The first form did a pair per lane, the second mate's report behind the first's: twice the chain.)
+// One PAIR per lane.  (A form with one READ per lane -- the mates in neighbouring lanes, exchanging position, strand and length by a shuffle, half
+// the chain of dependent loads per lane -- was built and measured slower, 62 against 39 ms per 100 M-read step: the staging, the flush, the
+// ballots and the statistics are per wave, and a wave then covers 32 pairs instead of 64; profiles/r06g_*.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void aln_trivial_kernel(AlnArgs a)
 {
 	__shared__ int64_t s_end[128];
-	__shared__ __attribute__((aligned(16))) uint32_t s_rec[4][64 * 28];          // per wave: the records of its 64 reads (7168 bytes)
+	__shared__ __attribute__((aligned(16))) uint32_t s_rec[4][32 * 2 * 28];          // per wave: the records of 32 pairs (7168 bytes)
 	const bool ends_in_lds = a.n_ends <= 128;
 	if (ends_in_lds)
 		for (int i = threadIdx.x; i < a.n_ends; i += blockDim.x) s_end[i] = a.contig_end[i];
@@ -1910,46 +1905,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 		return lo;
 	};
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const bool second = lane & 1;                                   // the lane holds mate 2
 	uint32_t *const stage = s_rec[wave];
 	const int64_t n_pairs = a.n_reads >> 1;
-	const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 1;      // pairs per round of the grid
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	const long long est = a.est_distance;
-	for (int64_t u0 = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) >> 1; u0 < n_pairs; u0 += stride) {      // u0: the wave's first pair
-		const int64_t u = u0 + (lane >> 1);
+	for (int64_t u0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); u0 < n_pairs; u0 += stride) {      // u0: the wave's first pair
+		const int64_t u = u0 + lane;
 		const bool live = u < n_pairs;
-		const int64_t r = (u << 1) + (second ? 1 : 0);
-		int n = 0, rl = 0;
-		int64_t c = 0, rb = 0;
-		kg_candidate k;
-		k.posDiff = 0; k.score = 0; k.count = 0; k.first = 0;
+		const int64_t r = u << 1;
+		bool trivial = false;
+		int n1 = 0, n2 = 0;
+		int64_t c1 = 0;
+		FastRep o1, o2;
+		o1.state = o2.state = FAST_SLOW;
+		long long dist = 0;
+		int rl1 = 0, rl2 = 0;
 		if (live) {
-			c = a.cand_off[r];
-			n = (int)(a.cand_off[r + 1] - c);
-			if (n == 1) k = a.cands[c];
+			c1 = a.cand_off[r];
+			const int64_t c2 = a.cand_off[r + 1], c3 = a.cand_off[r + 2];
+			n1 = (int)(c2 - c1); n2 = (int)(c3 - c2);
+			if (n1 == 1 && n2 == 1) {
+				const kg_candidate k1 = a.cands[c1], k2 = a.cands[c2];
+				dist = k2.posDiff - k1.posDiff;
+				// each is the other's only and best mate (score > 0; a tie or a better rival needs a second candidate), :362-391
+				if (k1.score > 0 && k2.score > 0 && dist >= 0 && dist < est) {
+					const int64_t b1 = a.read_off[r], b2 = a.read_off[r + 1], b3 = a.read_off[r + 2];
+					rl1 = (int)(b2 - b1); rl2 = (int)(b3 - b2);
+					o1 = fast_report(a, k1.count, a.cand_seeds + k1.first, b1, rl1, true, lower_bound, end_at);
+					if (o1.state == FAST_DECIDED && o1.score > 0)
+						o2 = fast_report(a, k2.count, a.cand_seeds + k2.first, b2, rl2, false, lower_bound, end_at);
+					trivial = o1.state == FAST_DECIDED && o2.state == FAST_DECIDED && o1.score > 0 && o2.score > 0 && o1.score <= kAlnMaxScore && o2.score <= kAlnMaxScore;
+				}
+			}
 		}
-		const int n_o = __shfl_xor(n, 1);
-		const int score_o = __shfl_xor(k.score, 1);
-		const int64_t pd_o = shfl_xor_i64(k.posDiff, 1);
-		// each is the other's only and best mate (score > 0; a tie or a better rival needs a second candidate), :362-391
-		const long long dist = second ? (long long)(k.posDiff - pd_o) : (long long)(pd_o - k.posDiff);       // PosDiff2 - PosDiff1
-		const bool pair_ok = live && n == 1 && n_o == 1 && k.score > 0 && score_o > 0 && dist >= 0 && dist < est;
-		FastRep o;
-		o.state = FAST_SLOW; o.score = 0; o.chr = 0; o.cigar_len = 0; o.pos = 0; o.fwd = true; o.t0 = o.t1 = 0;
-		if (pair_ok) {
-			rb = a.read_off[r];
-			rl = (int)(a.read_off[r + 1] - rb);
-			o = fast_report(a, k.count, a.cand_seeds + k.first, rb, rl, !second, lower_bound, end_at);
-		}
-		const bool mine = pair_ok && o.state == FAST_DECIDED && o.score > 0 && o.score <= kAlnMaxScore;
-		const int mine_o = __shfl_xor(mine ? 1 : 0, 1);              // (every lane takes part in the exchange: not behind `mine &&`)
-		const bool trivial = mine && mine_o != 0;
-		// ---- the pairs left to the general kernels, and their candidates, densely (the first mate's lane speaks for the pair) ----
+		// ---- the pairs left to the general kernels, and their candidates, densely ----
 		{
-			const bool slow = live && !trivial && !second;
+			const bool slow = live && !trivial;
 			const uint64_t mask = __ballot(slow);
 			if (mask) {
-				const int nc = slow ? n + n_o : 0;
+				const int nc = slow ? n1 + n2 : 0;
 				int pre = nc;                                   // inclusive prefix sum of the lanes' candidate counts
 #pragma unroll
 				for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(pre, off); if (lane >= off) pre += t; }
@@ -1966,48 +1960,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 					const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 					a.slow_pairs[at_p + (unsigned long long)__popcll(mask & below)] = (int32_t)u;
 					int32_t *dst = a.slow_cands + at_c + (unsigned long long)(pre - nc);
-					for (int q = 0; q < nc; ++q) dst[q] = (int32_t)(c + q);          // (the two lists are one run of the dense candidates)
+					for (int k = 0; k < nc; ++k) dst[k] = (int32_t)(c1 + k);
 				}
 			}
 		}
 		// ---- the trivial pairs' records ----
 		const uint64_t tmask = __ballot(trivial);
 		if (tmask == 0) continue;
-		const int64_t pos_o = shfl_xor_i64(o.pos, 1);
-		const int fwd_o = __shfl_xor(o.fwd ? 1 : 0, 1), rl_o = __shfl_xor(rl, 1);
-		int tl = 0;                                                         // of mate 1's record, :204-207; mate 2's is its negative
+		int tl = 0;
+		long long ad = 0;
 		if (trivial) {
-			const int64_t p1 = second ? pos_o : o.pos, p2 = second ? o.pos : pos_o;
-			const bool f1 = second ? fwd_o != 0 : o.fwd;
-			const int l1 = second ? rl_o : rl, l2 = second ? rl : rl_o;
-			tl = (int)(p2 - p1 + (f1 ? l2 : 0 - l1));
-			stage_record(stage + lane * 28, o.pos, pos_o, (second ? 0x83 : 0x43) | (o.fwd ? 0x20 : 0x10), o.chr, second ? 0 - tl : tl, o.score, (int)dist, second ? o.fwd : !o.fwd, o);
+			tl = (int)(o2.pos - o1.pos + (o1.fwd ? rl2 : 0 - rl1));      // :204-207
+			ad = tl < 0 ? -(long long)tl : (long long)tl;
+			if (ad >= 10000) ad = 0;                                        // :211
 		}
-		// (a wave's LDS traffic is in program order; the fences keep the compiler from moving the reads above the writes of OTHER lanes)
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		{
-			uint4 *const out = reinterpret_cast<uint4 *>(a.records + (u0 << 1));
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			const bool mine = trivial && (lane >> 5) == half;
+			if (mine) {
+				uint32_t *w = stage + (lane & 31) * 56;
+				stage_record(w, o1.pos, o2.pos, 0x43 | (o1.fwd ? 0x20 : 0x10), o1.chr, tl, o1.score, (int)dist, !o1.fwd, o1);
+				stage_record(w + 28, o2.pos, o1.pos, 0x83 | (o2.fwd ? 0x20 : 0x10), o2.chr, 0 - tl, o2.score, (int)dist, o2.fwd, o2);
+			}
+			// (a wave's LDS traffic is in program order; the fences keep the compiler from moving the reads above the writes of OTHER lanes)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			const uint32_t hm = (uint32_t)(tmask >> (32 * half));
+			if (hm == 0) continue;
+			uint4 *const out = reinterpret_cast<uint4 *>(a.records + ((u0 + 32 * half) << 1));
 			const uint4 *const in = reinterpret_cast<const uint4 *>(stage);
 #pragma unroll
 			for (int it = 0; it < 7; ++it) {
-				const int q = it * 64 + lane;                   // 16-byte chunk of the wave's 7168 bytes; 7 chunks per record
-				if ((tmask >> (q / 7)) & 1ull) out[q] = in[q];
+				const int q = it * 64 + lane;                   // 16-byte chunk of the half's 7168 bytes; 14 chunks per pair
+				if ((hm >> (q / 14)) & 1u) out[q] = in[q];
 			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		// ---- what the pairs add to their chunks: iPaired / iDistance, the reads of MAPQ 60, the chunk's EstDistance interval (the first mate's lane) ----
-		const bool speak = trivial && !second;
-		long long ad = 0;
-		if (speak) { ad = tl < 0 ? -(long long)tl : (long long)tl; if (ad >= 10000) ad = 0; }          // :211
+		// ---- what the pairs add to their chunks: iPaired / iDistance, the reads of MAPQ 60, the chunk's EstDistance interval ----
 		int ck = -1;
-		if (speak) ck = chunk_of(a, r);
-		const uint64_t smask = __ballot(speak);
-		const int ck0 = __shfl(ck, __ffsll((unsigned long long)smask) - 1);
-		if (__ballot(speak && ck != ck0) == 0) {
-			long long lo = speak ? dist : -1, sum = ad;
+		if (trivial) ck = chunk_of(a, r);
+		const int ck0 = __shfl(ck, __ffsll((unsigned long long)tmask) - 1);
+		if (__ballot(trivial && ck != ck0) == 0) {
+			long long lo = trivial ? dist : -1, sum = ad;
 			for (int off = 32; off > 0; off >>= 1) {
 				const long long l2 = __shfl_xor(lo, off);
 				lo = l2 > lo ? l2 : lo;
@@ -2015,20 +2011,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 			}
 			if (lane == 0) {
 				kg_chunk_stats &cs = a.chunk_stats[ck0];
-				const int np = __popcll(smask);
+				const int np = __popcll(tmask);
 				atomicAdd((unsigned long long *)&cs.paired, 2ull * (unsigned long long)np);
 				if (sum) atomicAdd((unsigned long long *)&cs.distance, (unsigned long long)sum);
 				atomicAdd(&cs.unique, 2 * np);
 				atomicMax((long long *)&cs.lo, lo);
 			}
-		} else if (speak) {
+		} else if (trivial) {
 			kg_chunk_stats &cs = a.chunk_stats[ck];
 			atomicAdd((unsigned long long *)&cs.paired, 2ull);
 			if (ad) atomicAdd((unsigned long long *)&cs.distance, (unsigned long long)ad);
 			atomicAdd(&cs.unique, 2);
 			atomicMax((long long *)&cs.lo, dist);
 		}
-		if (lane == 0) atomicAdd(&a.ctl[36], (unsigned long long)__popcll(smask));      // (pairs decided here, this batch)
+		if (lane == 0) atomicAdd(&a.ctl[36], (unsigned long long)__popcll(tmask));      // (pairs decided here, this batch)
 	}
 }
 
@@ -2673,7 +2669,7 @@ hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 	hipLaunchKernelGGL(aln_reset_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 8)), dim3(256), 0, stream, a);
 	if (a.slow_pairs) {
 		kt_begin(KT_ALN_TRIVIAL, stream);
-		hipLaunchKernelGGL(aln_trivial_kernel, dim3(grid_for_aln(a.n_reads + 2, 256, n_cu * 16)), dim3(256), 0, stream, a);
+		hipLaunchKernelGGL(aln_trivial_kernel, dim3(grid_for_aln(a.n_reads / 2 + 1, 256, n_cu * 16)), dim3(256), 0, stream, a);
 		kt_end(KT_ALN_TRIVIAL, stream);
 	}
 	kt_begin(KT_ALN_PAIR, stream);
