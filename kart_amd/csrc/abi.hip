@@ -1110,6 +1110,7 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 	{ static const bool nopart = getenv("KG_DBG_NO_PARTITION") != nullptr; a.dbg_no_partition = nopart ? 1 : 0; }
 	{ static const bool scan = getenv("KG_RESCUE_SCAN") != nullptr; a.dbg_rescue_scan = scan ? 1 : 0; }
 	{ static const bool no_heavy = getenv("KG_ALN_NO_HEAVY") != nullptr; a.dbg_no_heavy = no_heavy ? 1 : 0; }
+	{ static const bool no_inline = getenv("KG_ALN_NO_INLINE") != nullptr; a.dbg_no_inline = no_inline ? 1 : 0; }
 	a.extra_capacity = 0;                                  // (set below, once the pinned array of this call is known)
 	a.mapq_tab = ix->d_mapq_tab;
 	{

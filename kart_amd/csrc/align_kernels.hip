@@ -1260,7 +1260,8 @@ __device__ int finish_tail(const AlnArgs &a, const Columns &c, int &gLen, int &r
 }
 
 // what pass 1 decided for a pair
-enum : uint8_t { W_NONE = 0, W_SIMPLE = 1, W_IMMEDIATE = 2, W_JOB = 3, W_PLAN = 4, W_PENDING = 5 };
+enum : uint8_t { W_NONE = 0, W_SIMPLE = 1, W_IMMEDIATE = 2, W_JOB = 3, W_PLAN = 4, W_PENDING = 5, W_INLINE = 6 };
+constexpr int kInlineJobs = 3;          // gap fragments of at most 8 x 8 a candidate may align in its own lane (aln_plan_kernel)
 struct Work {
 	uint8_t kind[kAlnMaxPairs];
 	uint8_t op[kAlnMaxPairs];
@@ -1290,7 +1291,13 @@ __device__ bool finish_candidate(const AlnArgs &a, int64_t cand, bool first, con
 			s = w.val[j];
 		} else {
 			Columns c;
-			if (w.kind[j] == W_JOB) {
+			if (w.kind[j] == W_INLINE) {
+				// aligned in the planning lane itself (nw8_inline): op string number val & 255 -- parked in the candidate's own CIGAR slot, which is
+				// written only after the last pair has been read (a lane-private array here sends the compiler's SimplifyCFG pass into a fault: ops
+				// would point into two address spaces) --, val >> 8 columns
+				c.ops = reinterpret_cast<const uint8_t *>(a.rep_cigar + cand * KG_ALN_CIGAR_MAX) + 16 * (w.val[j] & 255);
+				c.len = w.val[j] >> 8;
+			} else if (w.kind[j] == W_JOB) {
 				const NwJobDesc jd = a.jobs[w.val[j]];
 				c.ops = a.nw_ops + jd.ops;
 				c.len = a.nw_len[w.val[j]];
@@ -2028,6 +2035,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 	}
 }
 
+// nw_alignment for a fragment pair of at most 8 x 8 (97 % of the gap fragments of 150 bp reads), in the planning lane's own registers:
+// the recurrences, the boundary values and the traceback's tie order of nw_small8_kernel (nw_kernels.hip; reference src/nw_alignment.cpp:18-80 on
+// doubled scores) -- so that a candidate whose only alignments are such fragments is finished where it is planned instead of being parked
+// (spill slot out and in, job descriptors, a pass of the NW kernels, aln_finish_kernel's pass over it).  ops[0 .. len) = the columns left to right.
+__device__ __forceinline__ int nw8_inline(const AlnArgs &a, const uint8_t *f1, int64_t g, int m, int n, uint8_t *ops)
+{
+	constexpr int kNeg = -(1 << 20);
+	const uint64_t w1 = reinterpret_cast<const AlnU64u *>(f1)->v;            // (the character array has 64 bytes of slack)
+	const uint32_t tw = (uint32_t)text_word32(a, g);
+	int c2[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) c2[j] = j < n ? (int)((tw >> (2 * j)) & 3u) : 8 + j;
+	int S[9], T[9];
+	S[0] = 0; T[0] = 0;
+#pragma unroll
+	for (int j = 1; j <= 8; ++j) { S[j] = -2 - j; T[j] = kNeg; }
+	uint64_t fr = 0, ft = 0;          // bit 8 (i - 1) + (j - 1): s == r / s == t at cell (i, j)
+#pragma unroll
+	for (int i = 1; i <= 8; ++i) {
+		if (i <= m) {
+			const unsigned u = (unsigned)((w1 >> (8 * (i - 1))) & 0xDFu);
+			const int c1 = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;          // nst_nt4_table
+			int diag = S[0];
+			S[0] = -2 - i;
+			int left_s = S[0], left_r = kNeg;
+#pragma unroll
+			for (int j = 1; j <= 8; ++j) {
+				const int up_s = S[j], up_t = T[j];
+				const int r = max(left_r - 1, left_s - 3);
+				const int tt = max(up_t - 1, up_s - 3);
+				const int d = diag + (c1 == c2[j - 1] ? 3 : -3);
+				const int sc = max(d, max(r, tt));
+				fr |= (uint64_t)(sc == r) << (8 * (i - 1) + (j - 1));
+				ft |= (uint64_t)(sc == tt) << (8 * (i - 1) + (j - 1));
+				diag = up_s; S[j] = sc; T[j] = tt; left_s = sc; left_r = r;
+			}
+		}
+	}
+	// the traceback yields the columns right to left (:59-72: s == r first, then s == t, else the diagonal)
+	int i = m, j = n, len = 0;
+	uint64_t lo = 0, hi = 0;
+	while (i > 0 || j > 0) {
+		const int bit = 8 * (i - 1) + (j - 1);
+		const bool g1 = i == 0 || (j > 0 && ((fr >> bit) & 1));
+		const bool g2 = !g1 && (j == 0 || ((ft >> bit) & 1));
+		const uint64_t op = g1 ? KG_OP_GAP1 : g2 ? KG_OP_GAP2 : KG_OP_DIAG;
+		const int at = 15 - len;
+		if (at >= 8) hi |= op << (8 * (at - 8)); else lo |= op << (8 * at);
+		len++;
+		if (g1) j--; else if (g2) i--; else { i--; j--; }
+	}
+	const int sh = 16 - len;                                                 // bytes to shift down
+	if (sh >= 8) { lo = sh == 8 ? hi : sh == 16 ? 0 : hi >> (8 * (sh - 8)); hi = 0; }
+	else if (sh > 0) { lo = (lo >> (8 * sh)) | (hi << (8 * (8 - sh))); hi >>= 8 * sh; }
+	reinterpret_cast<AlnU64u *>(ops)->v = lo;
+	reinterpret_cast<AlnU64u *>(ops + 8)->v = hi;
+	return len;
+}
+
 // ---- pass 1: one candidate per lane -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void aln_plan_kernel(AlnArgs a)
 {
@@ -2041,8 +2107,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 		Pairs v;
 		Work w;
 		int64_t cand = 0, r = 0, rbase = 0;
-		int num = 0, n_new_jobs = 0, new_ops = 0, n_pending = 0;
-		bool pending = false;
+		int num = 0, n_new_jobs = 0, new_ops = 0, n_pending = 0, n_small = 0, n_inline = 0;
+		bool pending = false, inline_all = false, first_mate = true;
 		// ---- phase 1: up to the point where the candidate is finished, handed to the host, or has to be parked ----
 		bool park = false;
 		do {
@@ -2068,6 +2134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 		const uint8_t *rd = a.enc + rbase;
 		const int ck = chunk_of(a, r);
 		const bool first = a.chunk_paired[ck] ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
+		first_mate = first;
 		v.num = cd.count;
 		for (int i = 0; i < cd.count; ++i) {
 			kg_seed s = seeds[i];
@@ -2127,6 +2194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 			// nw_alignment(rL, frag1, gL, frag2): a job for the NW kernels (its slot and op bytes are reserved below, with everything else the candidate needs)
 			w.kind[j] = W_JOB; w.val[j] = -1;
 			n_new_jobs++; new_ops += rL + gL;
+			n_small += (rL <= 8 && gL <= 8) ? 1 : 0;
 			jobs = true;
 		}
 		if (host) { flag_host(a, r, why); break; }
@@ -2134,14 +2202,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 			if (!finish_candidate(a, cand, first, rd, v, w)) flag_host(a, r, WHY_CIGAR);
 			break;
 		}
-		park = true;
+		inline_all = !pending && n_small == n_new_jobs && n_new_jobs <= kInlineJobs && !a.dbg_no_inline;
+		park = !inline_all;
 		} while (false);
+		if (inline_all) {
+			// every alignment the candidate needs is at most 8 x 8: they are made here, in this lane's registers, and the candidate is finished at
+			// once -- nothing of it goes through the spill list, the job list, the NW kernels or aln_finish_kernel
+			uint8_t *const inl = reinterpret_cast<uint8_t *>(a.rep_cigar + cand * KG_ALN_CIGAR_MAX);      // (3 x 16 bytes: the candidate's CIGAR slot, free until its text is written)
+			int k = 0;
+			for (int j = 0; j < num; ++j) {
+				if (w.kind[j] != W_JOB) continue;
+				const int len = nw8_inline(a, a.enc + rbase + v.rPos[j], v.gPos[j], v.rLen[j], v.gLen[j], inl + 16 * k);
+				w.kind[j] = W_INLINE; w.val[j] = k | (len << 8);
+				k++;
+			}
+			if (!finish_candidate(a, cand, first_mate, a.enc + rbase, v, w)) flag_host(a, r, WHY_CIGAR);
+			n_inline = k;
+		}
 		// park the candidate until its alignments exist.  What the wave's candidates need of the lists -- a spill slot each, their NW jobs and op
 		// bytes, their partition tasks -- is reserved with ONE atomic per list for the whole wave (wave_reserve)
 		const unsigned long long sp = wave_reserve(&a.ctl[0], park ? 1ull : 0ull);
 		unsigned long long job_at = wave_reserve(&a.ctl[1], park ? (unsigned long long)n_new_jobs : 0ull);
 		unsigned long long ops_at = wave_reserve(&a.ctl[2], park ? (unsigned long long)new_ops : 0ull);
 		unsigned long long task_at = wave_reserve(&a.ctl[3], park ? (unsigned long long)n_pending : 0ull);
+		(void)wave_reserve(&a.ctl[37], (unsigned long long)n_inline);          // (tally: alignments made in the planning lanes, this batch)
 		if (!park) continue;
 		const bool sp_ok = sp < (unsigned long long)a.spill_capacity;
 		const bool jobs_ok = job_at + (unsigned long long)n_new_jobs <= (unsigned long long)a.job_capacity && ops_at + (unsigned long long)new_ops <= (unsigned long long)a.ops_capacity;
@@ -2647,7 +2731,7 @@ __global__ void aln_reset_kernel(AlnArgs a)
 	if (i == 0) a.ctl[33] += a.ctl[32];                  // (running tally: candidates the fast plan kernel left to the general one)
 	if (i < 8) a.ctl[i] = 0;
 	if (i >= 24 && i < 33) a.ctl[i] = 0;
-	if (i >= 34 && i <= 36) a.ctl[i] = 0;                // (aln_trivial_kernel: candidates / pairs it leaves to the general kernels, pairs it decided)
+	if (i >= 34 && i <= 37) a.ctl[i] = 0;                // (aln_trivial_kernel: candidates / pairs it leaves to the general kernels, pairs it decided)
 	for (int c = i; c < a.n_chunks; c += gridDim.x * blockDim.x) {
 		kg_chunk_stats z;
 		z.paired = 0; z.distance = 0; z.lo = -1; z.hi = 0x7fffffffffffffffll; z.unmapped = 0; z.unique = 0; z.host_pairs = 0; z.rescue_wanted = 0;
