@@ -57,6 +57,7 @@ namespace {
 #include "detail/chunk_state.inc"
 #include "detail/writer.inc"
 #include "detail/chunk_stages.inc"
+#include "detail/pgzip.inc"
 #include "detail/batch_reader.inc"
 #include "detail/deferred.inc"
 #include "detail/pipeline.inc"
@@ -230,8 +231,8 @@ int run_mapping(const Options &opt, const RefData &ref, KernelBackend &kern, FIL
 			src.g1.path = f1; if (sep) src.g2.path = opt.files2[lib];
 			// bgzip-ped files are inflated member by member on several threads (both mate files are filled side by side: half each)
 			const int per_file = std::max(1, opt.threads / (sep ? 2 : 1));
-			src.g1.try_bgzf(f1.c_str(), per_file);
-			if (sep) src.g2.try_bgzf(opt.files2[lib].c_str(), per_file);
+			if (!src.g1.try_bgzf(f1.c_str(), per_file)) src.g1.try_pgz(f1.c_str(), per_file);
+			if (sep && !src.g2.try_bgzf(opt.files2[lib].c_str(), per_file)) src.g2.try_pgz(opt.files2[lib].c_str(), per_file);
 		}
 		if (shard.active()) {
 			// only a single library of plain 4-line FASTQ is split; anything else is mapped by shard 0 alone
