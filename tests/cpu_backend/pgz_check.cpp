@@ -42,8 +42,16 @@ int main(int argc, char **argv)
 		if (!g) { fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
 		gzbuffer(g, 1 << 20);
 		std::vector<char> buf((size_t)16 << 20);
-		for (;;) { int n = gzread(g, buf.data(), (unsigned)buf.size()); if (n <= 0) break; ref.insert(ref.end(), buf.data(), buf.data() + n); }
+		bool damaged = false;
+		for (;;) { int n = gzread(g, buf.data(), (unsigned)buf.size()); if (n < 0) damaged = true; if (n <= 0) break; ref.insert(ref.end(), buf.data(), buf.data() + n); }
 		gzclose(g);
+		if (damaged) {
+			// a damaged stream: a large gzread() fails as a whole; what zlib could still inflate is what small reads deliver before the error
+			ref.clear();
+			g = gzopen(argv[1], "rb");
+			for (;;) { int n = gzread(g, buf.data(), 1); if (n <= 0) break; ref.push_back(buf[0]); }
+			gzclose(g);
+		}
 	}
 	const double zlib_s = now() - z0;
 	kart::Pgz z;
