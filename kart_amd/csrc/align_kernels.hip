@@ -2349,6 +2349,354 @@ __global__ __launch_bounds__(256) void aln_finish_kernel(AlnArgs a)
 	}
 }
 
+// ---- pass 2 by the wave ----------------------------------------------------------------------------------------------------------
+// aln_finish_kernel above gives a candidate to a lane: the lane walks the columns of each of its alignments one after the other, two to four
+// times (CheckLocalAlignmentQuality, the trimming of the head / tail, AddNewCigarElements), 64 candidates of different shapes per wave in lock
+// step -- a launch lasted as long as its slowest wave, 0.8 ms for 150 k candidates (profiles/r06h).  Here the WAVE takes a candidate and its
+// lanes take the columns: lane c of tile k looks at column 64 k + c -- the op, the read's character and the text's, found through prefix counts
+// of the ops in front of it -- and three ballots turn the tile into bit sets: the read side shows '-', the text side shows '-', both show the
+// same character.  Everything the reference's loops derive from the columns is bit arithmetic on those sets (uniform, a few instructions per
+// run instead of tens per column); the normal pairs of the candidate live one per lane, the CIGAR elements one per lane.  Same records.
+namespace {
+
+__device__ __forceinline__ int rl32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int64_t rl64(int64_t v, int lane)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, lane);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), lane);
+	return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni64(int64_t v)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+	return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint64_t bits_below(int n) { return n >= 64 ? ~0ull : n <= 0 ? 0ull : ((1ull << n) - 1); }
+
+// the columns of one alignment as bit sets; tile k (columns 64 k .. 64 k + 63) is held by lane k
+struct WaveCols {
+	uint64_t m1, m2, eq;
+	int len;
+	__device__ __forceinline__ uint64_t valid(int k) const { return bits_below(len - 64 * k); }
+	__device__ __forceinline__ uint64_t M1(int k) const { return (uint64_t)rl64((int64_t)m1, k) & valid(k); }       // the read side shows '-' (a gap, or a literal '-' of the read)
+	__device__ __forceinline__ uint64_t M2(int k) const { return (uint64_t)rl64((int64_t)m2, k) & valid(k); }       // the text side shows '-'
+	__device__ __forceinline__ uint64_t EQ(int k) const { return (uint64_t)rl64((int64_t)eq, k) & valid(k); }       // both sides show the same character
+};
+
+__device__ __forceinline__ void wave_columns(const AlnArgs &a, const uint8_t *ops, int len, const uint8_t *rd, int64_t g, int lane, WaveCols &wc)
+{
+	wc.m1 = 0; wc.m2 = 0; wc.eq = 0; wc.len = len;
+	int ri = 0, gi = 0;
+	const uint64_t lt = bits_below(lane);
+	for (int k = 0; k * 64 < len; ++k) {
+		const int col = k * 64 + lane;
+		const bool valid = col < len;
+		const uint8_t op = valid ? ops[col] : (uint8_t)KG_OP_DIAG;
+		const bool n1 = valid && op != KG_OP_GAP1, n2 = valid && op != KG_OP_GAP2;          // the column consumes a read / a text character
+		const uint64_t b1 = __ballot(n1), b2 = __ballot(n2);
+		char c1 = '-', c2 = '-';
+		if (n1) c1 = (char)rd[ri + __popcll(b1 & lt)];
+		if (n2) c2 = text_char(a, g + gi + __popcll(b2 & lt));
+		const uint64_t M1 = __ballot(valid && c1 == '-'), M2 = __ballot(valid && c2 == '-'), EQ = __ballot(valid && c1 == c2);
+		if (lane == k) { wc.m1 = M1; wc.m2 = M2; wc.eq = EQ; }
+		ri += __popcll(b1); gi += __popcll(b2);
+	}
+}
+
+struct WaveCigar {                  // element i in lane i
+	int my_len, my_op;
+	int n;
+	bool overflow;
+	__device__ __forceinline__ void push(int l, char o, int lane)
+	{
+		if (n < kAlnMaxCigar) { if (lane == n) { my_len = l; my_op = (int)o; } n++; }
+		else overflow = true;
+	}
+};
+
+// AddNewCigarElements over columns [from, to), src/tools.cpp:49-104: a run per class -- 'D' where the read side shows '-', else 'I' where the text side
+// does, else 'M' -- and the number of identical characters among the 'M' columns
+__device__ int wave_add_cigar(const WaveCols &wc, int from, int to, int lane, WaveCigar &cig)
+{
+	int score = 0;
+	for (int k = from >> 6; k * 64 < to; ++k) {
+		const uint64_t range = ~bits_below(from - 64 * k) & bits_below(to - 64 * k);
+		score += __popcll(wc.EQ(k) & ~wc.M1(k) & ~wc.M2(k) & range);
+	}
+	char state = '*';
+	int cnt = 0, col = from;
+	while (col < to) {
+		int k = col >> 6;
+		const int bit = col & 63;
+		uint64_t m1 = wc.M1(k), b = ~m1 & wc.M2(k);
+		const bool cur1 = ((m1 >> bit) & 1) != 0, curb = ((b >> bit) & 1) != 0;
+		const char st = cur1 ? 'D' : curb ? 'I' : 'M';
+		const uint64_t f1 = cur1 ? ~0ull : 0ull, fb = curb ? ~0ull : 0ull;
+		uint64_t x = ((m1 ^ f1) | (b ^ fb)) & ~bits_below(bit + 1);            // columns behind col, in its tile, of another class
+		int end = to;
+		for (;;) {
+			if (x) { end = k * 64 + (int)__builtin_ctzll(x); break; }
+			++k;
+			if (k * 64 >= to) break;
+			m1 = wc.M1(k); b = ~m1 & wc.M2(k);
+			x = (m1 ^ f1) | (b ^ fb);
+		}
+		if (end > to) end = to;
+		const int run = end - col;
+		if (st == state) cnt += run;
+		else {
+			if (cnt > 0) cig.push(cnt, state, lane);
+			cnt = run;
+			state = st;
+		}
+		col = end;
+	}
+	if (cnt > 0) cig.push(cnt, state, lane);
+	return score;
+}
+
+// CheckLocalAlignmentQuality, src/tools.cpp:255-290
+__device__ bool wave_quality_ok(const WaveCols &wc)
+{
+	int n = 0, mis = 0, runs = 0;
+	uint64_t c1 = 0, cb = 0;
+	for (int k = 0; k * 64 < wc.len; ++k) {
+		const uint64_t v = wc.valid(k), m1 = wc.M1(k), m2 = wc.M2(k), b = ~m1 & m2, t2 = v & ~m1 & ~m2;
+		n += __popcll(t2);
+		mis += __popcll(t2 & ~wc.EQ(k));
+		uint64_t chg = ((m1 ^ ((m1 << 1) | c1)) | (b ^ ((b << 1) | cb))) & v;
+		if (k == 0) chg |= 1;                                            // (the first column always opens a run)
+		runs += __popcll(chg);
+		c1 = m1 >> 63; cb = b >> 63;
+	}
+	return !(runs >= 4 || (mis >= 3 && mis >= (int)(n * 0.3)));
+}
+
+// columns from `start` on whose bit is set in the set whose tile this lane holds in `mine`
+__device__ int wave_lead_run(const WaveCols &wc, uint64_t mine, int start)
+{
+	int c = start;
+	while (c < wc.len) {
+		const int k = c >> 6, bit = c & 63;
+		const uint64_t x = ~((uint64_t)rl64((int64_t)mine, k) & wc.valid(k)) & ~bits_below(bit);
+		if (x) { c = k * 64 + (int)__builtin_ctzll(x); break; }
+		c = (k + 1) * 64;
+	}
+	if (c > wc.len) c = wc.len;
+	return c - start;
+}
+// ... and the columns in front of `end`, backwards
+__device__ int wave_trail_run(const WaveCols &wc, uint64_t mine, int end)
+{
+	int c = end;
+	while (c > 0) {
+		const int k = (c - 1) >> 6, bit = (c - 1) & 63;
+		const uint64_t x = ~((uint64_t)rl64((int64_t)mine, k) & wc.valid(k)) & bits_below(bit + 1);
+		if (x) { c = k * 64 + 64 - (int)__builtin_clzll(x); break; }
+		c = k * 64;
+	}
+	return end - c;
+}
+
+// finish_candidate for the candidate of spill slot t, by the wave (every lane of it is here)
+__device__ void finish_candidate_wave(const AlnArgs &a, unsigned long long t, int lane)
+{
+	const AlnSpill &sp = a.spill[t];
+	const int64_t cand = (int64_t)uni(sp.cand);
+	const int64_t r = (int64_t)uni((int)a.c_read[cand]);
+	if (uni((int)a.r_host[r])) return;
+	const int ck = uni(chunk_of(a, r));
+	const bool first = uni((int)a.chunk_paired[ck]) ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
+	const int num = uni(sp.num);
+	const uint8_t *rd = a.enc + a.read_off[r];
+	// pair j in lane j
+	int64_t gPos = 0;
+	int rPos = 0, rLen = 0, gLen = 0, val = 0, op_len = 0, kind = W_NONE, op = 0;
+	if (lane < num) {
+		const AlnSpillPair q = sp.p[lane];
+		gPos = q.gPos; rPos = q.rPos; rLen = q.rLen; gLen = q.gLen; val = q.val; op_len = q.op_len; kind = q.kind; op = q.op;
+	}
+	WaveCigar cig;
+	cig.my_len = 0; cig.my_op = 0; cig.n = 0; cig.overflow = false;
+	int score = 0;
+	for (int j = 0; j < num; ++j) {
+		const int kj = rl32(kind, j);
+		if (kj == W_NONE) continue;
+		const int rLj = rl32(rLen, j);
+		if (kj == W_SIMPLE) {
+			cig.push(rLj, 'M', lane);
+			score += rLj;
+			continue;
+		}
+		const bool head = j == 0, tail = j == num - 1 && !head;
+		int s;
+		if (kj == W_IMMEDIATE) {
+			const int oj = rl32(op, j);
+			if (oj != 0) cig.push(rl32(op_len, j), (char)oj, lane);
+			s = rl32(val, j);
+		} else {
+			const int vj = rl32(val, j);
+			const uint8_t *ops;
+			int len;
+			if (kj == W_INLINE) {
+				ops = reinterpret_cast<const uint8_t *>(a.rep_cigar + cand * KG_ALN_CIGAR_MAX) + 16 * (vj & 255);
+				len = vj >> 8;
+			} else if (kj == W_JOB) {
+				ops = a.nw_ops + uni64(a.jobs[vj].ops);
+				len = uni(a.nw_len[vj]);
+			} else {
+				// the partitioned fragment: literal runs and the sub-fragments' op strings laid one behind the other (src/tools.cpp:165-208), 64 bytes per step
+				const AlnPlan pl = a.plans[vj];
+				uint8_t *out = a.nw_ops + uni64(pl.ops);
+				const int first_piece = uni(pl.first), n_pieces = uni(pl.count);
+				int at = 0;
+				for (int k = 0; k < n_pieces; ++k) {
+					const AlnPiece pc = a.pieces[first_piece + k];
+					const int pk = uni((int)pc.kind), pv = uni(pc.v);
+					if (pk <= KG_OP_GAP2) {
+						for (int i = lane; i < pv; i += 64) out[at + i] = (uint8_t)pk;
+						at += pv > 0 ? pv : 0;
+					} else {
+						const uint8_t *src = a.nw_ops + uni64(a.jobs[pv].ops);
+						const int L = uni(a.nw_len[pv]);
+						for (int i = lane; i < L; i += 64) out[at + i] = src[i];
+						at += L > 0 ? L : 0;
+					}
+				}
+				wave_sync_mem();
+				ops = out;
+				len = at;
+			}
+			WaveCols wc;
+			wave_columns(a, ops, len, rd + rl32(rPos, j), rl64(gPos, j), lane, wc);
+			if (head) {
+				// ProcessHeadSequencePair after the alignment, src/tools.cpp:314-339
+				if (!wave_quality_ok(wc)) { cig.push(rLj, 'S', lane); s = 0; }
+				else {
+					const int p = wave_lead_run(wc, wc.m1, 0);
+					const int p2 = wave_lead_run(wc, wc.m2, p);
+					if (lane == j) {
+						if (p > 0) { gPos += p; gLen -= p; }
+						if (p2 > 0) { rPos += p2; rLen -= p2; }
+					}
+					if (p2 > 0) cig.push(p2, 'S', lane);
+					s = wave_add_cigar(wc, p + p2, len, lane, cig);
+				}
+			} else if (tail) {
+				// ProcessTailSequencePair after the alignment, src/tools.cpp:366-394
+				if (!wave_quality_ok(wc)) { cig.push(rLj, 'S', lane); s = 0; }
+				else {
+					const int cnt = wave_trail_run(wc, wc.m1, len);
+					const int cnt2 = wave_trail_run(wc, wc.m2, len - cnt);
+					if (lane == j) {
+						if (cnt > 0) gLen -= cnt;
+						if (cnt2 > 0) rLen -= cnt2;
+					}
+					s = wave_add_cigar(wc, 0, len - cnt - cnt2, lane, cig);
+					if (cnt2 > 0) cig.push(cnt2, 'S', lane);
+				}
+			} else s = wave_add_cigar(wc, 0, len, lane, cig);
+		}
+		if (head) {
+			if (s > 0) score += s;
+			if (s <= 0) { const int64_t g1 = rl64(gPos, 1); if (lane == 0) { gPos = g1; gLen = 0; } }         // :674-686
+		} else if (tail) {
+			if (s > 0) score += s;
+			if (s <= 0) { const int64_t gp = rl64(gPos, j - 1) + rl32(gLen, j - 1); if (lane == j) { gPos = gp; gLen = 0; } }
+		} else score += s;
+	}
+	if (cig.overflow) { if (lane == 0) flag_host(a, r, WHY_CIGAR); return; }
+	int rep_chr = 0, rep_fwd = 1, rep_len = 0;
+	int64_t rep_pos = 0;
+	bool scored = true;                                                     // false: "continue" before the best / second-best step (c_score -1)
+	bool fits = true;
+	if (cig.n > 1) {                                                       // GapPenalty, :612-622, :701-706
+		const int gp = wave_sum(lane < cig.n && (cig.my_op == 'I' || cig.my_op == 'D') ? cig.my_len : 0);
+		score -= gp;
+		if (score <= 0) { score = 0; scored = false; }
+	}
+	if (scored) {
+		if (cig.n == 0) score = 0;
+		else {
+			// GenCoordinateInfo, :515-562
+			const int64_t gPos0 = rl64(gPos, 0), end_gPos = rl64(gPos, num - 1) + rl32(gLen, num - 1) - 1;
+			bool fwd, rev = false;
+			int chr;
+			int64_t pos;
+			if (gPos0 < a.genome_size) {
+				fwd = first;
+				if (a.n_chr == 1) { chr = 0; pos = gPos0 + 1; }
+				else {
+					const int it = uni(end_lower_bound(a, gPos0));
+					chr = uni(a.end_chr[it]);
+					pos = gPos0 + 1 - a.chr_fwd_start[chr];
+				}
+			} else {
+				fwd = !first;
+				rev = true;
+				if (a.n_chr == 1) { chr = 0; pos = a.two_genome_size - end_gPos; }
+				else {
+					int it = uni(end_lower_bound(a, gPos0));
+					if (it == a.n_ends) it = a.n_ends - 1;
+					pos = a.contig_end[it] - end_gPos + 1;
+					chr = uni(a.end_chr[it]);
+				}
+			}
+			// GenerateCIGAR, :492-513 (the reverse strand shows the elements in reverse order)
+			char *out = a.rep_cigar + cand * KG_ALN_CIGAR_MAX;
+			int at = 0, cnt = 0, state = 0;
+			auto emit = [&](int nn, int st) {
+				int nd = 1;
+				for (int x = nn; x >= 10; x /= 10) nd++;
+				if (at + nd + 1 > KG_ALN_CIGAR_MAX - 1) { fits = false; return; }
+				for (int d = nd - 1; d >= 0; --d) { if (lane == 0) out[at + d] = (char)('0' + nn % 10); nn /= 10; }
+				if (lane == 0) out[at + nd] = (char)st;
+				at += nd + 1;
+			};
+			for (int q = 0; q < cig.n; ++q) {
+				const int i = rev ? cig.n - 1 - q : q;
+				const int l = rl32(cig.my_len, i), o = rl32(cig.my_op, i);
+				if (o != state) {
+					if (cnt > 0) emit(cnt, state);
+					cnt = l;
+					state = o;
+				} else cnt += l;
+			}
+			if (cnt > 0) emit(cnt, state);
+			if (fits) {
+				rep_len = at; rep_chr = chr; rep_pos = pos; rep_fwd = fwd ? 1 : 0;
+				if (pos <= 0) score = 0;
+			}
+		}
+	}
+	if (lane == 0) {
+		if (!fits) {
+			// (the lane form leaves the candidate's report fields zeroed and hands the read to the host)
+			a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
+			flag_host(a, r, WHY_CIGAR);
+		} else {
+			a.rep_chr[cand] = rep_chr;
+			a.rep_pos[cand] = rep_pos;
+			a.rep_fwd[cand] = (uint8_t)rep_fwd;
+			a.rep_cigar_len[cand] = (uint8_t)rep_len;
+			a.rep_score[cand] = score;
+			if (!scored) a.c_score[cand] = -1;
+		}
+	}
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void aln_finish_wave_kernel(AlnArgs a)
+{
+	unsigned long long n = a.ctl[0];
+	if (n > (unsigned long long)a.spill_capacity) n = (unsigned long long)a.spill_capacity;
+	const int lane = threadIdx.x & 63;
+	const unsigned long long n_waves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+	for (unsigned long long t = (unsigned long long)uni((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))); t < n; t += n_waves) finish_candidate_wave(a, t, lane);
+}
+
 // ---- per read: best / second best, final pair check, flags, MAPQ, records ----------------------------------------------------
 namespace {
 
@@ -2784,7 +3132,8 @@ hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 hipError_t launch_align_back(const AlnArgs &a, int n_cu, hipStream_t stream)
 {
 	kt_begin(KT_ALN_FINISH, stream);
-	hipLaunchKernelGGL(aln_finish_kernel, dim3(grid_for_aln(a.spill_capacity, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	if (a.dbg_finish_lanes) hipLaunchKernelGGL(aln_finish_kernel, dim3(grid_for_aln(a.spill_capacity, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	else hipLaunchKernelGGL(aln_finish_wave_kernel, dim3(n_cu * 8), dim3(256), 0, stream, a);
 	kt_end(KT_ALN_FINISH, stream);
 	kt_begin(KT_ALN_FINAL, stream);
 	hipLaunchKernelGGL(aln_final_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
