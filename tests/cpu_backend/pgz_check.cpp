@@ -10,6 +10,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <atomic>
