@@ -716,7 +716,10 @@ def run(args, fallback_note):
             pass
     if world == 1 and large and not args.no_other_configs:
         try:
-            line["other_configs"] = other_configs(args, sess, prefix, workdir, codes, dev, threads, cores, host_memory())
+            if os.environ.get("KART_BENCH_ONLY_GZ_LEG"):             # (an experiment's short cut: the gz leg alone)
+                line["other_configs"] = {"gz_input": gz_leg(sess, workdir, codes, dev, threads, cores, (host_memory().get("usable") or (64 << 30)) * MEM_SHARE)}
+            else:
+                line["other_configs"] = other_configs(args, sess, prefix, workdir, codes, dev, threads, cores, host_memory())
         except Exception as exc:      # a side measurement must never cost the line
             line["other_configs"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     sess.close()
@@ -918,6 +921,53 @@ def seeding_leg(args, api, prefix, codes, dev, n_reads_leg, oracle_sample):
     return out
 
 
+def gz_leg(sess, workdir, codes, dev, threads, cores, budget):
+    """the same reads as plain files, as ordinary gzip files through the several-thread reader, and through one gzread() stream per file"""
+    import hashlib
+    from benchkit.gz import gzip_one_member
+    n_gz = int(max(100_000, min(int(os.environ.get("KART_BENCH_GZ_PAIRS", "4000000")), budget // (4 * REC_BYTES + 2 * 500))))
+    f1, f2 = os.path.join(workdir, "gz_1.fq"), os.path.join(workdir, "gz_2.fq")
+    write_fastq_pairs(codes, n_gz, 43, f1, f2, dev, err=0.01)
+    t0 = time.perf_counter()
+    sizes = [gzip_one_member(f, f + ".gz", 6, max(1, cores)) for f in (f1, f2)]
+    t_pack = time.perf_counter() - t0
+    sam = os.path.join(workdir, "gz.sam")
+
+    def one(files, env):
+        for k_, v_ in env.items():
+            os.environ[k_] = v_
+        try:
+            if os.path.exists(sam):
+                os.remove(sam)
+            st_ = sess.map(["-silent", "-f", files[0], "-f2", files[1], "-o", sam])
+        finally:
+            for k_ in env:
+                del os.environ[k_]
+        h = hashlib.sha256()
+        with open(sam, "rb") as fh:
+            for blk in iter(lambda: fh.read(64 << 20), b""):
+                h.update(blk)
+        return (st_.total_reads - st_.unmapped) / st_.map_seconds, round(st_.map_seconds, 3), h.hexdigest()
+
+    plain = one((f1, f2), {})
+    gz = (f1 + ".gz", f2 + ".gz")
+    one(gz, {})                                              # (warm-up: the general path's buffers)
+    par = one(gz, {})
+    ser = one(gz, {"KART_AMD_NO_PGZ": "1"})
+    result = {"workload": "%d x 150 bp paired-end reads (wgsim model -e 0.01) as two ordinary single-member gzip files (level 6, %.2f GB of text in %.2f GB; "
+                                   "written by benchkit/gz.py in %.1f s), hg38-sized index" % (2 * n_gz, sum(x[0] for x in sizes) / 1e9, sum(x[1] for x in sizes) / 1e9, t_pack),
+                       "value": par[0], "unit": "mapped reads/s", "map_seconds": par[1],
+                       "one_gzread_stream_per_file": {"value": ser[0], "map_seconds": ser[1], "what": "KART_AMD_NO_PGZ=1: the reference's way (gzgets(), src/GetData.cpp:145-219) and this repository's until round 5"},
+                       "plain_files": {"value": plain[0], "map_seconds": plain[1]},
+                       "same_sam_bytes_all_three": bool(plain[2] == par[2] == ser[2]), "threads": threads,
+                       "what": "host/detail/pgzip.inc: block starts found by search, the unknown 32 KB in front of each chunk carried as symbols and resolved in order, "
+                               "CRC-32 of the pieces combined and held against the trailer; the text then takes the host reader's path (line index, views) -- not the device's FASTQ parser"}
+    for f in (f1, f2, gz[0], gz[1], sam):
+        if os.path.exists(f):
+            os.remove(f)
+    return result
+
+
 def other_configs(args, sess, prefix, workdir, codes, dev, threads, cores, mem):
     """configs[4] (-m, 2.1 % error) and configs[3] (-pacbio, 7 kb reads at 15 % error) through the same session, one run each, with
     SAM identity against the reference's -t 1 on a prefix (for -m: up to the FLAGs the reference never assigns, App. B-12)."""
@@ -988,50 +1038,8 @@ def other_configs(args, sess, prefix, workdir, codes, dev, threads, cores, mem):
     for f in (f1, f2):
         os.remove(f)
 
-    # ---- gz input: the same reads as plain files, as ordinary gzip files through the several-thread reader, and through one gzread() stream per file ----
     if not os.environ.get("KART_BENCH_NO_GZ_LEG"):
-        import hashlib
-        from benchkit.gz import gzip_one_member
-        n_gz = int(max(100_000, min(int(os.environ.get("KART_BENCH_GZ_PAIRS", "4000000")), budget // (4 * REC_BYTES + 2 * 500))))
-        f1, f2 = os.path.join(workdir, "gz_1.fq"), os.path.join(workdir, "gz_2.fq")
-        write_fastq_pairs(codes, n_gz, 43, f1, f2, dev, err=0.01)
-        t0 = time.perf_counter()
-        sizes = [gzip_one_member(f, f + ".gz", 6, max(1, cores)) for f in (f1, f2)]
-        t_pack = time.perf_counter() - t0
-        sam = os.path.join(workdir, "gz.sam")
-
-        def one(files, env):
-            for k_, v_ in env.items():
-                os.environ[k_] = v_
-            try:
-                if os.path.exists(sam):
-                    os.remove(sam)
-                st_ = sess.map(["-silent", "-f", files[0], "-f2", files[1], "-o", sam])
-            finally:
-                for k_ in env:
-                    del os.environ[k_]
-            h = hashlib.sha256()
-            with open(sam, "rb") as fh:
-                for blk in iter(lambda: fh.read(64 << 20), b""):
-                    h.update(blk)
-            return (st_.total_reads - st_.unmapped) / st_.map_seconds, round(st_.map_seconds, 3), h.hexdigest()
-
-        plain = one((f1, f2), {})
-        gz = (f1 + ".gz", f2 + ".gz")
-        one(gz, {})                                              # (warm-up: the general path's buffers)
-        par = one(gz, {})
-        ser = one(gz, {"KART_AMD_NO_PGZ": "1"})
-        out["gz_input"] = {"workload": "%d x 150 bp paired-end reads (wgsim model -e 0.01) as two ordinary single-member gzip files (level 6, %.2f GB of text in %.2f GB; "
-                                       "written by benchkit/gz.py in %.1f s), hg38-sized index" % (2 * n_gz, sum(x[0] for x in sizes) / 1e9, sum(x[1] for x in sizes) / 1e9, t_pack),
-                           "value": par[0], "unit": "mapped reads/s", "map_seconds": par[1],
-                           "one_gzread_stream_per_file": {"value": ser[0], "map_seconds": ser[1], "what": "KART_AMD_NO_PGZ=1: the reference's way (gzgets(), src/GetData.cpp:145-219) and this repository's until round 5"},
-                           "plain_files": {"value": plain[0], "map_seconds": plain[1]},
-                           "same_sam_bytes_all_three": bool(plain[2] == par[2] == ser[2]), "threads": threads,
-                           "what": "host/detail/pgzip.inc: block starts found by search, the unknown 32 KB in front of each chunk carried as symbols and resolved in order, "
-                                   "CRC-32 of the pieces combined and held against the trailer; the text then takes the host reader's path (line index, views) -- not the device's FASTQ parser"}
-        for f in (f1, f2, gz[0], gz[1], sam):
-            if os.path.exists(f):
-                os.remove(f)
+        out["gz_input"] = gz_leg(sess, workdir, codes, dev, threads, cores, budget)
 
     # ---- configs[3]: -pacbio -------------------------------------------------------------------------------------------
     read_len = 7000
