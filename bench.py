@@ -953,15 +953,18 @@ def gz_leg(sess, workdir, codes, dev, threads, cores, budget):
     gz = (f1 + ".gz", f2 + ".gz")
     one(gz, {})                                              # (warm-up: the general path's buffers)
     par = one(gz, {})
-    ser = one(gz, {"KART_AMD_NO_PGZ": "1"})
+    ser = one(gz, {"KART_AMD_NO_PGZ": "1", "KART_AMD_NO_GZ_STREAM": "1"})
+    host = one(gz, {"KART_AMD_NO_GZ_STREAM": "1"})
     result = {"workload": "%d x 150 bp paired-end reads (wgsim model -e 0.01) as two ordinary single-member gzip files (level 6, %.2f GB of text in %.2f GB; "
                                    "written by benchkit/gz.py in %.1f s), hg38-sized index" % (2 * n_gz, sum(x[0] for x in sizes) / 1e9, sum(x[1] for x in sizes) / 1e9, t_pack),
                        "value": par[0], "unit": "mapped reads/s", "map_seconds": par[1],
-                       "one_gzread_stream_per_file": {"value": ser[0], "map_seconds": ser[1], "what": "KART_AMD_NO_PGZ=1: the reference's way (gzgets(), src/GetData.cpp:145-219) and this repository's until round 5"},
+                       "one_gzread_stream_per_file": {"value": ser[0], "map_seconds": ser[1], "what": "KART_AMD_NO_PGZ=1 KART_AMD_NO_GZ_STREAM=1: the reference's way (gzgets(), src/GetData.cpp:145-219) and this repository's until round 5"},
+                       "several_threads_into_the_hosts_gz_reader": {"value": host[0], "map_seconds": host[1], "what": "KART_AMD_NO_GZ_STREAM=1: inflated by several threads, then line index and views on the host"},
                        "plain_files": {"value": plain[0], "map_seconds": plain[1]},
-                       "same_sam_bytes_all_three": bool(plain[2] == par[2] == ser[2]), "threads": threads,
+                       "same_sam_bytes_all_four": bool(plain[2] == par[2] == ser[2] == host[2]), "threads": threads,
                        "what": "host/detail/pgzip.inc: block starts found by search, the unknown 32 KB in front of each chunk carried as symbols and resolved in order, "
-                               "CRC-32 of the pieces combined and held against the trailer; the text then takes the host reader's path (line index, views) -- not the device's FASTQ parser"}
+                               "CRC-32 of the pieces combined and held against the trailer; a thread per file writes the text into a growing block that the device's "
+                               "FASTQ-in / SAM-out stream reads like a mapped plain file (GzProducer, host/detail/batch_reader.inc)"}
     for f in (f1, f2, gz[0], gz[1], sam):
         if os.path.exists(f):
             os.remove(f)

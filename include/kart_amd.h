@@ -357,6 +357,10 @@ typedef struct {
 	int32_t two_files;           /* -f / -f2: read 2q comes from file 0, read 2q+1 from file 1; else every read from file 0 */
 	int32_t paired;              /* the second read of every pair is held reverse-complemented, qualities reversed (src/GetData.cpp:125-135) */
 	int32_t chunk_reads;         /* ReadChunkSize (src/structure.h:21): 4000 */
+	int32_t gz_lines;            /* != 0: the text was inflated from a gz file, which the reference reads through gzgets() with a 1000-byte buffer
+	                                (src/GetData.cpp:145-219): a record with a line of more than 999 bytes (its newline included), or whose header line
+	                                does not start with '@' / '>' or names nothing (:162), is read differently there -- it ends the batch
+	                                (KG_STREAM_STOP_IRREGULAR) and the caller's gz reader continues in front of it */
 	int64_t want_reads;          /* take at most this many reads (a multiple of chunk_reads, <= max_reads) */
 } kg_stream_window;
 #define KG_STREAM_STOP_NONE      0

@@ -105,7 +105,7 @@ class StreamConfig(C.Structure):
 
 class StreamWindow(C.Structure):
     _fields_ = [("begin", C.c_int64 * 2), ("end", C.c_int64 * 2), ("eof", C.c_int32 * 2), ("two_files", C.c_int32), ("paired", C.c_int32),
-                ("chunk_reads", C.c_int32), ("want_reads", C.c_int64)]
+                ("chunk_reads", C.c_int32), ("gz_lines", C.c_int32), ("want_reads", C.c_int64)]
 
 
 class StreamParsed(C.Structure):

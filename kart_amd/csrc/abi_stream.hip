@@ -344,6 +344,7 @@ int kg_stream_parse(kg_stream *s, int lane, const kg_stream_window *w, kg_stream
 	a.two_files = w->two_files ? 1 : 0;
 	a.paired = w->paired ? 1 : 0;
 	a.chunk_reads = w->chunk_reads;
+	a.gz_lines = w->gz_lines ? 1 : 0;
 	a.max_reads = s->cfg.max_reads;
 	a.want_reads = w->want_reads;
 	a.meta = l.d_meta;

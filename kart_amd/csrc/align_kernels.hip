@@ -2697,6 +2697,343 @@ __global__ __launch_bounds__(256) void aln_finish_wave_kernel(AlnArgs a)
 	for (unsigned long long t = (unsigned long long)uni((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))); t < n; t += n_waves) finish_candidate_wave(a, t, lane);
 }
 
+// ---- pass 2 by groups of sixteen lanes ---------------------------------------------------------------------------------------------
+// A candidate per wave (above) spends a whole wave's issue slot on every instruction of what is mostly bit arithmetic common to the wave:
+// ~1700 instructions per candidate, 150 k candidates per launch, 0.48 ms -- bound by instruction issue.  Here sixteen lanes take a candidate,
+// four candidates share a wave's instructions: the same scheme on tiles of sixteen columns, with the candidate's normal pairs, CIGAR elements
+// and column sets in the LDS (1 KB per group).  The groups of a wave run apart where their candidates differ (different numbers of pairs,
+// different kinds of pairs); every ballot and shuffle stays inside one group, whose lanes always run together.
+namespace {
+
+constexpr int kFinG = 16;                                  // lanes per candidate
+constexpr int kFinGroups = 256 / kFinG;                    // ... per block
+constexpr int kFinTiles = (2 * kAlnMaxFrag + kFinG - 1) / kFinG;
+struct FinShared {
+	AlnSpillPair p[kAlnMaxPairs];
+	int32_t cig_len[kAlnMaxCigar];
+	uint8_t cig_op[kAlnMaxCigar + 4];
+	uint16_t m1[kFinTiles], m2[kFinTiles], eq[kFinTiles];
+};
+
+struct Fin {
+	FinShared *sh;
+	int gl, gb;            // lane in the group, the group's first lane in the wave
+	int len;               // columns of the alignment at hand
+	int cig_n;
+	bool cig_overflow;
+	__device__ __forceinline__ uint32_t ballot(bool p) const { return (uint32_t)((__ballot(p) >> gb) & ((1ull << kFinG) - 1)); }
+	static __device__ __forceinline__ uint32_t below(int n) { return n >= kFinG ? ((1u << kFinG) - 1) : n <= 0 ? 0u : ((1u << n) - 1); }
+	__device__ __forceinline__ uint32_t valid(int k) const { return below(len - kFinG * k); }
+	__device__ __forceinline__ uint32_t M1(int k) const { return (uint32_t)sh->m1[k]; }
+	__device__ __forceinline__ uint32_t M2(int k) const { return (uint32_t)sh->m2[k]; }
+	__device__ __forceinline__ uint32_t EQ(int k) const { return (uint32_t)sh->eq[k]; }
+	__device__ __forceinline__ void push(int l, char o)
+	{
+		if (cig_n < kAlnMaxCigar) { if (gl == 0) { sh->cig_len[cig_n] = l; sh->cig_op[cig_n] = (uint8_t)o; } cig_n++; }
+		else cig_overflow = true;
+	}
+	// the columns of the alignment as bit sets, a tile of kFinG columns per entry (wave_columns)
+	__device__ __forceinline__ void columns(const AlnArgs &a, const uint8_t *ops, int n_cols, const uint8_t *rd, int64_t g)
+	{
+		len = n_cols;
+		int ri = 0, gi = 0;
+		const uint32_t lt = below(gl);
+		for (int k = 0; k * kFinG < n_cols; ++k) {
+			const int col = k * kFinG + gl;
+			const bool ok = col < n_cols;
+			const uint8_t op = ok ? ops[col] : (uint8_t)KG_OP_DIAG;
+			const bool n1 = ok && op != KG_OP_GAP1, n2 = ok && op != KG_OP_GAP2;
+			const uint32_t b1 = ballot(n1), b2 = ballot(n2);
+			char c1 = '-', c2 = '-';
+			if (n1) c1 = (char)rd[ri + __popc(b1 & lt)];
+			if (n2) c2 = text_char(a, g + gi + __popc(b2 & lt));
+			const uint32_t m1 = ballot(ok && c1 == '-'), m2 = ballot(ok && c2 == '-'), eq = ballot(ok && c1 == c2);
+			if (gl == 0) { sh->m1[k] = (uint16_t)m1; sh->m2[k] = (uint16_t)m2; sh->eq[k] = (uint16_t)eq; }
+			ri += __popc(b1); gi += __popc(b2);
+		}
+	}
+	// AddNewCigarElements over columns [from, to), src/tools.cpp:49-104 (wave_add_cigar)
+	__device__ int add_cigar(int from, int to)
+	{
+		constexpr uint32_t all = (1u << kFinG) - 1;
+		int score = 0;
+		for (int k = from / kFinG; k * kFinG < to; ++k) {
+			const uint32_t range = ~below(from - kFinG * k) & below(to - kFinG * k);
+			score += __popc(EQ(k) & ~M1(k) & ~M2(k) & range);
+		}
+		char state = '*';
+		int cnt = 0, col = from;
+		while (col < to) {
+			int k = col / kFinG;
+			const int bit = col - k * kFinG;
+			uint32_t m1 = M1(k), b = ~m1 & M2(k);
+			const bool cur1 = ((m1 >> bit) & 1) != 0, curb = ((b >> bit) & 1) != 0;
+			const char st = cur1 ? 'D' : curb ? 'I' : 'M';
+			const uint32_t f1 = cur1 ? all : 0u, fb = curb ? all : 0u;
+			uint32_t x = ((m1 ^ f1) | (b ^ fb)) & ~below(bit + 1) & all;
+			int end = to;
+			for (;;) {
+				if (x) { end = k * kFinG + (__ffs((int)x) - 1); break; }
+				++k;
+				if (k * kFinG >= to) break;
+				m1 = M1(k); b = ~m1 & M2(k);
+				x = ((m1 ^ f1) | (b ^ fb)) & all;
+			}
+			if (end > to) end = to;
+			const int run = end - col;
+			if (st == state) cnt += run;
+			else {
+				if (cnt > 0) push(cnt, state);
+				cnt = run;
+				state = st;
+			}
+			col = end;
+		}
+		if (cnt > 0) push(cnt, state);
+		return score;
+	}
+	// CheckLocalAlignmentQuality, src/tools.cpp:255-290
+	__device__ bool quality_ok() const
+	{
+		int n = 0, mis = 0, runs = 0;
+		uint32_t c1 = 0, cb = 0;
+		for (int k = 0; k * kFinG < len; ++k) {
+			const uint32_t v = valid(k), m1 = M1(k), m2 = M2(k), b = ~m1 & m2, t2 = v & ~m1 & ~m2;
+			n += __popc(t2);
+			mis += __popc(t2 & ~EQ(k));
+			uint32_t chg = ((m1 ^ ((m1 << 1) | c1)) | (b ^ ((b << 1) | cb))) & v;
+			if (k == 0) chg |= 1;
+			runs += __popc(chg);
+			c1 = (m1 >> (kFinG - 1)) & 1; cb = (b >> (kFinG - 1)) & 1;
+		}
+		return !(runs >= 4 || (mis >= 3 && mis >= (int)(n * 0.3)));
+	}
+	__device__ int lead_run(const uint16_t *set, int start) const
+	{
+		constexpr uint32_t all = (1u << kFinG) - 1;
+		int c = start;
+		while (c < len) {
+			const int k = c / kFinG, bit = c - k * kFinG;
+			const uint32_t x = ~((uint32_t)set[k] & valid(k)) & ~below(bit) & all;
+			if (x) { c = k * kFinG + (__ffs((int)x) - 1); break; }
+			c = (k + 1) * kFinG;
+		}
+		if (c > len) c = len;
+		return c - start;
+	}
+	__device__ int trail_run(const uint16_t *set, int end) const
+	{
+		int c = end;
+		while (c > 0) {
+			const int k = (c - 1) / kFinG, bit = (c - 1) - k * kFinG;
+			const uint32_t x = ~((uint32_t)set[k] & valid(k)) & below(bit + 1);
+			if (x) { c = k * kFinG + 32 - __clz((int)x); break; }
+			c = k * kFinG;
+		}
+		return end - c;
+	}
+};
+
+// finish_candidate for the candidate of spill slot t, by a group of kFinG lanes (all of them here)
+__device__ void finish_candidate_group(const AlnArgs &a, unsigned long long t, Fin &fi)
+{
+	const AlnSpill &sp = a.spill[t];
+	const int64_t cand = sp.cand;
+	const int64_t r = a.c_read[cand];
+	if (a.r_host[r]) return;
+	const int ck = chunk_of(a, r);
+	const bool first = a.chunk_paired[ck] ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
+	const int num = sp.num;
+	const uint8_t *rd = a.enc + a.read_off[r];
+	FinShared *sh = fi.sh;
+	const int gl = fi.gl;
+	{
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(sp.p);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(sh->p);
+		const int words = num * (int)(sizeof(AlnSpillPair) / 4);
+		for (int i = gl; i < words; i += kFinG) dst[i] = src[i];
+	}
+	fi.cig_n = 0; fi.cig_overflow = false;
+	int score = 0;
+	for (int j = 0; j < num; ++j) {
+		const int kj = sh->p[j].kind;
+		if (kj == W_NONE) continue;
+		const int rLj = sh->p[j].rLen;
+		if (kj == W_SIMPLE) {
+			fi.push(rLj, 'M');
+			score += rLj;
+			continue;
+		}
+		const bool head = j == 0, tail = j == num - 1 && !head;
+		int s;
+		if (kj == W_IMMEDIATE) {
+			const int oj = sh->p[j].op;
+			if (oj != 0) fi.push(sh->p[j].op_len, (char)oj);
+			s = sh->p[j].val;
+		} else {
+			const int vj = sh->p[j].val;
+			const uint8_t *ops;
+			int len;
+			if (kj == W_INLINE) {
+				ops = reinterpret_cast<const uint8_t *>(a.rep_cigar + cand * KG_ALN_CIGAR_MAX) + 16 * (vj & 255);
+				len = vj >> 8;
+			} else if (kj == W_JOB) {
+				ops = a.nw_ops + a.jobs[vj].ops;
+				len = a.nw_len[vj];
+			} else {
+				// the partitioned fragment: literal runs and the sub-fragments' op strings laid one behind the other (src/tools.cpp:165-208)
+				const AlnPlan pl = a.plans[vj];
+				uint8_t *out = a.nw_ops + pl.ops;
+				int at = 0;
+				for (int k = 0; k < pl.count; ++k) {
+					const AlnPiece pc = a.pieces[pl.first + k];
+					if (pc.kind <= KG_OP_GAP2) {
+						for (int i = gl; i < pc.v; i += kFinG) out[at + i] = pc.kind;
+						at += pc.v > 0 ? pc.v : 0;
+					} else {
+						const uint8_t *src = a.nw_ops + a.jobs[pc.v].ops;
+						const int L = a.nw_len[pc.v];
+						for (int i = gl; i < L; i += kFinG) out[at + i] = src[i];
+						at += L > 0 ? L : 0;
+					}
+				}
+				wave_sync_mem();
+				ops = out;
+				len = at;
+			}
+			fi.columns(a, ops, len, rd + sh->p[j].rPos, sh->p[j].gPos);
+			if (head) {
+				// ProcessHeadSequencePair after the alignment, src/tools.cpp:314-339
+				if (!fi.quality_ok()) { fi.push(rLj, 'S'); s = 0; }
+				else {
+					const int p = fi.lead_run(sh->m1, 0);
+					const int p2 = fi.lead_run(sh->m2, p);
+					if (gl == 0) {
+						if (p > 0) { sh->p[j].gPos += p; sh->p[j].gLen = (int16_t)(sh->p[j].gLen - p); }
+						if (p2 > 0) { sh->p[j].rPos += p2; sh->p[j].rLen = (int16_t)(sh->p[j].rLen - p2); }
+					}
+					if (p2 > 0) fi.push(p2, 'S');
+					s = fi.add_cigar(p + p2, len);
+				}
+			} else if (tail) {
+				// ProcessTailSequencePair after the alignment, src/tools.cpp:366-394
+				if (!fi.quality_ok()) { fi.push(rLj, 'S'); s = 0; }
+				else {
+					const int cnt = fi.trail_run(sh->m1, len);
+					const int cnt2 = fi.trail_run(sh->m2, len - cnt);
+					if (gl == 0) {
+						if (cnt > 0) sh->p[j].gLen = (int16_t)(sh->p[j].gLen - cnt);
+						if (cnt2 > 0) sh->p[j].rLen = (int16_t)(sh->p[j].rLen - cnt2);
+					}
+					s = fi.add_cigar(0, len - cnt - cnt2);
+					if (cnt2 > 0) fi.push(cnt2, 'S');
+				}
+			} else s = fi.add_cigar(0, len);
+		}
+		if (head) {
+			if (s > 0) score += s;
+			if (s <= 0) { const int64_t g1 = sh->p[1].gPos; if (gl == 0) { sh->p[0].gPos = g1; sh->p[0].gLen = 0; } }         // :674-686
+		} else if (tail) {
+			if (s > 0) score += s;
+			if (s <= 0) { const int64_t gp = sh->p[j - 1].gPos + sh->p[j - 1].gLen; if (gl == 0) { sh->p[j].gPos = gp; sh->p[j].gLen = 0; } }
+		} else score += s;
+	}
+	if (fi.cig_overflow) { if (gl == 0) flag_host(a, r, WHY_CIGAR); return; }
+	int rep_chr = 0, rep_fwd = 1, rep_len = 0;
+	int64_t rep_pos = 0;
+	bool scored = true, fits = true;
+	const int cn = fi.cig_n;
+	if (cn > 1) {                                                          // GapPenalty, :612-622, :701-706
+		int gp = 0;
+		for (int i = 0; i < cn; ++i) { const int o = sh->cig_op[i]; if (o == 'I' || o == 'D') gp += sh->cig_len[i]; }
+		score -= gp;
+		if (score <= 0) { score = 0; scored = false; }
+	}
+	if (scored) {
+		if (cn == 0) score = 0;
+		else {
+			// GenCoordinateInfo, :515-562
+			const int64_t gPos0 = sh->p[0].gPos, end_gPos = sh->p[num - 1].gPos + sh->p[num - 1].gLen - 1;
+			bool fwd, rev = false;
+			int chr;
+			int64_t pos;
+			if (gPos0 < a.genome_size) {
+				fwd = first;
+				if (a.n_chr == 1) { chr = 0; pos = gPos0 + 1; }
+				else {
+					const int it = end_lower_bound(a, gPos0);
+					chr = a.end_chr[it];
+					pos = gPos0 + 1 - a.chr_fwd_start[chr];
+				}
+			} else {
+				fwd = !first;
+				rev = true;
+				if (a.n_chr == 1) { chr = 0; pos = a.two_genome_size - end_gPos; }
+				else {
+					int it = end_lower_bound(a, gPos0);
+					if (it == a.n_ends) it = a.n_ends - 1;
+					pos = a.contig_end[it] - end_gPos + 1;
+					chr = a.end_chr[it];
+				}
+			}
+			// GenerateCIGAR, :492-513 (the reverse strand shows the elements in reverse order)
+			char *out = a.rep_cigar + cand * KG_ALN_CIGAR_MAX;
+			int at = 0, cnt = 0, state = 0;
+			auto emit = [&](int nn, int st) {
+				int nd = 1;
+				for (int x = nn; x >= 10; x /= 10) nd++;
+				if (at + nd + 1 > KG_ALN_CIGAR_MAX - 1) { fits = false; return; }
+				for (int d = nd - 1; d >= 0; --d) { if (gl == 0) out[at + d] = (char)('0' + nn % 10); nn /= 10; }
+				if (gl == 0) out[at + nd] = (char)st;
+				at += nd + 1;
+			};
+			for (int q = 0; q < cn; ++q) {
+				const int i = rev ? cn - 1 - q : q;
+				const int l = sh->cig_len[i], o = sh->cig_op[i];
+				if (o != state) {
+					if (cnt > 0) emit(cnt, state);
+					cnt = l;
+					state = o;
+				} else cnt += l;
+			}
+			if (cnt > 0) emit(cnt, state);
+			if (fits) {
+				rep_len = at; rep_chr = chr; rep_pos = pos; rep_fwd = fwd ? 1 : 0;
+				if (pos <= 0) score = 0;
+			}
+		}
+	}
+	if (gl == 0) {
+		if (!fits) {
+			a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
+			flag_host(a, r, WHY_CIGAR);
+		} else {
+			a.rep_chr[cand] = rep_chr;
+			a.rep_pos[cand] = rep_pos;
+			a.rep_fwd[cand] = (uint8_t)rep_fwd;
+			a.rep_cigar_len[cand] = (uint8_t)rep_len;
+			a.rep_score[cand] = score;
+			if (!scored) a.c_score[cand] = -1;
+		}
+	}
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void aln_finish_group_kernel(AlnArgs a)
+{
+	__shared__ FinShared s_fin[kFinGroups];
+	unsigned long long n = a.ctl[0];
+	if (n > (unsigned long long)a.spill_capacity) n = (unsigned long long)a.spill_capacity;
+	Fin fi;
+	fi.gl = threadIdx.x & (kFinG - 1);
+	fi.gb = (threadIdx.x & 63) & ~(kFinG - 1);
+	fi.sh = &s_fin[threadIdx.x / kFinG];
+	fi.len = 0; fi.cig_n = 0; fi.cig_overflow = false;
+	const unsigned long long n_groups = (unsigned long long)gridDim.x * kFinGroups;
+	for (unsigned long long t = (unsigned long long)blockIdx.x * kFinGroups + threadIdx.x / kFinG; t < n; t += n_groups) finish_candidate_group(a, t, fi);
+}
+
 // ---- per read: best / second best, final pair check, flags, MAPQ, records ----------------------------------------------------
 namespace {
 
@@ -3132,8 +3469,9 @@ hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 hipError_t launch_align_back(const AlnArgs &a, int n_cu, hipStream_t stream)
 {
 	kt_begin(KT_ALN_FINISH, stream);
-	if (a.dbg_finish_lanes) hipLaunchKernelGGL(aln_finish_kernel, dim3(grid_for_aln(a.spill_capacity, 256, n_cu * 8)), dim3(256), 0, stream, a);
-	else hipLaunchKernelGGL(aln_finish_wave_kernel, dim3(n_cu * 8), dim3(256), 0, stream, a);
+	if (a.dbg_finish_lanes == 1) hipLaunchKernelGGL(aln_finish_kernel, dim3(grid_for_aln(a.spill_capacity, 256, n_cu * 8)), dim3(256), 0, stream, a);
+	else if (a.dbg_finish_lanes == 2) hipLaunchKernelGGL(aln_finish_wave_kernel, dim3(n_cu * 8), dim3(256), 0, stream, a);
+	else hipLaunchKernelGGL(aln_finish_group_kernel, dim3(n_cu * 16), dim3(256), 0, stream, a);
 	kt_end(KT_ALN_FINISH, stream);
 	kt_begin(KT_ALN_FINAL, stream);
 	hipLaunchKernelGGL(aln_final_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);

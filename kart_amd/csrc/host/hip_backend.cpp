@@ -117,6 +117,7 @@ public:
 		}
 		kg_index_destroy(ix_);
 	}
+	bool has_stream() const override { return getenv("KART_AMD_NO_STREAM") == nullptr && getenv("KART_AMD_HOST_ALIGN") == nullptr; }
 	StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes, int seed_group) override
 	{
 		static const bool off = getenv("KART_AMD_NO_STREAM") != nullptr || getenv("KART_AMD_HOST_ALIGN") != nullptr;      // A/B aids: the host parses and prints, as before

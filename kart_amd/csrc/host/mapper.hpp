@@ -127,6 +127,7 @@ struct KernelBackend {
 	virtual bool has_fragments() const { return false; }
 	// a stream with at least this capacity (kept by the backend across runs), or null: the backend has no such path
 	// seed_group > 1: one seeding launch over the batches of that many lanes (kg_stream_config::seed_group)
+	virtual bool has_stream() const { return false; }          // stream() can succeed (asked before a gz library starts inflating towards it)
 	virtual StreamBackend *stream(int64_t max_reads, int64_t max_window, int lanes, int seed_group = 0) { (void)max_reads; (void)max_window; (void)lanes; (void)seed_group; return nullptr; }
 	// index constants the host needs
 	virtual int min_seed_len() const = 0;

@@ -161,7 +161,12 @@ __global__ __launch_bounds__(256) void fq_record_kernel(FqArgs a, int f)
 		w.rec_qlen[j] = qlen;
 		// an empty read ends a chunk early in the reference (src/GetData.cpp:117,121); a header too long for the 16-bit fields,
 		// a read beyond any short-read length: not taken here
-		if (rlen <= 0 || rlen > (1 << 20) || p1 > 0xFFFF || name_len > 0xFFFF) atomicMin((long long *)&a.meta[FQM_BAD0 + f], (long long)j);
+		bool bad = rlen <= 0 || rlen > (1 << 20) || p1 > 0xFFFF || name_len > 0xFFFF;
+		// the text of a gz file: gzgets() hands out at most 999 bytes per call (a longer line arrives in pieces that the reference takes for the
+		// record's next lines), and an entry whose first line does not start with '@' / '>' or names nothing ends after that line
+		// (src/GetData.cpp:152-162): such a record is the caller's line reader's
+		if (a.gz_lines) bad = bad || l1 - l0 > 999u || l2 - l1 > 999u || l3 - l2 > 999u || l4 - l3 > 999u || (h[0] != '@' && h[0] != '>') || name_len == 0;
+		if (bad) atomicMin((long long *)&a.meta[FQM_BAD0 + f], (long long)j);
 		const int64_t i = a.two_files ? 2 * j + f : j;
 		if (i < a.max_reads) a.read_len[i] = rlen > 0 ? rlen : 0;
 	}

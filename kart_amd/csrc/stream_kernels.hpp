@@ -46,6 +46,7 @@ struct FqArgs {
 	int two_files;             // mates alternate between the windows (else every read comes from window 0)
 	int paired;                // the second read of every pair is held reverse-complemented (src/GetData.cpp:125-135)
 	int chunk_reads;           // ReadChunkSize (4000)
+	int gz_lines;              // the text comes out of a gz file: records that gzgets() with its 1000-byte buffer reads differently end the batch (kg_stream_window)
 	int64_t max_reads;         // capacity of the batch (a multiple of chunk_reads)
 	int64_t want_reads;        // take at most this many (a multiple of chunk_reads, <= max_reads)
 	int64_t *meta;             // [FQM_WORDS]

@@ -76,3 +76,90 @@ def test_reads_with_dashes_match_live_reference(built_lib, tmp_path):
     want = run(KART_REF, long_ + ["-t", "1"], str(tmp_path / "r.sam"))
     assert run(KART_AMD, long_ + ["-t", "16"], out) == want
     assert run(KART_AMD, long_ + ["-t", "16"], out, {"KART_AMD_FINISH_STRINGS": "1"}) == want
+
+
+def run_log(binary, args, out, env=None):
+    r = subprocess.run([binary, "-silent", "-i", SMALL_PREFIX] + args + ["-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout.decode()[-400:]
+    return open(out, "rb").read(), r.stdout.decode()
+
+
+def test_gz_libraries_go_through_the_device_stream(built_lib, tmp_path):
+    """A gz library is inflated by threads of its own into a growing block that the device's FASTQ-in / SAM-out stream reads like a mapped
+    plain file (Source::gz_stream_begin, GzProducer): ordinary gzip (the several-thread reader, chunks of a few KB so that rounds, block
+    search and window resolution all occur), BGZF, one zlib stream (KART_AMD_NO_PGZ), an interleaved file, -m; a small look-ahead so that
+    the inflating thread waits for the stream and pages are given back; and the switch that keeps the text on the host's gz reader."""
+    r1 = gzip.open(os.path.join(SAM, "pe_1.fq.gz")).read()
+    r2 = gzip.open(os.path.join(SAM, "pe_2.fq.gz")).read()
+    want = gzip.open(os.path.join(SAM, "pe.sam.gz")).read()
+    out = str(tmp_path / "o.sam")
+
+    def put(name, data):
+        path = str(tmp_path / name)
+        open(path, "wb").write(data)
+        return path
+
+    g1, g2 = put("p1.fq.gz", gzip.compress(r1)), put("p2.fq.gz", gzip.compress(r2, 9))
+    small = {"KART_AMD_PGZ_MIN_KB": "0", "KART_AMD_PGZ_CHUNK_KB": "16", "KART_AMD_VERBOSE": "1"}
+    got, log = run_log(KART_AMD, ["-f", g1, "-f2", g2, "-t", "16"], out, small)
+    assert got == want and "device stream:" in log, log[-600:]
+    got, log = run_log(KART_AMD, ["-f", g1, "-f2", g2, "-t", "16"], out, dict(small, KART_AMD_NO_GZ_STREAM="1"))
+    assert got == want and "device stream:" not in log
+    got, log = run_log(KART_AMD, ["-f", g1, "-f2", g2, "-t", "16"], out, dict(small, KART_AMD_NO_PGZ="1", KART_AMD_GZ_AHEAD_MB="64"))
+    assert got == want and "device stream:" in log
+    got, log = run_log(KART_AMD, ["-f", g1, "-f2", g2, "-t", "4", "-m"], out, small)
+    assert got == gzip.open(os.path.join(SAM, "pe_m.sam.gz")).read() and "device stream:" in log
+    inter = gzip.open(os.path.join(SAM, "pe_interleaved.fq.gz")).read()
+    got, log = run_log(KART_AMD, ["-f", put("i.fq.gz", gzip.compress(inter)), "-p", "-t", "16"], out, small)
+    assert got == gzip.open(os.path.join(SAM, "pe_interleaved.sam.gz")).read() and "device stream:" in log
+    got, log = run_log(KART_AMD, ["-f", os.path.join(SAM, "se.fq.gz"), "-t", "16"], out, small)
+    assert got == gzip.open(os.path.join(SAM, "se.sam.gz")).read()
+
+
+def test_gz_text_that_gzgets_reads_differently_leaves_the_device_stream(built_lib, tmp_path):
+    """The reference reads gz text through gzgets() with a 1000-byte buffer (src/GetData.cpp:152-162): a 1500-character header comes back in
+    pieces that are taken for the record's next lines, an entry whose first line does not start with '@' ends after that line.  The device
+    parser stops in front of such a record (kg_stream_window::gz_lines), the stream hands the rest of the text to the host's gz reader, and
+    that one to its line reader: same SAM as kart -t 1 -- several batches in, in either mate file, and in a damaged stream."""
+    assert os.path.exists(KART_REF), "oracle/_ref/kart did not travel to the GPU box"
+    r1 = gzip.open(os.path.join(SAM, "pe_1.fq.gz")).read()
+    r2 = gzip.open(os.path.join(SAM, "pe_2.fq.gz")).read()
+
+    def put(name, data):
+        path = str(tmp_path / name)
+        open(path, "wb").write(data)
+        return path
+
+    env = {"KART_AMD_PGZ_MIN_KB": "0", "KART_AMD_PGZ_CHUNK_KB": "16", "KART_AMD_VERBOSE": "1"}
+    l2 = r2.split(b"\n")
+    l2[4 * 3000] += b" " + b"y" * 1500
+    l1 = r1.split(b"\n")
+    l1[4 * 1000] = b"X" + l1[4 * 1000][1:]
+    long_seq = r1.split(b"\n")
+    long_seq[4 * 2000 + 1] = long_seq[4 * 2000 + 1] * 8                # a 1200-base read: its line does not fit gzgets()'s buffer
+    long_seq[4 * 2000 + 3] = long_seq[4 * 2000 + 3] * 8
+    cases = {
+        "long_header_mate2": ["-f", put("a1.fq.gz", gzip.compress(r1)), "-f2", put("a2.fq.gz", gzip.compress(b"\n".join(l2)))],
+        "no_at_sign": ["-f", put("b1.fq.gz", gzip.compress(b"\n".join(l1))), "-f2", put("b2.fq.gz", gzip.compress(r2))],
+        "no_at_sign_single": ["-f", put("c1.fq.gz", gzip.compress(b"\n".join(l1)))],
+        "long_read": ["-f", put("d1.fq.gz", gzip.compress(b"\n".join(long_seq))), "-f2", put("d2.fq.gz", gzip.compress(r2))],
+    }
+    for name, args in cases.items():
+        ref = run(KART_REF, args + ["-t", "1"], str(tmp_path / "r.sam"))
+        got, log = run_log(KART_AMD, args + ["-t", "16"], str(tmp_path / "o.sam"), env)
+        assert got == ref, name
+        assert "device stream:" in log, name                              # (the records in front of the odd one did go through it)
+    # a damaged stream: the reads before the damage, as the reference's gzgets() loop still sees them
+    d = bytearray(gzip.compress(r1))
+    d[len(d) * 6 // 10] ^= 0x55
+    bad1, good2 = put("e1.fq.gz", bytes(d)), put("e2.fq.gz", gzip.compress(r2))
+    r = subprocess.run([KART_REF, "-silent", "-i", SMALL_PREFIX, "-f", bad1, "-f2", good2, "-t", "1", "-o", str(tmp_path / "r.sam")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    got, _ = run_log(KART_AMD, ["-f", bad1, "-f2", good2, "-t", "16"], str(tmp_path / "o.sam"), env)
+    got = got.split(b"\n")
+    assert len(got) > 1000
+    if r.returncode == 0:
+        ref = open(str(tmp_path / "r.sam"), "rb").read().split(b"\n")
+        assert len(got) == len(ref)
+        differing = [i for i, (x, y) in enumerate(zip(ref, got)) if x != y]
+        assert len(differing) <= 1 and all(i >= len(ref) - 4 for i in differing), differing[:5]
