@@ -41,7 +41,7 @@ for k, cs in list(out.items()):
 # per-kernel counter traffic per step, for the "kernels" entries of the bench line (the passes ran steps + warmup = 3 steps)
 slots = {"chain": ["chain_kernel"], "aln_trivial": ["aln_trivial_kernel"], "aln_pair": ["aln_pair_kernel"], "aln_rescue": ["aln_rescue_kernel", "aln_post_rescue_kernel"], "aln_plan_fast": ["aln_plan_fast_kernel"],
          "aln_plan": ["aln_plan_kernel"], "aln_partition": ["aln_partition_kernel"], "nw": ["nw_small8_kernel", "nw_small32_kernel", "nw_big_kernel", "nw_classify_kernel"],
-         "aln_finish": ["aln_finish_kernel"], "aln_final": ["aln_final_kernel"], "sam_size": ["sam_size_kernel"], "sam_format": ["sam_format_kernel"],
+         "aln_finish": ["aln_finish_kernel", "aln_finish_wave_kernel", "aln_finish_group_kernel"], "aln_final": ["aln_final_kernel"], "sam_size": ["sam_size_kernel"], "sam_format": ["sam_format_kernel"],
          "fq_parse": ["fq_count_kernel", "fq_index_kernel", "fq_record_kernel", "fq_plan_kernel", "fq_reset_kernel"], "fq_materialise": ["fq_materialise_kernel"]}
 STEPS = 3
 kt = {}
