@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void aln_pair_kernel(AlnArgs a)
 		bool heavy = false;
 		if (u < n_units && heavy_on) {
 			const int64_t c0 = a.cand_off[r], c1 = a.cand_off[r + 1], c2 = a.cand_off[r + 2];
-			heavy = (c1 - c0) * (c2 - c1) > kPairHeavy;
+			heavy = (c1 - c0) * (c2 - c1) > (int64_t)a.pair_heavy;
 		}
 		if (u < n_units && !heavy) pair_front(a, r, ck, lo, hi, st);
 		uint64_t hm = __ballot(heavy);
