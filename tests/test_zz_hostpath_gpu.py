@@ -143,7 +143,7 @@ def test_gz_text_that_gzgets_reads_differently_leaves_the_device_stream(built_li
         "long_header_mate2": ["-f", put("a1.fq.gz", gzip.compress(r1)), "-f2", put("a2.fq.gz", gzip.compress(b"\n".join(l2)))],
         "no_at_sign": ["-f", put("b1.fq.gz", gzip.compress(b"\n".join(l1))), "-f2", put("b2.fq.gz", gzip.compress(r2))],
         "no_at_sign_single": ["-f", put("c1.fq.gz", gzip.compress(b"\n".join(l1)))],
-        "long_read": ["-f", put("d1.fq.gz", gzip.compress(b"\n".join(long_seq))), "-f2", put("d2.fq.gz", gzip.compress(r2))],
+        "long_read": ["-f", put("d1.fq.gz", gzip.compress(b"\n".join(long_seq)))],      # (single-end: with a mate file the reference encodes mate 2 with mate 1's length and corrupts its heap)
     }
     for name, args in cases.items():
         ref = run(KART_REF, args + ["-t", "1"], str(tmp_path / "r.sam"))
