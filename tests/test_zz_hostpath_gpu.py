@@ -162,4 +162,7 @@ def test_gz_text_that_gzgets_reads_differently_leaves_the_device_stream(built_li
         ref = open(str(tmp_path / "r.sam"), "rb").read().split(b"\n")
         assert len(got) == len(ref)
         differing = [i for i, (x, y) in enumerate(zip(ref, got)) if x != y]
-        assert len(differing) <= 1 and all(i >= len(ref) - 4 for i in differing), differing[:5]
+        # (the pair the damage cuts in two: the reference prints stale contents of its line buffer for mate 1's missing lines and encodes mate 2 with
+        #  mate 1's -- now meaningless -- length, SURVEY App. B-5: both records of that last pair may differ, nothing before them; with and without
+        #  the device stream alike, profiles/r06p_damaged_gz.log)
+        assert len(differing) <= 2 and all(i >= len(ref) - 4 for i in differing), differing[:5]
