@@ -2705,18 +2705,19 @@ __global__ __launch_bounds__(256) void aln_finish_wave_kernel(AlnArgs a)
 // different kinds of pairs); every ballot and shuffle stays inside one group, whose lanes always run together.
 namespace {
 
-constexpr int kFinG = 16;                                  // lanes per candidate
-constexpr int kFinGroups = 256 / kFinG;                    // ... per block
-constexpr int kFinTiles = (2 * kAlnMaxFrag + kFinG - 1) / kFinG;
+// (kFinG lanes per candidate, a template parameter: sixteen is the product's, eight an A/B form -- KG_ALN_FINISH_G8)
+template <int kFinG>
 struct FinShared {
+	static constexpr int kFinTiles = (2 * kAlnMaxFrag + kFinG - 1) / kFinG;
 	AlnSpillPair p[kAlnMaxPairs];
 	int32_t cig_len[kAlnMaxCigar];
 	uint8_t cig_op[kAlnMaxCigar + 4];
 	uint16_t m1[kFinTiles], m2[kFinTiles], eq[kFinTiles];
 };
 
+template <int kFinG>
 struct Fin {
-	FinShared *sh;
+	FinShared<kFinG> *sh;
 	int gl, gb;            // lane in the group, the group's first lane in the wave
 	int len;               // columns of the alignment at hand
 	int cig_n;
@@ -2835,7 +2836,8 @@ struct Fin {
 };
 
 // finish_candidate for the candidate of spill slot t, by a group of kFinG lanes (all of them here)
-__device__ void finish_candidate_group(const AlnArgs &a, unsigned long long t, Fin &fi)
+template <int kFinG>
+__device__ void finish_candidate_group(const AlnArgs &a, unsigned long long t, Fin<kFinG> &fi)
 {
 	const AlnSpill &sp = a.spill[t];
 	const int64_t cand = sp.cand;
@@ -2845,7 +2847,7 @@ __device__ void finish_candidate_group(const AlnArgs &a, unsigned long long t, F
 	const bool first = a.chunk_paired[ck] ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
 	const int num = sp.num;
 	const uint8_t *rd = a.enc + a.read_off[r];
-	FinShared *sh = fi.sh;
+	FinShared<kFinG> *sh = fi.sh;
 	const int gl = fi.gl;
 	{
 		const uint32_t *src = reinterpret_cast<const uint32_t *>(sp.p);
@@ -3020,12 +3022,14 @@ __device__ void finish_candidate_group(const AlnArgs &a, unsigned long long t, F
 
 }  // namespace
 
+template <int kFinG>
 __global__ __launch_bounds__(256) void aln_finish_group_kernel(AlnArgs a)
 {
-	__shared__ FinShared s_fin[kFinGroups];
+	constexpr int kFinGroups = 256 / kFinG;
+	__shared__ FinShared<kFinG> s_fin[kFinGroups];
 	unsigned long long n = a.ctl[0];
 	if (n > (unsigned long long)a.spill_capacity) n = (unsigned long long)a.spill_capacity;
-	Fin fi;
+	Fin<kFinG> fi;
 	fi.gl = threadIdx.x & (kFinG - 1);
 	fi.gb = (threadIdx.x & 63) & ~(kFinG - 1);
 	fi.sh = &s_fin[threadIdx.x / kFinG];
@@ -3471,7 +3475,8 @@ hipError_t launch_align_back(const AlnArgs &a, int n_cu, hipStream_t stream)
 	kt_begin(KT_ALN_FINISH, stream);
 	if (a.dbg_finish_lanes == 1) hipLaunchKernelGGL(aln_finish_kernel, dim3(grid_for_aln(a.spill_capacity, 256, n_cu * 8)), dim3(256), 0, stream, a);
 	else if (a.dbg_finish_lanes == 2) hipLaunchKernelGGL(aln_finish_wave_kernel, dim3(n_cu * 8), dim3(256), 0, stream, a);
-	else hipLaunchKernelGGL(aln_finish_group_kernel, dim3(n_cu * 16), dim3(256), 0, stream, a);
+	else if (a.dbg_finish_lanes == 3) hipLaunchKernelGGL(aln_finish_group_kernel<8>, dim3(n_cu * 16), dim3(256), 0, stream, a);
+	else hipLaunchKernelGGL(aln_finish_group_kernel<16>, dim3(n_cu * 16), dim3(256), 0, stream, a);
 	kt_end(KT_ALN_FINISH, stream);
 	kt_begin(KT_ALN_FINAL, stream);
 	hipLaunchKernelGGL(aln_final_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
