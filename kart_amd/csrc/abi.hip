@@ -1111,7 +1111,7 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 	{ static const bool scan = getenv("KG_RESCUE_SCAN") != nullptr; a.dbg_rescue_scan = scan ? 1 : 0; }
 	{ static const bool no_heavy = getenv("KG_ALN_NO_HEAVY") != nullptr; a.dbg_no_heavy = no_heavy ? 1 : 0; }
 	{ static const int pair_heavy = getenv("KG_ALN_PAIR_HEAVY") ? std::max(1, atoi(getenv("KG_ALN_PAIR_HEAVY"))) : 32; a.pair_heavy = pair_heavy; }
-	{ static const int finish_form = getenv("KG_ALN_FINISH_LANES") ? 1 : getenv("KG_ALN_FINISH_WAVE") ? 2 : getenv("KG_ALN_FINISH_G8") ? 3 : 0; a.dbg_finish_lanes = finish_form; }
+	{ static const int finish_form = getenv("KG_ALN_FINISH_LANES") ? 1 : getenv("KG_ALN_FINISH_WAVE") ? 2 : getenv("KG_ALN_FINISH_G16") ? 3 : 0; a.dbg_finish_lanes = finish_form; }
 	// (KG_ALN_INLINE: a candidate whose alignments are all at most 8 x 8 makes them in its planning lane and is finished at once.  Built and measured
 	//  in round 6: 24 % fewer parked candidates, but aln_plan 31 -> 47 ms per step and aln_finish unchanged -- the stage's kernels are bound by
 	//  their heaviest lanes, not by the number of candidates -- so it is off unless asked for; profiles/r06i_*)

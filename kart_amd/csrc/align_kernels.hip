@@ -2697,15 +2697,15 @@ __global__ __launch_bounds__(256) void aln_finish_wave_kernel(AlnArgs a)
 	for (unsigned long long t = (unsigned long long)uni((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))); t < n; t += n_waves) finish_candidate_wave(a, t, lane);
 }
 
-// ---- pass 2 by groups of sixteen lanes ---------------------------------------------------------------------------------------------
+// ---- pass 2 by groups of eight (or sixteen) lanes ---------------------------------------------------------------------------------------------
 // A candidate per wave (above) spends a whole wave's issue slot on every instruction of what is mostly bit arithmetic common to the wave:
-// ~1700 instructions per candidate, 150 k candidates per launch, 0.48 ms -- bound by instruction issue.  Here sixteen lanes take a candidate,
-// four candidates share a wave's instructions: the same scheme on tiles of sixteen columns, with the candidate's normal pairs, CIGAR elements
+// ~1700 instructions per candidate, 150 k candidates per launch, 0.48 ms -- bound by instruction issue.  Here kFinG lanes take a candidate,
+// 64 / kFinG candidates share a wave's instructions: the same scheme on tiles of kFinG columns, with the candidate's normal pairs, CIGAR elements
 // and column sets in the LDS (1 KB per group).  The groups of a wave run apart where their candidates differ (different numbers of pairs,
 // different kinds of pairs); every ballot and shuffle stays inside one group, whose lanes always run together.
 namespace {
 
-// (kFinG lanes per candidate, a template parameter: sixteen is the product's, eight an A/B form -- KG_ALN_FINISH_G8)
+// (kFinG lanes per candidate, a template parameter: eight is the product's -- 26.8 ms per step against 30.5 with sixteen, profiles/r06q --, sixteen an A/B form: KG_ALN_FINISH_G16)
 template <int kFinG>
 struct FinShared {
 	static constexpr int kFinTiles = (2 * kAlnMaxFrag + kFinG - 1) / kFinG;
@@ -3475,8 +3475,8 @@ hipError_t launch_align_back(const AlnArgs &a, int n_cu, hipStream_t stream)
 	kt_begin(KT_ALN_FINISH, stream);
 	if (a.dbg_finish_lanes == 1) hipLaunchKernelGGL(aln_finish_kernel, dim3(grid_for_aln(a.spill_capacity, 256, n_cu * 8)), dim3(256), 0, stream, a);
 	else if (a.dbg_finish_lanes == 2) hipLaunchKernelGGL(aln_finish_wave_kernel, dim3(n_cu * 8), dim3(256), 0, stream, a);
-	else if (a.dbg_finish_lanes == 3) hipLaunchKernelGGL(aln_finish_group_kernel<8>, dim3(n_cu * 16), dim3(256), 0, stream, a);
-	else hipLaunchKernelGGL(aln_finish_group_kernel<16>, dim3(n_cu * 16), dim3(256), 0, stream, a);
+	else if (a.dbg_finish_lanes == 3) hipLaunchKernelGGL(aln_finish_group_kernel<16>, dim3(n_cu * 16), dim3(256), 0, stream, a);
+	else hipLaunchKernelGGL(aln_finish_group_kernel<8>, dim3(n_cu * 16), dim3(256), 0, stream, a);
 	kt_end(KT_ALN_FINISH, stream);
 	kt_begin(KT_ALN_FINAL, stream);
 	hipLaunchKernelGGL(aln_final_kernel, dim3(grid_for_aln(a.n_reads, 256, n_cu * 16)), dim3(256), 0, stream, a);
