@@ -1110,6 +1110,7 @@ int kgi_align_resident(kg_workspace *ws, const int64_t *chunk_off, const uint8_t
 	{ static const bool nopart = getenv("KG_DBG_NO_PARTITION") != nullptr; a.dbg_no_partition = nopart ? 1 : 0; }
 	{ static const bool scan = getenv("KG_RESCUE_SCAN") != nullptr; a.dbg_rescue_scan = scan ? 1 : 0; }
 	{ static const bool no_heavy = getenv("KG_ALN_NO_HEAVY") != nullptr; a.dbg_no_heavy = no_heavy ? 1 : 0; }
+	{ static const bool plan_group = getenv("KG_ALN_PLAN_GROUP") != nullptr; a.dbg_plan_group = plan_group ? 1 : 0; }
 	{ static const int pair_heavy = getenv("KG_ALN_PAIR_HEAVY") ? std::max(1, atoi(getenv("KG_ALN_PAIR_HEAVY"))) : 32; a.pair_heavy = pair_heavy; }
 	{ static const int finish_form = getenv("KG_ALN_FINISH_LANES") ? 1 : getenv("KG_ALN_FINISH_WAVE") ? 2 : getenv("KG_ALN_FINISH_G16") ? 3 : 0; a.dbg_finish_lanes = finish_form; }
 	// (KG_ALN_INLINE: a candidate whose alignments are all at most 8 x 8 makes them in its planning lane and is finished at once.  Built and measured

@@ -905,7 +905,16 @@ struct Pairs {                      // vector<SeedPair_t> of one candidate, in t
 	int num;
 };
 
-__device__ __forceinline__ void erase_empty(Pairs &v)
+// the same vector in a group's LDS block (aln_plan_group_kernel): the algorithms below are templates over either
+struct PairsRef {
+	int64_t *gPos;
+	int32_t *rPos, *rLen, *gLen;
+	uint8_t *simple;
+	int num;
+};
+
+template <class P>
+__device__ __forceinline__ void erase_empty(P &v)
 {
 	int w = 0;
 	for (int i = 0; i < v.num; ++i)
@@ -917,7 +926,8 @@ __device__ __forceinline__ void erase_empty(Pairs &v)
 }
 
 // RemoveTandemRepeatSeeds, src/AlignmentCandidates.cpp:235-260: every read position hit by more than one seed goes
-__device__ void remove_tandem_repeats(Pairs &v)
+template <class P>
+__device__ void remove_tandem_repeats(P &v)
 {
 	if (v.num < 2) return;
 	bool any = false;
@@ -933,7 +943,8 @@ __device__ void remove_tandem_repeats(Pairs &v)
 
 // RemoveTranslocatedSeeds, src/AlignmentCandidates.cpp:262-321.  ord[k] = index (in genome order) of the seed with the k-th
 // smallest read position (read positions are distinct once the tandem repeats are gone)
-__device__ void remove_translocated(Pairs &v)
+template <class P>
+__device__ void remove_translocated(P &v)
 {
 	const int num = v.num;
 	if (num < 2) return;
@@ -965,7 +976,8 @@ __device__ void remove_translocated(Pairs &v)
 }
 
 // CheckSeedOverlapping, src/AlignmentCandidates.cpp:323-373
-__device__ bool resolve_overlap(Pairs &v, int i, int j)
+template <class P>
+__device__ bool resolve_overlap(P &v, int i, int j)
 {
 	bool master = true;
 	int ov;
@@ -991,7 +1003,8 @@ __device__ bool resolve_overlap(Pairs &v, int i, int j)
 }
 
 // CheckOverlappingSeeds, src/AlignmentCandidates.cpp:375-418
-__device__ void check_overlaps(Pairs &v)
+template <class P>
+__device__ void check_overlaps(P &v)
 {
 	const int num = v.num;
 	if (num < 2) return;
@@ -1026,7 +1039,8 @@ __device__ __forceinline__ bool by_gpos_less(int64_t g1, int r1, int64_t g2, int
 
 // IdentifyNormalPairs(rlen, glen, v), src/AlignmentCandidates.cpp:420-490 (glen = -1 for a read against the genome, the
 // fragment's genome length inside GenerateNormalPairAlignment).  false: more gap pairs than the envelope holds
-__device__ bool identify_normal_pairs(int rlen, int glen, Pairs &v)
+template <class P>
+__device__ bool identify_normal_pairs(int rlen, int glen, P &v)
 {
 	if (v.num > 1) {
 		remove_tandem_repeats(v);
@@ -1089,7 +1103,8 @@ __device__ bool identify_normal_pairs(int rlen, int glen, Pairs &v)
 }
 
 // CheckCoordinateValidity, src/AlignmentCandidates.cpp:582-610
-__device__ bool coordinates_valid(const AlnArgs &a, const Pairs &v)
+template <class P>
+__device__ bool coordinates_valid(const AlnArgs &a, const P &v)
 {
 	int64_t g1 = 0, g2 = a.two_genome_size;
 	for (int i = 0; i < v.num; ++i)
@@ -2835,6 +2850,88 @@ struct Fin {
 	}
 };
 
+// GapPenalty, GenCoordinateInfo, GenerateCIGAR and the candidate's report fields (src/AlignmentCandidates.cpp:612-622, 492-562, 701-722) by a group of
+// lanes that all hold the same values (lane 0 of it stores): cn CIGAR elements, the first pair's gPos, the last pair's last text coordinate
+__device__ void report_by_group(const AlnArgs &a, int64_t cand, int64_t r, bool first, int gl, int score, int cn, const int32_t *cig_len, const uint8_t *cig_op,
+                                int64_t gPos0, int64_t end_gPos)
+{
+	int rep_chr = 0, rep_fwd = 1, rep_len = 0;
+	int64_t rep_pos = 0;
+	bool scored = true, fits = true;
+	if (cn > 1) {                                                          // GapPenalty, :612-622, :701-706
+		int gp = 0;
+		for (int i = 0; i < cn; ++i) { const int o = cig_op[i]; if (o == 'I' || o == 'D') gp += cig_len[i]; }
+		score -= gp;
+		if (score <= 0) { score = 0; scored = false; }
+	}
+	if (scored) {
+		if (cn == 0) score = 0;
+		else {
+			// GenCoordinateInfo, :515-562
+			bool fwd, rev = false;
+			int chr;
+			int64_t pos;
+			if (gPos0 < a.genome_size) {
+				fwd = first;
+				if (a.n_chr == 1) { chr = 0; pos = gPos0 + 1; }
+				else {
+					const int it = end_lower_bound(a, gPos0);
+					chr = a.end_chr[it];
+					pos = gPos0 + 1 - a.chr_fwd_start[chr];
+				}
+			} else {
+				fwd = !first;
+				rev = true;
+				if (a.n_chr == 1) { chr = 0; pos = a.two_genome_size - end_gPos; }
+				else {
+					int it = end_lower_bound(a, gPos0);
+					if (it == a.n_ends) it = a.n_ends - 1;
+					pos = a.contig_end[it] - end_gPos + 1;
+					chr = a.end_chr[it];
+				}
+			}
+			// GenerateCIGAR, :492-513 (the reverse strand shows the elements in reverse order)
+			char *out = a.rep_cigar + cand * KG_ALN_CIGAR_MAX;
+			int at = 0, cnt = 0, state = 0;
+			auto emit = [&](int nn, int st) {
+				int nd = 1;
+				for (int x = nn; x >= 10; x /= 10) nd++;
+				if (at + nd + 1 > KG_ALN_CIGAR_MAX - 1) { fits = false; return; }
+				for (int d = nd - 1; d >= 0; --d) { if (gl == 0) out[at + d] = (char)('0' + nn % 10); nn /= 10; }
+				if (gl == 0) out[at + nd] = (char)st;
+				at += nd + 1;
+			};
+			for (int q = 0; q < cn; ++q) {
+				const int i = rev ? cn - 1 - q : q;
+				const int l = cig_len[i], o = cig_op[i];
+				if (o != state) {
+					if (cnt > 0) emit(cnt, state);
+					cnt = l;
+					state = o;
+				} else cnt += l;
+			}
+			if (cnt > 0) emit(cnt, state);
+			if (fits) {
+				rep_len = at; rep_chr = chr; rep_pos = pos; rep_fwd = fwd ? 1 : 0;
+				if (pos <= 0) score = 0;
+			}
+		}
+	}
+	if (gl == 0) {
+		if (!fits) {
+			a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
+			flag_host(a, r, WHY_CIGAR);
+		} else {
+			a.rep_chr[cand] = rep_chr;
+			a.rep_pos[cand] = rep_pos;
+			a.rep_fwd[cand] = (uint8_t)rep_fwd;
+			a.rep_cigar_len[cand] = (uint8_t)rep_len;
+			a.rep_score[cand] = score;
+			if (!scored) a.c_score[cand] = -1;
+		}
+	}
+}
+
 // finish_candidate for the candidate of spill slot t, by a group of kFinG lanes (all of them here)
 template <int kFinG>
 __device__ void finish_candidate_group(const AlnArgs &a, unsigned long long t, Fin<kFinG> &fi)
@@ -2941,83 +3038,7 @@ __device__ void finish_candidate_group(const AlnArgs &a, unsigned long long t, F
 		} else score += s;
 	}
 	if (fi.cig_overflow) { if (gl == 0) flag_host(a, r, WHY_CIGAR); return; }
-	int rep_chr = 0, rep_fwd = 1, rep_len = 0;
-	int64_t rep_pos = 0;
-	bool scored = true, fits = true;
-	const int cn = fi.cig_n;
-	if (cn > 1) {                                                          // GapPenalty, :612-622, :701-706
-		int gp = 0;
-		for (int i = 0; i < cn; ++i) { const int o = sh->cig_op[i]; if (o == 'I' || o == 'D') gp += sh->cig_len[i]; }
-		score -= gp;
-		if (score <= 0) { score = 0; scored = false; }
-	}
-	if (scored) {
-		if (cn == 0) score = 0;
-		else {
-			// GenCoordinateInfo, :515-562
-			const int64_t gPos0 = sh->p[0].gPos, end_gPos = sh->p[num - 1].gPos + sh->p[num - 1].gLen - 1;
-			bool fwd, rev = false;
-			int chr;
-			int64_t pos;
-			if (gPos0 < a.genome_size) {
-				fwd = first;
-				if (a.n_chr == 1) { chr = 0; pos = gPos0 + 1; }
-				else {
-					const int it = end_lower_bound(a, gPos0);
-					chr = a.end_chr[it];
-					pos = gPos0 + 1 - a.chr_fwd_start[chr];
-				}
-			} else {
-				fwd = !first;
-				rev = true;
-				if (a.n_chr == 1) { chr = 0; pos = a.two_genome_size - end_gPos; }
-				else {
-					int it = end_lower_bound(a, gPos0);
-					if (it == a.n_ends) it = a.n_ends - 1;
-					pos = a.contig_end[it] - end_gPos + 1;
-					chr = a.end_chr[it];
-				}
-			}
-			// GenerateCIGAR, :492-513 (the reverse strand shows the elements in reverse order)
-			char *out = a.rep_cigar + cand * KG_ALN_CIGAR_MAX;
-			int at = 0, cnt = 0, state = 0;
-			auto emit = [&](int nn, int st) {
-				int nd = 1;
-				for (int x = nn; x >= 10; x /= 10) nd++;
-				if (at + nd + 1 > KG_ALN_CIGAR_MAX - 1) { fits = false; return; }
-				for (int d = nd - 1; d >= 0; --d) { if (gl == 0) out[at + d] = (char)('0' + nn % 10); nn /= 10; }
-				if (gl == 0) out[at + nd] = (char)st;
-				at += nd + 1;
-			};
-			for (int q = 0; q < cn; ++q) {
-				const int i = rev ? cn - 1 - q : q;
-				const int l = sh->cig_len[i], o = sh->cig_op[i];
-				if (o != state) {
-					if (cnt > 0) emit(cnt, state);
-					cnt = l;
-					state = o;
-				} else cnt += l;
-			}
-			if (cnt > 0) emit(cnt, state);
-			if (fits) {
-				rep_len = at; rep_chr = chr; rep_pos = pos; rep_fwd = fwd ? 1 : 0;
-				if (pos <= 0) score = 0;
-			}
-		}
-	}
-	if (gl == 0) {
-		if (!fits) {
-			a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0;
-			flag_host(a, r, WHY_CIGAR);
-		} else {
-			a.rep_chr[cand] = rep_chr;
-			a.rep_pos[cand] = rep_pos;
-			a.rep_fwd[cand] = (uint8_t)rep_fwd;
-			a.rep_cigar_len[cand] = (uint8_t)rep_len;
-			a.rep_score[cand] = score;
-			if (!scored) a.c_score[cand] = -1;
-		}
-	}
+	report_by_group(a, cand, r, first, gl, score, fi.cig_n, sh->cig_len, sh->cig_op, sh->p[0].gPos, num > 0 ? sh->p[num - 1].gPos + sh->p[num - 1].gLen - 1 : 0);
 }
 
 }  // namespace
@@ -3036,6 +3057,207 @@ __global__ __launch_bounds__(256) void aln_finish_group_kernel(AlnArgs a)
 	fi.len = 0; fi.cig_n = 0; fi.cig_overflow = false;
 	const unsigned long long n_groups = (unsigned long long)gridDim.x * kFinGroups;
 	for (unsigned long long t = (unsigned long long)blockIdx.x * kFinGroups + threadIdx.x / kFinG; t < n; t += n_groups) finish_candidate_group(a, t, fi);
+}
+
+// ---- pass 1 by groups of eight lanes -----------------------------------------------------------------------------------------------
+// aln_plan_kernel gives a candidate to a lane, and the lane keeps the candidate's normal pairs and what it decides about them in 1344 B of
+// private (scratch) memory: IdentifyNormalPairs' loops are chains of dependent scratch accesses, ~13 k wave-instructions in a wave that lasts
+// 0.38 ms (profiles/r06h: waiting 0.78 of its cycles).  Here eight lanes take a candidate: its pairs live in the LDS (1 KB per group) --
+// IdentifyNormalPairs and CheckCoordinateValidity are the same code (templates over the storage), run by the eight lanes alike --, the pairs
+// are classified eight at a time (the mismatch count of each is a chain of its own), and a candidate that needs no alignment is reported by
+// the group (report_by_group).  What is parked is written exactly as aln_plan_kernel writes it: the same spill slots, jobs and tasks.
+// (The alignments of aln_plan_kernel's own lanes, KG_ALN_INLINE, stay that kernel's.)
+namespace {
+
+constexpr int kPlanG = 8;
+struct PlanShared {
+	int64_t gPos[kAlnMaxPairs];
+	int32_t rPos[kAlnMaxPairs], rLen[kAlnMaxPairs], gLen[kAlnMaxPairs];
+	int32_t op_len[kAlnMaxPairs], val[kAlnMaxPairs];
+	int32_t cig_len[kAlnMaxCigar];
+	uint8_t simple[kAlnMaxPairs + 2], kind[kAlnMaxPairs + 2], op[kAlnMaxPairs + 2];
+	uint8_t cig_op[kAlnMaxCigar + 4];
+};
+
+__device__ __forceinline__ int group_sum(int v) { for (int off = kPlanG / 2; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void aln_plan_group_kernel(AlnArgs a)
+{
+	constexpr int kGroups = 256 / kPlanG;
+	__shared__ PlanShared s_plan[kGroups];
+	PlanShared *const sh = &s_plan[threadIdx.x / kPlanG];
+	const int gl = threadIdx.x & (kPlanG - 1);
+	const int lead = (threadIdx.x & 63) & ~(kPlanG - 1);                       // the group's first lane in the wave
+	const int64_t n_groups = (int64_t)gridDim.x * kGroups;
+	int64_t n_all = plan_slots(a);
+	if (a.plan_slow) n_all = (int64_t)a.ctl[32];
+	// (the wave's groups stay together through the loop: the list entries of all of them are reserved by one atomic per list)
+	for (int64_t slot0 = ((int64_t)blockIdx.x * kGroups + (threadIdx.x >> 6) * (64 / kPlanG)); slot0 < n_all; slot0 += n_groups) {
+		const int64_t slot = slot0 + ((threadIdx.x & 63) / kPlanG);
+		int64_t cand = 0, r = 0, rbase = 0;
+		int num = 0, n_new_jobs = 0, new_ops = 0, n_pending = 0;
+		bool park = false;
+		do {
+		if (slot >= n_all) break;
+		cand = a.plan_slow ? (int64_t)a.plan_slow[slot] : a.plan_order ? (int64_t)a.plan_order[slot] : slot_cand(a, slot);
+		if (gl == 0) { a.rep_score[cand] = 0; a.rep_chr[cand] = 0; a.rep_pos[cand] = 0; a.rep_fwd[cand] = 1; a.rep_cigar_len[cand] = 0; }
+		r = a.c_read[cand];
+		if (a.r_host[r]) break;
+		if (a.c_score[cand] == 0) break;                                  // GenMappingReport skips it, :643
+		const bool rescued = cand >= a.n_cands;
+		int count;
+		const kg_seed *seeds;
+		if (!rescued) { const kg_candidate cd = a.cands[cand]; count = cd.count; seeds = a.cand_seeds + cd.first; }
+		else {
+			const int64_t t = cand - a.n_cands;
+			count = a.resc_count[t];
+			seeds = a.resc_seeds + t * kAlnMaxSeeds;
+		}
+		if (count > kAlnMaxSeeds) { if (gl == 0) flag_host(a, r, WHY_SEEDS); break; }
+		rbase = a.read_off[r];
+		const int rlen = (int)(a.read_off[r + 1] - rbase);
+		const uint8_t *rd = a.enc + rbase;
+		const int ck = chunk_of(a, r);
+		const bool first = a.chunk_paired[ck] ? (((r - a.chunk_off[ck]) & 1) == 0) : true;
+		for (int i = gl; i < count; i += kPlanG) {
+			const kg_seed sd = seeds[i];
+			sh->gPos[i] = sd.gPos; sh->rPos[i] = sd.rPos; sh->rLen[i] = sd.len; sh->gLen[i] = sd.len; sh->simple[i] = 1;
+		}
+		if (rlen > 4000) { if (gl == 0) flag_host(a, r, WHY_READ_LEN); break; }
+		PairsRef v;
+		v.gPos = sh->gPos; v.rPos = sh->rPos; v.rLen = sh->rLen; v.gLen = sh->gLen; v.simple = sh->simple; v.num = count;
+		if (!identify_normal_pairs(rlen, -1, v)) { if (gl == 0) flag_host(a, r, WHY_GAPS); break; }
+		if (!coordinates_valid(a, v)) { if (gl == 0) a.c_score[cand] = -1; break; }      // no report, and no best/second-best step (:647)
+		num = v.num;
+		// ---- the pairs, kPlanG at a time: what aln_plan_kernel's loop decides for pair j ----
+		int host_l = 0, jobs_l = 0;
+		for (int j = gl; j < num; j += kPlanG) {
+			int kind = W_NONE, op = 0, op_len = 0, val = 0;
+			const int rL = sh->rLen[j], gL = sh->gLen[j];
+			do {
+				if (rL == 0 && gL == 0) break;
+				if (sh->simple[j]) { kind = W_SIMPLE; break; }
+				const int role = j == 0 ? 0 : j == num - 1 ? 2 : 1;
+				if (role != 1 && rL > 3000) { kind = W_IMMEDIATE; op = 'S'; op_len = rL; val = -1; break; }               // :671-676, :690-695
+				if (role == 1 && (rL == 0 || gL == 0)) {                                                                    // ProcessNormalSequencePair, src/tools.cpp:229-233
+					kind = W_IMMEDIATE;
+					if (rL > 0) { op = 'I'; op_len = rL; }
+					else if (gL > 0) { op = 'D'; op_len = gL; }
+					break;
+				}
+				const uint8_t *f1 = rd + sh->rPos[j];
+				const int64_t g = sh->gPos[j];
+				if (rL == gL) {                                                     // the <= 2-mismatch shortcut, :240, :301, :352
+					bool dash_ = false;
+					const int n = fast_gap_mismatches(a, f1, g, rL, 3, dash_);
+					if (n <= 2 && n <= (int)(rL * 0.2)) { kind = W_IMMEDIATE; op = 'M'; op_len = rL; val = rL - n; break; }
+				}
+				if ((role == 0 && rL > 50) || (role == 2 && rL > 100)) { kind = W_IMMEDIATE; op = 'S'; op_len = rL; val = 0; break; }   // :307-311, :358-362
+				if (rL == 1 && gL == 1 && f1[0] != '-') { kind = W_IMMEDIATE; op = 'M'; op_len = 1; val = (char)f1[0] == text_char(a, g) ? 1 : 0; break; }
+				if (rL > kAlnMaxFrag || gL > kAlnMaxFrag || rL <= 0 || gL <= 0) { host_l = 1; break; }
+				if (rL > 30 && gL > 30) {
+					if (a.dbg_no_partition) { host_l = 1; break; }
+					kind = W_PENDING; jobs_l = 1; n_pending++;
+					break;
+				}
+				kind = W_JOB; val = -1;
+				n_new_jobs++; new_ops += rL + gL;
+				jobs_l = 1;
+			} while (false);
+			sh->kind[j] = (uint8_t)kind; sh->op[j] = (uint8_t)op; sh->op_len[j] = op_len; sh->val[j] = val;
+		}
+		const bool host = group_sum(host_l) != 0, jobs = group_sum(jobs_l) != 0;
+		n_new_jobs = group_sum(n_new_jobs); new_ops = group_sum(new_ops); n_pending = group_sum(n_pending);
+		if (host) { if (gl == 0) flag_host(a, r, WHY_PARTITION); break; }
+		if (!jobs) {
+			// no alignment needed: GenMappingReport's pair loop over simple pairs and elements known at once (finish_candidate), then the report
+			int cn = 0, score = 0;
+			bool overflow = false;
+			auto push = [&](int l, int o) {
+				if (cn < kAlnMaxCigar) { if (gl == 0) { sh->cig_len[cn] = l; sh->cig_op[cn] = (uint8_t)o; } cn++; }
+				else overflow = true;
+			};
+			for (int j = 0; j < num; ++j) {
+				const int kj = sh->kind[j];
+				if (kj == W_NONE) continue;
+				if (kj == W_SIMPLE) { push(sh->rLen[j], 'M'); score += sh->rLen[j]; continue; }
+				const bool head = j == 0, tail = j == num - 1 && !head;
+				if (sh->op[j] != 0) push(sh->op_len[j], sh->op[j]);
+				const int sj = sh->val[j];
+				if (head) {
+					if (sj > 0) score += sj;
+					if (sj <= 0) { const int64_t g1 = sh->gPos[1]; if (gl == 0) { sh->gPos[0] = g1; sh->gLen[0] = 0; } }         // :674-686
+				} else if (tail) {
+					if (sj > 0) score += sj;
+					if (sj <= 0) { const int64_t gp = sh->gPos[j - 1] + sh->gLen[j - 1]; if (gl == 0) { sh->gPos[j] = gp; sh->gLen[j] = 0; } }
+				} else score += sj;
+			}
+			if (overflow) { if (gl == 0) flag_host(a, r, WHY_CIGAR); break; }
+			report_by_group(a, cand, r, first, gl, score, cn, sh->cig_len, sh->cig_op, sh->gPos[0], num > 0 ? sh->gPos[num - 1] + sh->gLen[num - 1] - 1 : 0);
+			break;
+		}
+		park = true;
+		} while (false);
+		// what the wave's parked candidates need of the lists, reserved with ONE atomic per list (the first lane of a group asks for its candidate)
+		const bool ask = park && gl == 0;
+		unsigned long long sp = wave_reserve(&a.ctl[0], ask ? 1ull : 0ull);
+		unsigned long long job_at = wave_reserve(&a.ctl[1], ask ? (unsigned long long)n_new_jobs : 0ull);
+		unsigned long long ops_at = wave_reserve(&a.ctl[2], ask ? (unsigned long long)new_ops : 0ull);
+		unsigned long long task_at = wave_reserve(&a.ctl[3], ask ? (unsigned long long)n_pending : 0ull);
+		auto from_lead = [&](unsigned long long x) { return ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(x >> 32), lead) << 32) | (uint32_t)__shfl((int)(uint32_t)x, lead); };
+		sp = from_lead(sp); job_at = from_lead(job_at); ops_at = from_lead(ops_at); task_at = from_lead(task_at);
+		if (!park) continue;
+		const bool sp_ok = sp < (unsigned long long)a.spill_capacity;
+		const bool jobs_ok = job_at + (unsigned long long)n_new_jobs <= (unsigned long long)a.job_capacity && ops_at + (unsigned long long)new_ops <= (unsigned long long)a.ops_capacity;
+		if (!sp_ok || !jobs_ok) {
+			// a list is full: the read is the host's; everything taken INSIDE the lists is still written (see aln_plan_kernel)
+			if (gl == 0) {
+				if (sp_ok) { a.spill[sp].cand = (int32_t)cand; a.spill[sp].num = 0; }
+				for (unsigned long long k = job_at; k < job_at + (unsigned long long)n_new_jobs && k < (unsigned long long)a.job_capacity; ++k) { NwJobDesc jd; jd.o1 = 0; jd.o2 = 0; jd.ops = 0; jd.m = 0; jd.n = 0; a.jobs[k] = jd; }
+				flag_host(a, r, WHY_CAPACITY);
+				for (unsigned long long k = task_at; k < task_at + (unsigned long long)n_pending && k < (unsigned long long)a.job_capacity; ++k) {
+					PartTask pt;
+					pt.enc_off = rbase; pt.g = 0; pt.spill = 0; pt.j = 0; pt.read = (int32_t)r; pt.rL = 0; pt.gL = 0;
+					a.part_tasks[k] = pt;
+				}
+			}
+			continue;
+		}
+		// the jobs in pair order (their places in the list follow from the pairs before them), the tasks likewise
+		if (gl == 0) {
+			for (int j = 0; j < num; ++j) {
+				if (sh->kind[j] != W_JOB) continue;
+				const int rL = sh->rLen[j], gL = sh->gLen[j];
+				NwJobDesc jd;
+				jd.o1 = rbase + sh->rPos[j]; jd.o2 = sh->gPos[j]; jd.ops = (int64_t)ops_at; jd.m = rL; jd.n = gL;
+				a.jobs[job_at] = jd;
+				sh->val[j] = (int32_t)job_at;
+				job_at++; ops_at += (unsigned long long)(rL + gL);
+			}
+			if (n_pending > 0) {
+				if (task_at + (unsigned long long)n_pending > (unsigned long long)a.job_capacity) flag_host(a, r, WHY_CAPACITY);
+				for (int j = 0; j < num; ++j) {
+					if (sh->kind[j] != W_PENDING) continue;
+					const unsigned long long t = task_at++;
+					if (t >= (unsigned long long)a.job_capacity) break;
+					PartTask pt;
+					pt.enc_off = rbase + sh->rPos[j]; pt.g = sh->gPos[j]; pt.spill = (int32_t)sp; pt.j = j; pt.read = (int32_t)r;
+					pt.rL = (int16_t)sh->rLen[j]; pt.gL = (int16_t)sh->gLen[j];
+					a.part_tasks[t] = pt;
+				}
+			}
+		}
+		AlnSpill &o = a.spill[sp];
+		if (gl == 0) { o.cand = (int32_t)cand; o.num = num; }
+		for (int j = gl; j < num; j += kPlanG) {
+			AlnSpillPair q;
+			q.gPos = sh->gPos[j]; q.rPos = sh->rPos[j]; q.rLen = (int16_t)sh->rLen[j]; q.gLen = (int16_t)sh->gLen[j];
+			q.val = sh->val[j]; q.kind = sh->kind[j]; q.op = sh->op[j]; q.op_len = (int16_t)sh->op_len[j];
+			o.p[j] = q;
+		}
+	}
 }
 
 // ---- per read: best / second best, final pair check, flags, MAPQ, records ----------------------------------------------------
@@ -3461,7 +3683,8 @@ hipError_t launch_align_front(const AlnArgs &a, int n_cu, hipStream_t stream)
 		if (a.plan_slow) hipLaunchKernelGGL(aln_plan_fast_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
 		kt_end(KT_ALN_PLAN_FAST, stream);
 		kt_begin(KT_ALN_PLAN, stream);
-		hipLaunchKernelGGL(aln_plan_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
+		if (a.dbg_plan_group && a.dbg_no_inline) hipLaunchKernelGGL(aln_plan_group_kernel, dim3(n_cu * 16), dim3(256), 0, stream, a);
+		else hipLaunchKernelGGL(aln_plan_kernel, dim3(grid_for_aln(a.n_cands + a.task_capacity / 8, 256, n_cu * 16)), dim3(256), 0, stream, a);
 		kt_end(KT_ALN_PLAN, stream);
 		kt_begin(KT_ALN_PARTITION, stream);
 		hipLaunchKernelGGL(aln_partition_kernel, dim3(grid_for_aln(a.n_cands / 8 + 1, 256, n_cu * 8)), dim3(256), 0, stream, a);

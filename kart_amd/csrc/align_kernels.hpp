@@ -104,6 +104,7 @@ struct AlnArgs {
 	int dbg_rescue_scan;            // A/B aid (KG_RESCUE_SCAN): the rescue kernel walks every diagonal of the window (rounds 2-3) instead of looking 10-mers up
 	int dbg_no_inline;              // 1 unless KG_ALN_INLINE: every alignment goes through the NW kernels
 	int dbg_finish_lanes;           // A/B aids: 1 (KG_ALN_FINISH_LANES) a candidate per lane in the finish pass (rounds 2-5), 2 (KG_ALN_FINISH_WAVE) a candidate per wave, 3 (KG_ALN_FINISH_G16) per sixteen lanes; 0: per group of eight lanes
+	int dbg_plan_group;             // KG_ALN_PLAN_GROUP: pass 1 by groups of eight lanes (aln_plan_group_kernel) instead of a candidate per lane
 	int pair_heavy;                 // pairs with more candidate pairs than this are the whole wave's (kPairHeavy; KG_ALN_PAIR_HEAVY)
 	int dbg_no_heavy;               // A/B aid (KG_ALN_NO_HEAVY): pairs with many candidates stay in their lane's loop (rounds 2-5)
 	int dbg_no_partition;           // diagnostics (KG_DBG_NO_PARTITION): fragments that need the 8-mer partition go back to the host
