@@ -925,7 +925,7 @@ def gz_leg(sess, workdir, codes, dev, threads, cores, budget):
     """the same reads as plain files, as ordinary gzip files through the several-thread reader, and through one gzread() stream per file"""
     import hashlib
     from benchkit.gz import gzip_one_member
-    n_gz = int(max(100_000, min(int(os.environ.get("KART_BENCH_GZ_PAIRS", "10000000")), budget // (4 * REC_BYTES + 2 * 500))))
+    n_gz = int(max(100_000, min(int(os.environ.get("KART_BENCH_GZ_PAIRS", "20000000")), budget // (4 * REC_BYTES + 2 * 500))))
     f1, f2 = os.path.join(workdir, "gz_1.fq"), os.path.join(workdir, "gz_2.fq")
     write_fastq_pairs(codes, n_gz, 43, f1, f2, dev, err=0.01)
     t0 = time.perf_counter()
