@@ -3061,12 +3061,13 @@ __global__ __launch_bounds__(256) void aln_finish_group_kernel(AlnArgs a)
 
 // ---- pass 1 by groups of eight lanes -----------------------------------------------------------------------------------------------
 // aln_plan_kernel gives a candidate to a lane, and the lane keeps the candidate's normal pairs and what it decides about them in 1344 B of
-// private (scratch) memory: IdentifyNormalPairs' loops are chains of dependent scratch accesses, ~13 k wave-instructions in a wave that lasts
-// 0.38 ms (profiles/r06h: waiting 0.78 of its cycles).  Here eight lanes take a candidate: its pairs live in the LDS (1 KB per group) --
+// private (scratch) memory (profiles/r06h: waiting 0.78 of its cycles).  The experiment: eight lanes take a candidate: its pairs live in the LDS (1 KB per group) --
 // IdentifyNormalPairs and CheckCoordinateValidity are the same code (templates over the storage), run by the eight lanes alike --, the pairs
 // are classified eight at a time (the mismatch count of each is a chain of its own), and a candidate that needs no alignment is reported by
 // the group (report_by_group).  What is parked is written exactly as aln_plan_kernel writes it: the same spill slots, jobs and tasks.
 // (The alignments of aln_plan_kernel's own lanes, KG_ALN_INLINE, stay that kernel's.)
+// MEASURED: correct (CHECK_ALIGN 0 of 5.2 M, profiles/r06s) and slower -- 86 ms per step against aln_plan_kernel's 31: IdentifyNormalPairs is serial per
+// candidate, and a wave that runs it for 8 candidates instead of 64 issues eight times the instructions.  An A/B form (KG_ALN_PLAN_GROUP), off.
 namespace {
 
 constexpr int kPlanG = 8;
