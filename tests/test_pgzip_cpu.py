@@ -191,3 +191,39 @@ def test_the_benchs_gzip_writer_writes_one_ordinary_member(pgz_check, tmp_path):
     gzip_one_member(src, dst, 6, 4, 100000)
     line = check(pgz_check, tmp_path, open(dst, "rb").read(), 4, 16)
     assert line["all_done"] == 1 and line["bytes"] == len(text)
+
+
+def test_a_gz_library_on_its_way_to_the_device_stream(tmp_path):
+    """GzText::fill_direct + GzProducer (kart_amd/csrc/host/detail/batch_reader.inc) without a device -- tests/cpu_backend/gzproducer_check.cpp plays the
+    stream's part: blocks of the growing text against zlib's, a look-ahead small enough that the inflating thread waits for the consumer's releases,
+    and the hand-over half-way that Source::gz_stream_end makes (the rest through the gz reader's carry and fill()).  Ordinary gzip through the
+    several-thread reader (rounds straight into the block), several members, BGZF, one zlib stream, a damaged stream; also under ThreadSanitizer
+    and AddressSanitizer / UBSan."""
+    from bgzf_util import bgzf
+    targets = [os.path.join("..", "..", "tests", "_build", "gzproducer_check" + s) for s in ("", "-tsan", "-asan")]
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpu_backend")] + targets, stdout=subprocess.DEVNULL)
+    text = fastq_text()
+
+    def run(data, suffix="", threads=4, block_kb=100, ahead_mb=64, env=None):
+        path = str(tmp_path / "t.gz")
+        open(path, "wb").write(data)
+        r = subprocess.run([os.path.join(ROOT, "tests", "_build", "gzproducer_check" + suffix), path, str(threads), str(block_kb), str(ahead_mb)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, KART_AMD_PGZ_MIN_KB="0", KART_AMD_PGZ_CHUNK_KB="16", ASAN_OPTIONS="detect_leaks=0", **(env or {})))
+        assert r.returncode == 0 and b"ThreadSanitizer" not in r.stderr and b"runtime error" not in r.stderr, (r.stdout, r.stderr[-800:])
+        line = json.loads(r.stdout)
+        assert line["equal"] == 1
+        return line
+
+    plain = gzip.compress(text)
+    for suffix in ("", "-tsan", "-asan"):
+        assert run(plain, suffix)["through_the_producer"] == len(text)
+        assert run(bgzf(text), suffix)["through_the_producer"] == len(text)
+    third = len(text) // 3
+    assert run(gzip.compress(text[:third]) + gzip.compress(text[third:], 1), block_kb=37)["with_a_hand_over_half_way"] == len(text)
+    assert run(plain, env={"KART_AMD_NO_PGZ": "1"}, block_kb=700)["through_the_producer"] == len(text)
+    assert run(plain, threads=8, block_kb=3)["through_the_producer"] == len(text)
+    damaged = bytearray(plain)
+    damaged[len(damaged) * 6 // 10] ^= 0x55
+    line = run(bytes(damaged), "-tsan")                       # (equal: the producer's text is what small zlib reads still deliver of it)
+    assert 0 < line["through_the_producer"] < len(text)
