@@ -52,6 +52,11 @@ def runs(tmp, pairs):
     out.append(("pe pwrite writer -t 6", pe + ["-t", "6"], {"KART_AMD_NO_MMAP_OUT": "1", "KART_AMD_PWRITE_THREADS": "3"}))
     out.append(("pe 3 reader threads -t 6", pe + ["-t", "6"], {"KART_AMD_READER_THREADS": "3"}))
     out.append(("se golden -t 4", ["-f", gz["se.fq"], "-t", "4"], {}))
+    # the seeded set as two ordinary gzip files: the several-thread reader (both files at once, chunks of 64 KB: several rounds) in front of the gz reader
+    for f in (f1, f2):
+        with open(f, "rb") as fi, open(f + ".gz", "wb") as fo:
+            fo.write(gzip.compress(fi.read()))
+    out.append(("pe gz, several-thread reader -t 8", ["-f", f1 + ".gz", "-f2", f2 + ".gz", "-t", "8"], {"KART_AMD_PGZ_MIN_KB": "0", "KART_AMD_PGZ_CHUNK_KB": "64"}))
     for env in ({}, {"KART_AMD_PACBIO_CHUNKS": "4", "KART_AMD_FRAG_DEPTH": "2"}, {"KART_AMD_LONG_NO_OVERLAP": "1"}):
         out.append(("pacbio golden -t 4 %s" % (env or ""), ["-f", gz["pacbio.fq"], "-pacbio", "-t", "4"], env))
     for dev in ("0,1", "0,1,2"):
