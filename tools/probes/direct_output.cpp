@@ -59,7 +59,7 @@ int main(int argc, char **argv)
 		const double t1 = now();
 		printf("{\"way\": \"page-locked buffer, then %d threads copy into the mapping\", \"GB\": %.1f, \"seconds\": %.3f, \"d2h_s\": %.3f, \"copy_s\": %.3f, \"GBps_serial\": %.2f, \"GBps_copy_alone\": %.2f}\n",
 		       threads, total / 1e9, t1 - t0, t_d2h, t_copy, total / 1e9 / (t1 - t0), total / 1e9 / t_copy);
-		hipHostFree(pin); munmap(map, total); close(fd); unlink("/dev/shm/kart_probe_a");
+		(void)hipHostFree(pin); munmap(map, total); close(fd); unlink("/dev/shm/kart_probe_a");
 	}
 	// ---- B: the windows of the mapping registered with the runtime, the copy engine writes into the file's pages ----
 	{
@@ -102,9 +102,34 @@ int main(int argc, char **argv)
 		}
 		reg.join();
 		const double t1 = now();
-		for (size_t i = 0; i < n; ++i) if (state[i] == 1) hipHostUnregister(map + i * window);
+		for (size_t i = 0; i < n; ++i) if (state[i] == 1) (void)hipHostUnregister(map + i * window);
 		printf("{\"way\": \"as above, registration one window ahead on its own thread\", \"GB\": %.1f, \"seconds\": %.3f, \"GBps\": %.2f, \"ok\": %s}\n", total / 1e9, t1 - t0, total / 1e9 / (t1 - t0), ok ? "true" : "false");
 		munmap(map, total); close(fd); unlink("/dev/shm/kart_probe_c");
+	}
+	// ---- D: the registration itself by T threads (disjoint 256 MB windows each): is pinning fresh pages of ONE file as parallel as copying into them? ----
+	for (int T : {1, 2, 4, 7, 12}) {
+		char *map; int fd;
+		if (!fresh("/dev/shm/kart_probe_d", map, fd)) return 0;
+		const size_t piece = (size_t)256 << 20, n = total / piece;
+		std::vector<char> okv((size_t)T, 1);
+		const double t0 = now();
+		std::vector<std::thread> th;
+		for (int t = 0; t < T; ++t) th.emplace_back([&, t]() { for (size_t i = (size_t)t; i < n; i += (size_t)T) if (hipHostRegister(map + i * piece, piece, hipHostRegisterDefault) != hipSuccess) { okv[(size_t)t] = 0; return; } });
+		for (std::thread &x : th) x.join();
+		const double t1 = now();
+		bool ok = true;
+		for (char c : okv) ok = ok && c;
+		double d2h = 0;
+		if (ok) {
+			const double a = now();
+			for (size_t off = 0; off + window <= total; off += window) { if (hipMemcpyAsync(map + off, dev, window, hipMemcpyDeviceToHost, st) != hipSuccess) ok = false; }
+			if (hipStreamSynchronize(st) != hipSuccess) ok = false;
+			d2h = now() - a;
+		}
+		for (size_t i = 0; i < n; ++i) (void)hipHostUnregister(map + i * piece);
+		printf("{\"way\": \"registration by %d threads, then the copies\", \"GB\": %.1f, \"register_s\": %.3f, \"register_GBps\": %.2f, \"d2h_s\": %.3f, \"d2h_GBps\": %.1f, \"ok\": %s}\n", T, total / 1e9, t1 - t0, total / 1e9 / (t1 - t0), d2h,
+		       d2h > 0 ? total / 1e9 / d2h : 0.0, ok ? "true" : "false");
+		munmap(map, total); close(fd); unlink("/dev/shm/kart_probe_d");
 	}
 	return 0;
 }
